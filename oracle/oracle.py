@@ -1,0 +1,148 @@
+"""ctypes wrapper around the CPU oracle (oracle/rr_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Never imported by real_robots_amd (the product path fails loudly without its HIP library instead).
+"parity unpinned" w.r.t. PyBullet -- see rr_oracle.h.
+"""
+import ctypes as C
+import gzip
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BLOB_GZ = os.path.join(_HERE, '..', 'real_robots_amd', 'data', 'realrobot_model.bin.gz')
+_blob_cache = None
+
+
+def model_blob():
+    global _blob_cache
+    if _blob_cache is None:
+        with gzip.open(_BLOB_GZ, 'rb') as f:
+            _blob_cache = f.read()
+    return _blob_cache
+
+
+class Params(C.Structure):
+    _fields_ = [('dt', C.c_double), ('gravity', C.c_double), ('solver_iters', C.c_int), ('erp', C.c_double),
+                ('margin', C.c_double), ('motor_kp', C.c_double), ('motor_kd', C.c_double),
+                ('motor_max_force', C.c_double), ('lin_damping', C.c_double), ('ang_damping', C.c_double),
+                ('rest_threshold', C.c_double), ('use_urdf_inertia', C.c_int)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, '_build', 'librr_oracle.so')
+    if force or not os.path.exists(so) or not os.path.exists(so.replace('.so', '_f32.so')):
+        subprocess.check_call(['make', '-C', _HERE, '-s'])
+    return so
+
+
+_libs = {}
+
+
+def _lib(f32=False):
+    if f32 not in _libs:
+        so = build()
+        if f32:
+            so = so.replace('.so', '_f32.so')
+        L = C.CDLL(so)
+        L.rro_create.restype = C.c_void_p
+        L.rro_create.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(Params)]
+        L.rro_destroy.argtypes = [C.c_void_p]
+        L.rro_reset.argtypes = [C.c_void_p]
+        L.rro_step.argtypes = [C.c_void_p, C.c_void_p]
+        L.rro_step.restype = C.c_int
+        L.rro_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rro_get_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.rro_set_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.rro_get_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rro_timestep.argtypes = [C.c_void_p]
+        L.rro_link_pose.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rro_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.rro_set_object_pose.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rro_mass_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rro_default_params.argtypes = [C.POINTER(Params)]
+        _libs[f32] = L
+    return _libs[f32]
+
+
+LINK_NAMES = open(os.path.join(_HERE, '..', 'real_robots_amd', 'data', 'realrobot_model_links.txt')).read().split()
+
+
+class Oracle:
+    """One REALRobot env on the CPU. f32=True uses the float build (same algorithm, fp32 arithmetic)."""
+
+    def __init__(self, n_objects=3, width=320, height=240, f32=False, **params):
+        self.L = _lib(f32)
+        p = Params()
+        self.L.rro_default_params(C.byref(p))
+        for k, v in params.items():
+            setattr(p, k, v)
+        blob = model_blob()
+        self.h = self.L.rro_create(blob, len(blob), n_objects, width, height, C.byref(p))
+        assert self.h
+        self.n_objects, self.W, self.H = n_objects, width, height
+
+    def __del__(self):
+        if getattr(self, 'h', None):
+            self.L.rro_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.L.rro_reset(self.h)
+
+    def step(self, action9=None):
+        if action9 is None:
+            return self.L.rro_step(self.h, None)
+        a = np.ascontiguousarray(action9, dtype=np.float64)
+        assert a.shape == (9,)
+        return self.L.rro_step(self.h, a.ctypes.data)
+
+    def render(self):
+        rgb = np.empty((self.H, self.W, 3), np.uint8)
+        depth = np.empty((self.H, self.W), np.float32)
+        mask = np.empty((self.H, self.W), np.int32)
+        self.L.rro_render(self.h, rgb.ctypes.data, depth.ctypes.data, mask.ctypes.data)
+        return rgb, depth, mask
+
+    @property
+    def state(self):
+        s = np.empty(61)
+        self.L.rro_get_state(self.h, s.ctypes.data)
+        return s
+
+    @state.setter
+    def state(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        assert s.shape == (61,)
+        self.L.rro_set_state(self.h, s.ctypes.data)
+
+    def obs(self):
+        j, t, p = np.empty(9), np.empty(4), np.empty(3 * self.n_objects)
+        self.L.rro_get_obs(self.h, j.ctypes.data, t.ctypes.data, p.ctypes.data)
+        return j, t, p.reshape(self.n_objects, 3)
+
+    @property
+    def timestep(self):
+        return self.L.rro_timestep(self.h)
+
+    def link_pose(self, name_or_idx):
+        i = LINK_NAMES.index(name_or_idx) if isinstance(name_or_idx, str) else name_or_idx
+        p = np.empty(7)
+        self.L.rro_link_pose(self.h, i, p.ctypes.data)
+        return p
+
+    def contacts(self):
+        out = np.empty((48, 12))
+        n = self.L.rro_contacts(self.h, out.ctypes.data, 48)
+        return out[:n]
+
+    def set_object_pose(self, obj, pose7):
+        p = np.ascontiguousarray(pose7, dtype=np.float64)
+        self.L.rro_set_object_pose(self.h, obj, p.ctypes.data)
+
+    def mass_matrix(self):
+        M, b = np.empty((11, 11)), np.empty(11)
+        self.L.rro_mass_matrix(self.h, M.ctypes.data, b.ctypes.data)
+        return M, b
