@@ -1,0 +1,122 @@
+/* realrobot.h -- C ABI of librealrobot_hip.so: batched REALRobot env.step() on MI355X (gfx950).
+ *
+ * Drop-in boundary.  The reference has no FFI for this path: its boundary is the duck-typed gym API
+ * `gym.make(id) -> REALRobotEnv` with reset()/step()/render() (real_robots/__init__.py:22-28,
+ * real_robots/envs/env.py:206-219,326-356) and, underneath, ~50 pybullet C-API calls per step
+ * (SURVEY.md 3.3).  This header is what a maintainer binds instead of `import pybullet` for the step path;
+ * every entry point cites the reference call(s) it replaces.  The ctypes binding is
+ * real_robots_amd/_native.py; INTEGRATION.md shows the stub to add to the reference.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns 0 on success or a
+ * negative RR_E* code and never throws/aborts; rr_last_error() gives the message of the last failure on the
+ * calling thread.  The library owns all device memory; the caller owns host buffers.  One rr_env may be
+ * used from one thread at a time.  Work is enqueued on the stream given at creation (or rr_set_stream) and
+ * is asynchronous until rr_sync / rr_copy_to_host.
+ * Layouts: every buffer is row-major with the env index outermost ([N, ...]).
+ */
+#ifndef REALROBOT_H
+#define REALROBOT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RR_ABI_VERSION 1
+
+enum {
+    RR_OK = 0,
+    RR_EINVAL = -1,     /* bad argument */
+    RR_EDEVICE = -2,    /* HIP runtime error (no GPU, out of memory, launch failure) */
+    RR_EMODEL = -3,     /* malformed model blob */
+    RR_EACTION = -4     /* non-finite action (the reference asserts, robot.py:189) */
+};
+
+/* fields of rr_get_buffer / rr_copy_to_host */
+enum {
+    RR_F_JOINTS = 0,    /* f32 [N, 9]        Kuka.calc_state()            robot.py:203-211 */
+    RR_F_TOUCH = 1,     /* f32 [N, 4]        Kuka.get_touch_sensors()     robot.py:152-163 */
+    RR_F_OBJ_POSE = 2,  /* f32 [N, n_obj, 7] object_bodies[..].get_pose() env.py:236-244 (xyz + xyzw quat) */
+    RR_F_RGB = 3,       /* u8  [N, H, W, 3]  retina                       env.py:249-255,560-562 */
+    RR_F_DEPTH = 4,     /* f32 [N, H, W]     GL depth in [0,1]            env.py:564-565 */
+    RR_F_MASK = 5,      /* i32 [N, H, W]     body unique id, -1 background  env.py:552-558 */
+    RR_F_TIMESTEP = 6,  /* i32 [N]           env.timestep                 env.py:217,346 */
+    RR_F_ERRFLAGS = 7,  /* u32 [N]           bit0: non-finite state detected (env auto-frozen) */
+    RR_F_STATE = 8,     /* f32 [N, 61]       q[11] qd[11] 3x(pos3 quat4 lin3 ang3)  (checkpoint / parity) */
+    RR_F_COUNT = 9
+};
+
+typedef struct rr_config {
+    int32_t abi_version;    /* RR_ABI_VERSION */
+    int32_t num_envs;       /* N envs on this device */
+    int32_t n_objects;      /* 1..3: cube, tomato, mustard      robot.py:49-50 */
+    int32_t width, height;  /* eye camera; reference default 320x240 (robot.py:30-31) */
+    int32_t device;         /* HIP device ordinal */
+    int32_t solver_iters;   /* PGS iterations; <=0 -> 50        SURVEY A.1.2 */
+    int32_t envs_per_block; /* physics kernels: envs (threads) per workgroup; <=0 -> default */
+    float dt;               /* <=0 -> 0.005                     env.py:203-204 */
+    float erp;              /* <=0 -> 0.2 */
+    float margin;           /* <=0 -> 0.02 */
+    int32_t use_urdf_inertia; /* 0: Bullet AABB inertia for robot links (default); 1: URDF <inertia> */
+    int32_t reserved[8];
+} rr_config;
+
+typedef struct rr_env rr_env;
+
+/* Replaces REALRobotEnv.__init__ + the lazy bullet client/world creation in reset()
+ * (env.py:36-122,202-219; robot.py:44-118,165-185: loadURDF of robot + table + objects).
+ * `model_blob` is the compiled model (tools/compile_model.py). `stream` is a hipStream_t or NULL (default stream). */
+int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, void *stream, rr_env **out);
+int rr_destroy(rr_env *env);
+int rr_set_stream(rr_env *env, void *stream);
+
+/* Replaces env.reset() (env.py:206-219; robot.py:120-129,165-185) for the envs whose mask byte is non-zero
+ * (env_mask == NULL: all envs). Device-side state copy from the template; does not render. */
+int rr_reset(rr_env *env, const uint8_t *env_mask_host);
+
+/* Replaces BodyPart.reset_pose via robot.object_bodies[name].reset_pose (env.py:159-162; zeroes velocity). */
+int rr_set_object_pose(rr_env *env, int32_t env_index, int32_t obj, const float *pose7);
+
+/* Replaces one REALRobotEnv.step_joints() (env.py:326-356) for all N envs:
+ *   limitActionByJoint (env.py:314-321), control_objects_limits (env.py:257-264), Kuka.apply_action
+ *   (robot.py:188-201), scene.global_step() -> stepSimulation (env.py:340), calc_state/get_touch_sensors
+ *   (robot.py:203-211,152-163) and, when render_mode != 0, get_retina (env.py:249-255).
+ * joint_cmd: f32 [N, 9] (device pointer if cmd_on_device, else host; NULL -> zeros as env.py:333-334).
+ * render_mode: 0 none, 1 all envs, 2 per-env flags in render_flags_host (u8 [N]). */
+int rr_step(rr_env *env, const float *joint_cmd, int32_t cmd_on_device, int32_t render_mode,
+            const uint8_t *render_flags_host);
+
+/* Replaces EyeCamera.render (env.py:536-567) for all envs at the current state (used by reset()/set_goal()). */
+int rr_render(rr_env *env);
+
+/* Device pointer + size of an observation/state buffer (valid until rr_destroy). */
+int rr_get_buffer(rr_env *env, int32_t field, void **dev_ptr, size_t *bytes);
+/* Synchronising copy of a whole field to host memory. */
+int rr_copy_to_host(rr_env *env, int32_t field, void *dst, size_t bytes);
+/* Overwrites the full simulation state from host memory (f32 [N, 61]); checkpoint restore / parity tests. */
+int rr_set_state(rr_env *env, const float *state_host);
+int rr_sync(rr_env *env);
+
+/* Replaces robot.parts[name].get_position()/get_pose() (env.py:230-232): world pose of the COM frame of
+ * every robot link, f32 [N, 17, 7] (URDF depth-first link order, see data/realrobot_model_links.txt). */
+int rr_link_poses(rr_env *env, float *out_host);
+/* Replaces Kuka.get_contacts (robot.py:131-150) for one env: up to max_contacts rows of 12 floats
+ * {bodyA, bodyB, linkA, x,y,z, nx,ny,nz, distance, normal_force, mu}; *count receives the number written. */
+int rr_get_contacts(rr_env *env, int32_t env_index, float *out_host, int32_t max_contacts, int32_t *count);
+
+/* Per-kernel device timing with HIP events on the library's stream (bench.py roofline leg).
+ * After rr_set_timing(env, 1), each rr_step/rr_render records events; rr_get_timing returns accumulated
+ * milliseconds and launch counts per kernel since the last call and resets them.
+ * kernel ids: 0 prep, 1 collide, 2 solve, 3 render_setup, 4 raster. */
+#define RR_NUM_KERNELS 5
+int rr_set_timing(rr_env *env, int32_t enable);
+int rr_get_timing(rr_env *env, float *ms_out /*[RR_NUM_KERNELS]*/, int32_t *launches_out /*[RR_NUM_KERNELS]*/);
+
+const char *rr_last_error(void);
+int rr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,101 @@
+"""ctypes binding of librealrobot_hip.so (C ABI in include/realrobot.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no GPU is present, creation fails
+loudly (RuntimeError) -- nothing here imports the oracle.
+"""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get('RR_LIB', os.path.join(_HERE, 'csrc', 'librealrobot_hip.so'))
+BLOB_GZ = os.path.join(_HERE, 'data', 'realrobot_model.bin.gz')
+LINK_NAMES = open(os.path.join(_HERE, 'data', 'realrobot_model_links.txt')).read().split()
+
+RR_ABI_VERSION = 1
+(F_JOINTS, F_TOUCH, F_OBJ_POSE, F_RGB, F_DEPTH, F_MASK, F_TIMESTEP, F_ERRFLAGS, F_STATE) = range(9)
+NUM_KERNELS = 5
+KERNEL_NAMES = ('k_prep', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster')
+
+# every symbol include/realrobot.h declares (tests check the library exports all of them)
+SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_object_pose', 'rr_step', 'rr_render',
+           'rr_get_buffer', 'rr_copy_to_host', 'rr_set_state', 'rr_sync', 'rr_link_poses', 'rr_get_contacts',
+           'rr_set_timing', 'rr_get_timing', 'rr_last_error', 'rr_abi_version')
+
+
+class Config(C.Structure):
+    _fields_ = [('abi_version', C.c_int32), ('num_envs', C.c_int32), ('n_objects', C.c_int32),
+                ('width', C.c_int32), ('height', C.c_int32), ('device', C.c_int32), ('solver_iters', C.c_int32),
+                ('envs_per_block', C.c_int32), ('dt', C.c_float), ('erp', C.c_float), ('margin', C.c_float),
+                ('use_urdf_inertia', C.c_int32), ('reserved', C.c_int32 * 8)]
+
+
+_lib = None
+_blob = None
+
+
+def model_blob():
+    global _blob
+    if _blob is None:
+        with gzip.open(BLOB_GZ, 'rb') as f:
+            _blob = f.read()
+    return _blob
+
+
+def load_library():
+    """Loads librealrobot_hip.so; raises RuntimeError with a build hint when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "real_robots_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C real_robots_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    L.rr_create.argtypes = [C.POINTER(Config), C.c_char_p, C.c_size_t, vp, C.POINTER(vp)]
+    L.rr_destroy.argtypes = [vp]
+    L.rr_set_stream.argtypes = [vp, vp]
+    L.rr_reset.argtypes = [vp, vp]
+    L.rr_set_object_pose.argtypes = [vp, i32, i32, vp]
+    L.rr_step.argtypes = [vp, vp, i32, i32, vp]
+    L.rr_render.argtypes = [vp]
+    L.rr_get_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.rr_copy_to_host.argtypes = [vp, i32, vp, C.c_size_t]
+    L.rr_set_state.argtypes = [vp, vp]
+    L.rr_sync.argtypes = [vp]
+    L.rr_link_poses.argtypes = [vp, vp]
+    L.rr_get_contacts.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
+    L.rr_set_timing.argtypes = [vp, i32]
+    L.rr_get_timing.argtypes = [vp, vp, vp]
+    L.rr_last_error.restype = C.c_char_p
+    L.rr_abi_version.restype = i32
+    for name in SYMBOLS:
+        if name not in ('rr_last_error', 'rr_abi_version'):
+            getattr(L, name).restype = i32
+    if L.rr_abi_version() != RR_ABI_VERSION:
+        raise RuntimeError("real_robots_amd: ABI version mismatch, rebuild the HIP library")
+    _lib = L
+    return L
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError("librealrobot_hip: error %d: %s" % (rc, load_library().rr_last_error().decode()))
+
+
+class DeviceBuffer:
+    """Device memory view exposing __cuda_array_interface__ (zero-copy into torch: torch.as_tensor(buf, device=...))."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.ptr, self.shape, self.typestr, self._owner = ptr, tuple(shape), typestr, owner
+
+    @property
+    def __cuda_array_interface__(self):
+        return {'shape': self.shape, 'typestr': self.typestr, 'data': (self.ptr, False), 'version': 2, 'strides': None}

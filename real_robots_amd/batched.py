@@ -1,0 +1,130 @@
+"""BatchedREALRobotEnv: N independent REALRobot envs stepped in lock-step on one MI355X.
+
+Host-side mirror of the reference's step protocol for a batch (REALRobotEnv.step_joints, env.py:326-356;
+Kuka.apply_action/calc_state/get_touch_sensors, robot.py:152-211), implemented by librealrobot_hip.so.
+Observations stay on the device; `obs_host()` copies what the caller asks for.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+
+OBJECT_NAMES = ['cube', 'tomato', 'mustard']       # robot.py:49-50 (after "table")
+
+
+class BatchedREALRobotEnv:
+    def __init__(self, num_envs, objects=3, width=320, height=240, device=0, solver_iters=50, envs_per_block=0,
+                 stream=None, use_urdf_inertia=False, dt=0.0, erp=0.0, margin=0.0):
+        self.L = nat.load_library()
+        cfg = nat.Config()
+        cfg.abi_version = nat.RR_ABI_VERSION
+        cfg.num_envs, cfg.n_objects, cfg.width, cfg.height = int(num_envs), int(objects), int(width), int(height)
+        cfg.device, cfg.solver_iters, cfg.envs_per_block = int(device), int(solver_iters), int(envs_per_block)
+        cfg.dt, cfg.erp, cfg.margin, cfg.use_urdf_inertia = dt, erp, margin, int(bool(use_urdf_inertia))
+        blob = nat.model_blob()
+        h = C.c_void_p()
+        self.h = None
+        nat.check(self.L.rr_create(C.byref(cfg), blob, len(blob), C.c_void_p(stream or 0), C.byref(h)))
+        self.h = h
+        self.N, self.n_objects, self.W, self.H, self.device = int(num_envs), int(objects), int(width), int(height), int(device)
+        self.object_names = OBJECT_NAMES[:self.n_objects]
+        self._shapes = {
+            nat.F_JOINTS: ((self.N, 9), np.float32), nat.F_TOUCH: ((self.N, 4), np.float32),
+            nat.F_OBJ_POSE: ((self.N, self.n_objects, 7), np.float32),
+            nat.F_RGB: ((self.N, self.H, self.W, 3), np.uint8), nat.F_DEPTH: ((self.N, self.H, self.W), np.float32),
+            nat.F_MASK: ((self.N, self.H, self.W), np.int32), nat.F_TIMESTEP: ((self.N,), np.int32),
+            nat.F_ERRFLAGS: ((self.N,), np.uint32), nat.F_STATE: ((self.N, 61), np.float32)}
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.rr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ stepping
+    def reset(self, env_mask=None):
+        if env_mask is None:
+            nat.check(self.L.rr_reset(self.h, None))
+        else:
+            m = np.ascontiguousarray(env_mask, dtype=np.uint8)
+            assert m.shape == (self.N,)
+            nat.check(self.L.rr_reset(self.h, m.ctypes.data))
+
+    def step(self, joint_cmd=None, render=False, device_ptr=None):
+        """joint_cmd: None (zeros, env.py:333-334), float array [N, 9] on the host, or `device_ptr` (int address of
+        an f32 [N, 9] device buffer). render: False / True / uint8 array [N] of per-env camera flags."""
+        mode, flags = (1 if render else 0), None
+        if isinstance(render, np.ndarray):
+            flags = np.ascontiguousarray(render, dtype=np.uint8)
+            assert flags.shape == (self.N,)
+            mode = 2
+        if device_ptr is not None:
+            nat.check(self.L.rr_step(self.h, C.c_void_p(device_ptr), 1, mode, flags.ctypes.data if flags is not None else None))
+            return
+        if joint_cmd is None:
+            nat.check(self.L.rr_step(self.h, None, 0, mode, flags.ctypes.data if flags is not None else None))
+            return
+        a = np.ascontiguousarray(joint_cmd, dtype=np.float32)
+        assert a.shape == (self.N, 9), "joint_command must have shape [N, 9]"      # robot.py:190
+        assert np.isfinite(a).all(), "joint_command must be finite"               # robot.py:189
+        nat.check(self.L.rr_step(self.h, a.ctypes.data, 0, mode, flags.ctypes.data if flags is not None else None))
+
+    def render(self):
+        nat.check(self.L.rr_render(self.h))
+
+    def sync(self):
+        nat.check(self.L.rr_sync(self.h))
+
+    # ------------------------------------------------------------------ data access
+    def host(self, field):
+        shape, dt = self._shapes[field]
+        out = np.empty(shape, dt)
+        nat.check(self.L.rr_copy_to_host(self.h, field, out.ctypes.data, out.nbytes))
+        return out
+
+    def device_buffer(self, field):
+        shape, dt = self._shapes[field]
+        p, n = C.c_void_p(), C.c_size_t()
+        nat.check(self.L.rr_get_buffer(self.h, field, C.byref(p), C.byref(n)))
+        return nat.DeviceBuffer(p.value, shape, np.dtype(dt).str, self)
+
+    @property
+    def state(self):
+        return self.host(nat.F_STATE)
+
+    @state.setter
+    def state(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float32)
+        assert s.shape == (self.N, 61)
+        nat.check(self.L.rr_set_state(self.h, s.ctypes.data))
+
+    def set_object_pose(self, env, obj, pose7):
+        p = np.ascontiguousarray(pose7, dtype=np.float32)
+        assert p.shape == (7,)
+        nat.check(self.L.rr_set_object_pose(self.h, int(env), int(obj), p.ctypes.data))
+
+    def link_poses(self):
+        out = np.empty((self.N, len(nat.LINK_NAMES), 7), np.float32)
+        nat.check(self.L.rr_link_poses(self.h, out.ctypes.data))
+        return out
+
+    def contacts(self, env):
+        out = np.empty((48, 12), np.float32)
+        n = C.c_int32()
+        nat.check(self.L.rr_get_contacts(self.h, int(env), out.ctypes.data, 48, C.byref(n)))
+        return out[:n.value]
+
+    def set_timing(self, on):
+        nat.check(self.L.rr_set_timing(self.h, int(on)))
+
+    def get_timing(self):
+        ms = np.zeros(nat.NUM_KERNELS, np.float32)
+        n = np.zeros(nat.NUM_KERNELS, np.int32)
+        nat.check(self.L.rr_get_timing(self.h, ms.ctypes.data, n.ctypes.data))
+        return dict(zip(nat.KERNEL_NAMES, zip(ms.tolist(), n.tolist())))

@@ -1,0 +1,1612 @@
+// realrobot.hip -- batched REALRobot env.step() for MI355X (gfx950): HIP kernels + C ABI (include/realrobot.h).
+//
+// One process per GPU; N independent envs per device.  State lives in HBM as SoA [field][env] fp32 so that a
+// wavefront whose lanes are consecutive envs reads/writes 256-byte contiguous lines.  The step is five kernels:
+//   k_prep          1 thread / env : action protocol (env.py:314-321, 257-264; robot.py:188-201), forward kinematics,
+//                                    joint-space mass matrix (composite rigid bodies) + bias (RNEA), Cholesky inverse,
+//                                    unconstrained velocities
+//   k_collide       1 thread / (env, shape pair): bounding-sphere cull, vertex-vs-plane convex tests, <=4 points
+//   k_solve         1 thread / env : row assembly (motors, joint limits, contact normal + 2 friction), PGS,
+//                                    semi-implicit Euler, touch sensors, observation pack (robot.py:152-163,203-211)
+//   k_render_setup  1 thread / env : FK at the new state -> per-instance model matrices
+//   k_raster        1 workgroup / (env, tile): triangle-parallel visibility buffer in LDS (64-bit atomic min of
+//                                    depth|triangle id), cooperative path for large triangles, deferred shading
+// The arithmetic restates what the reference delegates to pybullet.stepSimulation / getCameraImage
+// (env.py:340, 536-567); the algorithm and its constants are specified in DESIGN.md and checked against
+// oracle/rr_oracle.c by tests/ (never linked here).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/realrobot.h"
+
+#define NB 11
+#define NOBJ 3
+#define MAXC 48
+#define NLINK_MAX 24
+#define MAXSHAPES 32
+#define VMAXC 32
+#define FMAXC 32
+#define MAXINST 32
+#define MAXPAIRS 96
+#define ROWF 40          // floats per contact row in scratch
+#define NSTATE 61
+
+// ---------------------------------------------------------------------------------------------- error handling
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                  \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) return fail(RR_EDEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------- model (device view)
+struct BodyParams {   // passed by value as kernel argument -> scalar loads, uniform across the wave
+    int parent[NB];
+    float jpos[NB][3], jrot[NB][9], axis[NB][3], mass[NB], com[NB][3], inertia[NB][6], damping[NB], limits[NB][2];
+    float robot_pos[3];
+    float obj_mass[NOBJ], obj_inertia[NOBJ][3], obj_pose0[NOBJ][7];
+    float table_z;
+    float act_min[9], act_max[9], act_maxdiff[9];
+    int touch_links[4];
+};
+
+struct SimParams {
+    int N, nobj, iters, npairs;
+    float dt, gravity, erp, margin, kp, kd, max_impulse, lin_damp, ang_damp, rest_thresh;
+};
+
+struct ShapeData {    // global memory, read uniformly
+    int otype[MAXSHAPES], oidx[MAXSHAPES], link[MAXSHAPES], nv[MAXSHAPES], nf[MAXSHAPES];
+    float verts[MAXSHAPES][VMAXC][3];
+    float planes[MAXSHAPES][FMAXC][4];
+    float sphere[MAXSHAPES][4];
+    float fric[MAXSHAPES], rest[MAXSHAPES];
+    int pair_a[MAXPAIRS], pair_b[MAXPAIRS];
+};
+
+struct RenderModel {
+    int ni, nt, W, H, tile_h, ntiles;
+    int in_otype[MAXINST], in_oidx[MAXINST], in_uid[MAXINST], in_tex[MAXINST];
+    float in_color[MAXINST][3];
+    int tex_off[16], tex_w[16], tex_h[16];
+    int link_body[NLINK_MAX];
+    float link_pos[NLINK_MAX][3], link_rot[NLINK_MAX][9];
+    int nl;
+    float VP[16];
+};
+
+// scratch slots (floats per env), SoA [slot][N]
+enum {
+    S_BR = 0,                    // 11*9
+    S_BP = S_BR + 99,            // 11*3
+    S_BAX = S_BP + 33,           // 11*3
+    S_MINV = S_BAX + 33,         // 121
+    S_QDS = S_MINV + 121,        // 11
+    S_OR = S_QDS + 11,           // 3*9
+    S_OIINV = S_OR + 27,         // 3*9
+    S_OVS = S_OIINV + 27,        // 9
+    S_OWS = S_OVS + 9,           // 9
+    S_PCOUNT = S_OWS + 9,        // MAXPAIRS (int)
+    S_PDATA = S_PCOUNT + MAXPAIRS,           // MAXPAIRS*4*7
+    S_ROWS = S_PDATA + MAXPAIRS * 28,        // 3*MAXC*ROWF
+    S_RMETA = S_ROWS + 3 * MAXC * ROWF,      // MAXC (int: bodyA | bodyB<<8 | linkA<<16)
+    S_CT = S_RMETA + MAXC,                   // MAXC*12 (contact records for the API)
+    S_NCT = S_CT + MAXC * 12,                // 1 (int)
+    S_MOT = S_NCT + 1,                       // 11 x {rhs, dinv, lambda}
+    S_LIM = S_MOT + 33,                      // 22 x {rhs, lambda}
+    S_TOTAL = S_LIM + 44
+};
+
+// state slots (floats per env), SoA [slot][N]
+enum {
+    ST_Q = 0, ST_QD = 11, ST_OPOS = 22, ST_OQUAT = 31, ST_OVEL = 43, ST_OANG = 52, ST_TGT = 61, ST_TOTAL = 72
+};
+
+struct DevPtrs {
+    float *state;      // [ST_TOTAL][N]
+    float *scratch;    // [S_TOTAL][N]
+    int *timestep;     // [N]
+    unsigned *errflags;// [N]
+    float *cmd;        // [N][9]
+    float *joints;     // [N][9]
+    float *touch;      // [N][4]
+    float *objpose;    // [N][nobj][7]
+    float *inst_xf;    // [N][MAXINST][12]  (R row-major 9, p 3)
+    unsigned char *render_flags; // [N]
+    unsigned char *rgb; float *depth; int *mask;
+    const float *tri_pos;   // SoA [9][NT]
+    const float *tri_nrm;   // AoS [NT][9]
+    const float *tri_uv;    // AoS [NT][6]
+    const int *tri_inst;    // [NT]
+    const unsigned *tex;    // RGBX texels
+    const ShapeData *shapes;
+};
+
+// Kinematic tree of the 11 moving bodies (lbr_iiwa_link_1..7 [+gripper base], finger_00, finger_01, finger_10,
+// finger_11); compile-time so that per-body register arrays are statically indexed. rr_create verifies the blob.
+__device__ constexpr int PARENT[NB] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 6, 9};
+static const int PARENT_HOST[NB] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 6, 9};
+
+// ---------------------------------------------------------------------------------------------- device math
+struct v3 { float x, y, z; };
+__device__ __forceinline__ v3 mk(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ v3 cross(v3 a, v3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+struct m3 { float m[9]; };
+__device__ __forceinline__ v3 mulv(const m3 &M, v3 v) {
+    return mk(M.m[0] * v.x + M.m[1] * v.y + M.m[2] * v.z, M.m[3] * v.x + M.m[4] * v.y + M.m[5] * v.z,
+              M.m[6] * v.x + M.m[7] * v.y + M.m[8] * v.z);
+}
+__device__ __forceinline__ v3 tmulv(const m3 &M, v3 v) {
+    return mk(M.m[0] * v.x + M.m[3] * v.y + M.m[6] * v.z, M.m[1] * v.x + M.m[4] * v.y + M.m[7] * v.z,
+              M.m[2] * v.x + M.m[5] * v.y + M.m[8] * v.z);
+}
+__device__ __forceinline__ m3 mul(const m3 &A, const m3 &B) {
+    m3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+    return r;
+}
+__device__ __forceinline__ m3 transpose(const m3 &A) {
+    m3 r = {{A.m[0], A.m[3], A.m[6], A.m[1], A.m[4], A.m[7], A.m[2], A.m[5], A.m[8]}};
+    return r;
+}
+__device__ __forceinline__ m3 axis_angle(v3 a, float ang) {
+    float s, c;
+    sincosf(ang, &s, &c);
+    float t = 1.0f - c;
+    m3 R = {{t * a.x * a.x + c, t * a.x * a.y - s * a.z, t * a.x * a.z + s * a.y,
+             t * a.x * a.y + s * a.z, t * a.y * a.y + c, t * a.y * a.z - s * a.x,
+             t * a.x * a.z - s * a.y, t * a.y * a.z + s * a.x, t * a.z * a.z + c}};
+    return R;
+}
+__device__ __forceinline__ m3 quat_to_m3(float x, float y, float z, float w) {
+    m3 R = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+             2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+             2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+    return R;
+}
+__device__ __forceinline__ void m3_to_quat(const m3 &R, float *q) {
+    const float *r = R.m;
+    float t = r[0] + r[4] + r[8];
+    if (t > 0) {
+        float s = sqrtf(t + 1) * 2;
+        q[3] = s / 4; q[0] = (r[7] - r[5]) / s; q[1] = (r[2] - r[6]) / s; q[2] = (r[3] - r[1]) / s;
+    } else if (r[0] > r[4] && r[0] > r[8]) {
+        float s = sqrtf(1 + r[0] - r[4] - r[8]) * 2;
+        q[3] = (r[7] - r[5]) / s; q[0] = s / 4; q[1] = (r[1] + r[3]) / s; q[2] = (r[2] + r[6]) / s;
+    } else if (r[4] > r[8]) {
+        float s = sqrtf(1 + r[4] - r[0] - r[8]) * 2;
+        q[3] = (r[2] - r[6]) / s; q[0] = (r[1] + r[3]) / s; q[1] = s / 4; q[2] = (r[5] + r[7]) / s;
+    } else {
+        float s = sqrtf(1 + r[8] - r[0] - r[4]) * 2;
+        q[3] = (r[3] - r[1]) / s; q[0] = (r[2] + r[6]) / s; q[1] = (r[5] + r[7]) / s; q[2] = s / 4;
+    }
+}
+// R diag(I6 as xx,yy,zz,xy,xz,yz) R^T
+__device__ __forceinline__ m3 inertia_world(const m3 &R, const float *I6) {
+    m3 I = {{I6[0], I6[3], I6[4], I6[3], I6[1], I6[5], I6[4], I6[5], I6[2]}};
+    return mul(mul(R, I), transpose(R));
+}
+
+#define SCR(slot) scratch[(size_t)(slot) * N + env]
+#define STT(slot) state[(size_t)(slot) * N + env]
+
+// Forward kinematics for all 11 bodies; results kept in registers/local arrays.
+__device__ void fk_all(const BodyParams &bp_, const float *q, m3 *bR, v3 *bp, v3 *bax) {
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        m3 Rp = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+        v3 pp = mk(bp_.robot_pos[0], bp_.robot_pos[1], bp_.robot_pos[2]);
+        constexpr int dummy_ = 0; (void)dummy_;
+        const int p = PARENT[b];
+        if (p >= 0) { Rp = bR[p >= 0 ? p : 0]; pp = bp[p >= 0 ? p : 0]; }
+        m3 jr;
+#pragma unroll
+        for (int k = 0; k < 9; k++) jr.m[k] = bp_.jrot[b][k];
+        m3 Rj = mul(Rp, jr);
+        v3 ax = mk(bp_.axis[b][0], bp_.axis[b][1], bp_.axis[b][2]);
+        bp[b] = pp + mulv(Rp, mk(bp_.jpos[b][0], bp_.jpos[b][1], bp_.jpos[b][2]));
+        bR[b] = mul(Rj, axis_angle(ax, q[b]));
+        bax[b] = mulv(Rj, ax);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- k_prep
+__global__ void __launch_bounds__(64) k_prep(BodyParams B, SimParams P, DevPtrs D) {
+    const int N = P.N;
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    float *state = D.state, *scratch = D.scratch;
+    if (D.errflags[env] & 1u) return;   // frozen env
+    D.errflags[env] &= ~2u;
+    float q[NB], qd[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) { q[i] = STT(ST_Q + i); qd[i] = STT(ST_QD + i); }
+    // ---- action protocol
+    float a[9], cur[9];
+#pragma unroll
+    for (int i = 0; i < 7; i++) cur[i] = q[i];
+    cur[7] = q[7]; cur[8] = -q[8];                                   // robot.py:203-211
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        float v = D.cmd[(size_t)env * 9 + i];
+        if (!isfinite(v)) bad = true;
+        float d = v - cur[i];                                        // env.py:314-321
+        d = fminf(d, B.act_maxdiff[i]);
+        d = fmaxf(d, -B.act_maxdiff[i]);
+        a[i] = cur[i] + d;
+    }
+    if (bad) { D.errflags[env] |= 2u; return; }                      // robot.py:189 (assert in the reference)
+    for (int i = 0; i < P.nobj; i++) {                               // env.py:257-264
+        float x = STT(ST_OPOS + 3 * i), z = STT(ST_OPOS + 3 * i + 2);
+        if (z < B.table_z || (x > 0.11f && z < 0.29f)) {
+            for (int k = 0; k < 3; k++) { STT(ST_OPOS + 3 * i + k) = B.obj_pose0[i][k]; STT(ST_OVEL + 3 * i + k) = 0; STT(ST_OANG + 3 * i + k) = 0; }
+            for (int k = 0; k < 4; k++) STT(ST_OQUAT + 4 * i + k) = B.obj_pose0[i][3 + k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) a[i] = fmaxf(B.act_min[i], fminf(a[i], B.act_max[i]));   // robot.py:192
+    a[8] = fmaxf(0.0f, fminf(2.0f * a[7], a[8]));                                        // robot.py:193
+    float tgt[NB];
+#pragma unroll
+    for (int i = 0; i < 7; i++) tgt[i] = a[i];
+    tgt[7] = a[7]; tgt[9] = a[7]; tgt[8] = -a[8]; tgt[10] = -a[8];                        // robot.py:195-201
+#pragma unroll
+    for (int i = 0; i < NB; i++) STT(ST_TGT + i) = tgt[i];
+
+    // ---- kinematics
+    m3 bR[NB]; v3 bp[NB], bax[NB], bcom[NB]; m3 bI[NB];
+    fk_all(B, q, bR, bp, bax);
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        bcom[b] = bp[b] + mulv(bR[b], mk(B.com[b][0], B.com[b][1], B.com[b][2]));
+        bI[b] = inertia_world(bR[b], B.inertia[b]);
+#pragma unroll
+        for (int k = 0; k < 9; k++) SCR(S_BR + 9 * b + k) = bR[b].m[k];
+        SCR(S_BP + 3 * b) = bp[b].x; SCR(S_BP + 3 * b + 1) = bp[b].y; SCR(S_BP + 3 * b + 2) = bp[b].z;
+        SCR(S_BAX + 3 * b) = bax[b].x; SCR(S_BAX + 3 * b + 1) = bax[b].y; SCR(S_BAX + 3 * b + 2) = bax[b].z;
+    }
+    // ---- composite rigid body mass matrix
+    float cm[NB]; v3 cc[NB]; m3 cI[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) { cm[b] = B.mass[b]; cc[b] = bcom[b]; cI[b] = bI[b]; }
+#pragma unroll
+    for (int b = NB - 1; b >= 1; b--) {
+        const int p = PARENT[b];
+        float mt = cm[p] + cm[b];
+        v3 c = (cc[p] * cm[p] + cc[b] * cm[b]) * (1.0f / mt);
+        v3 d1 = cc[p] - c, d2 = cc[b] - c;
+        float s1 = dot(d1, d1), s2 = dot(d2, d2);
+        float d1a[3] = {d1.x, d1.y, d1.z}, d2a[3] = {d2.x, d2.y, d2.z};
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                float e = (i == j) ? 1.0f : 0.0f;
+                cI[p].m[3 * i + j] = cI[p].m[3 * i + j] + cI[b].m[3 * i + j] + cm[p] * (s1 * e - d1a[i] * d1a[j]) + cm[b] * (s2 * e - d2a[i] * d2a[j]);
+            }
+        cm[p] = mt;
+        cc[p] = c;
+    }
+    float M[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+        for (int j = 0; j < NB; j++) M[i][j] = 0;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        v3 Ia = mulv(cI[j], bax[j]);
+        v3 f = cross(bax[j], cc[j] - bp[j]) * cm[j];
+#pragma unroll
+        for (int i = j; i >= 0; i--) {
+            // ancestors-or-self of j: chain 0..6 is linear; fingers branch at body 6
+            bool anc = (i == j) || (i <= 6 && j <= 6) || (i <= 6 && j >= 7) || (i == 7 && j == 8) || (i == 9 && j == 10);
+            if (!anc) continue;
+            v3 nn = Ia + cross(cc[j] - bp[i], f);
+            float v = dot(bax[i], nn);
+            M[i][j] = v; M[j][i] = v;
+        }
+    }
+    // ---- RNEA bias (qdd = 0, base acceleration +g)
+    v3 w[NB], al[NB], ap[NB], F[NB], Nn[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int p = PARENT[b];
+        v3 wp = mk(0, 0, 0), alp = mk(0, 0, 0), app = mk(0, 0, P.gravity), pp = mk(B.robot_pos[0], B.robot_pos[1], B.robot_pos[2]);
+        if (p >= 0) { wp = w[p >= 0 ? p : 0]; alp = al[p >= 0 ? p : 0]; app = ap[p >= 0 ? p : 0]; pp = bp[p >= 0 ? p : 0]; }
+        w[b] = wp + bax[b] * qd[b];
+        al[b] = alp + cross(wp, bax[b]) * qd[b];
+        v3 d = bp[b] - pp;
+        ap[b] = app + cross(alp, d) + cross(wp, cross(wp, d));
+        v3 r = bcom[b] - bp[b];
+        v3 ac = ap[b] + cross(al[b], r) + cross(w[b], cross(w[b], r));
+        F[b] = ac * B.mass[b];
+        Nn[b] = mulv(bI[b], al[b]) + cross(w[b], mulv(bI[b], w[b])) + cross(r, F[b]);
+    }
+    float bias[NB];
+#pragma unroll
+    for (int b = NB - 1; b >= 0; b--) {
+        bias[b] = dot(bax[b], Nn[b]);
+        const int p = PARENT[b];
+        if (p >= 0) {
+            const int pi = p >= 0 ? p : 0;
+            Nn[pi] = Nn[pi] + Nn[b] + cross(bp[b] - bp[pi], F[b]);
+            F[pi] = F[pi] + F[b];
+        }
+    }
+    // ---- Cholesky + inverse
+    float L[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            float s = M[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+            if (i == j) L[i][i] = sqrtf(s);
+            else L[i][j] = s / L[j][j];
+        }
+    }
+    float rhs[NB], qdd[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) { rhs[i] = -bias[i] - B.damping[i] * qd[i]; qdd[i] = 0; }
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+        float y[NB], xcol[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            float s = (i == c) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int k = 0; k < i; k++) s -= L[i][k] * y[k];
+            y[i] = s / L[i][i];
+        }
+#pragma unroll
+        for (int i = NB - 1; i >= 0; i--) {
+            float s = y[i];
+#pragma unroll
+            for (int k = i + 1; k < NB; k++) s -= L[k][i] * xcol[k];
+            xcol[i] = s / L[i][i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            SCR(S_MINV + i * NB + c) = xcol[i];
+            qdd[i] += xcol[i] * rhs[c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) SCR(S_QDS + i) = qd[i] + P.dt * qdd[i];
+    // ---- objects: rotation, inverse inertia, unconstrained velocities
+    for (int i = 0; i < P.nobj; i++) {
+        m3 R = quat_to_m3(STT(ST_OQUAT + 4 * i), STT(ST_OQUAT + 4 * i + 1), STT(ST_OQUAT + 4 * i + 2), STT(ST_OQUAT + 4 * i + 3));
+        float I6[6] = {B.obj_inertia[i][0], B.obj_inertia[i][1], B.obj_inertia[i][2], 0, 0, 0};
+        float Ii6[6] = {1.0f / B.obj_inertia[i][0], 1.0f / B.obj_inertia[i][1], 1.0f / B.obj_inertia[i][2], 0, 0, 0};
+        m3 Iw = inertia_world(R, I6), Iinv = inertia_world(R, Ii6);
+        v3 v = mk(STT(ST_OVEL + 3 * i), STT(ST_OVEL + 3 * i + 1), STT(ST_OVEL + 3 * i + 2));
+        v3 om = mk(STT(ST_OANG + 3 * i), STT(ST_OANG + 3 * i + 1), STT(ST_OANG + 3 * i + 2));
+        float vn = sqrtf(dot(v, v)), wn = sqrtf(dot(om, om));
+        v3 vs = v + (v * (-(P.lin_damp + P.lin_damp * vn))) * P.dt;
+        vs.z -= P.dt * P.gravity;
+        v3 alo = mulv(Iinv, cross(om, mulv(Iw, om)));
+        v3 ws = om + (alo * -1.0f - om * (P.ang_damp + P.ang_damp * wn)) * P.dt;
+        for (int k = 0; k < 9; k++) { SCR(S_OR + 9 * i + k) = R.m[k]; SCR(S_OIINV + 9 * i + k) = Iinv.m[k]; }
+        SCR(S_OVS + 3 * i) = vs.x; SCR(S_OVS + 3 * i + 1) = vs.y; SCR(S_OVS + 3 * i + 2) = vs.z;
+        SCR(S_OWS + 3 * i) = ws.x; SCR(S_OWS + 3 * i + 1) = ws.y; SCR(S_OWS + 3 * i + 2) = ws.z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- k_collide
+struct Xf { m3 R; v3 p; };
+
+__device__ __forceinline__ Xf load_xf(const ShapeData *S, int s, const float *state, const float *scratch, int N, int env) {
+    Xf X;
+    int ot = S->otype[s], oi = S->oidx[s];
+    if (ot == 0) {
+        m3 I = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+        X.R = I; X.p = mk(0, 0, 0);
+    } else if (ot == 1) {
+        for (int k = 0; k < 9; k++) X.R.m[k] = SCR(S_BR + 9 * oi + k);
+        X.p = mk(SCR(S_BP + 3 * oi), SCR(S_BP + 3 * oi + 1), SCR(S_BP + 3 * oi + 2));
+    } else {
+        for (int k = 0; k < 9; k++) X.R.m[k] = SCR(S_OR + 9 * oi + k);
+        X.p = mk(STT(ST_OPOS + 3 * oi), STT(ST_OPOS + 3 * oi + 1), STT(ST_OPOS + 3 * oi + 2));
+    }
+    return X;
+}
+
+struct Cand { float x, y, z, s; int code; };   // code: plane index | (direction << 8)
+// Candidates live in LDS, laid out [candidate][lane] so a wave's accesses are conflict free. The arrays are
+// file-scope __shared__ objects addressed directly (ds_read/ds_write): generic (flat) pointers into LDS or
+// private memory must not be used in this library -- see DESIGN.md "address spaces".
+#define COLLIDE_THREADS 32
+__shared__ float4 g_cand_xs[2 * VMAXC * COLLIDE_THREADS];
+__shared__ int g_cand_code[2 * VMAXC * COLLIDE_THREADS];
+struct CandStore {
+    __device__ __forceinline__ void put(int i, const Cand &c) {
+        g_cand_xs[i * COLLIDE_THREADS + threadIdx.x] = make_float4(c.x, c.y, c.z, c.s);
+        g_cand_code[i * COLLIDE_THREADS + threadIdx.x] = c.code;
+    }
+    __device__ __forceinline__ Cand get(int i) const {
+        float4 v = g_cand_xs[i * COLLIDE_THREADS + threadIdx.x];
+        Cand c = {v.x, v.y, v.z, v.w, g_cand_code[i * COLLIDE_THREADS + threadIdx.x]};
+        return c;
+    }
+};
+
+__device__ int verts_in_planes(const ShapeData *S, int sa, const Xf &Xa, int sb, const Xf &Xb, int dirflag, float margin,
+                               CandStore &out, int n) {
+    int nv = S->nv[sa], nf = S->nf[sb];
+    for (int v = 0; v < nv; v++) {
+        v3 xw = mulv(Xa.R, mk(S->verts[sa][v][0], S->verts[sa][v][1], S->verts[sa][v][2])) + Xa.p;
+        v3 xl = tmulv(Xb.R, xw - Xb.p);
+        float best = -1e30f;
+        int bf = 0;
+        for (int f = 0; f < nf; f++) {
+            float s = S->planes[sb][f][0] * xl.x + S->planes[sb][f][1] * xl.y + S->planes[sb][f][2] * xl.z - S->planes[sb][f][3];
+            if (s > best) { best = s; bf = f; }
+        }
+        if (best < margin) {
+            v3 nw = mulv(Xb.R, mk(S->planes[sb][bf][0], S->planes[sb][bf][1], S->planes[sb][bf][2]));
+            Cand c;
+            c.x = xw.x - 0.5f * best * nw.x; c.y = xw.y - 0.5f * best * nw.y; c.z = xw.z - 0.5f * best * nw.z;
+            c.s = best;
+            c.code = bf | (dirflag << 8);
+            out.put(n++, c);
+        }
+    }
+    return n;
+}
+
+__global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtrs D, int nblk) {
+    const int N = P.N;
+    int pair = blockIdx.x / nblk;
+    int env = (blockIdx.x - pair * nblk) * COLLIDE_THREADS + threadIdx.x;
+    if (env >= N) return;
+    const float *state = D.state;
+    float *scratch = D.scratch;
+    if (D.errflags[env]) return;
+    const ShapeData *S = D.shapes;
+    int sa = S->pair_a[pair], sb = S->pair_b[pair];
+    Xf Xa = load_xf(S, sa, state, scratch, N, env), Xb = load_xf(S, sb, state, scratch, N, env);
+    v3 ca = mulv(Xa.R, mk(S->sphere[sa][0], S->sphere[sa][1], S->sphere[sa][2])) + Xa.p;
+    v3 cb = mulv(Xb.R, mk(S->sphere[sb][0], S->sphere[sb][1], S->sphere[sb][2])) + Xb.p;
+    v3 d = ca - cb;
+    float rr = S->sphere[sa][3] + S->sphere[sb][3] + P.margin;
+    int *pcount = (int *)&SCR(S_PCOUNT + pair);
+    if (dot(d, d) > rr * rr) { *pcount = 0; return; }
+    CandStore cand;
+    int n = 0;
+    n = verts_in_planes(S, sa, Xa, sb, Xb, 0, P.margin, cand, n);
+    n = verts_in_planes(S, sb, Xb, sa, Xa, 1, P.margin, cand, n);
+    int sel[4], k = 0;
+    if (n <= 4) { for (int i = 0; i < n; i++) sel[i] = i; k = n; }
+    else {
+        int k0 = 0;
+        { float sbest = cand.get(0).s; for (int i = 1; i < n; i++) { float si = cand.get(i).s; if (si < sbest) { sbest = si; k0 = i; } } }
+        Cand c0_ = cand.get(k0); v3 x0 = mk(c0_.x, c0_.y, c0_.z);
+        int k1 = -1; float best = -1;
+        for (int i = 0; i < n; i++) {
+            if (i == k0) continue;
+            Cand ci_ = cand.get(i); v3 dd = mk(ci_.x, ci_.y, ci_.z) - x0;
+            float v = dot(dd, dd);
+            if (v > best) { best = v; k1 = i; }
+        }
+        Cand c1_ = cand.get(k1); v3 e = mk(c1_.x, c1_.y, c1_.z) - x0;
+        int k2 = -1; best = -1; v3 cr2 = mk(0, 0, 0);
+        for (int i = 0; i < n; i++) {
+            if (i == k0 || i == k1) continue;
+            Cand ci_ = cand.get(i); v3 cr = cross(mk(ci_.x, ci_.y, ci_.z) - x0, e);
+            float v = dot(cr, cr);
+            if (v > best) { best = v; k2 = i; cr2 = cr; }
+        }
+        int k3 = -1; best = 0;
+        for (int i = 0; i < n; i++) {
+            if (i == k0 || i == k1 || i == k2) continue;
+            Cand ci_ = cand.get(i); v3 cr = cross(mk(ci_.x, ci_.y, ci_.z) - x0, e);
+            float v = -dot(cr, cr2);
+            if (v > best) { best = v; k3 = i; }
+        }
+        sel[0] = k0; sel[1] = k1; sel[2] = k2; k = 3;
+        if (k3 >= 0) { sel[3] = k3; k = 4; }
+    }
+    *pcount = k;
+    for (int i = 0; i < k; i++) {
+        Cand c = cand.get(sel[i]);
+        int dirflag = c.code >> 8, bf = c.code & 255;
+        v3 nw;
+        if (dirflag == 0) nw = mulv(Xb.R, mk(S->planes[sb][bf][0], S->planes[sb][bf][1], S->planes[sb][bf][2]));
+        else nw = mulv(Xa.R, mk(S->planes[sa][bf][0], S->planes[sa][bf][1], S->planes[sa][bf][2])) * -1.0f;
+        int base = S_PDATA + (pair * 4 + i) * 7;
+        SCR(base) = c.x; SCR(base + 1) = c.y; SCR(base + 2) = c.z;
+        SCR(base + 3) = nw.x; SCR(base + 4) = nw.y; SCR(base + 5) = nw.z;
+        SCR(base + 6) = c.s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- k_solve
+__device__ __forceinline__ void plane_space(v3 n, v3 &p, v3 &q) {   // btPlaneSpace1
+    if (fabsf(n.z) > 0.70710678118654752440f) {
+        float a = n.y * n.y + n.z * n.z;
+        float k = 1.0f / sqrtf(a);
+        p = mk(0, -n.z * k, n.y * k);
+        q = mk(a * k, -n.x * p.z, n.x * p.y);
+    } else {
+        float a = n.x * n.x + n.y * n.y;
+        float k = 1.0f / sqrtf(a);
+        p = mk(-n.y * k, n.x * k, 0);
+        q = mk(-n.z * p.y, n.z * p.x, a * k);
+    }
+}
+
+// row layout in scratch (ROWF floats): 0..10 Ja, 11..21 MJa, 22..24 dir, 25..27 aa, 28..30 maa, 31..33 ab, 34..36 mab,
+// 37 rhs, 38 dinv, 39 lambda
+#define ROW(r, f) SCR(S_ROWS + (r) * ROWF + (f))
+
+__device__ float build_row(const BodyParams &B, const SimParams &P, const DevPtrs &D, int env, int row, int bodyA, int bodyB,
+                           v3 x, v3 dir) {
+    const int N = P.N;
+    float *scratch = D.scratch;
+    const float *state = D.state;
+    float diag = 0, rel = 0;
+    bool robot = false;
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        int body = side == 0 ? bodyA : bodyB;
+        float sg = side == 0 ? 1.0f : -1.0f;
+        if (body < 0) continue;
+        if (body < 16) {
+            robot = true;
+            float Ja[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) Ja[k] = 0;
+            int k = body;
+            while (k >= 0) {
+                v3 pk = mk(SCR(S_BP + 3 * k), SCR(S_BP + 3 * k + 1), SCR(S_BP + 3 * k + 2));
+                v3 ak = mk(SCR(S_BAX + 3 * k), SCR(S_BAX + 3 * k + 1), SCR(S_BAX + 3 * k + 2));
+                float v = sg * dot(dir, cross(ak, x - pk));
+#pragma unroll
+                for (int kk = 0; kk < NB; kk++) if (kk == k) Ja[kk] = v;
+                k = PARENT[k];
+            }
+#pragma unroll
+            for (int i = 0; i < NB; i++) ROW(row, i) = Ja[i];
+#pragma unroll 1
+            for (int i = 0; i < NB; i++) {
+                float s = 0, jai = 0;
+#pragma unroll
+                for (int j = 0; j < NB; j++) { s += SCR(S_MINV + i * NB + j) * Ja[j]; if (j == i) jai = Ja[j]; }
+                ROW(row, 11 + i) = s;
+                diag += jai * s;
+                rel += jai * SCR(S_QDS + i);
+            }
+        } else {
+            int ob = body - 16;
+            v3 op = mk(STT(ST_OPOS + 3 * ob), STT(ST_OPOS + 3 * ob + 1), STT(ST_OPOS + 3 * ob + 2));
+            v3 lin = dir * sg;
+            v3 ang = cross(x - op, lin);
+            m3 Iinv;
+#pragma unroll
+            for (int k = 0; k < 9; k++) Iinv.m[k] = SCR(S_OIINV + 9 * ob + k);
+            v3 mang = mulv(Iinv, ang);
+            int o = side == 0 ? 25 : 31;
+            ROW(row, o) = ang.x; ROW(row, o + 1) = ang.y; ROW(row, o + 2) = ang.z;
+            ROW(row, o + 3) = mang.x; ROW(row, o + 4) = mang.y; ROW(row, o + 5) = mang.z;
+            v3 vs = mk(SCR(S_OVS + 3 * ob), SCR(S_OVS + 3 * ob + 1), SCR(S_OVS + 3 * ob + 2));
+            v3 ws = mk(SCR(S_OWS + 3 * ob), SCR(S_OWS + 3 * ob + 1), SCR(S_OWS + 3 * ob + 2));
+            diag += dot(lin, lin) * (1.0f / B.obj_mass[ob]) + dot(ang, mang);
+            rel += dot(lin, vs) + dot(ang, ws);
+        }
+    }
+    (void)robot;
+    ROW(row, 22) = dir.x; ROW(row, 23) = dir.y; ROW(row, 24) = dir.z;
+    ROW(row, 38) = diag > 0 ? 1.0f / diag : 0.0f;
+    ROW(row, 39) = 0.0f;
+    return rel;
+}
+
+
+// dv/dw live in registers: select by object index without dynamic indexing (dynamic indexing would move the
+// arrays to private scratch memory)
+struct ObjDelta { v3 dv[NOBJ], dw[NOBJ]; };
+__device__ __forceinline__ float obj_jv(const ObjDelta &o, int ob, v3 lin, v3 ang) {
+    float r = 0;
+#pragma unroll
+    for (int k = 0; k < NOBJ; k++) if (k == ob) r = dot(lin, o.dv[k]) + dot(ang, o.dw[k]);
+    return r;
+}
+__device__ __forceinline__ void obj_apply(ObjDelta &o, int ob, v3 dlin, v3 dang) {
+#pragma unroll
+    for (int k = 0; k < NOBJ; k++) if (k == ob) { o.dv[k] = o.dv[k] + dlin; o.dw[k] = o.dw[k] + dang; }
+}
+
+__global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs D) {
+    const int N = P.N;
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    float *state = D.state, *scratch = D.scratch;
+    if (D.errflags[env]) return;
+    const ShapeData *S = D.shapes;
+    const float dt = P.dt;
+    // ---- gather contacts in pair order, build rows
+    int nc = 0;
+    for (int pair = 0; pair < P.npairs && nc < MAXC; pair++) {
+        int cnt = *(const int *)&SCR(S_PCOUNT + pair);
+        if (cnt == 0) continue;
+        int sa = S->pair_a[pair], sb = S->pair_b[pair];
+        int bodyA = S->otype[sa] == 0 ? -1 : (S->otype[sa] == 1 ? S->oidx[sa] : 16 + S->oidx[sa]);
+        int bodyB = S->otype[sb] == 0 ? -1 : (S->otype[sb] == 1 ? S->oidx[sb] : 16 + S->oidx[sb]);
+        float mu = S->fric[sa] * S->fric[sb], rest = S->rest[sa] * S->rest[sb];
+        for (int i = 0; i < cnt && nc < MAXC; i++, nc++) {
+            int base = S_PDATA + (pair * 4 + i) * 7;
+            v3 x = mk(SCR(base), SCR(base + 1), SCR(base + 2));
+            v3 n = mk(SCR(base + 3), SCR(base + 4), SCR(base + 5));
+            float dist = SCR(base + 6);
+            *(int *)&SCR(S_RMETA + nc) = (bodyA & 255) | ((bodyB & 255) << 8) | ((S->link[sa] & 255) << 16);
+            float *ct = &SCR(S_CT + nc * 12);
+            const size_t Ns = (size_t)N;
+            ct[0] = (float)bodyA; ct[Ns] = (float)bodyB; ct[2 * Ns] = (float)S->link[sa];
+            ct[3 * Ns] = x.x; ct[4 * Ns] = x.y; ct[5 * Ns] = x.z; ct[6 * Ns] = n.x; ct[7 * Ns] = n.y; ct[8 * Ns] = n.z;
+            ct[9 * Ns] = dist; ct[10 * Ns] = 0; ct[11 * Ns] = mu;
+            // normal row
+            float rel = build_row(B, P, D, env, 3 * nc, bodyA, bodyB, x, n);
+            float r = 0;
+            if (fabsf(rel) >= P.rest_thresh) { r = rest * -rel; if (r < 0) r = 0; }
+            float verr = r - rel, perr = 0;
+            if (dist > 0) verr -= dist / dt;
+            else perr = -dist * P.erp / dt;
+            ROW(3 * nc, 37) = (perr + verr) * ROW(3 * nc, 38);
+            v3 t1, t2;
+            plane_space(n, t1, t2);
+            rel = build_row(B, P, D, env, 3 * nc + 1, bodyA, bodyB, x, t1);
+            ROW(3 * nc + 1, 37) = -rel * ROW(3 * nc + 1, 38);
+            rel = build_row(B, P, D, env, 3 * nc + 2, bodyA, bodyB, x, t2);
+            ROW(3 * nc + 2, 37) = -rel * ROW(3 * nc + 2, 38);
+        }
+    }
+    *(int *)&SCR(S_NCT) = nc;
+    // ---- motor + limit rows (kept in the per-env scratch slab: registers are needed for dq and the object deltas;
+    //      this kernel must not spill -- see DESIGN.md "no private scratch")
+    float q[NB], qds[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) { q[j] = STT(ST_Q + j); qds[j] = SCR(S_QDS + j); }
+#pragma unroll 1
+    for (int j = 0; j < NB; j++) {
+        float qj = STT(ST_Q + j), qdj = SCR(S_QDS + j);
+        float dinv = 1.0f / SCR(S_MINV + j * NB + j);
+        float vt = P.kp * (STT(ST_TGT + j) - qj) / dt + qdj + P.kd * (0.0f - qdj);
+        SCR(S_MOT + 3 * j) = (vt - qdj) * dinv;
+        SCR(S_MOT + 3 * j + 1) = dinv;
+        SCR(S_MOT + 3 * j + 2) = 0.0f;
+        float lo = B.limits[j][0], hi = B.limits[j][1];
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            float dist = side == 0 ? qj - lo : hi - qj;
+            bool on = (lo < hi) && (dist < 0.5f);
+            float sg = side == 0 ? 1.0f : -1.0f;
+            float rel = sg * qdj;
+            float verr = -rel, perr = 0;
+            if (dist > 0) verr -= dist / dt;
+            else perr = -dist * P.erp / dt;
+            SCR(S_LIM + 2 * (2 * j + side)) = on ? (perr + verr) * dinv : -1e30f;   // -1e30: row absent
+            SCR(S_LIM + 2 * (2 * j + side) + 1) = 0.0f;
+        }
+    }
+    // ---- PGS
+    float dq[NB];
+    ObjDelta od;
+#pragma unroll
+    for (int i = 0; i < NB; i++) dq[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NOBJ; i++) { od.dv[i] = mk(0, 0, 0); od.dw[i] = mk(0, 0, 0); }
+    const float max_imp = P.max_impulse;
+    for (int it = 0; it < P.iters; it++) {
+#pragma unroll 1
+        for (int j = 0; j < NB; j++) {          // motors
+            float dqj = 0;
+#pragma unroll
+            for (int i = 0; i < NB; i++) if (i == j) dqj = dq[i];
+            float mdinv = SCR(S_MOT + 3 * j + 1), mlam = SCR(S_MOT + 3 * j + 2);
+            float dl = SCR(S_MOT + 3 * j) - dqj * mdinv;
+            float sum = mlam + dl;
+            if (sum < -max_imp) { dl = -max_imp - mlam; sum = -max_imp; }
+            else if (sum > max_imp) { dl = max_imp - mlam; sum = max_imp; }
+            SCR(S_MOT + 3 * j + 2) = sum;
+#pragma unroll
+            for (int i = 0; i < NB; i++) dq[i] += SCR(S_MINV + i * NB + j) * dl;
+        }
+#pragma unroll 1
+        for (int js = 0; js < 2 * NB; js++) {   // joint limits
+            float lr = SCR(S_LIM + 2 * js);
+            if (lr <= -1e29f) continue;
+            int j = js >> 1;
+            float dqj = 0;
+#pragma unroll
+            for (int i = 0; i < NB; i++) if (i == j) dqj = dq[i];
+            float ll = SCR(S_LIM + 2 * js + 1);
+            float sg = (js & 1) == 0 ? 1.0f : -1.0f;
+            float dl = lr - sg * dqj * SCR(S_MOT + 3 * j + 1);
+            float sum = ll + dl;
+            if (sum < 0) { dl = -ll; sum = 0; }
+            else if (sum > 100.0f) { dl = 100.0f - ll; sum = 100.0f; }
+            SCR(S_LIM + 2 * js + 1) = sum;
+            float sd = sg * dl;
+#pragma unroll
+            for (int i = 0; i < NB; i++) dq[i] += SCR(S_MINV + i * NB + j) * sd;
+        }
+        for (int pass = 0; pass < 2; pass++) {  // all normals, then all frictions
+            for (int c = 0; c < nc; c++) {
+                int meta = *(const int *)&SCR(S_RMETA + c);
+                int bodyA = (signed char)(meta & 255), bodyB = (signed char)((meta >> 8) & 255);
+                bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
+                float ln = ROW(3 * c, 39);
+                float mu = SCR(S_CT + c * 12 + 11);
+                int r0 = pass == 0 ? 3 * c : 3 * c + 1, r1 = pass == 0 ? 3 * c + 1 : 3 * c + 3;
+                for (int r = r0; r < r1; r++) {
+                    float lo = 0, hi = 1e10f;
+                    if (pass == 1) { hi = mu * ln; lo = -hi; }
+                    float jv = 0;
+                    v3 dir = mk(ROW(r, 22), ROW(r, 23), ROW(r, 24));
+                    if (robot) {
+#pragma unroll
+                        for (int i = 0; i < NB; i++) jv += ROW(r, i) * dq[i];
+                    }
+                    if (bodyA >= 16) jv += obj_jv(od, bodyA - 16, dir, mk(ROW(r, 25), ROW(r, 26), ROW(r, 27)));
+                    if (bodyB >= 16) jv += obj_jv(od, bodyB - 16, dir * -1.0f, mk(ROW(r, 31), ROW(r, 32), ROW(r, 33)));
+                    float lam = ROW(r, 39);
+                    float dl = ROW(r, 37) - jv * ROW(r, 38);
+                    float sum = lam + dl;
+                    if (sum < lo) { dl = lo - lam; sum = lo; }
+                    else if (sum > hi) { dl = hi - lam; sum = hi; }
+                    ROW(r, 39) = sum;
+                    if (robot) {
+#pragma unroll
+                        for (int i = 0; i < NB; i++) dq[i] += ROW(r, 11 + i) * dl;
+                    }
+                    if (bodyA >= 16) {
+                        int ob = bodyA - 16;
+                        float im = dl / B.obj_mass[ob];
+                        obj_apply(od, ob, dir * im, mk(ROW(r, 28), ROW(r, 29), ROW(r, 30)) * dl);
+                    }
+                    if (bodyB >= 16) {
+                        int ob = bodyB - 16;
+                        float im = -dl / B.obj_mass[ob];
+                        obj_apply(od, ob, dir * im, mk(ROW(r, 34), ROW(r, 35), ROW(r, 36)) * dl);
+                    }
+                }
+            }
+        }
+    }
+    // ---- integrate
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        float v = qds[i] + dq[i];
+        float qn = q[i] + dt * v;
+        finite = finite && isfinite(qn);
+        STT(ST_QD + i) = v;
+        STT(ST_Q + i) = qn;
+        q[i] = qn;
+    }
+#pragma unroll
+    for (int i = 0; i < NOBJ; i++) {
+        if (i >= P.nobj) break;
+        float v[3], w[3];
+        const float dvi[3] = {od.dv[i].x, od.dv[i].y, od.dv[i].z}, dwi[3] = {od.dw[i].x, od.dw[i].y, od.dw[i].z};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            v[k] = SCR(S_OVS + 3 * i + k) + dvi[k];
+            w[k] = SCR(S_OWS + 3 * i + k) + dwi[k];
+            float pn = STT(ST_OPOS + 3 * i + k) + dt * v[k];
+            finite = finite && isfinite(pn);
+            STT(ST_OVEL + 3 * i + k) = v[k];
+            STT(ST_OANG + 3 * i + k) = w[k];
+            STT(ST_OPOS + 3 * i + k) = pn;
+        }
+        float wn = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        float ang = wn * dt, d0, d1, d2, d3;
+        if (ang > 1e-12f) {
+            float sn, cs;
+            sincosf(ang * 0.5f, &sn, &cs);
+            float s = sn / wn;
+            d0 = w[0] * s; d1 = w[1] * s; d2 = w[2] * s; d3 = cs;
+        } else {
+            d0 = w[0] * dt * 0.5f; d1 = w[1] * dt * 0.5f; d2 = w[2] * dt * 0.5f; d3 = 1.0f;
+        }
+        float q0 = STT(ST_OQUAT + 4 * i), q1 = STT(ST_OQUAT + 4 * i + 1), q2 = STT(ST_OQUAT + 4 * i + 2), q3 = STT(ST_OQUAT + 4 * i + 3);
+        float r0 = d3 * q0 + d0 * q3 + d1 * q2 - d2 * q1;
+        float r1 = d3 * q1 - d0 * q2 + d1 * q3 + d2 * q0;
+        float r2 = d3 * q2 + d0 * q1 - d1 * q0 + d2 * q3;
+        float r3 = d3 * q3 - d0 * q0 - d1 * q1 - d2 * q2;
+        float inv = 1.0f / sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+        STT(ST_OQUAT + 4 * i) = r0 * inv; STT(ST_OQUAT + 4 * i + 1) = r1 * inv;
+        STT(ST_OQUAT + 4 * i + 2) = r2 * inv; STT(ST_OQUAT + 4 * i + 3) = r3 * inv;
+        float *op = D.objpose + ((size_t)env * P.nobj + i) * 7;
+        for (int k = 0; k < 3; k++) op[k] = STT(ST_OPOS + 3 * i + k);
+        op[3] = r0 * inv; op[4] = r1 * inv; op[5] = r2 * inv; op[6] = r3 * inv;
+    }
+    if (!finite) D.errflags[env] |= 1u;
+    // ---- touch sensors (robot.py:152-163) + contact forces
+    float touch[4] = {0, 0, 0, 0};
+    for (int c = 0; c < nc; c++) {
+        int meta = *(const int *)&SCR(S_RMETA + c);
+        int bodyA = (signed char)(meta & 255), link = (signed char)((meta >> 16) & 255);
+        float lam = ROW(3 * c, 39);
+        float f = lam / dt;
+        SCR(S_CT + c * 12 + 10) = f;
+        if (bodyA < 0 || bodyA >= 16) continue;
+        if (fabsf(SCR(S_CT + c * 12 + 9)) >= 0.1f) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (link == B.touch_links[k]) touch[k] = fmaxf(touch[k], f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) D.touch[(size_t)env * 4 + k] = touch[k];
+#pragma unroll
+    for (int i = 0; i < 7; i++) D.joints[(size_t)env * 9 + i] = q[i];
+    D.joints[(size_t)env * 9 + 7] = q[7];
+    D.joints[(size_t)env * 9 + 8] = -q[8];
+    D.timestep[env] += 1;
+}
+
+// obs pack without stepping (after reset / set_state)
+__global__ void k_obs(SimParams P, DevPtrs D) {
+    const int N = P.N;
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    const float *state = D.state;
+    for (int i = 0; i < 7; i++) D.joints[(size_t)env * 9 + i] = STT(ST_Q + i);
+    D.joints[(size_t)env * 9 + 7] = STT(ST_Q + 7);
+    D.joints[(size_t)env * 9 + 8] = -STT(ST_Q + 8);
+    for (int i = 0; i < P.nobj; i++) {
+        float *op = D.objpose + ((size_t)env * P.nobj + i) * 7;
+        for (int k = 0; k < 3; k++) op[k] = STT(ST_OPOS + 3 * i + k);
+        for (int k = 0; k < 4; k++) op[3 + k] = STT(ST_OQUAT + 4 * i + k);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- reset / state io
+__global__ void k_reset(BodyParams B, SimParams P, DevPtrs D, const unsigned char *mask) {
+    const int N = P.N;
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    if (mask && !mask[env]) return;
+    float *state = D.state;
+    for (int i = 0; i < ST_TOTAL; i++) STT(i) = 0;
+    for (int i = 0; i < NOBJ; i++) {
+        for (int k = 0; k < 3; k++) STT(ST_OPOS + 3 * i + k) = B.obj_pose0[i][k];
+        for (int k = 0; k < 4; k++) STT(ST_OQUAT + 4 * i + k) = B.obj_pose0[i][3 + k];
+    }
+    D.timestep[env] = 0;
+    D.errflags[env] = 0;
+    for (int k = 0; k < 4; k++) D.touch[(size_t)env * 4 + k] = 0;
+    *(int *)&D.scratch[(size_t)S_NCT * N + env] = 0;
+}
+
+__global__ void k_state_io(SimParams P, DevPtrs D, float *aos /*[N][61]*/, int to_aos) {
+    const int N = P.N;
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    float *state = D.state;
+    // AoS order (same as the oracle's 61-vector): q[11] qd[11] then per object pos3 quat4 lin3 ang3
+    float *a = aos + (size_t)env * NSTATE;
+    for (int i = 0; i < 22; i++) {
+        if (to_aos) a[i] = STT(i); else STT(i) = a[i];
+    }
+    for (int o = 0; o < NOBJ; o++) {
+        float *b = a + 22 + 13 * o;
+        for (int k = 0; k < 3; k++) {
+            if (to_aos) { b[k] = STT(ST_OPOS + 3 * o + k); b[7 + k] = STT(ST_OVEL + 3 * o + k); b[10 + k] = STT(ST_OANG + 3 * o + k); }
+            else { STT(ST_OPOS + 3 * o + k) = b[k]; STT(ST_OVEL + 3 * o + k) = b[7 + k]; STT(ST_OANG + 3 * o + k) = b[10 + k]; }
+        }
+        for (int k = 0; k < 4; k++) {
+            if (to_aos) b[3 + k] = STT(ST_OQUAT + 4 * o + k); else STT(ST_OQUAT + 4 * o + k) = b[3 + k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- render setup
+__global__ void __launch_bounds__(64) k_render_setup(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D) {
+    const RenderModel &RM = *RMp;
+    const int N = P.N;
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    const float *state = D.state;
+    float q[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) q[i] = STT(ST_Q + i);
+    m3 bR[NB]; v3 bp[NB], bax[NB];
+    fk_all(B, q, bR, bp, bax);
+    for (int i = 0; i < RM.ni; i++) {
+        m3 R = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+        v3 p = mk(0, 0, 0);
+        int ot = RM.in_otype[i], oi = RM.in_oidx[i];
+        if (ot == 1) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) if (b == oi) { R = bR[b]; p = bp[b]; }
+        } else if (ot == 2) {
+            R = quat_to_m3(STT(ST_OQUAT + 4 * oi), STT(ST_OQUAT + 4 * oi + 1), STT(ST_OQUAT + 4 * oi + 2), STT(ST_OQUAT + 4 * oi + 3));
+            p = mk(STT(ST_OPOS + 3 * oi), STT(ST_OPOS + 3 * oi + 1), STT(ST_OPOS + 3 * oi + 2));
+        }
+        float *o = D.inst_xf + ((size_t)env * MAXINST + i) * 12;
+        for (int k = 0; k < 9; k++) o[k] = R.m[k];
+        o[9] = p.x; o[10] = p.y; o[11] = p.z;
+    }
+}
+
+// link poses (COM frame) for rr_link_poses
+__global__ void __launch_bounds__(64) k_link_poses(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D, float *out /*[N][nl][7]*/) {
+    const RenderModel &RM = *RMp;
+    const int N = P.N;
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    const float *state = D.state;
+    float q[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) q[i] = STT(ST_Q + i);
+    m3 bR[NB]; v3 bp[NB], bax[NB];
+    fk_all(B, q, bR, bp, bax);
+    for (int l = 0; l < RM.nl; l++) {
+        int b = RM.link_body[l];
+        m3 lr;
+        for (int k = 0; k < 9; k++) lr.m[k] = RM.link_rot[l][k];
+        v3 lp = mk(RM.link_pos[l][0], RM.link_pos[l][1], RM.link_pos[l][2]);
+        m3 R = lr;
+        v3 p = mk(B.robot_pos[0], B.robot_pos[1], B.robot_pos[2]) + lp;
+        if (b >= 0) {
+            m3 Rb = bR[0]; v3 pb = bp[0];
+#pragma unroll
+            for (int bb = 0; bb < NB; bb++) if (bb == b) { Rb = bR[bb]; pb = bp[bb]; }
+            R = mul(Rb, lr);
+            p = mulv(Rb, lp) + pb;
+        }
+        float qq[4];
+        m3_to_quat(R, qq);
+        float *o = out + ((size_t)env * RM.nl + l) * 7;
+        o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = qq[0]; o[4] = qq[1]; o[5] = qq[2]; o[6] = qq[3];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- rasteriser
+// One workgroup per (env, tile). Tile = full-width strip of tile_h rows (<= 16384 pixels -> 128 KiB of LDS keys).
+#define RASTER_THREADS 1024
+#define TILE_PIX 16384
+#define BIGQ 256
+#define SMALL_AREA 64
+
+struct STri { float sx[3], sy[3], sz[3], w[3]; };
+
+__device__ __forceinline__ bool project_tri(const float *mvp, const float *tp /*9 floats*/, int W, int H, STri &s) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float vx = tp[3 * k], vy = tp[3 * k + 1], vz = tp[3 * k + 2];
+        float cx = mvp[0] * vx + mvp[1] * vy + mvp[2] * vz + mvp[3];
+        float cy = mvp[4] * vx + mvp[5] * vy + mvp[6] * vz + mvp[7];
+        float cz = mvp[8] * vx + mvp[9] * vy + mvp[10] * vz + mvp[11];
+        float cw = mvp[12] * vx + mvp[13] * vy + mvp[14] * vz + mvp[15];
+        if (cw < 0.1f) return false;
+        float iw = 1.0f / cw;
+        s.sx[k] = (cx * iw + 1.0f) * (0.5f * (float)W);
+        s.sy[k] = (cy * iw + 1.0f) * (0.5f * (float)H);
+        s.sz[k] = cz * iw;
+        s.w[k] = cw;
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool bary(const STri &s, float px, float py, float *b) {
+    float x0 = s.sx[0], y0 = s.sy[0], x1 = s.sx[1], y1 = s.sy[1], x2 = s.sx[2], y2 = s.sy[2];
+    float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+    if (fabsf(area) < 1e-12f) return false;
+    float ia = 1.0f / area;
+    b[0] = ((x1 - px) * (y2 - py) - (x2 - px) * (y1 - py)) * ia;
+    b[1] = ((x2 - px) * (y0 - py) - (x0 - px) * (y2 - py)) * ia;
+    b[2] = 1.0f - b[0] - b[1];
+    return b[0] >= 0 && b[1] >= 0 && b[2] >= 0;
+}
+
+__device__ __forceinline__ void raster_pixel(const STri &s, int t, int px, int py, int H, int W, int row0, int rows,
+                                             unsigned long long *vis) {
+    int row = H - 1 - py;
+    if (row < row0 || row >= row0 + rows) return;
+    float b[3];
+    if (!bary(s, (float)px, (float)py, b)) return;
+    float z = b[0] * s.sz[0] + b[1] * s.sz[1] + b[2] * s.sz[2];
+    float d = 0.5f * z + 0.5f;
+    if (!(d >= 0.0f && d <= 1.0f)) return;
+    unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
+    atomicMin(&vis[(row - row0) * W + px], key);
+}
+
+__global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used) {
+    const RenderModel &RM = *RMp;
+    __shared__ unsigned long long vis[TILE_PIX];
+    __shared__ float mvp[MAXINST][16];
+    __shared__ int bigq[BIGQ];
+    __shared__ int nbig;
+    const int env = blockIdx.x, tile = blockIdx.y;
+    if (D.render_flags && !D.render_flags[env]) return;
+    const int W = RM.W, H = RM.H;
+    const int row0 = tile * RM.tile_h;
+    const int rows = min(RM.tile_h, H - row0);
+    const int npix = rows * W;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < npix; i += RASTER_THREADS) vis[i] = ~0ull;
+    if (tid == 0) nbig = 0;
+    if (tid < RM.ni * 16) {
+        int inst = tid >> 4, e = tid & 15, r = e >> 2, c = e & 3;
+        const float *xf = D.inst_xf + ((size_t)env * MAXINST + inst) * 12;
+        // MVP = VP * [R p; 0 1]
+        float a = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) a += RM.VP[4 * r + k] * (c < 3 ? xf[3 * k + c] : xf[9 + k]);
+        if (c == 3) a += RM.VP[4 * r + 3];
+        mvp[inst][e] = a;
+    }
+    __syncthreads();
+    // tile bounds in screen y (py = H-1-row)
+    const float ty0 = (float)(H - 1 - (row0 + rows - 1)), ty1 = (float)(H - 1 - row0);
+    const int NT = RM.nt;
+    for (int t = tid; t < NT; t += RASTER_THREADS) {
+        int inst = D.tri_inst[t];
+        if (inst >= n_inst_used) continue;
+        float tp[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) tp[k] = D.tri_pos[(size_t)k * NT + t];
+        STri s;
+        if (!project_tri(mvp[inst], tp, W, H, s)) continue;
+        float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
+        float ymin = fminf(s.sy[0], fminf(s.sy[1], s.sy[2])), ymax = fmaxf(s.sy[0], fmaxf(s.sy[1], s.sy[2]));
+        if (xmax < 0 || ymax < ty0 || xmin > (float)(W - 1) || ymin > ty1) continue;
+        int x0 = (int)ceilf(fmaxf(xmin, 0.0f)), x1 = (int)floorf(fminf(xmax, (float)(W - 1)));
+        int y0 = (int)ceilf(fmaxf(ymin, ty0)), y1 = (int)floorf(fminf(ymax, ty1));
+        if (x1 < x0 || y1 < y0) continue;
+        int area = (x1 - x0 + 1) * (y1 - y0 + 1);
+        if (area > SMALL_AREA) {
+            int slot = atomicAdd(&nbig, 1);
+            if (slot < BIGQ) { bigq[slot] = t; continue; }
+            // queue overflow: fall through and rasterise serially (still correct)
+        }
+        for (int py = y0; py <= y1; py++)
+            for (int px = x0; px <= x1; px++) raster_pixel(s, t, px, py, H, W, row0, rows, vis);
+    }
+    __syncthreads();
+    int nb = min(nbig, BIGQ);
+    for (int qi = 0; qi < nb; qi++) {
+        int t = bigq[qi];
+        int inst = D.tri_inst[t];
+        float tp[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) tp[k] = D.tri_pos[(size_t)k * NT + t];
+        STri s;
+        project_tri(mvp[inst], tp, W, H, s);
+        float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
+        float ymin = fminf(s.sy[0], fminf(s.sy[1], s.sy[2])), ymax = fmaxf(s.sy[0], fmaxf(s.sy[1], s.sy[2]));
+        int x0 = (int)ceilf(fmaxf(xmin, 0.0f)), x1 = (int)floorf(fminf(xmax, (float)(W - 1)));
+        int y0 = (int)ceilf(fmaxf(ymin, ty0)), y1 = (int)floorf(fminf(ymax, ty1));
+        int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+        for (int i = tid; i < bw * bh; i += RASTER_THREADS) {
+            int px = x0 + i % bw, py = y0 + i / bw;
+            raster_pixel(s, t, px, py, H, W, row0, rows, vis);
+        }
+    }
+    __syncthreads();
+    // ---- resolve: 4 consecutive pixels per thread iteration (W % 4 == 0 enforced at create)
+    const float Lx = -50.0f, Ly = 30.0f, Lz = 100.0f;
+    const float linv = 1.0f / sqrtf(Lx * Lx + Ly * Ly + Lz * Lz);
+    const float L0 = Lx * linv, L1 = Ly * linv, L2 = Lz * linv;
+    const size_t img_base = ((size_t)env * H + row0) * W;
+    for (int g = tid; g < npix / 4; g += RASTER_THREADS) {
+        unsigned rgbw[3] = {0, 0, 0};
+        unsigned char rgb12[12];
+        float dep[4]; int msk[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int pi = 4 * g + j;
+            unsigned long long key = vis[pi];
+            int lrow = pi / W, px = pi - lrow * W;
+            int row = row0 + lrow;
+            if (key == ~0ull) {
+                rgb12[3 * j] = 255; rgb12[3 * j + 1] = 255; rgb12[3 * j + 2] = 255;
+                dep[j] = 1.0f; msk[j] = -1;
+                continue;
+            }
+            int t = (int)(key & 0xffffffffu);
+            float d = __uint_as_float((unsigned)(key >> 32));
+            int inst = D.tri_inst[t];
+            float tp[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) tp[k] = D.tri_pos[(size_t)k * NT + t];
+            STri s;
+            project_tri(mvp[inst], tp, W, H, s);
+            float b[3] = {0, 0, 0};
+            bary(s, (float)px, (float)(H - 1 - row), b);
+            float c0 = b[0] / s.w[0], c1 = b[1] / s.w[1], c2 = b[2] / s.w[2];
+            float cs = 1.0f / (c0 + c1 + c2);
+            c0 *= cs; c1 *= cs; c2 *= cs;
+            const float *nn = D.tri_nrm + (size_t)9 * t, *uv = D.tri_uv + (size_t)6 * t;
+            float n0 = c0 * nn[0] + c1 * nn[3] + c2 * nn[6], n1 = c0 * nn[1] + c1 * nn[4] + c2 * nn[7], n2 = c0 * nn[2] + c1 * nn[5] + c2 * nn[8];
+            const float *xf = D.inst_xf + ((size_t)env * MAXINST + inst) * 12;
+            float w0 = xf[0] * n0 + xf[1] * n1 + xf[2] * n2, w1 = xf[3] * n0 + xf[4] * n1 + xf[5] * n2, w2 = xf[6] * n0 + xf[7] * n1 + xf[8] * n2;
+            float nlen = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
+            if (nlen > 0) { w0 /= nlen; w1 /= nlen; w2 /= nlen; }
+            float ndl = w0 * L0 + w1 * L1 + w2 * L2;
+            float diff = fmaxf(ndl, 0.0f);
+            float r0 = w0 * (2 * ndl) - L0, r1 = w1 * (2 * ndl) - L1, r2 = w2 * (2 * ndl) - L2;
+            float rl = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+            float rz = rl > 0 ? fmaxf(r2 / rl, 0.0f) : 0.0f;
+            float spec = rz * rz;
+            float tex0 = 255.0f, tex1 = 255.0f, tex2 = 255.0f;
+            int tidx = RM.in_tex[inst];
+            if (tidx >= 0) {
+                float u = c0 * uv[0] + c1 * uv[2] + c2 * uv[4], v = c0 * uv[1] + c1 * uv[3] + c2 * uv[5];
+                u = u - floorf(u); v = v - floorf(v);
+                int tw = RM.tex_w[tidx], th = RM.tex_h[tidx];
+                int tx = min((int)(u * (float)tw), tw - 1), ty = min((int)(v * (float)th), th - 1);
+                unsigned px4 = D.tex[(size_t)RM.tex_off[tidx] + (size_t)(th - 1 - ty) * tw + tx];
+                tex0 = (float)(px4 & 255); tex1 = (float)((px4 >> 8) & 255); tex2 = (float)((px4 >> 16) & 255);
+            }
+            float shade = 0.6f + 0.35f * diff + 0.05f * spec;
+            rgb12[3 * j] = (unsigned char)min((int)(tex0 * RM.in_color[inst][0] * shade), 255);
+            rgb12[3 * j + 1] = (unsigned char)min((int)(tex1 * RM.in_color[inst][1] * shade), 255);
+            rgb12[3 * j + 2] = (unsigned char)min((int)(tex2 * RM.in_color[inst][2] * shade), 255);
+            dep[j] = d; msk[j] = RM.in_uid[inst];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            rgbw[k] = (unsigned)rgb12[4 * k] | ((unsigned)rgb12[4 * k + 1] << 8) | ((unsigned)rgb12[4 * k + 2] << 16) | ((unsigned)rgb12[4 * k + 3] << 24);
+        size_t pbase = img_base + (size_t)4 * g;
+        unsigned *rgbp = (unsigned *)(D.rgb + pbase * 3);
+        rgbp[0] = rgbw[0]; rgbp[1] = rgbw[1]; rgbp[2] = rgbw[2];
+        *(float4 *)(D.depth + pbase) = make_float4(dep[0], dep[1], dep[2], dep[3]);
+        *(int4 *)(D.mask + pbase) = make_int4(msk[0], msk[1], msk[2], msk[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+struct BlobEntry {
+    char name[32];
+    uint32_t dtype, ndim, shape[4];
+    uint64_t offset, nbytes;
+};
+
+struct Blob {
+    const char *base; size_t size; uint32_t n; const BlobEntry *e;
+    bool init(const void *p, size_t sz) {
+        base = (const char *)p; size = sz;
+        if (sz < 16 || memcmp(base, "RRMODEL1", 8) != 0) return false;
+        memcpy(&n, base + 8, 4);
+        if (16 + (size_t)n * sizeof(BlobEntry) > sz) return false;
+        e = (const BlobEntry *)(base + 16);
+        for (uint32_t i = 0; i < n; i++) if (e[i].offset + e[i].nbytes > sz) return false;
+        return true;
+    }
+    const BlobEntry *find(const char *name, uint32_t dtype) const {
+        for (uint32_t i = 0; i < n; i++) if (strncmp(e[i].name, name, 32) == 0 && e[i].dtype == dtype) return &e[i];
+        return nullptr;
+    }
+    const float *f32(const char *name, size_t min_count = 0) const {
+        const BlobEntry *x = find(name, 0);
+        if (!x || x->nbytes < min_count * 4) return nullptr;
+        return (const float *)(base + x->offset);
+    }
+    const int32_t *i32(const char *name, size_t min_count = 0) const {
+        const BlobEntry *x = find(name, 1);
+        if (!x || x->nbytes < min_count * 4) return nullptr;
+        return (const int32_t *)(base + x->offset);
+    }
+    const uint8_t *u8(const char *name, size_t *nbytes) const {
+        const BlobEntry *x = find(name, 2);
+        if (!x) return nullptr;
+        *nbytes = x->nbytes;
+        return (const uint8_t *)(base + x->offset);
+    }
+};
+
+struct rr_env {
+    rr_config cfg;
+    BodyParams B;
+    SimParams P;
+    RenderModel RM;
+    RenderModel *RM_dev;
+    DevPtrs D;
+    hipStream_t stream;
+    int epb;                 // envs per block for physics kernels
+    int n_inst_used;
+    size_t field_bytes[RR_F_COUNT];
+    void *field_ptr[RR_F_COUNT];
+    float *state_aos;        // [N][61] staging for RR_F_STATE
+    unsigned char *mask_dev; // [N]
+    float *link_out;         // [N][nl][7]
+    std::vector<void *> allocs;
+    bool timing;
+    hipEvent_t ev[2 * RR_NUM_KERNELS];
+    float t_ms[RR_NUM_KERNELS];
+    int t_n[RR_NUM_KERNELS];
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+};
+
+template <typename T>
+static int dev_alloc(rr_env *e, T **p, size_t count, bool zero = true) {
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, count * sizeof(T) + 16));
+    if (zero) HIPCHK(hipMemset(q, 0, count * sizeof(T) + 16));
+    e->allocs.push_back(q);
+    *p = (T *)q;
+    return RR_OK;
+}
+
+static void look_at_persp(float *VP, const float *table_pos, int W, int H) {
+    float eye[3] = {0.01f, 0.0f, 1.2f};                       // env.py:136
+    float tgt[3] = {table_pos[0], table_pos[1], table_pos[2]};  // env.py:253-255 (table position)
+    float up[3] = {0, 0, 1};
+    float f[3] = {tgt[0] - eye[0], tgt[1] - eye[1], tgt[2] - eye[2]};
+    float fl = sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+    f[0] /= fl; f[1] /= fl; f[2] /= fl;
+    float s[3] = {f[1] * up[2] - f[2] * up[1], f[2] * up[0] - f[0] * up[2], f[0] * up[1] - f[1] * up[0]};
+    float sl = sqrtf(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+    s[0] /= sl; s[1] /= sl; s[2] /= sl;
+    float u[3] = {s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0]};
+    float V[16] = {s[0], s[1], s[2], -(s[0] * eye[0] + s[1] * eye[1] + s[2] * eye[2]),
+                   u[0], u[1], u[2], -(u[0] * eye[0] + u[1] * eye[1] + u[2] * eye[2]),
+                   -f[0], -f[1], -f[2], (f[0] * eye[0] + f[1] * eye[1] + f[2] * eye[2]),
+                   0, 0, 0, 1};
+    float fov = 80.0f, nearv = 0.1f, farv = 100.0f;           // env.py:518,548-551
+    float aspect = (float)W / (float)H;
+    float yscale = 1.0f / tanf(fov * 3.14159265358979323846f / 360.0f);
+    float xscale = yscale / aspect;
+    float Pm[16] = {xscale, 0, 0, 0, 0, yscale, 0, 0, 0, 0, (nearv + farv) / (nearv - farv), 2 * nearv * farv / (nearv - farv), 0, 0, -1, 0};
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float a = 0;
+            for (int k = 0; k < 4; k++) a += Pm[4 * i + k] * V[4 * k + j];
+            VP[4 * i + j] = a;
+        }
+}
+
+extern "C" {
+
+const char *rr_last_error(void) { return g_err.c_str(); }
+int rr_abi_version(void) { return RR_ABI_VERSION; }
+
+int rr_destroy(rr_env *e) {
+    if (!e) return RR_OK;
+    hipSetDevice(e->cfg.device);
+    hipStreamSynchronize(e->stream);
+    for (void *p : e->allocs) hipFree(p);
+    for (int i = 0; i < 2 * RR_NUM_KERNELS; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
+    delete e;
+    return RR_OK;
+}
+
+int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, void *stream, rr_env **out) {
+    if (!cfg || !model_blob || !out) return fail(RR_EINVAL, "rr_create: null argument");
+    if (cfg->abi_version != RR_ABI_VERSION) return fail(RR_EINVAL, "rr_create: abi_version mismatch");
+    if (cfg->num_envs < 1) return fail(RR_EINVAL, "rr_create: num_envs < 1");
+    if (cfg->n_objects < 1 || cfg->n_objects > NOBJ) return fail(RR_EINVAL, "rr_create: n_objects must be 1..3");
+    if (cfg->width < 4 || cfg->height < 1 || cfg->width % 4 != 0 || cfg->width > TILE_PIX)
+        return fail(RR_EINVAL, "rr_create: width must be a multiple of 4 in [4,16384]");
+    Blob b;
+    if (!b.init(model_blob, blob_bytes)) return fail(RR_EMODEL, "rr_create: bad model blob header");
+    const int32_t *dims = b.i32("dims", 11);
+    if (!dims) return fail(RR_EMODEL, "rr_create: blob has no dims");
+    int nb = dims[0], nl = dims[1], ns = dims[2], ni = dims[3], nt = dims[4], ntex = dims[5], n_static = dims[6], n_robot = dims[7];
+    if (nb != NB || ns > MAXSHAPES || dims[8] != VMAXC || dims[9] != FMAXC || ni > MAXINST || nl > NLINK_MAX || ntex > 16 ||
+        n_static != 3 || n_robot != 16)
+        return fail(RR_EMODEL, "rr_create: blob dims do not match this build");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(RR_EDEVICE, "rr_create: no HIP device available (this library has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(RR_EINVAL, "rr_create: bad device ordinal");
+    HIPCHK(hipSetDevice(cfg->device));
+
+    rr_env *e = new rr_env();
+    memset(&e->B, 0, sizeof e->B); memset(&e->RM, 0, sizeof e->RM); memset(&e->D, 0, sizeof e->D);
+    memset(e->ev, 0, sizeof e->ev); memset(e->t_ms, 0, sizeof e->t_ms); memset(e->t_n, 0, sizeof e->t_n);
+    e->timing = false;
+    e->cfg = *cfg;
+    e->stream = (hipStream_t)stream;
+    const int N = cfg->num_envs;
+#define NEED(p) if (!(p)) { rr_destroy(e); return fail(RR_EMODEL, "rr_create: blob entry missing/short: " #p); }
+    const float *f; const int32_t *ip;
+    BodyParams &B = e->B;
+    NEED(ip = b.i32("body_parent", NB)); memcpy(B.parent, ip, sizeof B.parent);
+    if (memcmp(B.parent, PARENT_HOST, sizeof PARENT_HOST) != 0) { rr_destroy(e); return fail(RR_EMODEL, "rr_create: kinematic tree differs from the compiled-in one"); }
+    NEED(f = b.f32("body_jpos", NB * 3)); memcpy(B.jpos, f, sizeof B.jpos);
+    NEED(f = b.f32("body_jrot", NB * 9)); memcpy(B.jrot, f, sizeof B.jrot);
+    NEED(f = b.f32("body_axis", NB * 3)); memcpy(B.axis, f, sizeof B.axis);
+    NEED(f = b.f32("body_mass", NB)); memcpy(B.mass, f, sizeof B.mass);
+    NEED(f = b.f32("body_com", NB * 3)); memcpy(B.com, f, sizeof B.com);
+    NEED(f = b.f32(cfg->use_urdf_inertia ? "body_inertia_urdf" : "body_inertia", NB * 6)); memcpy(B.inertia, f, sizeof B.inertia);
+    NEED(f = b.f32("body_damping", NB)); memcpy(B.damping, f, sizeof B.damping);
+    NEED(f = b.f32("body_limits", NB * 2)); memcpy(B.limits, f, sizeof B.limits);
+    NEED(f = b.f32("robot_pos", 3)); memcpy(B.robot_pos, f, sizeof B.robot_pos);
+    NEED(f = b.f32("obj_mass", NOBJ)); memcpy(B.obj_mass, f, sizeof B.obj_mass);
+    NEED(f = b.f32("obj_inertia", NOBJ * 3)); memcpy(B.obj_inertia, f, sizeof B.obj_inertia);
+    NEED(f = b.f32("obj_pose0", NOBJ * 7)); memcpy(B.obj_pose0, f, sizeof B.obj_pose0);
+    const float *table_pos;
+    NEED(table_pos = b.f32("table_pos", 3)); B.table_z = table_pos[2];
+    NEED(f = b.f32("act_min", 9)); memcpy(B.act_min, f, sizeof B.act_min);
+    NEED(f = b.f32("act_max", 9)); memcpy(B.act_max, f, sizeof B.act_max);
+    NEED(f = b.f32("act_maxdiff", 9)); memcpy(B.act_maxdiff, f, sizeof B.act_maxdiff);
+    NEED(ip = b.i32("touch_links", 4)); memcpy(B.touch_links, ip, sizeof B.touch_links);
+
+    SimParams &P = e->P;
+    P.N = N; P.nobj = cfg->n_objects; P.iters = cfg->solver_iters > 0 ? cfg->solver_iters : 50;
+    P.dt = cfg->dt > 0 ? cfg->dt : 0.005f; P.gravity = 9.81f; P.erp = cfg->erp > 0 ? cfg->erp : 0.2f;
+    P.margin = cfg->margin > 0 ? cfg->margin : 0.02f; P.kp = 0.1f; P.kd = 1.0f; P.max_impulse = 100000.0f * P.dt;
+    P.lin_damp = 0.04f; P.ang_damp = 0.04f; P.rest_thresh = 0.2f;
+    e->epb = cfg->envs_per_block > 0 ? cfg->envs_per_block : 64;
+    if (e->epb > 64) e->epb = 64;   // physics kernels are compiled with __launch_bounds__(64)
+
+    // shapes + pair table (same order as the oracle's collide())
+    std::vector<ShapeData> sdv(1);
+    ShapeData &S = sdv[0];
+    memset(&S, 0, sizeof S);
+    NEED(ip = b.i32("shape_owner", ns * 4));
+    for (int s = 0; s < ns; s++) { S.otype[s] = ip[4 * s]; S.oidx[s] = ip[4 * s + 1]; S.link[s] = ip[4 * s + 2]; }
+    NEED(ip = b.i32("shape_nv", ns)); memcpy(S.nv, ip, ns * 4);
+    NEED(ip = b.i32("shape_nf", ns)); memcpy(S.nf, ip, ns * 4);
+    NEED(f = b.f32("shape_verts", ns * VMAXC * 3)); memcpy(S.verts, f, (size_t)ns * VMAXC * 3 * 4);
+    NEED(f = b.f32("shape_planes", ns * FMAXC * 4)); memcpy(S.planes, f, (size_t)ns * FMAXC * 4 * 4);
+    NEED(f = b.f32("shape_sphere", ns * 4)); memcpy(S.sphere, f, (size_t)ns * 4 * 4);
+    NEED(f = b.f32("shape_mat", ns * 2));
+    for (int s = 0; s < ns; s++) { S.fric[s] = f[2 * s]; S.rest[s] = f[2 * s + 1]; }
+    int np = 0, s_obj0 = n_static + n_robot;
+    for (int i = 0; i < P.nobj; i++) for (int s = 0; s < n_static; s++) { S.pair_a[np] = s_obj0 + i; S.pair_b[np++] = s; }
+    for (int i = 0; i < P.nobj; i++) for (int j = i + 1; j < P.nobj; j++) { S.pair_a[np] = s_obj0 + i; S.pair_b[np++] = s_obj0 + j; }
+    for (int r = 0; r < n_robot; r++) for (int s = 0; s < 2; s++) { S.pair_a[np] = n_static + r; S.pair_b[np++] = s; }
+    for (int r = 0; r < n_robot; r++) for (int i = 0; i < P.nobj; i++) { S.pair_a[np] = n_static + r; S.pair_b[np++] = s_obj0 + i; }
+    P.npairs = np;
+
+    // render model
+    RenderModel &RM = e->RM;
+    RM.ni = ni; RM.nt = nt; RM.W = cfg->width; RM.H = cfg->height; RM.nl = nl;
+    RM.tile_h = TILE_PIX / RM.W; if (RM.tile_h > RM.H) RM.tile_h = RM.H;
+    RM.ntiles = (RM.H + RM.tile_h - 1) / RM.tile_h;
+    NEED(ip = b.i32("inst_owner", ni * 4));
+    for (int i = 0; i < ni; i++) { RM.in_otype[i] = ip[4 * i]; RM.in_oidx[i] = ip[4 * i + 1]; RM.in_uid[i] = ip[4 * i + 2]; RM.in_tex[i] = ip[4 * i + 3]; }
+    NEED(f = b.f32("inst_color", ni * 3)); memcpy(RM.in_color, f, (size_t)ni * 12);
+    NEED(ip = b.i32("tex_info", ntex * 3));
+    for (int t = 0; t < ntex; t++) { RM.tex_off[t] = ip[3 * t]; RM.tex_w[t] = ip[3 * t + 1]; RM.tex_h[t] = ip[3 * t + 2]; }
+    NEED(ip = b.i32("link_body", nl)); memcpy(RM.link_body, ip, nl * 4);
+    NEED(f = b.f32("link_pos", nl * 3)); memcpy(RM.link_pos, f, (size_t)nl * 12);
+    NEED(f = b.f32("link_rot", nl * 9)); memcpy(RM.link_rot, f, (size_t)nl * 36);
+    look_at_persp(RM.VP, table_pos, RM.W, RM.H);
+    e->n_inst_used = ni - (NOBJ - P.nobj);
+
+    // device allocations
+    DevPtrs &D = e->D;
+    int rc;
+#define ALLOC(ptr, count) if ((rc = dev_alloc(e, &(ptr), (count))) != RR_OK) { rr_destroy(e); return rc; }
+    ALLOC(D.state, (size_t)ST_TOTAL * N);
+    ALLOC(D.scratch, (size_t)S_TOTAL * N);
+    ALLOC(D.timestep, (size_t)N);
+    ALLOC(D.errflags, (size_t)N);
+    ALLOC(D.cmd, (size_t)N * 9);
+    ALLOC(D.joints, (size_t)N * 9);
+    ALLOC(D.touch, (size_t)N * 4);
+    ALLOC(D.objpose, (size_t)N * P.nobj * 7);
+    ALLOC(D.inst_xf, (size_t)N * MAXINST * 12);
+    ALLOC(D.render_flags, (size_t)N);
+    const size_t npx = (size_t)N * RM.W * RM.H;
+    ALLOC(D.rgb, npx * 3);
+    ALLOC(D.depth, npx);
+    ALLOC(D.mask, npx);
+    ALLOC(e->state_aos, (size_t)N * NSTATE);
+    ALLOC(e->mask_dev, (size_t)N);
+    ALLOC(e->link_out, (size_t)N * nl * 7);
+    {   // geometry: positions SoA [9][NT], normals/uv AoS
+        const float *tp, *tn, *tu; const int32_t *ti;
+        NEED(tp = b.f32("tri_pos", (size_t)nt * 9)); NEED(tn = b.f32("tri_nrm", (size_t)nt * 9));
+        NEED(tu = b.f32("tri_uv", (size_t)nt * 6)); NEED(ti = b.i32("tri_inst", nt));
+        std::vector<float> soa((size_t)nt * 9);
+        for (int t = 0; t < nt; t++) for (int k = 0; k < 9; k++) soa[(size_t)k * nt + t] = tp[(size_t)t * 9 + k];
+        float *dp, *dn, *du; int *di; unsigned *dt_; ShapeData *ds;
+        ALLOC(dp, (size_t)nt * 9); ALLOC(dn, (size_t)nt * 9); ALLOC(du, (size_t)nt * 6); ALLOC(di, (size_t)nt);
+        hipMemcpy(dp, soa.data(), (size_t)nt * 36, hipMemcpyHostToDevice);
+        hipMemcpy(dn, tn, (size_t)nt * 36, hipMemcpyHostToDevice);
+        hipMemcpy(du, tu, (size_t)nt * 24, hipMemcpyHostToDevice);
+        hipMemcpy(di, ti, (size_t)nt * 4, hipMemcpyHostToDevice);
+        size_t texbytes = 0;
+        const uint8_t *tex = b.u8("tex_data", &texbytes);
+        NEED(tex);
+        ALLOC(dt_, texbytes / 4 + 1);
+        hipMemcpy(dt_, tex, texbytes, hipMemcpyHostToDevice);
+        ALLOC(ds, 1);
+        hipMemcpy(ds, &S, sizeof S, hipMemcpyHostToDevice);
+        ALLOC(e->RM_dev, 1);
+        hipMemcpy(e->RM_dev, &e->RM, sizeof e->RM, hipMemcpyHostToDevice);
+        D.tri_pos = dp; D.tri_nrm = dn; D.tri_uv = du; D.tri_inst = di; D.tex = dt_; D.shapes = ds;
+    }
+    for (int i = 0; i < 2 * RR_NUM_KERNELS; i++) hipEventCreate(&e->ev[i]);
+    e->field_ptr[RR_F_JOINTS] = D.joints; e->field_bytes[RR_F_JOINTS] = (size_t)N * 9 * 4;
+    e->field_ptr[RR_F_TOUCH] = D.touch; e->field_bytes[RR_F_TOUCH] = (size_t)N * 4 * 4;
+    e->field_ptr[RR_F_OBJ_POSE] = D.objpose; e->field_bytes[RR_F_OBJ_POSE] = (size_t)N * P.nobj * 7 * 4;
+    e->field_ptr[RR_F_RGB] = D.rgb; e->field_bytes[RR_F_RGB] = npx * 3;
+    e->field_ptr[RR_F_DEPTH] = D.depth; e->field_bytes[RR_F_DEPTH] = npx * 4;
+    e->field_ptr[RR_F_MASK] = D.mask; e->field_bytes[RR_F_MASK] = npx * 4;
+    e->field_ptr[RR_F_TIMESTEP] = D.timestep; e->field_bytes[RR_F_TIMESTEP] = (size_t)N * 4;
+    e->field_ptr[RR_F_ERRFLAGS] = D.errflags; e->field_bytes[RR_F_ERRFLAGS] = (size_t)N * 4;
+    e->field_ptr[RR_F_STATE] = e->state_aos; e->field_bytes[RR_F_STATE] = (size_t)N * NSTATE * 4;
+    *out = e;
+    int r = rr_reset(e, nullptr);
+    if (r != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
+    return RR_OK;
+}
+
+int rr_set_stream(rr_env *e, void *stream) {
+    if (!e) return fail(RR_EINVAL, "null env");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->stream = (hipStream_t)stream;
+    return RR_OK;
+}
+
+static inline dim3 env_grid(const rr_env *e) { return dim3((e->P.N + e->epb - 1) / e->epb); }
+
+int rr_reset(rr_env *e, const uint8_t *mask_host) {
+    if (!e) return fail(RR_EINVAL, "null env");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const unsigned char *m = nullptr;
+    if (mask_host) {
+        HIPCHK(hipMemcpyAsync(e->mask_dev, mask_host, e->P.N, hipMemcpyHostToDevice, e->stream));
+        m = e->mask_dev;
+    }
+    hipLaunchKernelGGL(k_reset, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->B, e->P, e->D, m);
+    hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
+    HIPCHK(hipGetLastError());
+    return RR_OK;
+}
+
+int rr_set_object_pose(rr_env *e, int32_t env_index, int32_t obj, const float *pose7) {
+    if (!e || !pose7) return fail(RR_EINVAL, "null argument");
+    if (env_index < 0 || env_index >= e->P.N || obj < 0 || obj >= e->P.nobj) return fail(RR_EINVAL, "rr_set_object_pose: index out of range");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t N = e->P.N;
+    float zero = 0.0f;
+    for (int k = 0; k < 3; k++) {
+        HIPCHK(hipMemcpyAsync(e->D.state + (ST_OPOS + 3 * obj + k) * N + env_index, pose7 + k, 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->D.state + (ST_OVEL + 3 * obj + k) * N + env_index, &zero, 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->D.state + (ST_OANG + 3 * obj + k) * N + env_index, &zero, 4, hipMemcpyHostToDevice, e->stream));
+    }
+    for (int k = 0; k < 4; k++)
+        HIPCHK(hipMemcpyAsync(e->D.state + (ST_OQUAT + 4 * obj + k) * N + env_index, pose7 + 3 + k, 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));   // pose7/zero are stack/host memory
+    hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
+    return RR_OK;
+}
+
+static bool g_debug_sync = getenv("RR_DEBUG_SYNC") != nullptr;
+static int g_skip = getenv("RR_SKIP") ? atoi(getenv("RR_SKIP")) : 0;
+#define TIMED(id, launch)                                                   \
+    do {                                                                    \
+        if (e->timing) hipEventRecord(e->ev[2 * (id)], e->stream);          \
+        if (!((g_skip >> (id)) & 1)) launch;                                \
+        if (g_debug_sync) { hipError_t e__ = hipStreamSynchronize(e->stream); fprintf(stderr, "[rr] kernel %d done: %s\n", (id), hipGetErrorString(e__)); } \
+        if (e->timing) {                                                    \
+            hipEventRecord(e->ev[2 * (id) + 1], e->stream);                 \
+            hipEventSynchronize(e->ev[2 * (id) + 1]);                       \
+            float ms_ = 0;                                                  \
+            hipEventElapsedTime(&ms_, e->ev[2 * (id)], e->ev[2 * (id) + 1]); \
+            e->t_ms[id] += ms_; e->t_n[id] += 1;                            \
+        }                                                                   \
+    } while (0)
+
+static int do_render(rr_env *e, bool use_flags) {
+    DevPtrs D = e->D;
+    if (!use_flags) D.render_flags = nullptr;
+    TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((e->P.N + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, D));
+    TIMED(4, hipLaunchKernelGGL(k_raster, dim3(e->P.N, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, D, e->n_inst_used));
+    HIPCHK(hipGetLastError());
+    return RR_OK;
+}
+
+int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t render_mode, const uint8_t *render_flags_host) {
+    if (!e) return fail(RR_EINVAL, "null env");
+    if (render_mode < 0 || render_mode > 2 || (render_mode == 2 && !render_flags_host)) return fail(RR_EINVAL, "rr_step: bad render_mode");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const int N = e->P.N;
+    if (!joint_cmd) HIPCHK(hipMemsetAsync(e->D.cmd, 0, (size_t)N * 36, e->stream));      // env.py:333-334
+    else HIPCHK(hipMemcpyAsync(e->D.cmd, joint_cmd, (size_t)N * 36, cmd_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    if (render_mode == 2) HIPCHK(hipMemcpyAsync(e->D.render_flags, render_flags_host, N, hipMemcpyHostToDevice, e->stream));
+    TIMED(0, hipLaunchKernelGGL(k_prep, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, e->D));
+    TIMED(1, hipLaunchKernelGGL(k_collide, dim3(((N + COLLIDE_THREADS - 1) / COLLIDE_THREADS) * e->P.npairs), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D, (N + COLLIDE_THREADS - 1) / COLLIDE_THREADS));
+    TIMED(2, hipLaunchKernelGGL(k_solve, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, e->D));
+    HIPCHK(hipGetLastError());
+    if (render_mode) return do_render(e, render_mode == 2);
+    return RR_OK;
+}
+
+int rr_render(rr_env *e) {
+    if (!e) return fail(RR_EINVAL, "null env");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    return do_render(e, false);
+}
+
+int rr_get_buffer(rr_env *e, int32_t field, void **dev_ptr, size_t *bytes) {
+    if (!e || field < 0 || field >= RR_F_COUNT) return fail(RR_EINVAL, "rr_get_buffer: bad field");
+    if (dev_ptr) *dev_ptr = e->field_ptr[field];
+    if (bytes) *bytes = e->field_bytes[field];
+    return RR_OK;
+}
+
+int rr_copy_to_host(rr_env *e, int32_t field, void *dst, size_t bytes) {
+    if (!e || !dst || field < 0 || field >= RR_F_COUNT) return fail(RR_EINVAL, "rr_copy_to_host: bad argument");
+    if (bytes != e->field_bytes[field]) return fail(RR_EINVAL, "rr_copy_to_host: size mismatch");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    if (field == RR_F_STATE)
+        hipLaunchKernelGGL(k_state_io, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D, e->state_aos, 1);
+    HIPCHK(hipMemcpyAsync(dst, e->field_ptr[field], bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return RR_OK;
+}
+
+int rr_set_state(rr_env *e, const float *state_host) {
+    if (!e || !state_host) return fail(RR_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipMemcpyAsync(e->state_aos, state_host, e->field_bytes[RR_F_STATE], hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_state_io, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D, e->state_aos, 0);
+    hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return RR_OK;
+}
+
+int rr_sync(rr_env *e) {
+    if (!e) return fail(RR_EINVAL, "null env");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return RR_OK;
+}
+
+int rr_link_poses(rr_env *e, float *out_host) {
+    if (!e || !out_host) return fail(RR_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipLaunchKernelGGL(k_link_poses, dim3((e->P.N + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D, e->link_out);
+    HIPCHK(hipMemcpyAsync(out_host, e->link_out, (size_t)e->P.N * e->RM.nl * 28, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return RR_OK;
+}
+
+int rr_get_contacts(rr_env *e, int32_t env_index, float *out_host, int32_t max_contacts, int32_t *count) {
+    if (!e || !out_host || !count) return fail(RR_EINVAL, "null argument");
+    if (env_index < 0 || env_index >= e->P.N) return fail(RR_EINVAL, "rr_get_contacts: env out of range");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t N = e->P.N;
+    int nc = 0;
+    HIPCHK(hipMemcpyAsync(&nc, e->D.scratch + (size_t)S_NCT * N + env_index, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (nc > max_contacts) nc = max_contacts;
+    if (nc > 0)   // strided gather: element (c, f) lives at scratch[(S_CT + c*12 + f) * N + env]
+        HIPCHK(hipMemcpy2DAsync(out_host, 4, e->D.scratch + (size_t)S_CT * N + env_index, N * 4, 4, (size_t)nc * 12,
+                                hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *count = nc;
+    return RR_OK;
+}
+
+int rr_set_timing(rr_env *e, int32_t enable) {
+    if (!e) return fail(RR_EINVAL, "null env");
+    e->timing = enable != 0;
+    memset(e->t_ms, 0, sizeof e->t_ms); memset(e->t_n, 0, sizeof e->t_n);
+    return RR_OK;
+}
+
+int rr_get_timing(rr_env *e, float *ms_out, int32_t *launches_out) {
+    if (!e || !ms_out || !launches_out) return fail(RR_EINVAL, "null argument");
+    for (int i = 0; i < RR_NUM_KERNELS; i++) { ms_out[i] = e->t_ms[i]; launches_out[i] = e->t_n[i]; e->t_ms[i] = 0; e->t_n[i] = 0; }
+    return RR_OK;
+}
+
+}  // extern "C"
