@@ -484,35 +484,48 @@ static int verts_in_planes(const rr_oracle *o, int sa, const xform_t *Xa, int sb
     return n;
 }
 
+/* Manifold reduction to <= 4 points: deepest point first, then the three points that spread the manifold most
+ * (farthest from the first, farthest from that line, farthest on the other side of it). Candidates within
+ * TIER_TOL of the deepest penetration ("tier 1": the features actually touching) are preferred at every pick;
+ * the remaining speculative candidates are only used when tier 1 has no admissible point. */
+#define TIER_TOL ((real)0.001)
 static int reduce4(const cand_t *c, int n, int *sel) {
     if (n <= 4) { for (int i = 0; i < n; i++) sel[i] = i; return n; }
     int k0 = 0;
     for (int i = 1; i < n; i++) if (c[i].s < c[k0].s) k0 = i;
-    int k1 = -1; real best = -1;
-    for (int i = 0; i < n; i++) {
-        if (i == k0) continue;
-        real d[3]; v3_sub(d, c[i].x, c[k0].x);
-        real v = v3_dot(d, d);
-        if (v > best) { best = v; k1 = i; }
+    real lim = c[k0].s + TIER_TOL;
+    int k1 = -1, k2 = -1, k3 = -1;
+    real e[3] = {0, 0, 0}, cr2[3] = {0, 0, 0};
+    for (int tier = 0; tier < 2 && k1 < 0; tier++) {
+        real best = -1;
+        for (int i = 0; i < n; i++) {
+            if (i == k0 || (tier == 0 && !(c[i].s < lim))) continue;
+            real d[3]; v3_sub(d, c[i].x, c[k0].x);
+            real v = v3_dot(d, d);
+            if (v > best) { best = v; k1 = i; }
+        }
     }
-    real e[3]; v3_sub(e, c[k1].x, c[k0].x);
-    int k2 = -1; best = -1;
-    real cr2[3] = {0, 0, 0};
-    for (int i = 0; i < n; i++) {
-        if (i == k0 || i == k1) continue;
-        real d[3], cr[3]; v3_sub(d, c[i].x, c[k0].x);
-        v3_cross(cr, d, e);
-        real v = v3_dot(cr, cr);
-        if (v > best) { best = v; k2 = i; v3_copy(cr2, cr); }
+    v3_sub(e, c[k1].x, c[k0].x);
+    for (int tier = 0; tier < 2 && k2 < 0; tier++) {
+        real best = -1;
+        for (int i = 0; i < n; i++) {
+            if (i == k0 || i == k1 || (tier == 0 && !(c[i].s < lim))) continue;
+            real d[3], cr[3]; v3_sub(d, c[i].x, c[k0].x);
+            v3_cross(cr, d, e);
+            real v = v3_dot(cr, cr);
+            if (v > best) { best = v; k2 = i; v3_copy(cr2, cr); }
+        }
     }
     sel[0] = k0; sel[1] = k1; sel[2] = k2;
-    int k3 = -1; best = 0;
-    for (int i = 0; i < n; i++) {
-        if (i == k0 || i == k1 || i == k2) continue;
-        real d[3], cr[3]; v3_sub(d, c[i].x, c[k0].x);
-        v3_cross(cr, d, e);
-        real v = -v3_dot(cr, cr2);
-        if (v > best) { best = v; k3 = i; }
+    for (int tier = 0; tier < 2 && k3 < 0; tier++) {
+        real best = 0;
+        for (int i = 0; i < n; i++) {
+            if (i == k0 || i == k1 || i == k2 || (tier == 0 && !(c[i].s < lim))) continue;
+            real d[3], cr[3]; v3_sub(d, c[i].x, c[k0].x);
+            v3_cross(cr, d, e);
+            real v = -v3_dot(cr, cr2);
+            if (v > best) { best = v; k3 = i; }
+        }
     }
     if (k3 >= 0) { sel[3] = k3; return 4; }
     return 3;

@@ -59,11 +59,13 @@ class BatchedREALRobotEnv:
     def step(self, joint_cmd=None, render=False, device_ptr=None):
         """joint_cmd: None (zeros, env.py:333-334), float array [N, 9] on the host, or `device_ptr` (int address of
         an f32 [N, 9] device buffer). render: False / True / uint8 array [N] of per-env camera flags."""
-        mode, flags = (1 if render else 0), None
-        if isinstance(render, np.ndarray):
+        flags = None
+        if isinstance(render, np.ndarray) and render.size > 1:
             flags = np.ascontiguousarray(render, dtype=np.uint8)
             assert flags.shape == (self.N,)
             mode = 2
+        else:
+            mode = 1 if np.any(render) else 0
         if device_ptr is not None:
             nat.check(self.L.rr_step(self.h, C.c_void_p(device_ptr), 1, mode, flags.ctypes.data if flags is not None else None))
             return

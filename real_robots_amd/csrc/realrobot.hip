@@ -494,30 +494,47 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
     int sel[4], k = 0;
     if (n <= 4) { for (int i = 0; i < n; i++) sel[i] = i; k = n; }
     else {
+        // manifold reduction, same rule as the oracle's reduce4(): deepest first, then maximal spread, preferring
+        // the candidates within TIER_TOL of the deepest penetration at every pick
         int k0 = 0;
-        { float sbest = cand.get(0).s; for (int i = 1; i < n; i++) { float si = cand.get(i).s; if (si < sbest) { sbest = si; k0 = i; } } }
-        Cand c0_ = cand.get(k0); v3 x0 = mk(c0_.x, c0_.y, c0_.z);
-        int k1 = -1; float best = -1;
-        for (int i = 0; i < n; i++) {
-            if (i == k0) continue;
-            Cand ci_ = cand.get(i); v3 dd = mk(ci_.x, ci_.y, ci_.z) - x0;
-            float v = dot(dd, dd);
-            if (v > best) { best = v; k1 = i; }
+        float sbest = cand.get(0).s;
+        for (int i = 1; i < n; i++) { float si = cand.get(i).s; if (si < sbest) { sbest = si; k0 = i; } }
+        const float lim = sbest + 0.001f;
+        Cand c0_ = cand.get(k0);
+        v3 x0 = mk(c0_.x, c0_.y, c0_.z);
+        int k1 = -1, k2 = -1, k3 = -1;
+        for (int tier = 0; tier < 2 && k1 < 0; tier++) {
+            float best = -1;
+            for (int i = 0; i < n; i++) {
+                Cand ci_ = cand.get(i);
+                if (i == k0 || (tier == 0 && !(ci_.s < lim))) continue;
+                v3 dd = mk(ci_.x, ci_.y, ci_.z) - x0;
+                float v = dot(dd, dd);
+                if (v > best) { best = v; k1 = i; }
+            }
         }
-        Cand c1_ = cand.get(k1); v3 e = mk(c1_.x, c1_.y, c1_.z) - x0;
-        int k2 = -1; best = -1; v3 cr2 = mk(0, 0, 0);
-        for (int i = 0; i < n; i++) {
-            if (i == k0 || i == k1) continue;
-            Cand ci_ = cand.get(i); v3 cr = cross(mk(ci_.x, ci_.y, ci_.z) - x0, e);
-            float v = dot(cr, cr);
-            if (v > best) { best = v; k2 = i; cr2 = cr; }
+        Cand c1_ = cand.get(k1);
+        v3 e = mk(c1_.x, c1_.y, c1_.z) - x0;
+        v3 cr2 = mk(0, 0, 0);
+        for (int tier = 0; tier < 2 && k2 < 0; tier++) {
+            float best = -1;
+            for (int i = 0; i < n; i++) {
+                Cand ci_ = cand.get(i);
+                if (i == k0 || i == k1 || (tier == 0 && !(ci_.s < lim))) continue;
+                v3 cr = cross(mk(ci_.x, ci_.y, ci_.z) - x0, e);
+                float v = dot(cr, cr);
+                if (v > best) { best = v; k2 = i; cr2 = cr; }
+            }
         }
-        int k3 = -1; best = 0;
-        for (int i = 0; i < n; i++) {
-            if (i == k0 || i == k1 || i == k2) continue;
-            Cand ci_ = cand.get(i); v3 cr = cross(mk(ci_.x, ci_.y, ci_.z) - x0, e);
-            float v = -dot(cr, cr2);
-            if (v > best) { best = v; k3 = i; }
+        for (int tier = 0; tier < 2 && k3 < 0; tier++) {
+            float best = 0;
+            for (int i = 0; i < n; i++) {
+                Cand ci_ = cand.get(i);
+                if (i == k0 || i == k1 || i == k2 || (tier == 0 && !(ci_.s < lim))) continue;
+                v3 cr = cross(mk(ci_.x, ci_.y, ci_.z) - x0, e);
+                float v = -dot(cr, cr2);
+                if (v > best) { best = v; k3 = i; }
+            }
         }
         sel[0] = k0; sel[1] = k1; sel[2] = k2; k = 3;
         if (k3 >= 0) { sel[3] = k3; k = 4; }

@@ -1,0 +1,282 @@
+"""REALRobotEnv: the gym-style single-environment facade of the reference (real_robots/envs/env.py:27-467) on top
+of the batched HIP backend (real_robots_amd.batched.BatchedREALRobotEnv with N = 1).
+
+Same constructor kwargs, action dictionaries, observation dictionaries, done logic, goal handling and scoring
+formula; the physics/render arithmetic runs in librealrobot_hip.so. Extra keyword arguments (`eye_width`,
+`eye_height`, `device`, `solver_iters`) have the reference's values as defaults.
+"""
+import os
+
+import numpy as np
+
+from .. import _native as nat
+from .. import spaces
+from ..batched import BatchedREALRobotEnv
+from ..kinematics import generate_plan, inverse_kinematics, quat_from_euler
+from .robot import Kuka
+
+
+def DefaultRewardFunc(observation):
+    return 0
+
+
+class Goal:
+    """Record of one extrinsic goal (env.py:15-24); instances are what goal datasets pickle."""
+
+    def __init__(self, initial_state=None, final_state=None, retina=None, retina_before=None, challenge=None,
+                 mask=None):
+        self.initial_state = initial_state
+        self.final_state = final_state
+        self.retina = retina
+        self.retina_before = retina_before
+        self.challenge = challenge
+        self.mask = mask
+
+
+class EnvCamera:
+    """Debug camera parameters of render('rgb_array') (env.py:470-513). Rendering it on the GPU is a "next" row
+    (SURVEY.md 8f-3); render() currently returns the eye camera frame."""
+
+    def __init__(self, distance, yaw, pitch, roll, pos, fov=80, width=320, height=240):
+        self.dist, self.yaw, self.pitch, self.roll, self.pos = distance, yaw, pitch, roll, pos
+        self.fov, self.render_width, self.render_height = fov, width, height
+
+
+class REALRobotEnv:
+    metadata = {'render.modes': ['human', 'rgb_array']}
+    intrinsic_timesteps = int(15e6)      # env.py:32-34
+    extrinsic_timesteps = int(10e3)
+    extrinsic_trials = int(50)
+
+    def __init__(self, render=False, objects=3, action_type='joints', additional_obs=True, eye_width=320,
+                 eye_height=240, device=0, solver_iters=50):
+        self.robot = Kuka(additional_obs, objects, eye_width, eye_height, env=self)
+        self.isRender = render
+        self._n_objects, self._device, self._solver_iters = objects, device, solver_iters
+        self._additional_obs = additional_obs
+        self._be = None
+        self.joints_space = self.robot.action_space
+        self.cartesian_space = spaces.Box(low=np.array([-0.25, -0.5, 0.40, -1, -1, -1, -1]),
+                                          high=np.array([0.25, 0.5, 0.60, 1, 1, 1, 1]), dtype=float)
+        self.macro_space = spaces.Box(low=np.array([[-0.25, -0.5], [-0.25, -0.5]]),
+                                      high=np.array([[0.05, 0.5], [0.05, 0.5]]), dtype=float)
+        self.gripper_space = spaces.Box(low=0, high=np.pi / 2, shape=(2,), dtype=float)
+        if action_type == 'joints':
+            self.action_space = spaces.Dict({"joint_command": self.joints_space, "render": spaces.MultiBinary(1)})
+            self.step = self.step_joints
+        elif action_type == 'cartesian':
+            self.action_space = spaces.Dict({"cartesian_command": self.cartesian_space,
+                                             "gripper_command": self.gripper_space, "render": spaces.MultiBinary(1)})
+            self.step = self.step_cartesian
+            self.requested_coords = None
+            self.requested_orient = None
+            self.last_ik = None
+        elif action_type == 'macro_action':
+            self.action_space = spaces.Dict({"macro_action": self.macro_space, "render": spaces.MultiBinary(1)})
+            self.step = self.step_macro
+            self.requested_action = None
+        else:
+            raise ValueError("action_type must be one 'joints', 'cartesian' or 'macro_action'")
+        self.observation_space = self.robot.observation_space
+        self._cam_dist, self._cam_yaw, self._cam_roll, self._cam_pitch = 1.2, 30, 0, -30
+        self._render_width, self._render_height = 320, 240
+        self._cam_pos = [0, 0, .4]
+        self.envCamera = EnvCamera(self._cam_dist, self._cam_yaw, self._cam_pitch, self._cam_roll, self._cam_pos,
+                                   width=self._render_width, height=self._render_height)
+        self.reward_func = DefaultRewardFunc
+        H, W = self.robot.eye_height, self.robot.eye_width
+        self.goal = Goal(retina=np.zeros((H, W, 3), np.uint8))
+        self.goals_dataset_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data",
+                                               "goals_dataset.npy.npz")
+        self.goals = None
+        self.goal_idx = -1
+        self.no_retina = np.zeros((H, W, 3), np.uint8)
+        self.no_depth = np.zeros((H, W), np.float64)
+        self.timestep = 0
+        if additional_obs:
+            self.get_observation = self.get_observation_extended
+            self.no_mask = np.zeros((H, W), np.int32)
+            self.goal.mask = self.no_mask
+
+    # ------------------------------------------------------------------ backend
+    def _backend(self):
+        if self._be is None:
+            self._be = BatchedREALRobotEnv(1, objects=self._n_objects, width=self.robot.eye_width,
+                                           height=self.robot.eye_height, device=self._device,
+                                           solver_iters=self._solver_iters)
+        return self._be
+
+    def close(self):
+        if self._be is not None:
+            self._be.close()
+            self._be = None
+
+    # ------------------------------------------------------------------ goals (env.py:143-200)
+    def load_goals(self):
+        self.goals = list(np.load(self.goals_dataset_path, allow_pickle=True).items())[0][1]
+
+    def set_goals_dataset_path(self, path):
+        assert os.path.exists(path), "Non existent path {}".format(path)
+        self.goals_dataset_path = path
+
+    def set_goal(self):
+        if self.goals is None:
+            self.load_goals()
+        self.goal_idx += 1
+        self.goal = self.goals[self.goal_idx]
+        for obj in self.goal.initial_state.keys():
+            position = self.goal.initial_state[obj][:3]
+            orientation = self.goal.initial_state[obj][3:]
+            self.robot.object_bodies[obj].reset_pose(position, orientation)
+        for obj in self.goal.final_state.keys():
+            self.goal.final_state[obj] = self.goal.final_state[obj][:3]
+        return self.get_observation()
+
+    def evaluateGoal(self):
+        score = 0
+        for obj in self.goal.final_state.keys():
+            if obj not in self.robot.object_bodies:
+                continue
+            p = np.array(self.robot.object_bodies[obj].get_position())
+            p_goal = np.array(self.goal.final_state[obj][:3])
+            pos_const = -np.log(0.25) / 0.10           # score falls to 0.25 within 10 cm
+            score += np.exp(-pos_const * np.linalg.norm(p_goal - p))
+        return self.goal.challenge, score
+
+    # ------------------------------------------------------------------ reset / render
+    def reset(self):
+        self._backend().reset()
+        self.timestep = 0
+        return self.get_observation()
+
+    def render(self, mode='human', close=False):
+        if mode == "human":
+            self.isRender = True
+        if mode != "rgb_array":
+            return np.array([])
+        retina, _, _ = self.get_retina()
+        return retina
+
+    def seed(self, seed=None):
+        return [seed]
+
+    # ------------------------------------------------------------------ queries (env.py:230-255)
+    def get_part_pos(self, name):
+        return self.robot.parts[name].get_position()
+
+    def get_obj_pos(self, name):
+        return self.robot.object_bodies[name].get_position()
+
+    def get_obj_pose(self, name):
+        return self.robot.object_bodies[name].get_pose()
+
+    def get_all_used_objects(self):
+        poses = self._backend().host(nat.F_OBJ_POSE)[0].astype(np.float64)
+        return {obj: poses[i, :3] for i, obj in enumerate(self.robot.used_objects[1:])}
+
+    def get_contacts(self):
+        return self.robot.get_contacts()
+
+    def get_retina(self):
+        be = self._backend()
+        be.render()
+        return be.host(nat.F_RGB)[0], be.host(nat.F_MASK)[0], be.host(nat.F_DEPTH)[0].astype(np.float64)
+
+    def _fetch_retina(self):
+        be = self._backend()
+        return be.host(nat.F_RGB)[0], be.host(nat.F_MASK)[0], be.host(nat.F_DEPTH)[0].astype(np.float64)
+
+    # ------------------------------------------------------------------ observations (env.py:266-312)
+    def get_observation(self, camera_on=True, _rendered=False):
+        joints = self.robot.calc_state()
+        sensors = self.robot.get_touch_sensors()
+        if camera_on:
+            retina, _, depth = self._fetch_retina() if _rendered else self.get_retina()
+        else:
+            retina, depth = self.no_retina, self.no_depth
+        O = Kuka.ObsSpaces
+        return {O.JOINT_POSITIONS: joints, O.TOUCH_SENSORS: sensors, O.RETINA: retina, O.DEPTH: depth,
+                O.GOAL: self.goal.retina}
+
+    def get_observation_extended(self, camera_on=True, _rendered=False):
+        joints = self.robot.calc_state()
+        sensors = self.robot.get_touch_sensors()
+        if camera_on:
+            retina, mask, depth = self._fetch_retina() if _rendered else self.get_retina()
+        else:
+            retina, mask, depth = self.no_retina, self.no_mask, self.no_depth
+        O = Kuka.ObsSpaces
+        return {O.JOINT_POSITIONS: joints, O.TOUCH_SENSORS: sensors, O.RETINA: retina, O.DEPTH: depth, O.MASK: mask,
+                O.OBJ_POS: self.get_all_used_objects(), O.GOAL: self.goal.retina, O.GOAL_MASK: self.goal.mask,
+                O.GOAL_POS: self.goal.final_state}
+
+    # ------------------------------------------------------------------ stepping (env.py:314-467)
+    def step_joints(self, action):
+        joint_action = action['joint_command']
+        camera_on = bool(np.any(action['render']))
+        if joint_action is None:
+            joint_action = np.zeros(9)
+        a = np.asarray(joint_action, dtype=np.float64)
+        assert np.isfinite(a).all()                     # robot.py:189
+        assert len(a) == self.robot.num_joints          # robot.py:190
+        self._backend().step(a.reshape(1, 9), render=camera_on)
+        observation = self.get_observation(camera_on, _rendered=True)
+        reward = self.reward_func(observation)
+        done = False
+        self.timestep += 1
+        if self.goal_idx < 0:
+            if self.timestep >= self.intrinsic_timesteps:
+                done = True
+        else:
+            if self.timestep >= self.extrinsic_timesteps:
+                done = True
+        return observation, reward, done, {}
+
+    def _q11(self):
+        return self._backend().state[0, :11].astype(np.float64)
+
+    def step_cartesian(self, action):
+        if action['cartesian_command'] is None:
+            joint_action = {"joint_command": np.zeros(9), "render": action['render']}
+        else:
+            coords = np.asarray(action['cartesian_command'][:3], dtype=np.float64)
+            orient = np.asarray(action['cartesian_command'][3:], dtype=np.float64)
+            same = (self.requested_coords is not None and np.all(coords == self.requested_coords)
+                    and np.all(orient == self.requested_orient))
+            if same:
+                arm_joints = self.last_ik
+            else:
+                arm_joints = inverse_kinematics(self._q11(), coords, orient)
+                self.last_ik = arm_joints
+                self.requested_coords = coords
+                self.requested_orient = orient
+            all_joints = np.hstack([arm_joints[:7], action['gripper_command']])
+            joint_action = {"joint_command": all_joints, "render": action['render']}
+        return self.step_joints(joint_action)
+
+    def step_macro(self, action):
+        macro_action = action['macro_action']
+        if macro_action is None:
+            joint_action = {"joint_command": np.zeros(9), "render": action['render']}
+        else:
+            macro_action = np.asarray(macro_action, dtype=np.float64)
+            same = self.requested_action is not None and np.all(macro_action == self.requested_action)
+            joints = self.next_step() if same else None
+            if not same or joints is None:
+                self.requested_action = macro_action
+                self.generate_plan(macro_action)
+                joints = self.next_step()
+            joint_action = {"joint_command": joints, "render": action['render']}
+        return self.step_joints(joint_action)
+
+    def generate_plan(self, macro_action):
+        """1000-step plan of 9-vectors (env.py:388-454): home2, above p1, at p1, p1->p2 in <=5 cm IK segments,
+        above p2, home2, home."""
+        self.planned_actions = generate_plan(self._q11(), macro_action)
+        self.plan_step = -1
+
+    def next_step(self):
+        self.plan_step += 1
+        if self.plan_step < len(self.planned_actions):
+            return self.planned_actions[self.plan_step, :]
+        return None

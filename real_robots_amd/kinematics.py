@@ -1,0 +1,165 @@
+"""Host-side kinematics of the Kuka + gripper (numpy, float64): forward kinematics, geometric Jacobian and a damped
+least squares IK for link 7 (gripper `base`) -- the host restatement of what the reference asks pybullet for in
+step_cartesian / generate_plan (real_robots/envs/env.py:372-375, 422-427:
+calculateInverseKinematics(0, 7, pos, orn, maxNumIterations=1000, residualThreshold=0.001)).
+Only (re)planning uses it (<= ~15 solves per 1000 steps); the per-step path stays on the GPU.
+"""
+import numpy as np
+
+from .model import load_model
+
+PARENT = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 6, 9]
+EE_LINK = 8          # URDF depth-first id of gripper `base` (pybullet link index 7), rigidly attached to body 6
+
+
+def _axis_angle(a, ang):
+    c, s = np.cos(ang), np.sin(ang)
+    t = 1 - c
+    x, y, z = a
+    return np.array([[t * x * x + c, t * x * y - s * z, t * x * z + s * y],
+                     [t * x * y + s * z, t * y * y + c, t * y * z - s * x],
+                     [t * x * z - s * y, t * y * z + s * x, t * z * z + c]])
+
+
+def quat_from_euler(r, p, y):
+    """pybullet.getQuaternionFromEuler (xyzw, rotation = Rz(y) Ry(p) Rx(r))."""
+    cr, sr, cp, sp, cy, sy = np.cos(r / 2), np.sin(r / 2), np.cos(p / 2), np.sin(p / 2), np.cos(y / 2), np.sin(y / 2)
+    return np.array([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy,
+                     cr * cp * cy + sr * sp * sy])
+
+
+def quat_to_mat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def forward(q11):
+    """Returns (R[11,3,3], p[11,3], axis_world[11,3]) of the 11 moving bodies."""
+    m = load_model()
+    R = np.zeros((11, 3, 3))
+    p = np.zeros((11, 3))
+    ax = np.zeros((11, 3))
+    for b in range(11):
+        if PARENT[b] < 0:
+            Rp, pp = np.eye(3), m['robot_pos'].astype(np.float64)
+        else:
+            Rp, pp = R[PARENT[b]], p[PARENT[b]]
+        Rj = Rp @ m['body_jrot'][b].astype(np.float64)
+        a = m['body_axis'][b].astype(np.float64)
+        p[b] = pp + Rp @ m['body_jpos'][b].astype(np.float64)
+        R[b] = Rj @ _axis_angle(a, q11[b])
+        ax[b] = Rj @ a
+    return R, p, ax
+
+
+def link_pose(q11, link):
+    """World (R, p) of the COM frame of robot link `link` (URDF depth-first id)."""
+    m = load_model()
+    b = int(m['link_body'][link])
+    lr = m['link_rot'][link].astype(np.float64)
+    lp = m['link_pos'][link].astype(np.float64)
+    if b < 0:
+        return lr, m['robot_pos'].astype(np.float64) + lp
+    R, p, _ = forward(q11)
+    return R[b] @ lr, p[b] + R[b] @ lp
+
+
+def ee_jacobian(q11):
+    """6x7 geometric Jacobian (linear; angular) of the gripper base frame w.r.t. the 7 arm joints."""
+    R, p, ax = forward(q11)
+    Re, pe = link_pose(q11, EE_LINK)
+    J = np.zeros((6, 7))
+    for k in range(7):
+        J[:3, k] = np.cross(ax[k], pe - p[k])
+        J[3:, k] = ax[k]
+    return J, Re, pe
+
+
+ELBOW_UP_SEED = np.array([0.0, 0.6, 0.0, -1.3, 0.0, 1.2, 0.0])
+
+
+def _dls(q, target_pos, Rt, max_iters, residual, damping):
+    lam2 = damping * damping
+    err = np.inf
+    for _ in range(int(max_iters)):
+        J, Re, pe = ee_jacobian(q)
+        dp = np.asarray(target_pos, dtype=np.float64) - pe
+        Rerr = Rt @ Re.T
+        w = 0.5 * np.array([Rerr[2, 1] - Rerr[1, 2], Rerr[0, 2] - Rerr[2, 0], Rerr[1, 0] - Rerr[0, 1]])
+        e = np.concatenate([dp, w])
+        err = np.linalg.norm(e)
+        if err < residual:
+            break
+        dq = J.T @ np.linalg.solve(J @ J.T + lam2 * np.eye(6), e)
+        n = np.abs(dq).max()
+        if n > 0.5:
+            dq *= 0.5 / n
+        q[:7] += dq
+        q[:7] = (q[:7] + np.pi) % (2 * np.pi) - np.pi
+    return q, err
+
+
+def inverse_kinematics(q11, target_pos, target_quat, max_iters=1000, residual=1e-3, damping=0.1, prefer=None):
+    """Damped least squares IK for link 7 (gripper base) position + orientation; returns all 11 dofs like pybullet
+    does (the fingers keep their current values).  pybullet seeds DLS with the current joints and the branch it lands
+    on is an implementation detail of its solver; here two seeds are tried (current joints, a canonical elbow-up
+    posture) and, among the converged ones, the solution with the highest elbow (link_4 origin) is returned -- the
+    collision-free branch the reference's tracking test expects (tests/test_actions.py:147-152)."""
+    q0 = np.array(q11, dtype=np.float64)
+    Rt = quat_to_mat(np.asarray(target_quat, dtype=np.float64) / np.linalg.norm(target_quat))
+    best, best_key = None, None
+    seeds = [q0[:7], ELBOW_UP_SEED] + ([np.asarray(prefer, dtype=np.float64)[:7]] if prefer is not None else [])
+    for seed in seeds:
+        q = q0.copy()
+        q[:7] = seed
+        q, err = _dls(q, target_pos, Rt, max_iters, residual, damping)
+        _, p, _ = forward(q)
+        if prefer is not None:     # continuity with the previous way-point of a plan
+            key = (err < 10 * residual, -float(np.abs(q[:7] - np.asarray(prefer)[:7]).max()))
+        else:                      # converged first, then elbow height
+            key = (err < 10 * residual, p[3][2])
+        if best is None or key > best_key:
+            best, best_key = q, key
+    return best
+
+
+def generate_plan(q_seed11, macro_action):
+    """The reference's 1000-step macro plan of 9-vectors (real_robots/envs/env.py:388-454): 100x home2, 100x above
+    p1 (z 0.6), 50x at p1 (z 0.46), 500x p1->p2 at z 0.46 in <= 5 cm IK segments, 50x above p2, 100x home2, 100x home.
+    IK orientation getQuaternionFromEuler([0, 3.14, -1.57]) (env.py:422); each IK result is cut to its first 9 dofs
+    (env.py:427)."""
+    point_1, point_2 = np.asarray(macro_action[0], dtype=np.float64), np.asarray(macro_action[1], dtype=np.float64)
+    home = np.zeros(9)
+    home2 = np.zeros(9)
+    home2[5] = np.pi / 2
+    home2[6] = np.pi / 2
+    orient = quat_from_euler(0, 3.14, -1.57)
+    q_seed = np.asarray(q_seed11, dtype=np.float64)
+
+    last = [None]
+
+    def goToPosXY(coords):
+        q = inverse_kinematics(q_seed, coords, orient, prefer=last[0])
+        last[0] = q
+        return q[:9].copy()
+
+    def interpolate3D(p1, p2, steps):
+        p1, p2 = np.array(p1), np.array(p2)
+        dist = np.linalg.norm(p2 - p1)
+        pieces = min(int(dist / 0.05) + 1, steps)
+        coords = np.linspace(p1, p2, pieces + 1)
+        joints = np.zeros((steps, 9))
+        chunk = int(steps / pieces)
+        for i, coord in enumerate(coords[1:]):
+            joints[i * chunk:, :] = goToPosXY(coord)
+        return joints
+
+    point_1_h = goToPosXY(np.hstack([point_1, 0.6]))
+    point_1_l = goToPosXY(np.hstack([point_1, 0.46]))
+    point_2_h = goToPosXY(np.hstack([point_2, 0.6]))
+    parts = [np.tile(home2, (100, 1)), np.tile(point_1_h, (100, 1)), np.tile(point_1_l, (50, 1)),
+             interpolate3D(np.hstack([point_1, 0.46]), np.hstack([point_2, 0.46]), 500),
+             np.tile(point_2_h, (50, 1)), np.tile(home2, (100, 1)), np.tile(home, (100, 1))]
+    return np.vstack(parts)

@@ -1,0 +1,3 @@
+#!/bin/bash
+mkdir -p gpurun_out
+python -m pytest tests/ -x -q -m gpu 2>&1 | tail -30

@@ -1,0 +1,234 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs, plus size-independent properties at the benchmark's full size.
+
+Tolerances (fp32 HIP path vs float64 oracle, stated per test):
+  free motion / resting contact, <= 300 steps : |dq| < 1e-4 rad, object position < 1e-3 m
+  robot-object contact (grasp script)         : compared against the fp32 build of the oracle over a short
+                                                horizon (contact switching amplifies rounding): < 5e-3 m
+  images                                      : <= 0.5 % pixels differing by more than 2 grey levels; mask identical
+                                                on >= 99.5 % pixels; depth within 1e-5 on agreeing pixels
+"""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from real_robots_amd import _native as nat
+from real_robots_amd.batched import BatchedREALRobotEnv
+from real_robots_amd.distributed import synthetic_actions
+
+pytestmark = pytest.mark.gpu
+
+
+def _objs(state):
+    return state[22:].reshape(3, 13)
+
+
+def test_free_motion_and_resting_contact_parity():
+    N, T = 16, 300
+    env = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    orcs = [Oracle(3, 64, 64) for _ in range(4)]
+    for t in range(T):
+        act = synthetic_actions(range(N), t, seed=7) * 0.4
+        act[:, 7:] = np.abs(act[:, 7:])
+        env.step(act)
+        for i, o in enumerate(orcs):
+            o.step(act[i].astype(np.float64))
+    st = env.state
+    joints = env.host(nat.F_JOINTS)
+    for i, o in enumerate(orcs):
+        ref = o.state
+        assert np.abs(st[i][:11] - ref[:11]).max() < 1e-4
+        assert np.abs(st[i][11:22] - ref[11:22]).max() < 1e-3
+        assert np.abs(_objs(st[i])[:, :3] - _objs(ref)[:, :3]).max() < 1e-3
+        assert np.abs(joints[i] - o.obs()[0]).max() < 1e-4
+    assert (env.host(nat.F_TIMESTEP) == T).all()
+    assert (env.host(nat.F_ERRFLAGS) == 0).all()
+    env.close()
+
+
+def _grasp_script(q_home):
+    from real_robots_amd.kinematics import inverse_kinematics, quat_from_euler
+    orient = quat_from_euler(0, 3.14, -1.57)
+    q_hi = inverse_kinematics(q_home, [-0.1, 0.0, 0.55], orient)
+    q_lo = inverse_kinematics(q_hi, [-0.1, 0.0, 0.47], orient)
+    seq = [(q_hi, [0.5, 0.0], 150), (q_lo, [0.5, 0.0], 120), (q_lo, [0.0, 0.0], 60)]
+    cmds = []
+    for q, g, n in seq:
+        cmds += [np.concatenate([q[:7], g])] * n
+    return np.array(cmds)
+
+
+def test_robot_object_contact_parity_and_touch_sensors():
+    cmds = _grasp_script(np.zeros(11))
+    env = BatchedREALRobotEnv(4, objects=1, width=64, height=64)
+    o = Oracle(1, 64, 64, f32=True)
+    for _ in range(100):
+        env.step(None)
+        o.step(None)
+    touch_max = 0
+    for t, c in enumerate(cmds):
+        env.step(np.tile(c.astype(np.float32), (4, 1)))
+        o.step(c.astype(np.float32).astype(np.float64))
+        if t >= 270:
+            touch_max = max(touch_max, env.host(nat.F_TOUCH).max())
+        if t in (149, 269, 290):
+            st = env.state[0]
+            assert np.abs(st[:11] - o.state[:11]).max() < 2e-3, t
+            assert np.abs(_objs(st)[0, :3] - _objs(o.state)[0, :3]).max() < 5e-3, t
+    st = env.state
+    assert np.abs(st - st[0]).max() == 0.0          # identical envs stay bitwise identical
+    assert touch_max > 1.0 and o.obs()[1].max() > 1.0
+    touch = env.host(nat.F_TOUCH)[0]
+    assert touch[[1, 3]].min() > 1.0                # distal skins of both fingers press on the cube
+    cont = env.contacts(0)
+    assert len(cont) > 0 and (cont[:, 10] >= 0).all()
+    env.close()
+
+
+@pytest.mark.parametrize("W,H", [(128, 128), (320, 240)])
+def test_raster_parity(W, H):
+    N = 4
+    env = BatchedREALRobotEnv(N, objects=3, width=W, height=H)
+    o = Oracle(3, W, H)
+    rng = np.random.default_rng(3)
+    act = rng.uniform(-1.2, 1.2, (N, 9)).astype(np.float32)
+    act[:, 7:] = np.abs(act[:, 7:])
+    for t in range(120):
+        env.step(act, render=(t == 119))
+    st = env.state
+    rgb, dep, msk = env.host(nat.F_RGB), env.host(nat.F_DEPTH), env.host(nat.F_MASK)
+    assert rgb.shape == (N, H, W, 3) and dep.shape == (N, H, W) and msk.dtype == np.int32
+    for i in range(N):
+        o.state = st[i].astype(np.float64)
+        r, d, m = o.render()
+        same = (m == msk[i])
+        assert same.mean() > 0.995
+        assert (np.abs(r.astype(int) - rgb[i].astype(int)).max(-1) > 2).mean() < 5e-3
+        assert np.abs(d - dep[i])[same].max() < 1e-5
+        assert set(np.unique(msk[i]).tolist()) <= {-1, 0, 1, 2, 3, 4}
+    env.close()
+
+
+def test_per_env_render_flags_and_none_action():
+    N = 8
+    env = BatchedREALRobotEnv(N, objects=2, width=64, height=64)
+    env.render()
+    before = env.host(nat.F_RGB).copy()
+    flags = np.zeros(N, np.uint8)
+    flags[::2] = 1
+    act = np.zeros((N, 9), np.float32)
+    act[:, 1] = 0.8
+    for _ in range(40):
+        env.step(act, render=flags)
+    after = env.host(nat.F_RGB)
+    assert (after[1::2] == before[1::2]).all()            # not rendered: buffers untouched
+    assert (after[::2] != before[::2]).any()
+    q0 = env.state[:, :11].copy()
+    env.step(None)                                        # env.py:333-334: None -> zeros(9)
+    assert (np.abs(env.state[:, 1]) < np.abs(q0[:, 1])).all()
+    env.close()
+
+
+def test_shard_equivalence_and_determinism():
+    """N envs on one device == the same envs split into two shards (bitwise); a repeated run is bitwise equal."""
+    N, T = 64, 60
+    def run(ids):
+        env = BatchedREALRobotEnv(len(ids), objects=3, width=64, height=64)
+        for t in range(T):
+            env.step(synthetic_actions(ids, t, seed=11) * 0.5)
+        s = env.state
+        env.close()
+        return s
+    full = run(list(range(N)))
+    again = run(list(range(N)))
+    assert (full == again).all()
+    a, b = run(list(range(0, 32))), run(list(range(32, 64)))
+    assert (np.concatenate([a, b]) == full).all()
+
+
+def test_reset_mask_set_state_and_oob_reset():
+    N = 6
+    env = BatchedREALRobotEnv(N, objects=2, width=64, height=64)
+    act = np.full((N, 9), 0.3, np.float32)
+    for _ in range(30):
+        env.step(act)
+    moved = env.state
+    mask = np.array([1, 0, 1, 0, 0, 0], np.uint8)
+    env.reset(mask)
+    st = env.state
+    assert (st[[0, 2], :22] == 0).all() and np.abs(st[1] - moved[1]).max() == 0
+    ts = env.host(nat.F_TIMESTEP)
+    assert ts[0] == 0 and ts[1] == 30
+    # checkpoint / restore
+    env.state = moved
+    assert (env.state == moved).all()
+    # out-of-bounds object is re-posed on the next step (env.py:257-264)
+    env.set_object_pose(3, 0, [0.5, 0.5, 0.02, 0, 0, 0, 1])
+    env.step(act)
+    p = env.host(nat.F_OBJ_POSE)[3, 0, :3]
+    assert np.allclose(p, [-0.1, 0.0, 0.45], atol=1e-3)
+    env.close()
+
+
+def test_link_poses_match_fk_fixture():
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'fk_golden.json')))
+    cases = gold['cases']
+    env = BatchedREALRobotEnv(len(cases), objects=1, width=64, height=64)
+    st = env.state
+    for i, c in enumerate(cases):
+        cmd = np.array(c['cmd'])
+        st[i, :7] = cmd[:7]
+        st[i, 7] = st[i, 9] = cmd[7]
+        st[i, 8] = st[i, 10] = -cmd[8]
+    env.state = st
+    lp = env.link_poses()
+    for i, c in enumerate(cases):
+        for link, pos in c['links'].items():
+            assert np.allclose(lp[i, nat.LINK_NAMES.index(link), :3], pos, atol=5e-6), link
+    env.close()
+
+
+def test_full_size_properties_4096_envs():
+    """BASELINE config 3 size (4096 envs, 3 objects, 128x128): size-independent checks."""
+    N = 4096
+    env = BatchedREALRobotEnv(N, objects=3, width=128, height=128)
+    ids = np.arange(N)
+    for t in range(150):
+        act = synthetic_actions(ids % 64, t, seed=5) * 0.3       # 64 distinct action streams, each repeated 64x
+        env.step(act, render=(t == 149))
+    st = env.state
+    assert np.isfinite(st).all() and (env.host(nat.F_ERRFLAGS) == 0).all()
+    # replicas of the same action stream are bitwise identical, wherever they sit in the batch
+    assert (st.reshape(64, 64, 61) == st.reshape(64, 64, 61)[0:1]).all()
+    objs = st[:, 22:].reshape(N, 3, 13)
+    top = 0.08 + 0.199403
+    assert (objs[:, :, 2] > top).all() and (objs[:, :, 2] < 0.46).all()
+    assert np.abs(np.linalg.norm(objs[:, :, 3:7], axis=2) - 1).max() < 1e-5
+    msk = env.host(nat.F_MASK)
+    assert (msk[:, 64, 64] >= -1).all() and ((msk == 1).sum(axis=(1, 2)) > 500).all()
+    rgb = env.host(nat.F_RGB)
+    assert (rgb.reshape(64, 64, -1) == rgb.reshape(64, 64, -1)[0:1]).all()
+    env.close()
+
+
+def test_gym_facade_step_contract():
+    import real_robots_amd as rr
+    env = rr.make('REALRobot2020-R1J3-v0', eye_width=64, eye_height=64)
+    obs = env.reset()
+    assert set(obs) == {'joint_positions', 'touch_sensors', 'retina', 'depth', 'mask', 'object_positions', 'goal',
+                        'goal_mask', 'goal_positions'}
+    assert obs['retina'].shape == (64, 64, 3) and obs['retina'].dtype == np.uint8 and obs['retina'].any()
+    assert set(obs['object_positions']) == {'cube', 'tomato', 'mustard'}
+    env.intrinsic_timesteps = 3
+    a = {'joint_command': np.full(9, 0.2), 'render': False}
+    for k in range(3):
+        obs, reward, done, info = env.step(a)
+        assert reward == 0 and info == {} and done == (k == 2)
+    assert not obs['retina'].any() and len(obs['joint_positions']) == 9       # camera off -> zero placeholders
+    with pytest.raises(AssertionError):
+        env.step({'joint_command': np.array([np.nan] * 9), 'render': False})
+    with pytest.raises(AssertionError):
+        env.step({'joint_command': np.zeros(8), 'render': False})
+    assert np.allclose(env.get_part_pos('base'), [-0.55, 0, 1.27], atol=0.05)
+    env.close()

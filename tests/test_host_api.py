@@ -1,0 +1,152 @@
+"""CPU tests (-m "not gpu") of the host layer and the C-ABI boundary (no compute calls: there is no GPU here)."""
+import ctypes as C
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+import real_robots_amd as rr
+from real_robots_amd import _native as nat
+from real_robots_amd import spaces
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'realrobot.h')).read()
+    declared = sorted(set(re.findall(r'\b(rr_[a-z_]+)\s*\(', header)))
+    assert declared == sorted(nat.SYMBOLS)
+    L = nat.load_library()
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.rr_abi_version() == nat.RR_ABI_VERSION
+
+
+def test_create_rejects_bad_arguments_and_fails_loudly_without_gpu():
+    L = nat.load_library()
+    blob = nat.model_blob()
+    h = C.c_void_p()
+    cfg = nat.Config()
+    cfg.abi_version, cfg.num_envs, cfg.n_objects, cfg.width, cfg.height = nat.RR_ABI_VERSION, 4, 3, 128, 128
+    assert L.rr_create(None, blob, len(blob), None, C.byref(h)) == -1
+    bad = nat.Config.from_buffer_copy(cfg)
+    bad.n_objects = 5
+    assert L.rr_create(C.byref(bad), blob, len(blob), None, C.byref(h)) == -1
+    assert b'n_objects' in L.rr_last_error()
+    bad = nat.Config.from_buffer_copy(cfg)
+    bad.abi_version = 99
+    assert L.rr_create(C.byref(bad), blob, len(blob), None, C.byref(h)) == -1
+    assert L.rr_create(C.byref(cfg), b'garbage' * 10, 70, None, C.byref(h)) == -3     # RR_EMODEL
+    import torch
+    if not torch.cuda.is_available():
+        rc = L.rr_create(C.byref(cfg), blob, len(blob), None, C.byref(h))
+        assert rc == -2 and b'no CPU fallback' in L.rr_last_error()                 # RR_EDEVICE
+        env = rr.make('REALRobot2020-R2J3-v0')
+        with pytest.raises(RuntimeError):
+            env.reset()
+
+
+def test_null_env_calls_return_einval():
+    L = nat.load_library()
+    assert L.rr_step(None, None, 0, 0, None) == -1
+    assert L.rr_reset(None, None) == -1
+    assert L.rr_render(None) == -1
+    assert L.rr_sync(None) == -1
+    assert L.rr_destroy(None) == 0
+
+
+def test_registry_has_the_18_reference_ids():
+    ids = rr.registered_ids()
+    assert len(ids) == 18
+    for rnd in ('R1', 'R2'):
+        for a in 'JCM':
+            for n in (1, 2, 3):
+                assert 'REALRobot2020-%s%s%d-v0' % (rnd, a, n) in ids
+    with pytest.raises(KeyError):
+        rr.make('REALRobot-v0')
+
+
+def test_env_spaces_and_constructor_contract():
+    env = rr.make('REALRobot2020-R1M2-v0')
+    assert env.robot.used_objects == ['table', 'cube', 'tomato']
+    assert set(env.action_space.spaces) == {'macro_action', 'render'}
+    assert env.macro_space.shape == (2, 2)
+    assert set(env.observation_space.spaces) == {'joint_positions', 'touch_sensors', 'retina', 'depth', 'goal', 'mask',
+                                                 'goal_mask', 'object_positions', 'goal_positions'}
+    assert env.observation_space.spaces['retina'].shape == (240, 320, 3)
+    env2 = rr.make('REALRobot2020-R2J3-v0')
+    assert set(env2.observation_space.spaces) == {'joint_positions', 'touch_sensors', 'retina', 'depth', 'goal'}
+    a = env2.action_space.sample()
+    assert a['joint_command'].shape == (9,) and env2.joints_space.contains(a['joint_command'])
+    lim = env2.robot.max_joints
+    assert np.allclose(lim[[0, 1, 2, 6, 7]], [0.666 * np.pi, 0.666 * np.pi, 0.944 * np.pi, 0.972 * np.pi, np.pi / 2])
+    assert (env2.intrinsic_timesteps, env2.extrinsic_timesteps, env2.extrinsic_trials) == (int(15e6), int(10e3), 50)
+    assert env2.goal_idx == -1 and (env2.goal.retina == 0).all()
+    with pytest.raises(ValueError):
+        rr.REALRobotEnv(action_type='teleport')
+    with pytest.raises(AssertionError):
+        env2.set_goals_dataset_path('/nonexistent/goals.npz')
+
+
+def test_evaluate_argument_checks():
+    class P(rr.BasePolicy):
+        def step(self, o, r, d):
+            return {'joint_command': np.zeros(9), 'render': False}
+    for kw in (dict(environment='R3'), dict(environment='R2', action_type='macro_action'), dict(action_type='fly'),
+               dict(n_objects=4)):
+        with pytest.raises(Exception):
+            rr.evaluate(P, goals_dataset_path=__file__, **kw)
+    with pytest.raises(Exception):
+        rr.evaluate(object, environment='R2', action_type='joints', goals_dataset_path=__file__)
+    with pytest.raises(NotImplementedError):
+        rr.BasePolicy(None, None).step(None, 0, False)
+
+
+def test_goal_dataset_format_roundtrip(tmp_path):
+    """np.savez_compressed(path, list_of_goals) / np.load(allow_pickle) of Goal objects (env.py:143-145)."""
+    from real_robots_amd.envs import Goal
+    g = Goal(initial_state={'cube': np.arange(7.0)}, final_state={'cube': np.ones(7)}, retina=np.zeros((4, 4, 3), np.uint8),
+             challenge='2D', mask=np.zeros((4, 4), np.int32))
+    path = str(tmp_path / 'goals.npy.npz')
+    np.savez_compressed(path, np.array([g, g], dtype=object))
+    env = rr.make('REALRobot2020-R1J1-v0')
+    env.set_goals_dataset_path(path)
+    env.load_goals()
+    assert len(env.goals) == 2 and env.goals[0].challenge == '2D'
+    assert pickle.loads(pickle.dumps(g)).final_state['cube'].shape == (7,)
+
+
+def test_spaces_standins():
+    b = spaces.Box(low=np.zeros(3), high=np.ones(3), dtype=float)
+    assert b.contains(b.sample()) and not b.contains(np.array([2.0, 0, 0]))
+    d = spaces.Dict({'a': b, 'r': spaces.MultiBinary(1)})
+    s = d.sample()
+    assert set(s) == {'a', 'r'} and d.contains(s)
+
+
+def test_model_blob_and_ik():
+    from real_robots_amd.kinematics import EE_LINK, inverse_kinematics, link_pose, quat_from_euler
+    from real_robots_amd.model import load_model
+    m = load_model()
+    assert tuple(m['dims'][:4]) == (11, 17, 22, 22)
+    assert abs(float(m['body_mass'].sum()) - 27.5) < 1e-4          # SURVEY A.2 total mass
+    q = inverse_kinematics(np.zeros(11), [0.0, 0.2, 0.5], quat_from_euler(0, 3.14, -1.57))
+    assert np.linalg.norm(link_pose(q, EE_LINK)[1] - [0.0, 0.2, 0.5]) < 2e-3
+
+
+def test_shard_ranges_partition_and_actions_are_shard_invariant():
+    from real_robots_amd.distributed import shard_range, shard_of, synthetic_actions
+    for total, world in ((4096, 8), (10, 3), (7, 8)):
+        covered = []
+        for r in range(world):
+            a, b = shard_range(total, r, world)
+            covered += list(range(a, b))
+        assert covered == list(range(total))
+    assert shard_of(5, 10, 3) == (1, 1)
+    full = synthetic_actions(range(16), step=7)
+    a, b = shard_range(16, 1, 2)
+    assert (synthetic_actions(range(a, b), step=7) == full[a:b]).all()
+    assert (synthetic_actions(range(16), step=8) == full).sum() > 0      # held
+    assert not (synthetic_actions(range(16), step=60) == full).all()     # resampled
