@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: aggregate env-steps/s of the batched REALRobot env.step() hot path.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): REALRobot2020-R2J3-v0, 4096 envs
+per GPU, 3 objects, 128x128 top-down RGB + depth rendered every step; one "step" = one env.step() of every env in
+the batch.  Weak scaling: every rank owns 4096 envs; no collective on the stepping path.  Joint commands are
+synthetic (README-style resample-and-hold keyed by global env id) and are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant kernel (by measured device time): algorithmic bytes per launch / HIP-event duration vs the
+                8 TB/s HBM peak; measured in a separate pass with the library's per-kernel HIP events
+  cpu_baseline  the CPU oracle (oracle/, the checker -- never the product) timed on this box's host cores on a
+                bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+N_OBJECTS = 3
+W = H = 128
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+# algorithmic bytes per env-step, per kernel (DESIGN.md "Roofline accounting")
+STATE_BYTES = (22 + 39 + 11) * 4 * 2 + 9 * 4 + (9 + 4 + 21) * 4          # state R/W + command + low-dim obs
+ALGO_BYTES = {
+    'k_prep': STATE_BYTES,
+    'k_collide': STATE_BYTES,
+    'k_solve': STATE_BYTES,
+    'k_render_setup': 11 * 4 + 39 * 4 + 22 * 12 * 4,
+    'k_raster': W * H * 3 + W * H * 4 + 22 * 12 * 4,                      # RGB u8 + depth f32 (+ instance matrices)
+}
+ALGO_BYTES_PER_ENV_STEP = STATE_BYTES + W * H * 3 + W * H * 4
+
+
+def _cpu_worker(args):
+    seconds, seed = args
+    import numpy as np
+    from oracle.oracle import Oracle
+    from real_robots_amd.distributed import synthetic_actions
+    o = Oracle(N_OBJECTS, W, H)
+    acts = [synthetic_actions([seed], t)[0].astype(np.float64) for t in range(0, 400, 20)]
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            o.step(acts[(n // 20) % len(acts)])
+            o.render()
+            n += 1
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(seconds=10.0):
+    """Oracle (kind "port") on the host cores this process may use, one env per process, same per-env workload
+    (step + 128x128 render); time-bounded sample."""
+    import multiprocessing as mp
+    from oracle import oracle as orc
+    orc.build()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(seconds, i) for i in range(cores)])
+    rate = sum(n / t for n, t in res)
+    return {"value": round(rate, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d processes x 1 env x %.0f s each (%d env-steps in total), 3 objects, 128x128 RGB+depth render "
+                      "every step (oracle/rr_oracle.c, float64 physics)" % (cores, seconds, sum(n for n, _ in res))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
+    ap.add_argument('--envs-per-block', type=int, default=0)
+    ap.add_argument('--solver-iters', type=int, default=50)
+    ap.add_argument('--presettle', type=int, default=150,
+                    help='untimed steps before the warmup so that the timed region runs in steady state '
+                         '(objects landed on the table, arms moving, contacts active)')
+    ap.add_argument('--no-render', action='store_true', help='dynamics-only variant (not the headline metric)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gather', action='store_true', help='also all-gather the low-dim observations every step (RCCL)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()             # before this process touches the GPU
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from real_robots_amd import _native as nat
+    from real_robots_amd.batched import BatchedREALRobotEnv
+    from real_robots_amd.distributed import shard_range, synthetic_actions
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')          # RCCL on ROCm
+
+    n_local = args.envs_per_gpu
+    total = n_local * world
+    start, stop = shard_range(total, rank, world)
+    ids = np.arange(start, stop)
+    env = BatchedREALRobotEnv(n_local, objects=N_OBJECTS, width=W, height=H, device=local_rank,
+                              envs_per_block=args.envs_per_block, solver_iters=args.solver_iters)
+    render = not args.no_render
+
+    # synthetic commands, resident in HBM before the timed region: one [n_local, 9] tensor per resample epoch
+    n_total_steps = args.presettle + args.warmup + args.steps
+    epochs = {}
+    cmd_of_step = []
+    for t in range(n_total_steps):
+        key = t // 20
+        if key not in epochs:
+            epochs[key] = torch.from_numpy(synthetic_actions(ids, key * 20, hold_prob=0.05) * 0.5).cuda()
+        cmd_of_step.append(epochs[key])
+    joints_buf = torch.as_tensor(env.device_buffer(nat.F_JOINTS), device='cuda:%d' % local_rank) if args.gather else None
+
+    def one_step(t):
+        env.step(device_ptr=cmd_of_step[t].data_ptr(), render=render)
+        if args.gather and world > 1:
+            parts = [torch.empty_like(joints_buf) for _ in range(world)]
+            dist.all_gather(parts, joints_buf)
+
+    for t in range(args.presettle + args.warmup):
+        one_step(t)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.presettle + args.warmup, n_total_steps):
+        one_step(t)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert (env.host(nat.F_ERRFLAGS) == 0).all(), "an env reported a non-finite state"
+
+    # per-kernel device time (HIP events on the library's stream), separate pass
+    env.set_timing(1)
+    nprof = min(20, args.steps)
+    for t in range(nprof):
+        one_step(args.presettle + args.warmup + t)
+    timing = env.get_timing()
+    env.set_timing(0)
+    kernels = {}
+    for k, (ms, n) in timing.items():
+        if n:
+            kernels[k] = {"avg_ms": round(ms / n, 4), "launches": n,
+                          "achieved_GBs": round(ALGO_BYTES[k] * n_local / (ms / n * 1e-3) / 1e9, 2)}
+    dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')      # PMC-derived HBM bytes per launch, if collected
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * n_local,
+                "whole_step_achieved_GBs": round(ALGO_BYTES_PER_ENV_STEP * n_local * args.steps / elapsed / 1e9, 2),
+                "kernels": kernels}
+
+    if rank == 0:
+        out = {
+            "metric": "env-steps/sec (whole node), 4096 envs, R2J3 3-obj + 128x128 cam",
+            "value": round(total * args.steps / elapsed, 1), "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "REALRobot2020-R2J3-v0, %d envs/GPU, 3 objects + contact solver, %s" %
+                                   (n_local, "128x128 top-down RGB+depth render every step" if render else "no render"),
+                       "envs_total": total, "solver_iters": args.solver_iters, "dt": 0.005, "parallelism": "env-shard x%d" % world},
+            "roofline": roofline}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

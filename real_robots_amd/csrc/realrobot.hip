@@ -58,7 +58,7 @@ struct BodyParams {   // passed by value as kernel argument -> scalar loads, uni
 };
 
 struct SimParams {
-    int N, nobj, iters, npairs;
+    int N, nobj, iters, npairs, ablate;
     float dt, gravity, erp, margin, kp, kd, max_impulse, lin_damp, ang_damp, rest_thresh;
 };
 
@@ -72,7 +72,7 @@ struct ShapeData {    // global memory, read uniformly
 };
 
 struct RenderModel {
-    int ni, nt, W, H, tile_h, ntiles;
+    int ni, nt, W, H, tile_h, ntiles, first_dynamic_tri;
     int in_otype[MAXINST], in_oidx[MAXINST], in_uid[MAXINST], in_tex[MAXINST];
     float in_color[MAXINST][3];
     int tex_off[16], tex_w[16], tex_h[16];
@@ -127,6 +127,8 @@ struct DevPtrs {
     const int *tri_inst;    // [NT]
     const unsigned *tex;    // RGBX texels
     const ShapeData *shapes;
+    const unsigned long long *static_vis;   // [H*W] visibility keys of the never-moving instances (or nullptr)
+    unsigned long long *static_vis_out;
 };
 
 // Kinematic tree of the 11 moving bodies (lbr_iiwa_link_1..7 [+gripper base], finger_00, finger_01, finger_10,
@@ -568,47 +570,100 @@ __device__ __forceinline__ void plane_space(v3 n, v3 &p, v3 &q) {   // btPlaneSp
     }
 }
 
-// row layout in scratch (ROWF floats): 0..10 Ja, 11..21 MJa, 22..24 dir, 25..27 aa, 28..30 maa, 31..33 ab, 34..36 mab,
-// 37 rhs, 38 dinv, 39 lambda
-#define ROW(r, f) SCR(S_ROWS + (r) * ROWF + (f))
+// ---- solver ------------------------------------------------------------------------------------------------------
+// One env per 16-lane group (4 envs per wavefront, SGRP groups per workgroup). The PGS chain of an env is sequential
+// (Gauss-Seidel), so the lanes of a group split each row instead:
+//   lanes 0..10  own joint velocity delta dq[lane]; a robot row contributes Ja[lane]*dq[lane] and applies MJa[lane]*dl
+//   lanes 11..13 own the velocity delta (dv, dw) of object lane-11
+//   J.v is a 16-lane butterfly sum (ds_swizzle/dpp via __shfl_xor); clamping is done redundantly by every lane.
+// All rows a sweep touches live in LDS (one slab per env):
+//   Minv (121), motor rows (11 x {rhs, dinv, lambda}), joint-limit rows (22 x {rhs, lambda}), contact meta (48 ints),
+//   friction coefficient (LC) and per contact row
+//     base  part (12): dir[3], aa[3], maa[3], rhs, dinv, lambda          -- first LC contacts
+//     robot part (22): Ja[11], MJa[11]                                   -- first LR robot-involved contacts
+//     Bside part  (6): ab[3], mab[3]                                     -- first LB object-object contacts
+// Contacts beyond those capacities (rare) keep their rows in the global scratch slab with the ROWF layout
+// (0..10 Ja, 11..21 MJa, 22..24 dir, 25..27 aa, 28..30 maa, 31..33 ab, 34..36 mab, 37 rhs, 38 dinv, 39 lambda);
+// arithmetic and row order are the same on both paths.
+#define SGRP 4           // envs per workgroup (64 threads)
+#define LC 32
+#define LR 14
+#define LB 8
+enum {
+    L_MINV = 0, L_MOT = L_MINV + 121, L_LIM = L_MOT + 33, L_META = L_LIM + 44, L_MU = L_META + MAXC,
+    L_BASE = L_MU + LC, L_ROB = L_BASE + LC * 3 * 12, L_BS = L_ROB + LR * 3 * 22, L_TOTAL = L_BS + LB * 3 * 6 + 2
+};
+static_assert(L_TOTAL * 16 * 4 <= 163840, "16 solver slabs must fit the 160 KiB LDS of a CU");
+__shared__ float g_slds[L_TOTAL * SGRP];
+#define LD(slot) g_slds[grp * L_TOTAL + (slot)]
+// Overflow rows in global memory are shared between the 16 lanes of a group (lane 0 writes rhs/dinv/lambda, every
+// lane reads them): the accesses bypass the per-CU vector L1 (agent-scope relaxed atomics -> sc1) and stores are
+// drained with a wavefront fence before other lanes read them.
+#define ROW_ADDR(r, f) (&SCR(S_ROWS + (r) * ROWF + (f)))
+#define ROWL(r, f) __hip_atomic_load(ROW_ADDR(r, f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ROWS(r, f, v) __hip_atomic_store(ROW_ADDR(r, f), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ROW_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
 
-__device__ float build_row(const BodyParams &B, const SimParams &P, const DevPtrs &D, int env, int row, int bodyA, int bodyB,
-                           v3 x, v3 dir) {
+// meta word: bodyA (8) | bodyB (8) | linkA (8) | robot slot (4, 15 = none/global) | Bside slot (4, 15 = none/global)
+__device__ __forceinline__ int meta_bodyA(int m) { return (signed char)(m & 255); }
+__device__ __forceinline__ int meta_bodyB(int m) { return (signed char)((m >> 8) & 255); }
+__device__ __forceinline__ int meta_link(int m) { return (signed char)((m >> 16) & 255); }
+__device__ __forceinline__ int meta_rslot(int m) { return (m >> 24) & 15; }
+__device__ __forceinline__ int meta_bslot(int m) { return (m >> 28) & 15; }
+
+// Sum over the 16 lanes of a group (= one DPP row), result in every lane: four rotate-and-add steps on the VALU
+// (v_add_f32 with row_ror:8/4/2/1), no LDS crossbar traffic. Every lane performs the same commutative pairings, so
+// all 16 lanes hold bitwise the same sum.
+template <int ROR>
+__device__ __forceinline__ float dpp_ror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + ROR, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += dpp_ror<8>(v);
+    v += dpp_ror<4>(v);
+    v += dpp_ror<2>(v);
+    v += dpp_ror<1>(v);
+    return v;
+}
+
+// ancestors-or-self of body b as a bit mask over joints (kinematic tree PARENT)
+__device__ constexpr unsigned ANC[NB] = {0x001, 0x003, 0x007, 0x00f, 0x01f, 0x03f, 0x07f, 0x0ff, 0x1ff, 0x27f, 0x67f};
+
+// Builds row k (0 normal, 1, 2 tangents) of contact c along `dir`; returns the relative velocity A - B along dir.
+// Executed by all 16 lanes of the env's group; `l` is the lane index within the group.
+__device__ float build_row(const BodyParams &B, const SimParams &P, const DevPtrs &D, int env, int grp, int l, int c, int k,
+                           bool fast, int rslot, int bslot, int bodyA, int bodyB, v3 x, v3 dir) {
     const int N = P.N;
     float *scratch = D.scratch;
     const float *state = D.state;
+    const int row = 3 * c + k;
     float diag = 0, rel = 0;
-    bool robot = false;
 #pragma unroll
     for (int side = 0; side < 2; side++) {
         int body = side == 0 ? bodyA : bodyB;
         float sg = side == 0 ? 1.0f : -1.0f;
         if (body < 0) continue;
         if (body < 16) {
-            robot = true;
-            float Ja[NB];
-#pragma unroll
-            for (int k = 0; k < NB; k++) Ja[k] = 0;
-            int k = body;
-            while (k >= 0) {
-                v3 pk = mk(SCR(S_BP + 3 * k), SCR(S_BP + 3 * k + 1), SCR(S_BP + 3 * k + 2));
-                v3 ak = mk(SCR(S_BAX + 3 * k), SCR(S_BAX + 3 * k + 1), SCR(S_BAX + 3 * k + 2));
-                float v = sg * dot(dir, cross(ak, x - pk));
-#pragma unroll
-                for (int kk = 0; kk < NB; kk++) if (kk == k) Ja[kk] = v;
-                k = PARENT[k];
+            // lane l < 11: Jacobian entry of joint l (zero unless joint l is an ancestor-or-self of the body)
+            float ja = 0;
+            const int lj = l < NB ? l : 0;
+            if (l < NB && ((ANC[body] >> l) & 1u)) {
+                v3 pk = mk(SCR(S_BP + 3 * lj), SCR(S_BP + 3 * lj + 1), SCR(S_BP + 3 * lj + 2));
+                v3 ak = mk(SCR(S_BAX + 3 * lj), SCR(S_BAX + 3 * lj + 1), SCR(S_BAX + 3 * lj + 2));
+                ja = sg * dot(dir, cross(ak, x - pk));
             }
+            float mja = 0;
 #pragma unroll
-            for (int i = 0; i < NB; i++) ROW(row, i) = Ja[i];
-#pragma unroll 1
-            for (int i = 0; i < NB; i++) {
-                float s = 0, jai = 0;
-#pragma unroll
-                for (int j = 0; j < NB; j++) { s += SCR(S_MINV + i * NB + j) * Ja[j]; if (j == i) jai = Ja[j]; }
-                ROW(row, 11 + i) = s;
-                diag += jai * s;
-                rel += jai * SCR(S_QDS + i);
+            for (int j = 0; j < NB; j++) {
+                float jj = __shfl(ja, j, 16);
+                mja += LD(L_MINV + lj * NB + j) * jj;
             }
+            if (l < NB) {
+                if (fast) { LD(L_ROB + (rslot * 3 + k) * 22 + l) = ja; LD(L_ROB + (rslot * 3 + k) * 22 + 11 + l) = mja; }
+                else { ROWS(row, l, ja); ROWS(row, 11 + l, mja); }
+            } else mja = 0;
+            diag += group_sum(ja * mja);
+            rel += group_sum(l < NB ? ja * SCR(S_QDS + lj) : 0.0f);
         } else {
             int ob = body - 16;
             v3 op = mk(STT(ST_OPOS + 3 * ob), STT(ST_OPOS + 3 * ob + 1), STT(ST_OPOS + 3 * ob + 2));
@@ -616,49 +671,54 @@ __device__ float build_row(const BodyParams &B, const SimParams &P, const DevPtr
             v3 ang = cross(x - op, lin);
             m3 Iinv;
 #pragma unroll
-            for (int k = 0; k < 9; k++) Iinv.m[k] = SCR(S_OIINV + 9 * ob + k);
+            for (int kk = 0; kk < 9; kk++) Iinv.m[kk] = SCR(S_OIINV + 9 * ob + kk);
             v3 mang = mulv(Iinv, ang);
-            int o = side == 0 ? 25 : 31;
-            ROW(row, o) = ang.x; ROW(row, o + 1) = ang.y; ROW(row, o + 2) = ang.z;
-            ROW(row, o + 3) = mang.x; ROW(row, o + 4) = mang.y; ROW(row, o + 5) = mang.z;
+            if (l == 0) {
+                if (fast) {
+                    // the base part holds the angular data of the contact's (first) object; the Bside part exists
+                    // only for object-object contacts
+                    const int o = (side == 0 || bodyA < 16) ? L_BASE + row * 12 + 3 : L_BS + (bslot * 3 + k) * 6;
+                    LD(o) = ang.x; LD(o + 1) = ang.y; LD(o + 2) = ang.z; LD(o + 3) = mang.x; LD(o + 4) = mang.y; LD(o + 5) = mang.z;
+                } else {
+                    int o = side == 0 ? 25 : 31;
+                    ROWS(row, o, ang.x); ROWS(row, o + 1, ang.y); ROWS(row, o + 2, ang.z);
+                    ROWS(row, o + 3, mang.x); ROWS(row, o + 4, mang.y); ROWS(row, o + 5, mang.z);
+                }
+            }
             v3 vs = mk(SCR(S_OVS + 3 * ob), SCR(S_OVS + 3 * ob + 1), SCR(S_OVS + 3 * ob + 2));
             v3 ws = mk(SCR(S_OWS + 3 * ob), SCR(S_OWS + 3 * ob + 1), SCR(S_OWS + 3 * ob + 2));
             diag += dot(lin, lin) * (1.0f / B.obj_mass[ob]) + dot(ang, mang);
             rel += dot(lin, vs) + dot(ang, ws);
         }
     }
-    (void)robot;
-    ROW(row, 22) = dir.x; ROW(row, 23) = dir.y; ROW(row, 24) = dir.z;
-    ROW(row, 38) = diag > 0 ? 1.0f / diag : 0.0f;
-    ROW(row, 39) = 0.0f;
+    float dinv = diag > 0 ? 1.0f / diag : 0.0f;
+    if (l == 0) {
+        if (fast) {
+            const int o = L_BASE + row * 12;
+            LD(o) = dir.x; LD(o + 1) = dir.y; LD(o + 2) = dir.z; LD(o + 10) = dinv; LD(o + 11) = 0.0f;
+        } else {
+            ROWS(row, 22, dir.x); ROWS(row, 23, dir.y); ROWS(row, 24, dir.z); ROWS(row, 38, dinv); ROWS(row, 39, 0.0f);
+        }
+    }
+    if (!fast) ROW_FENCE();
     return rel;
-}
-
-
-// dv/dw live in registers: select by object index without dynamic indexing (dynamic indexing would move the
-// arrays to private scratch memory)
-struct ObjDelta { v3 dv[NOBJ], dw[NOBJ]; };
-__device__ __forceinline__ float obj_jv(const ObjDelta &o, int ob, v3 lin, v3 ang) {
-    float r = 0;
-#pragma unroll
-    for (int k = 0; k < NOBJ; k++) if (k == ob) r = dot(lin, o.dv[k]) + dot(ang, o.dw[k]);
-    return r;
-}
-__device__ __forceinline__ void obj_apply(ObjDelta &o, int ob, v3 dlin, v3 dang) {
-#pragma unroll
-    for (int k = 0; k < NOBJ; k++) if (k == ob) { o.dv[k] = o.dv[k] + dlin; o.dw[k] = o.dw[k] + dang; }
 }
 
 __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs D) {
     const int N = P.N;
-    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int env = blockIdx.x * SGRP + grp;
     if (env >= N) return;
     float *state = D.state, *scratch = D.scratch;
     if (D.errflags[env]) return;
     const ShapeData *S = D.shapes;
     const float dt = P.dt;
-    // ---- gather contacts in pair order, build rows
-    int nc = 0;
+    const int lj = l < NB ? l : 0;               // joint owned by this lane (lanes >= 11 alias joint 0, masked)
+    const int lo_ = (l >= NB && l < NB + NOBJ) ? l - NB : -1;   // object owned by this lane
+    // ---- stage Minv in LDS
+    for (int i = l; i < NB * NB; i += 16) LD(L_MINV + i) = SCR(S_MINV + i);
+    // ---- gather contacts in pair order, build rows (all lanes of the group run the control flow redundantly)
+    int nc = 0, nrob = 0, nbs = 0;
     for (int pair = 0; pair < P.npairs && nc < MAXC; pair++) {
         int cnt = *(const int *)&SCR(S_PCOUNT + pair);
         if (cnt == 0) continue;
@@ -666,162 +726,180 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         int bodyA = S->otype[sa] == 0 ? -1 : (S->otype[sa] == 1 ? S->oidx[sa] : 16 + S->oidx[sa]);
         int bodyB = S->otype[sb] == 0 ? -1 : (S->otype[sb] == 1 ? S->oidx[sb] : 16 + S->oidx[sb]);
         float mu = S->fric[sa] * S->fric[sb], rest = S->rest[sa] * S->rest[sb];
+        const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
+        const bool objobj = bodyA >= 16 && bodyB >= 16;
         for (int i = 0; i < cnt && nc < MAXC; i++, nc++) {
             int base = S_PDATA + (pair * 4 + i) * 7;
             v3 x = mk(SCR(base), SCR(base + 1), SCR(base + 2));
             v3 n = mk(SCR(base + 3), SCR(base + 4), SCR(base + 5));
             float dist = SCR(base + 6);
-            *(int *)&SCR(S_RMETA + nc) = (bodyA & 255) | ((bodyB & 255) << 8) | ((S->link[sa] & 255) << 16);
-            float *ct = &SCR(S_CT + nc * 12);
-            const size_t Ns = (size_t)N;
-            ct[0] = (float)bodyA; ct[Ns] = (float)bodyB; ct[2 * Ns] = (float)S->link[sa];
-            ct[3 * Ns] = x.x; ct[4 * Ns] = x.y; ct[5 * Ns] = x.z; ct[6 * Ns] = n.x; ct[7 * Ns] = n.y; ct[8 * Ns] = n.z;
-            ct[9 * Ns] = dist; ct[10 * Ns] = 0; ct[11 * Ns] = mu;
+            int rslot = 15, bslot = 15;
+            bool fast = nc < LC;
+            if (robot) { if (nrob < LR && fast) rslot = nrob; else fast = false; nrob++; }
+            if (objobj) { if (nbs < LB && fast) bslot = nbs; else fast = false; nbs++; }
+            if (!fast) { rslot = 15; bslot = 15; }
+            // "fast" is recoverable from the meta word: c < LC and (no robot side or rslot != 15) and (no B object or bslot != 15)
+            int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((S->link[sa] & 255) << 16) | (rslot << 24) | (bslot << 28);
+            if (l == 0) {
+                *(int *)&LD(L_META + nc) = meta;
+                if (nc < LC) LD(L_MU + nc) = mu;
+                float *ct = &SCR(S_CT + nc * 12);
+                const size_t Ns = (size_t)N;
+                ct[0] = (float)bodyA; ct[Ns] = (float)bodyB; ct[2 * Ns] = (float)S->link[sa];
+                ct[3 * Ns] = x.x; ct[4 * Ns] = x.y; ct[5 * Ns] = x.z; ct[6 * Ns] = n.x; ct[7 * Ns] = n.y; ct[8 * Ns] = n.z;
+                ct[9 * Ns] = dist; ct[10 * Ns] = 0; ct[11 * Ns] = mu;
+            }
             // normal row
-            float rel = build_row(B, P, D, env, 3 * nc, bodyA, bodyB, x, n);
+            float rel = build_row(B, P, D, env, grp, l, nc, 0, fast, rslot, bslot, bodyA, bodyB, x, n);
             float r = 0;
             if (fabsf(rel) >= P.rest_thresh) { r = rest * -rel; if (r < 0) r = 0; }
             float verr = r - rel, perr = 0;
             if (dist > 0) verr -= dist / dt;
             else perr = -dist * P.erp / dt;
-            ROW(3 * nc, 37) = (perr + verr) * ROW(3 * nc, 38);
             v3 t1, t2;
             plane_space(n, t1, t2);
-            rel = build_row(B, P, D, env, 3 * nc + 1, bodyA, bodyB, x, t1);
-            ROW(3 * nc + 1, 37) = -rel * ROW(3 * nc + 1, 38);
-            rel = build_row(B, P, D, env, 3 * nc + 2, bodyA, bodyB, x, t2);
-            ROW(3 * nc + 2, 37) = -rel * ROW(3 * nc + 2, 38);
+            float rel1 = build_row(B, P, D, env, grp, l, nc, 1, fast, rslot, bslot, bodyA, bodyB, x, t1);
+            float rel2 = build_row(B, P, D, env, grp, l, nc, 2, fast, rslot, bslot, bodyA, bodyB, x, t2);
+            if (l == 0) {
+                if (fast) {
+                    LD(L_BASE + (3 * nc) * 12 + 9) = (perr + verr) * LD(L_BASE + (3 * nc) * 12 + 10);
+                    LD(L_BASE + (3 * nc + 1) * 12 + 9) = -rel1 * LD(L_BASE + (3 * nc + 1) * 12 + 10);
+                    LD(L_BASE + (3 * nc + 2) * 12 + 9) = -rel2 * LD(L_BASE + (3 * nc + 2) * 12 + 10);
+                } else {
+                    ROWS(3 * nc, 37, (perr + verr) * ROWL(3 * nc, 38));
+                    ROWS(3 * nc + 1, 37, -rel1 * ROWL(3 * nc + 1, 38));
+                    ROWS(3 * nc + 2, 37, -rel2 * ROWL(3 * nc + 2, 38));
+                }
+            }
+            if (!fast) ROW_FENCE();
         }
     }
-    *(int *)&SCR(S_NCT) = nc;
-    // ---- motor + limit rows (kept in the per-env scratch slab: registers are needed for dq and the object deltas;
-    //      this kernel must not spill -- see DESIGN.md "no private scratch")
-    float q[NB], qds[NB];
-#pragma unroll
-    for (int j = 0; j < NB; j++) { q[j] = STT(ST_Q + j); qds[j] = SCR(S_QDS + j); }
-#pragma unroll 1
-    for (int j = 0; j < NB; j++) {
-        float qj = STT(ST_Q + j), qdj = SCR(S_QDS + j);
-        float dinv = 1.0f / SCR(S_MINV + j * NB + j);
-        float vt = P.kp * (STT(ST_TGT + j) - qj) / dt + qdj + P.kd * (0.0f - qdj);
-        SCR(S_MOT + 3 * j) = (vt - qdj) * dinv;
-        SCR(S_MOT + 3 * j + 1) = dinv;
-        SCR(S_MOT + 3 * j + 2) = 0.0f;
-        float lo = B.limits[j][0], hi = B.limits[j][1];
+    if (l == 0) *(int *)&SCR(S_NCT) = nc;
+    // ---- motor + limit rows: lane j < 11 builds the rows of joint j
+    const float q_l = STT(ST_Q + lj), qds_l = SCR(S_QDS + lj);
+    if (l < NB) {
+        float dinv = 1.0f / LD(L_MINV + l * NB + l);
+        float vt = P.kp * (STT(ST_TGT + l) - q_l) / dt + qds_l + P.kd * (0.0f - qds_l);
+        LD(L_MOT + 3 * l) = (vt - qds_l) * dinv;
+        LD(L_MOT + 3 * l + 1) = dinv;
+        LD(L_MOT + 3 * l + 2) = 0.0f;
+        float lo = B.limits[l][0], hi = B.limits[l][1];
 #pragma unroll
         for (int side = 0; side < 2; side++) {
-            float dist = side == 0 ? qj - lo : hi - qj;
+            float dist = side == 0 ? q_l - lo : hi - q_l;
             bool on = (lo < hi) && (dist < 0.5f);
             float sg = side == 0 ? 1.0f : -1.0f;
-            float rel = sg * qdj;
+            float rel = sg * qds_l;
             float verr = -rel, perr = 0;
             if (dist > 0) verr -= dist / dt;
             else perr = -dist * P.erp / dt;
-            SCR(S_LIM + 2 * (2 * j + side)) = on ? (perr + verr) * dinv : -1e30f;   // -1e30: row absent
-            SCR(S_LIM + 2 * (2 * j + side) + 1) = 0.0f;
+            LD(L_LIM + 2 * (2 * l + side)) = on ? (perr + verr) * dinv : -1e30f;   // -1e30: row absent
+            LD(L_LIM + 2 * (2 * l + side) + 1) = 0.0f;
         }
     }
-    // ---- PGS
-    float dq[NB];
-    ObjDelta od;
-#pragma unroll
-    for (int i = 0; i < NB; i++) dq[i] = 0;
-#pragma unroll
-    for (int i = 0; i < NOBJ; i++) { od.dv[i] = mk(0, 0, 0); od.dw[i] = mk(0, 0, 0); }
+    // ---- PGS.  Lane state: dq (lanes 0..10) or (dv, dw) of object lane-11 (lanes 11..13)
+    float dq = 0;
+    v3 dv = mk(0, 0, 0), dw = mk(0, 0, 0);
+    const float inv_mass = lo_ >= 0 ? 1.0f / B.obj_mass[lo_ >= 0 ? lo_ : 0] : 0.0f;
     const float max_imp = P.max_impulse;
     for (int it = 0; it < P.iters; it++) {
 #pragma unroll 1
         for (int j = 0; j < NB; j++) {          // motors
-            float dqj = 0;
-#pragma unroll
-            for (int i = 0; i < NB; i++) if (i == j) dqj = dq[i];
-            float mdinv = SCR(S_MOT + 3 * j + 1), mlam = SCR(S_MOT + 3 * j + 2);
-            float dl = SCR(S_MOT + 3 * j) - dqj * mdinv;
+            float dqj = group_sum(l == j ? dq : 0.0f);
+            float mdinv = LD(L_MOT + 3 * j + 1), mlam = LD(L_MOT + 3 * j + 2);
+            float dl = LD(L_MOT + 3 * j) - dqj * mdinv;
             float sum = mlam + dl;
             if (sum < -max_imp) { dl = -max_imp - mlam; sum = -max_imp; }
             else if (sum > max_imp) { dl = max_imp - mlam; sum = max_imp; }
-            SCR(S_MOT + 3 * j + 2) = sum;
-#pragma unroll
-            for (int i = 0; i < NB; i++) dq[i] += SCR(S_MINV + i * NB + j) * dl;
+            if (l == 0) LD(L_MOT + 3 * j + 2) = sum;
+            if (l < NB) dq += LD(L_MINV + l * NB + j) * dl;
         }
 #pragma unroll 1
         for (int js = 0; js < 2 * NB; js++) {   // joint limits
-            float lr = SCR(S_LIM + 2 * js);
+            float lr = LD(L_LIM + 2 * js);
             if (lr <= -1e29f) continue;
             int j = js >> 1;
-            float dqj = 0;
-#pragma unroll
-            for (int i = 0; i < NB; i++) if (i == j) dqj = dq[i];
-            float ll = SCR(S_LIM + 2 * js + 1);
+            float dqj = group_sum(l == j ? dq : 0.0f);
+            float ll = LD(L_LIM + 2 * js + 1);
             float sg = (js & 1) == 0 ? 1.0f : -1.0f;
-            float dl = lr - sg * dqj * SCR(S_MOT + 3 * j + 1);
+            float dl = lr - sg * dqj * LD(L_MOT + 3 * j + 1);
             float sum = ll + dl;
             if (sum < 0) { dl = -ll; sum = 0; }
             else if (sum > 100.0f) { dl = 100.0f - ll; sum = 100.0f; }
-            SCR(S_LIM + 2 * js + 1) = sum;
-            float sd = sg * dl;
-#pragma unroll
-            for (int i = 0; i < NB; i++) dq[i] += SCR(S_MINV + i * NB + j) * sd;
+            if (l == 0) LD(L_LIM + 2 * js + 1) = sum;
+            if (l < NB) dq += LD(L_MINV + l * NB + j) * (sg * dl);
         }
         for (int pass = 0; pass < 2; pass++) {  // all normals, then all frictions
             for (int c = 0; c < nc; c++) {
-                int meta = *(const int *)&SCR(S_RMETA + c);
-                int bodyA = (signed char)(meta & 255), bodyB = (signed char)((meta >> 8) & 255);
-                bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
-                float ln = ROW(3 * c, 39);
-                float mu = SCR(S_CT + c * 12 + 11);
-                int r0 = pass == 0 ? 3 * c : 3 * c + 1, r1 = pass == 0 ? 3 * c + 1 : 3 * c + 3;
+                const int meta = *(const int *)&LD(L_META + c);
+                const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta), rslot = meta_rslot(meta), bslot = meta_bslot(meta);
+                const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
+                const bool fast = (c < LC) && (!robot || rslot != 15) && (!(bodyA >= 16 && bodyB >= 16) || bslot != 15);
+                const int r0 = pass == 0 ? 3 * c : 3 * c + 1, r1 = pass == 0 ? 3 * c + 1 : 3 * c + 3;
+                const bool mineA = (lo_ >= 0) && (bodyA == 16 + lo_), mineB = (lo_ >= 0) && (bodyB == 16 + lo_);
+                const float ln = fast ? LD(L_BASE + (3 * c) * 12 + 11) : ROWL(3 * c, 39);
+                const float mu = fast ? LD(L_MU + (c < LC ? c : 0)) : SCR(S_CT + c * 12 + 11);
                 for (int r = r0; r < r1; r++) {
+                    const int kk = r - 3 * c;
                     float lo = 0, hi = 1e10f;
                     if (pass == 1) { hi = mu * ln; lo = -hi; }
-                    float jv = 0;
-                    v3 dir = mk(ROW(r, 22), ROW(r, 23), ROW(r, 24));
-                    if (robot) {
-#pragma unroll
-                        for (int i = 0; i < NB; i++) jv += ROW(r, i) * dq[i];
+                    // this lane's share of J.v
+                    float part = 0;
+                    v3 dir, ang = mk(0, 0, 0), mang = mk(0, 0, 0);
+                    float mja = 0, rhs, dinv, lam;
+                    if (fast) {
+                        const int ob_ = L_BASE + r * 12;
+                        dir = mk(LD(ob_), LD(ob_ + 1), LD(ob_ + 2));
+                        rhs = LD(ob_ + 9); dinv = LD(ob_ + 10); lam = LD(ob_ + 11);
+                        if (robot && l < NB) {
+                            const int orb = L_ROB + (rslot * 3 + kk) * 22;
+                            part = LD(orb + l) * dq;
+                            mja = LD(orb + 11 + l);
+                        }
+                        if (mineA) { ang = mk(LD(ob_ + 3), LD(ob_ + 4), LD(ob_ + 5)); mang = mk(LD(ob_ + 6), LD(ob_ + 7), LD(ob_ + 8)); }
+                        if (mineB) {
+                            const int obs_ = bodyA >= 16 ? L_BS + (bslot * 3 + kk) * 6 : ob_ + 3;
+                            ang = mk(LD(obs_), LD(obs_ + 1), LD(obs_ + 2)); mang = mk(LD(obs_ + 3), LD(obs_ + 4), LD(obs_ + 5));
+                        }
+                    } else {
+                        dir = mk(ROWL(r, 22), ROWL(r, 23), ROWL(r, 24));
+                        rhs = ROWL(r, 37); dinv = ROWL(r, 38); lam = ROWL(r, 39);
+                        if (robot && l < NB) { part = ROWL(r, l) * dq; mja = ROWL(r, 11 + l); }
+                        if (mineA) { ang = mk(ROWL(r, 25), ROWL(r, 26), ROWL(r, 27)); mang = mk(ROWL(r, 28), ROWL(r, 29), ROWL(r, 30)); }
+                        if (mineB) { ang = mk(ROWL(r, 31), ROWL(r, 32), ROWL(r, 33)); mang = mk(ROWL(r, 34), ROWL(r, 35), ROWL(r, 36)); }
                     }
-                    if (bodyA >= 16) jv += obj_jv(od, bodyA - 16, dir, mk(ROW(r, 25), ROW(r, 26), ROW(r, 27)));
-                    if (bodyB >= 16) jv += obj_jv(od, bodyB - 16, dir * -1.0f, mk(ROW(r, 31), ROW(r, 32), ROW(r, 33)));
-                    float lam = ROW(r, 39);
-                    float dl = ROW(r, 37) - jv * ROW(r, 38);
+                    if (mineA) part = dot(dir, dv) + dot(ang, dw);
+                    if (mineB) part = -dot(dir, dv) + dot(ang, dw);
+                    const float jv = group_sum(part);
+                    float dl = rhs - jv * dinv;
                     float sum = lam + dl;
                     if (sum < lo) { dl = lo - lam; sum = lo; }
                     else if (sum > hi) { dl = hi - lam; sum = hi; }
-                    ROW(r, 39) = sum;
-                    if (robot) {
-#pragma unroll
-                        for (int i = 0; i < NB; i++) dq[i] += ROW(r, 11 + i) * dl;
-                    }
-                    if (bodyA >= 16) {
-                        int ob = bodyA - 16;
-                        float im = dl / B.obj_mass[ob];
-                        obj_apply(od, ob, dir * im, mk(ROW(r, 28), ROW(r, 29), ROW(r, 30)) * dl);
-                    }
-                    if (bodyB >= 16) {
-                        int ob = bodyB - 16;
-                        float im = -dl / B.obj_mass[ob];
-                        obj_apply(od, ob, dir * im, mk(ROW(r, 34), ROW(r, 35), ROW(r, 36)) * dl);
-                    }
+                    if (l == 0) { if (fast) LD(L_BASE + r * 12 + 11) = sum; else ROWS(r, 39, sum); }
+                    if (!fast) ROW_FENCE();
+                    dq += mja * dl;
+                    if (mineA) { dv = dv + dir * (dl * inv_mass); dw = dw + mang * dl; }
+                    if (mineB) { dv = dv + dir * (-dl * inv_mass); dw = dw + mang * dl; }
                 }
             }
         }
     }
-    // ---- integrate
+    // ---- integrate: lanes 0..10 joints, lanes 11..13 objects
     bool finite = true;
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        float v = qds[i] + dq[i];
-        float qn = q[i] + dt * v;
-        finite = finite && isfinite(qn);
-        STT(ST_QD + i) = v;
-        STT(ST_Q + i) = qn;
-        q[i] = qn;
+    if (l < NB) {
+        float v = qds_l + dq;
+        float qn = q_l + dt * v;
+        finite = isfinite(qn);
+        STT(ST_QD + l) = v;
+        STT(ST_Q + l) = qn;
+        if (l < 7) D.joints[(size_t)env * 9 + l] = qn;                 // robot.py:203-211
+        else if (l == 7) D.joints[(size_t)env * 9 + 7] = qn;
+        else if (l == 8) D.joints[(size_t)env * 9 + 8] = -qn;
     }
-#pragma unroll
-    for (int i = 0; i < NOBJ; i++) {
-        if (i >= P.nobj) break;
+    if (lo_ >= 0 && lo_ < P.nobj) {
+        const int i = lo_;
         float v[3], w[3];
-        const float dvi[3] = {od.dv[i].x, od.dv[i].y, od.dv[i].z}, dwi[3] = {od.dw[i].x, od.dw[i].y, od.dw[i].z};
+        const float dvi[3] = {dv.x, dv.y, dv.z}, dwi[3] = {dw.x, dw.y, dw.z};
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             v[k] = SCR(S_OVS + 3 * i + k) + dvi[k];
@@ -854,27 +932,27 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         for (int k = 0; k < 3; k++) op[k] = STT(ST_OPOS + 3 * i + k);
         op[3] = r0 * inv; op[4] = r1 * inv; op[5] = r2 * inv; op[6] = r3 * inv;
     }
-    if (!finite) D.errflags[env] |= 1u;
-    // ---- touch sensors (robot.py:152-163) + contact forces
-    float touch[4] = {0, 0, 0, 0};
-    for (int c = 0; c < nc; c++) {
-        int meta = *(const int *)&SCR(S_RMETA + c);
-        int bodyA = (signed char)(meta & 255), link = (signed char)((meta >> 16) & 255);
-        float lam = ROW(3 * c, 39);
-        float f = lam / dt;
-        SCR(S_CT + c * 12 + 10) = f;
-        if (bodyA < 0 || bodyA >= 16) continue;
-        if (fabsf(SCR(S_CT + c * 12 + 9)) >= 0.1f) continue;
+    if (!finite) atomicOr(&D.errflags[env], 1u);
+    // ---- touch sensors (robot.py:152-163) + contact forces: lane 0
+    if (l == 0) {
+        float touch[4] = {0, 0, 0, 0};
+        for (int c = 0; c < nc; c++) {
+            const int meta = *(const int *)&LD(L_META + c);
+            const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta), link = meta_link(meta);
+            const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
+            const bool fast = (c < LC) && (!robot || meta_rslot(meta) != 15) && (!(bodyA >= 16 && bodyB >= 16) || meta_bslot(meta) != 15);
+            float lam = fast ? LD(L_BASE + (3 * c) * 12 + 11) : ROWL(3 * c, 39);
+            float f = lam / dt;
+            SCR(S_CT + c * 12 + 10) = f;
+            if (bodyA < 0 || bodyA >= 16) continue;
+            if (fabsf(SCR(S_CT + c * 12 + 9)) >= 0.1f) continue;
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (link == B.touch_links[k]) touch[k] = fmaxf(touch[k], f);
+            for (int k = 0; k < 4; k++) if (link == B.touch_links[k]) touch[k] = fmaxf(touch[k], f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) D.touch[(size_t)env * 4 + k] = touch[k];
+        D.timestep[env] += 1;
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) D.touch[(size_t)env * 4 + k] = touch[k];
-#pragma unroll
-    for (int i = 0; i < 7; i++) D.joints[(size_t)env * 9 + i] = q[i];
-    D.joints[(size_t)env * 9 + 7] = q[7];
-    D.joints[(size_t)env * 9 + 8] = -q[8];
-    D.timestep[env] += 1;
 }
 
 // obs pack without stepping (after reset / set_state)
@@ -999,8 +1077,8 @@ __global__ void __launch_bounds__(64) k_link_poses(BodyParams B, SimParams P, co
 // One workgroup per (env, tile). Tile = full-width strip of tile_h rows (<= 16384 pixels -> 128 KiB of LDS keys).
 #define RASTER_THREADS 1024
 #define TILE_PIX 16384
-#define BIGQ 256
-#define SMALL_AREA 64
+#define QCAP 512         // queued (non-tiny) triangles per tile; overflow falls back to the serial path
+#define SMALL_AREA 4     // bbox area (pixels) up to which the owning thread rasterises a triangle itself
 
 struct STri { float sx[3], sy[3], sz[3], w[3]; };
 
@@ -1046,21 +1124,33 @@ __device__ __forceinline__ void raster_pixel(const STri &s, int t, int px, int p
     atomicMin(&vis[(row - row0) * W + px], key);
 }
 
-__global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used) {
+// pass: 0 = per-env frame (starts from the static layer when D.static_vis != nullptr and rasterises only the
+// triangles of moving instances), 1 = static layer (instances that never move: table, shelf, robot base link_0;
+// one launch at creation, result shared by all envs).
+__global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int pass) {
     const RenderModel &RM = *RMp;
     __shared__ unsigned long long vis[TILE_PIX];
     __shared__ float mvp[MAXINST][16];
-    __shared__ int bigq[BIGQ];
-    __shared__ int nbig;
+    __shared__ float qf[9][QCAP];        // queued triangles: screen x[3], y[3], z[3]
+    __shared__ int qid[QCAP];            // triangle id
+    __shared__ unsigned qbb[QCAP];       // bbox packed x0 | y0<<8 | (x1-x0)<<16 | (y1-y0)<<24  (tile-local, W,H <= 16384 -> use 2 words)
+    __shared__ unsigned qbb2[QCAP];
+    __shared__ int nq;
     const int env = blockIdx.x, tile = blockIdx.y;
-    if (D.render_flags && !D.render_flags[env]) return;
+    if (pass == 0 && D.render_flags && !D.render_flags[env]) return;
     const int W = RM.W, H = RM.H;
     const int row0 = tile * RM.tile_h;
     const int rows = min(RM.tile_h, H - row0);
     const int npix = rows * W;
     const int tid = threadIdx.x;
-    for (int i = tid; i < npix; i += RASTER_THREADS) vis[i] = ~0ull;
-    if (tid == 0) nbig = 0;
+    const bool layered = (pass == 0) && (D.static_vis != nullptr);
+    if (layered) {
+        const unsigned long long *sv = D.static_vis + (size_t)row0 * W;
+        for (int i = tid; i < npix; i += RASTER_THREADS) vis[i] = sv[i];
+    } else {
+        for (int i = tid; i < npix; i += RASTER_THREADS) vis[i] = ~0ull;
+    }
+    if (tid == 0) nq = 0;
     if (tid < RM.ni * 16) {
         int inst = tid >> 4, e = tid & 15, r = e >> 2, c = e & 3;
         const float *xf = D.inst_xf + ((size_t)env * MAXINST + inst) * 12;
@@ -1075,7 +1165,9 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     // tile bounds in screen y (py = H-1-row)
     const float ty0 = (float)(H - 1 - (row0 + rows - 1)), ty1 = (float)(H - 1 - row0);
     const int NT = RM.nt;
-    for (int t = tid; t < NT; t += RASTER_THREADS) {
+    const int t_begin = layered ? RM.first_dynamic_tri : 0;
+    const int t_end = (pass == 1) ? RM.first_dynamic_tri : NT;
+    for (int t = t_begin + tid; t < ((P.ablate & 8) ? 0 : t_end); t += RASTER_THREADS) {
         int inst = D.tri_inst[t];
         if (inst >= n_inst_used) continue;
         float tp[9];
@@ -1091,34 +1183,46 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         if (x1 < x0 || y1 < y0) continue;
         int area = (x1 - x0 + 1) * (y1 - y0 + 1);
         if (area > SMALL_AREA) {
-            int slot = atomicAdd(&nbig, 1);
-            if (slot < BIGQ) { bigq[slot] = t; continue; }
+            int slot = atomicAdd(&nq, 1);
+            if (slot < QCAP) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) { qf[k][slot] = s.sx[k]; qf[3 + k][slot] = s.sy[k]; qf[6 + k][slot] = s.sz[k]; }
+                qid[slot] = t;
+                qbb[slot] = (unsigned)x0 | ((unsigned)y0 << 16);
+                qbb2[slot] = (unsigned)(x1 - x0) | ((unsigned)(y1 - y0) << 16);
+                continue;
+            }
             // queue overflow: fall through and rasterise serially (still correct)
         }
+        if (P.ablate & 1) continue;
         for (int py = y0; py <= y1; py++)
             for (int px = x0; px <= x1; px++) raster_pixel(s, t, px, py, H, W, row0, rows, vis);
     }
     __syncthreads();
-    int nb = min(nbig, BIGQ);
-    for (int qi = 0; qi < nb; qi++) {
-        int t = bigq[qi];
-        int inst = D.tri_inst[t];
-        float tp[9];
+    // queued triangles: one wave per triangle, lanes sweep the bbox in 8x8 pixel blocks
+    {
+        const int nb = (P.ablate & 2) ? 0 : min(nq, QCAP);
+        const int wave = tid >> 6, lane = tid & 63, lx = lane & 7, ly = lane >> 3;
+        for (int qi = wave; qi < nb; qi += RASTER_THREADS / 64) {
+            STri s;
 #pragma unroll
-        for (int k = 0; k < 9; k++) tp[k] = D.tri_pos[(size_t)k * NT + t];
-        STri s;
-        project_tri(mvp[inst], tp, W, H, s);
-        float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
-        float ymin = fminf(s.sy[0], fminf(s.sy[1], s.sy[2])), ymax = fmaxf(s.sy[0], fmaxf(s.sy[1], s.sy[2]));
-        int x0 = (int)ceilf(fmaxf(xmin, 0.0f)), x1 = (int)floorf(fminf(xmax, (float)(W - 1)));
-        int y0 = (int)ceilf(fmaxf(ymin, ty0)), y1 = (int)floorf(fminf(ymax, ty1));
-        int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
-        for (int i = tid; i < bw * bh; i += RASTER_THREADS) {
-            int px = x0 + i % bw, py = y0 + i / bw;
-            raster_pixel(s, t, px, py, H, W, row0, rows, vis);
+            for (int k = 0; k < 3; k++) { s.sx[k] = qf[k][qi]; s.sy[k] = qf[3 + k][qi]; s.sz[k] = qf[6 + k][qi]; s.w[k] = 1.0f; }
+            const int t = qid[qi];
+            const unsigned b1 = qbb[qi], b2 = qbb2[qi];
+            const int x0 = b1 & 0xffff, y0 = b1 >> 16, bw = (b2 & 0xffff) + 1, bh = (b2 >> 16) + 1;
+            for (int by = 0; by < bh; by += 8)
+                for (int bx = 0; bx < bw; bx += 8) {
+                    int ox = bx + lx, oy = by + ly;
+                    if (ox < bw && oy < bh) raster_pixel(s, t, x0 + ox, y0 + oy, H, W, row0, rows, vis);
+                }
         }
     }
     __syncthreads();
+    if (pass == 1) {   // publish the static layer
+        unsigned long long *sv = D.static_vis_out + (size_t)row0 * W;
+        for (int i = tid; i < npix; i += RASTER_THREADS) sv[i] = vis[i];
+        return;
+    }
     // ---- resolve: 4 consecutive pixels per thread iteration (W % 4 == 0 enforced at create)
     const float Lx = -50.0f, Ly = 30.0f, Lz = 100.0f;
     const float linv = 1.0f / sqrtf(Lx * Lx + Ly * Ly + Lz * Lz);
@@ -1134,7 +1238,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
             unsigned long long key = vis[pi];
             int lrow = pi / W, px = pi - lrow * W;
             int row = row0 + lrow;
-            if (key == ~0ull) {
+            if (key == ~0ull || (P.ablate & 4)) {
                 rgb12[3 * j] = 255; rgb12[3 * j + 1] = 255; rgb12[3 * j + 2] = 255;
                 dep[j] = 1.0f; msk[j] = -1;
                 continue;
@@ -1363,6 +1467,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     P.N = N; P.nobj = cfg->n_objects; P.iters = cfg->solver_iters > 0 ? cfg->solver_iters : 50;
     P.dt = cfg->dt > 0 ? cfg->dt : 0.005f; P.gravity = 9.81f; P.erp = cfg->erp > 0 ? cfg->erp : 0.2f;
     P.margin = cfg->margin > 0 ? cfg->margin : 0.02f; P.kp = 0.1f; P.kd = 1.0f; P.max_impulse = 100000.0f * P.dt;
+    P.ablate = getenv("RR_ABLATE") ? atoi(getenv("RR_ABLATE")) : 0;
     P.lin_damp = 0.04f; P.ang_damp = 0.04f; P.rest_thresh = 0.2f;
     e->epb = cfg->envs_per_block > 0 ? cfg->envs_per_block : 64;
     if (e->epb > 64) e->epb = 64;   // physics kernels are compiled with __launch_bounds__(64)
@@ -1400,6 +1505,12 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     NEED(ip = b.i32("link_body", nl)); memcpy(RM.link_body, ip, nl * 4);
     NEED(f = b.f32("link_pos", nl * 3)); memcpy(RM.link_pos, f, (size_t)nl * 12);
     NEED(f = b.f32("link_rot", nl * 9)); memcpy(RM.link_rot, f, (size_t)nl * 36);
+    {
+        const int32_t *ir;
+        NEED(ir = b.i32("inst_range", ni * 2));
+        int n_static_inst = dims[10];
+        RM.first_dynamic_tri = (n_static_inst < ni) ? ir[2 * n_static_inst] : nt;
+    }
     look_at_persp(RM.VP, table_pos, RM.W, RM.H);
     e->n_inst_used = ni - (NOBJ - P.nobj);
 
@@ -1460,6 +1571,16 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     *out = e;
     int r = rr_reset(e, nullptr);
     if (r != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
+    if (!getenv("RR_NO_STATIC_LAYER")) {
+        // static layer: table, shelf and robot base never move and the eye camera is fixed (env.py:136-141, 253-255)
+        unsigned long long *sv = nullptr;
+        if ((r = dev_alloc(e, &sv, (size_t)RM.W * RM.H)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
+        e->D.static_vis_out = sv;
+        hipLaunchKernelGGL(k_render_setup, dim3((N + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D);
+        hipLaunchKernelGGL(k_raster, dim3(1, RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1);
+        if (hipStreamSynchronize(e->stream) != hipSuccess) { rr_destroy(e); *out = nullptr; return fail(RR_EDEVICE, "rr_create: static layer pass failed"); }
+        e->D.static_vis = sv;
+    }
     return RR_OK;
 }
 
@@ -1525,7 +1646,7 @@ static int do_render(rr_env *e, bool use_flags) {
     DevPtrs D = e->D;
     if (!use_flags) D.render_flags = nullptr;
     TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((e->P.N + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, D));
-    TIMED(4, hipLaunchKernelGGL(k_raster, dim3(e->P.N, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, D, e->n_inst_used));
+    TIMED(4, hipLaunchKernelGGL(k_raster, dim3(e->P.N, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, D, e->n_inst_used, 0));
     HIPCHK(hipGetLastError());
     return RR_OK;
 }
@@ -1540,7 +1661,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     if (render_mode == 2) HIPCHK(hipMemcpyAsync(e->D.render_flags, render_flags_host, N, hipMemcpyHostToDevice, e->stream));
     TIMED(0, hipLaunchKernelGGL(k_prep, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, e->D));
     TIMED(1, hipLaunchKernelGGL(k_collide, dim3(((N + COLLIDE_THREADS - 1) / COLLIDE_THREADS) * e->P.npairs), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D, (N + COLLIDE_THREADS - 1) / COLLIDE_THREADS));
-    TIMED(2, hipLaunchKernelGGL(k_solve, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, e->D));
+    TIMED(2, hipLaunchKernelGGL(k_solve, dim3((N + SGRP - 1) / SGRP), dim3(SGRP * 16), 0, e->stream, e->B, e->P, e->D));
     HIPCHK(hipGetLastError());
     if (render_mode) return do_render(e, render_mode == 2);
     return RR_OK;
