@@ -1038,6 +1038,8 @@ static inline int bary(const stri_t *s, float px, float py, float *b) {
     return b[0] >= 0 && b[1] >= 0 && b[2] >= 0;
 }
 
+int32_t *rro_debug_tri = NULL;   /* optional [H*W] buffer receiving the winning triangle id (tests/debug) */
+void rro_set_debug_tri(int32_t *p) { rro_debug_tri = p; }
 void rro_render(rr_oracle *o, uint8_t *rgb, float *depth, int32_t *mask) {
     const model_t *m = &o->m;
     int W = o->W, H = o->H;
@@ -1093,6 +1095,7 @@ void rro_render(rr_oracle *o, uint8_t *rgb, float *depth, int32_t *mask) {
         for (int px = 0; px < W; px++) {
             int idx = row * W + px;
             uint64_t key = vis[idx];
+            if (rro_debug_tri) rro_debug_tri[idx] = key == ~0ull ? -1 : (int32_t)(key & 0xffffffffu);
             if (key == ~0ull) {
                 rgb[3 * idx] = rgb[3 * idx + 1] = rgb[3 * idx + 2] = 255;
                 depth[idx] = 1.0f;

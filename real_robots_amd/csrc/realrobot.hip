@@ -58,7 +58,7 @@ struct BodyParams {   // passed by value as kernel argument -> scalar loads, uni
 };
 
 struct SimParams {
-    int N, nobj, iters, npairs, ablate;
+    int N, nobj, iters, npairs, ablate, small_area;
     float dt, gravity, erp, margin, kp, kd, max_impulse, lin_damp, ang_damp, rest_thresh;
 };
 
@@ -73,7 +73,7 @@ struct ShapeData {    // global memory, read uniformly
 
 struct RenderModel {
     int ni, nt, W, H, tile_h, ntiles, first_dynamic_tri;
-    int in_otype[MAXINST], in_oidx[MAXINST], in_uid[MAXINST], in_tex[MAXINST];
+    int in_otype[MAXINST], in_oidx[MAXINST], in_uid[MAXINST], in_tex[MAXINST], in_cull[MAXINST];
     float in_color[MAXINST][3];
     int tex_off[16], tex_w[16], tex_h[16];
     int link_body[NLINK_MAX];
@@ -590,11 +590,13 @@ __device__ __forceinline__ void plane_space(v3 n, v3 &p, v3 &q) {   // btPlaneSp
 #define LR 14
 #define LB 8
 enum {
-    L_MINV = 0, L_MOT = L_MINV + 121, L_LIM = L_MOT + 33, L_META = L_LIM + 44, L_MU = L_META + MAXC,
-    L_BASE = L_MU + LC, L_ROB = L_BASE + LC * 3 * 12, L_BS = L_ROB + LR * 3 * 22, L_TOTAL = L_BS + LB * 3 * 6 + 2
+    L_MINV = 0, L_MOT = L_MINV + 124, L_LIM = L_MOT + 36, L_META = L_LIM + 44, L_MU = L_META + MAXC,
+    L_BASE = L_MU + LC, L_ROB = L_BASE + LC * 3 * 12, L_BS = L_ROB + LR * 3 * 22, L_TOTAL = L_BS + LB * 3 * 6
+    // every section starts on a multiple of 4 floats so that base parts can be read with ds_read_b128
 };
 static_assert(L_TOTAL * 16 * 4 <= 163840, "16 solver slabs must fit the 160 KiB LDS of a CU");
-__shared__ float g_slds[L_TOTAL * SGRP];
+static_assert(L_BASE % 4 == 0 && L_TOTAL % 4 == 0, "base parts must be 16-byte aligned");
+__shared__ __attribute__((aligned(16))) float g_slds[L_TOTAL * SGRP];
 #define LD(slot) g_slds[grp * L_TOTAL + (slot)]
 // Overflow rows in global memory are shared between the 16 lanes of a group (lane 0 writes rhs/dinv/lambda, every
 // lane reads them): the accesses bypass the per-CU vector L1 (agent-scope relaxed atomics -> sc1) and stores are
@@ -834,40 +836,60 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                 const int meta = *(const int *)&LD(L_META + c);
                 const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta), rslot = meta_rslot(meta), bslot = meta_bslot(meta);
                 const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
-                const bool fast = (c < LC) && (!robot || rslot != 15) && (!(bodyA >= 16 && bodyB >= 16) || bslot != 15);
+                const bool objobj = bodyA >= 16 && bodyB >= 16;
+                const bool fast = (c < LC) && (!robot || rslot != 15) && (!objobj || bslot != 15);
                 const int r0 = pass == 0 ? 3 * c : 3 * c + 1, r1 = pass == 0 ? 3 * c + 1 : 3 * c + 3;
                 const bool mineA = (lo_ >= 0) && (bodyA == 16 + lo_), mineB = (lo_ >= 0) && (bodyB == 16 + lo_);
-                const float ln = fast ? LD(L_BASE + (3 * c) * 12 + 11) : ROWL(3 * c, 39);
-                const float mu = fast ? LD(L_MU + (c < LC ? c : 0)) : SCR(S_CT + c * 12 + 11);
-                for (int r = r0; r < r1; r++) {
-                    const int kk = r - 3 * c;
-                    float lo = 0, hi = 1e10f;
-                    if (pass == 1) { hi = mu * ln; lo = -hi; }
-                    // this lane's share of J.v
-                    float part = 0;
-                    v3 dir, ang = mk(0, 0, 0), mang = mk(0, 0, 0);
-                    float mja = 0, rhs, dinv, lam;
-                    if (fast) {
-                        const int ob_ = L_BASE + r * 12;
-                        dir = mk(LD(ob_), LD(ob_ + 1), LD(ob_ + 2));
-                        rhs = LD(ob_ + 9); dinv = LD(ob_ + 10); lam = LD(ob_ + 11);
-                        if (robot && l < NB) {
-                            const int orb = L_ROB + (rslot * 3 + kk) * 22;
-                            part = LD(orb + l) * dq;
-                            mja = LD(orb + 11 + l);
-                        }
-                        if (mineA) { ang = mk(LD(ob_ + 3), LD(ob_ + 4), LD(ob_ + 5)); mang = mk(LD(ob_ + 6), LD(ob_ + 7), LD(ob_ + 8)); }
-                        if (mineB) {
-                            const int obs_ = bodyA >= 16 ? L_BS + (bslot * 3 + kk) * 6 : ob_ + 3;
+                if (fast) {
+                    // LDS-resident contact: predicated, branch-light row steps.
+                    // sgn: +1 when this lane owns object A, -1 when it owns object B, 0 otherwise
+                    // (selects, not multiplications by 0/1: unused slots of a part may hold non-finite garbage)
+                    const float sgn = mineA ? 1.0f : (mineB ? -1.0f : 0.0f);
+                    const bool own = mineA || mineB;
+                    const bool rob = robot && l < NB;
+                    const float ln = LD(L_BASE + (3 * c) * 12 + 11), mu = LD(L_MU + c);
+                    const float hi = pass == 0 ? 1e10f : mu * ln, lo = pass == 0 ? 0.0f : -hi;
+                    const int orb0 = robot ? L_ROB + (rslot * 3) * 22 + lj : lj;    // harmless address when no robot part
+                    for (int r = r0; r < r1; r++) {
+                        const int kk = r - 3 * c;
+                        const float4 b0 = *(const float4 *)&LD(L_BASE + r * 12);        // dir.xyz, ang.x
+                        const float4 b1 = *(const float4 *)&LD(L_BASE + r * 12 + 4);    // ang.yz, mang.xy
+                        const float4 b2 = *(const float4 *)&LD(L_BASE + r * 12 + 8);    // mang.z, rhs, dinv, lambda
+                        const float jal = LD(orb0 + kk * 22), mjal = LD(orb0 + kk * 22 + 11);
+                        v3 dir = mk(b0.x, b0.y, b0.z), ang = mk(b0.w, b1.x, b1.y), mang = mk(b1.z, b1.w, b2.x);
+                        if (objobj && mineB) {   // second object of an object-object contact: Bside part
+                            const int obs_ = L_BS + (bslot * 3 + kk) * 6;
                             ang = mk(LD(obs_), LD(obs_ + 1), LD(obs_ + 2)); mang = mk(LD(obs_ + 3), LD(obs_ + 4), LD(obs_ + 5));
                         }
-                    } else {
-                        dir = mk(ROWL(r, 22), ROWL(r, 23), ROWL(r, 24));
-                        rhs = ROWL(r, 37); dinv = ROWL(r, 38); lam = ROWL(r, 39);
-                        if (robot && l < NB) { part = ROWL(r, l) * dq; mja = ROWL(r, 11 + l); }
-                        if (mineA) { ang = mk(ROWL(r, 25), ROWL(r, 26), ROWL(r, 27)); mang = mk(ROWL(r, 28), ROWL(r, 29), ROWL(r, 30)); }
-                        if (mineB) { ang = mk(ROWL(r, 31), ROWL(r, 32), ROWL(r, 33)); mang = mk(ROWL(r, 34), ROWL(r, 35), ROWL(r, 36)); }
+                        float part = 0.0f;
+                        if (rob) part = jal * dq;
+                        if (own) part = sgn * dot(dir, dv) + dot(ang, dw);
+                        const float jv = group_sum(part);
+                        const float lam = b2.w;
+                        float dl = b2.y - jv * b2.z;
+                        float sum = lam + dl;
+                        if (sum < lo) { dl = lo - lam; sum = lo; }
+                        else if (sum > hi) { dl = hi - lam; sum = hi; }
+                        if (l == 0) LD(L_BASE + r * 12 + 11) = sum;
+                        if (rob) dq += mjal * dl;
+                        if (own) { dv = dv + dir * (sgn * dl * inv_mass); dw = dw + mang * dl; }
                     }
+                    continue;
+                }
+                // overflow contact: rows in global memory (same arithmetic)
+                const float ln = ROWL(3 * c, 39);
+                const float mu = SCR(S_CT + c * 12 + 11);
+                for (int r = r0; r < r1; r++) {
+                    float lo = 0, hi = 1e10f;
+                    if (pass == 1) { hi = mu * ln; lo = -hi; }
+                    float part = 0;
+                    v3 ang = mk(0, 0, 0), mang = mk(0, 0, 0);
+                    float mja = 0;
+                    const v3 dir = mk(ROWL(r, 22), ROWL(r, 23), ROWL(r, 24));
+                    const float rhs = ROWL(r, 37), dinv = ROWL(r, 38), lam = ROWL(r, 39);
+                    if (robot && l < NB) { part = ROWL(r, l) * dq; mja = ROWL(r, 11 + l); }
+                    if (mineA) { ang = mk(ROWL(r, 25), ROWL(r, 26), ROWL(r, 27)); mang = mk(ROWL(r, 28), ROWL(r, 29), ROWL(r, 30)); }
+                    if (mineB) { ang = mk(ROWL(r, 31), ROWL(r, 32), ROWL(r, 33)); mang = mk(ROWL(r, 34), ROWL(r, 35), ROWL(r, 36)); }
                     if (mineA) part = dot(dir, dv) + dot(ang, dw);
                     if (mineB) part = -dot(dir, dv) + dot(ang, dw);
                     const float jv = group_sum(part);
@@ -875,8 +897,8 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     float sum = lam + dl;
                     if (sum < lo) { dl = lo - lam; sum = lo; }
                     else if (sum > hi) { dl = hi - lam; sum = hi; }
-                    if (l == 0) { if (fast) LD(L_BASE + r * 12 + 11) = sum; else ROWS(r, 39, sum); }
-                    if (!fast) ROW_FENCE();
+                    if (l == 0) ROWS(r, 39, sum);
+                    ROW_FENCE();
                     dq += mja * dl;
                     if (mineA) { dv = dv + dir * (dl * inv_mass); dw = dw + mang * dl; }
                     if (mineB) { dv = dv + dir * (-dl * inv_mass); dw = dw + mang * dl; }
@@ -1082,7 +1104,11 @@ __global__ void __launch_bounds__(64) k_link_poses(BodyParams B, SimParams P, co
 
 struct STri { float sx[3], sy[3], sz[3], w[3]; };
 
+// Coverage decisions are discontinuous: projection, barycentrics and depth are evaluated without FMA contraction so
+// that they round exactly like the oracle's (gcc -ffp-contract=off) -- geometry a few cm from the near plane projects to
+// huge screen coordinates where one rounding flips whole pixel bands.
 __device__ __forceinline__ bool project_tri(const float *mvp, const float *tp /*9 floats*/, int W, int H, STri &s) {
+#pragma clang fp contract(off)
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float vx = tp[3 * k], vy = tp[3 * k + 1], vz = tp[3 * k + 2];
@@ -1101,6 +1127,7 @@ __device__ __forceinline__ bool project_tri(const float *mvp, const float *tp /*
 }
 
 __device__ __forceinline__ bool bary(const STri &s, float px, float py, float *b) {
+#pragma clang fp contract(off)
     float x0 = s.sx[0], y0 = s.sy[0], x1 = s.sx[1], y1 = s.sy[1], x2 = s.sx[2], y2 = s.sy[2];
     float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
     if (fabsf(area) < 1e-12f) return false;
@@ -1113,6 +1140,7 @@ __device__ __forceinline__ bool bary(const STri &s, float px, float py, float *b
 
 __device__ __forceinline__ void raster_pixel(const STri &s, int t, int px, int py, int H, int W, int row0, int rows,
                                              unsigned long long *vis) {
+#pragma clang fp contract(off)
     int row = H - 1 - py;
     if (row < row0 || row >= row0 + rows) return;
     float b[3];
@@ -1155,11 +1183,15 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         int inst = tid >> 4, e = tid & 15, r = e >> 2, c = e & 3;
         const float *xf = D.inst_xf + ((size_t)env * MAXINST + inst) * 12;
         // MVP = VP * [R p; 0 1]
-        float a = 0;
+        {
+#pragma clang fp contract(off)
+            // same summation order as the oracle's 4x4 product: k = 0..3 with the implicit [0 0 0 1] row
+            float a = 0;
 #pragma unroll
-        for (int k = 0; k < 3; k++) a += RM.VP[4 * r + k] * (c < 3 ? xf[3 * k + c] : xf[9 + k]);
-        if (c == 3) a += RM.VP[4 * r + 3];
-        mvp[inst][e] = a;
+            for (int k = 0; k < 3; k++) a += RM.VP[4 * r + k] * (c < 3 ? xf[3 * k + c] : xf[9 + k]);
+            a += RM.VP[4 * r + 3] * (c == 3 ? 1.0f : 0.0f);
+            mvp[inst][e] = a;
+        }
     }
     __syncthreads();
     // tile bounds in screen y (py = H-1-row)
@@ -1178,11 +1210,13 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
         float ymin = fminf(s.sy[0], fminf(s.sy[1], s.sy[2])), ymax = fmaxf(s.sy[0], fmaxf(s.sy[1], s.sy[2]));
         if (xmax < 0 || ymax < ty0 || xmin > (float)(W - 1) || ymin > ty1) continue;
+        // back faces of closed, consistently wound meshes can never win the depth test
+        if (RM.in_cull[inst] && (s.sx[1] - s.sx[0]) * (s.sy[2] - s.sy[0]) - (s.sx[2] - s.sx[0]) * (s.sy[1] - s.sy[0]) <= 0.0f) continue;
         int x0 = (int)ceilf(fmaxf(xmin, 0.0f)), x1 = (int)floorf(fminf(xmax, (float)(W - 1)));
         int y0 = (int)ceilf(fmaxf(ymin, ty0)), y1 = (int)floorf(fminf(ymax, ty1));
         if (x1 < x0 || y1 < y0) continue;
         int area = (x1 - x0 + 1) * (y1 - y0 + 1);
-        if (area > SMALL_AREA) {
+        if (area > P.small_area) {
             int slot = atomicAdd(&nq, 1);
             if (slot < QCAP) {
 #pragma unroll
@@ -1468,6 +1502,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     P.dt = cfg->dt > 0 ? cfg->dt : 0.005f; P.gravity = 9.81f; P.erp = cfg->erp > 0 ? cfg->erp : 0.2f;
     P.margin = cfg->margin > 0 ? cfg->margin : 0.02f; P.kp = 0.1f; P.kd = 1.0f; P.max_impulse = 100000.0f * P.dt;
     P.ablate = getenv("RR_ABLATE") ? atoi(getenv("RR_ABLATE")) : 0;
+    P.small_area = getenv("RR_SMALL_AREA") ? atoi(getenv("RR_SMALL_AREA")) : SMALL_AREA;
     P.lin_damp = 0.04f; P.ang_damp = 0.04f; P.rest_thresh = 0.2f;
     e->epb = cfg->envs_per_block > 0 ? cfg->envs_per_block : 64;
     if (e->epb > 64) e->epb = 64;   // physics kernels are compiled with __launch_bounds__(64)
@@ -1500,6 +1535,9 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     NEED(ip = b.i32("inst_owner", ni * 4));
     for (int i = 0; i < ni; i++) { RM.in_otype[i] = ip[4 * i]; RM.in_oidx[i] = ip[4 * i + 1]; RM.in_uid[i] = ip[4 * i + 2]; RM.in_tex[i] = ip[4 * i + 3]; }
     NEED(f = b.f32("inst_color", ni * 3)); memcpy(RM.in_color, f, (size_t)ni * 12);
+    // Back-face culling of closed meshes is opt-in (RR_CULL=1): it is invisible unless the near plane cuts through a
+    // mesh (then TinyRenderer shows the inside faces), so the default keeps exact parity with the two-sided oracle.
+    if (getenv("RR_CULL")) { NEED(ip = b.i32("inst_cull", ni)); memcpy(RM.in_cull, ip, (size_t)ni * 4); }
     NEED(ip = b.i32("tex_info", ntex * 3));
     for (int t = 0; t < ntex; t++) { RM.tex_off[t] = ip[3 * t]; RM.tex_w[t] = ip[3 * t + 1]; RM.tex_h[t] = ip[3 * t + 2]; }
     NEED(ip = b.i32("link_body", nl)); memcpy(RM.link_body, ip, nl * 4);

@@ -5,8 +5,8 @@ Tolerances (fp32 HIP path vs float64 oracle, stated per test):
   free motion / resting contact, <= 300 steps : |dq| < 1e-4 rad, object position < 1e-3 m
   robot-object contact (grasp script)         : compared against the fp32 build of the oracle over a short
                                                 horizon (contact switching amplifies rounding): < 5e-3 m
-  images                                      : <= 0.5 % pixels differing by more than 2 grey levels; mask identical
-                                                on >= 99.5 % pixels; depth within 1e-5 on agreeing pixels
+  images                                      : mask identical, RGB within 1 grey level, depth within 1e-6
+                                                (coverage math runs without FMA contraction on both sides)
 """
 import numpy as np
 import pytest
@@ -101,10 +101,11 @@ def test_raster_parity(W, H):
     for i in range(N):
         o.state = st[i].astype(np.float64)
         r, d, m = o.render()
+        # coverage math is evaluated without FMA contraction on both sides -> the images agree exactly
         same = (m == msk[i])
-        assert same.mean() > 0.995
-        assert (np.abs(r.astype(int) - rgb[i].astype(int)).max(-1) > 2).mean() < 5e-3
-        assert np.abs(d - dep[i])[same].max() < 1e-5
+        assert same.all()
+        assert np.abs(r.astype(int) - rgb[i].astype(int)).max() <= 1
+        assert np.abs(d - dep[i]).max() < 1e-6
         assert set(np.unique(msk[i]).tolist()) <= {-1, 0, 1, 2, 3, 4}
     env.close()
 

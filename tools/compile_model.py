@@ -583,6 +583,26 @@ def main(out_path):
         in_color[i] = I['col']
         print('inst %-16s owner(%d,%2d) uid %d tex %2d tris %5d' % (I['name'], I['otype'], I['oidx'], I['uid'],
                                                                     I['tex'], I['count']))
+    # back-face culling eligibility: consistently wound (geometric normal agrees with the vertex normals), positive
+    # signed volume (outward CCW) and (nearly) closed surface.  Culling such a mesh does not change what a z-buffered
+    # renderer shows (back faces of a closed surface are always hidden); fingers/skins do not qualify and are
+    # always rasterised two-sided, like TinyRenderer does for everything.
+    from collections import Counter
+    in_cull = np.zeros(NI, np.int32)
+    for i, I in enumerate(inst):
+        P = tri_pos[I['start']:I['start'] + I['count']]
+        Nn = tri_nrm[I['start']:I['start'] + I['count']]
+        gn = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+        agree = float(((gn * Nn.mean(1)).sum(1) > 0).mean())
+        vol = float(np.einsum('ij,ij->i', P[:, 0], np.cross(P[:, 1], P[:, 2])).sum() / 6)
+        edges = Counter()
+        for t in P:
+            k = [tuple(np.round(v, 6)) for v in t]
+            for a, b in ((0, 1), (1, 2), (2, 0)):
+                edges[tuple(sorted((k[a], k[b])))] += 1
+        closed = float(np.mean([c == 2 for c in edges.values()]))
+        in_cull[i] = int(agree >= 0.999 and vol > 0 and closed >= 0.9999)   # arm links are open at the joints: not culled
+        print('cull %-16s agree %.3f closed %.3f vol %+.2e -> %d' % (I['name'], agree, closed, vol, in_cull[i]))
     tri_inst = np.zeros(len(tri_pos), np.int32)
     for i, I in enumerate(inst):
         tri_inst[I['start']:I['start'] + I['count']] = i
@@ -646,6 +666,7 @@ def main(out_path):
     B.add('inst_owner', in_owner, I32)
     B.add('inst_range', in_range, I32)
     B.add('inst_color', in_color, F)
+    B.add('inst_cull', in_cull, I32)
     B.add('tri_pos', tri_pos, F)
     B.add('tri_nrm', tri_nrm, F)
     B.add('tri_uv', tri_uv, F)
