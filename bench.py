@@ -121,7 +121,8 @@ def main():
     start, stop = shard_range(total, rank, world)
     ids = np.arange(start, stop)
     env = BatchedREALRobotEnv(n_local, objects=N_OBJECTS, width=W, height=H, device=local_rank,
-                              envs_per_block=args.envs_per_block, solver_iters=args.solver_iters)
+                              envs_per_block=args.envs_per_block, solver_iters=args.solver_iters,
+                              want_mask=False)     # R2 observations carry no mask (robot.py:99-112)
     render = not args.no_render
 
     # synthetic commands, resident in HBM before the timed region: one [n_local, 9] tensor per resample epoch

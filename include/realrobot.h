@@ -47,6 +47,9 @@ enum {
     RR_F_COUNT = 9
 };
 
+/* rr_config.flags */
+#define RR_FLAG_NO_MASK 1   /* R2 environments have no `mask` observation (robot.py:99-112): do not produce RR_F_MASK */
+
 typedef struct rr_config {
     int32_t abi_version;    /* RR_ABI_VERSION */
     int32_t num_envs;       /* N envs on this device */
@@ -59,7 +62,8 @@ typedef struct rr_config {
     float erp;              /* <=0 -> 0.2 */
     float margin;           /* <=0 -> 0.02 */
     int32_t use_urdf_inertia; /* 0: Bullet AABB inertia for robot links (default); 1: URDF <inertia> */
-    int32_t reserved[8];
+    int32_t flags;          /* RR_FLAG_* */
+    int32_t reserved[7];
 } rr_config;
 
 typedef struct rr_env rr_env;

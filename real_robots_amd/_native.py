@@ -29,7 +29,10 @@ class Config(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('num_envs', C.c_int32), ('n_objects', C.c_int32),
                 ('width', C.c_int32), ('height', C.c_int32), ('device', C.c_int32), ('solver_iters', C.c_int32),
                 ('envs_per_block', C.c_int32), ('dt', C.c_float), ('erp', C.c_float), ('margin', C.c_float),
-                ('use_urdf_inertia', C.c_int32), ('reserved', C.c_int32 * 8)]
+                ('use_urdf_inertia', C.c_int32), ('flags', C.c_int32), ('reserved', C.c_int32 * 7)]
+
+
+FLAG_NO_MASK = 1
 
 
 _lib = None

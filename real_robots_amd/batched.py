@@ -15,13 +15,14 @@ OBJECT_NAMES = ['cube', 'tomato', 'mustard']       # robot.py:49-50 (after "tabl
 
 class BatchedREALRobotEnv:
     def __init__(self, num_envs, objects=3, width=320, height=240, device=0, solver_iters=50, envs_per_block=0,
-                 stream=None, use_urdf_inertia=False, dt=0.0, erp=0.0, margin=0.0):
+                 stream=None, use_urdf_inertia=False, dt=0.0, erp=0.0, margin=0.0, want_mask=True):
         self.L = nat.load_library()
         cfg = nat.Config()
         cfg.abi_version = nat.RR_ABI_VERSION
         cfg.num_envs, cfg.n_objects, cfg.width, cfg.height = int(num_envs), int(objects), int(width), int(height)
         cfg.device, cfg.solver_iters, cfg.envs_per_block = int(device), int(solver_iters), int(envs_per_block)
         cfg.dt, cfg.erp, cfg.margin, cfg.use_urdf_inertia = dt, erp, margin, int(bool(use_urdf_inertia))
+        cfg.flags = 0 if want_mask else nat.FLAG_NO_MASK
         blob = nat.model_blob()
         h = C.c_void_p()
         self.h = None

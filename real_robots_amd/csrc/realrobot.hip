@@ -799,6 +799,9 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             LD(L_LIM + 2 * (2 * l + side) + 1) = 0.0f;
         }
     }
+    // compact list of the limit rows that exist (usually the two finger lower limits), in row order
+    unsigned limmask = 0;
+    for (int js = 0; js < 2 * NB; js++) if (LD(L_LIM + 2 * js) > -1e29f) limmask |= 1u << js;
     // ---- PGS.  Lane state: dq (lanes 0..10) or (dv, dw) of object lane-11 (lanes 11..13)
     float dq = 0;
     v3 dv = mk(0, 0, 0), dw = mk(0, 0, 0);
@@ -817,9 +820,9 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             if (l < NB) dq += LD(L_MINV + l * NB + j) * dl;
         }
 #pragma unroll 1
-        for (int js = 0; js < 2 * NB; js++) {   // joint limits
+        for (unsigned rem = limmask; rem; rem &= rem - 1) {   // joint limits (existing rows only)
+            const int js = __ffs(rem) - 1;
             float lr = LD(L_LIM + 2 * js);
-            if (lr <= -1e29f) continue;
             int j = js >> 1;
             float dqj = group_sum(l == j ? dq : 0.0f);
             float ll = LD(L_LIM + 2 * js + 1);
@@ -848,6 +851,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     const bool own = mineA || mineB;
                     const bool rob = robot && l < NB;
                     const float ln = LD(L_BASE + (3 * c) * 12 + 11), mu = LD(L_MU + c);
+                    if (pass == 1 && !(mu * ln > 0.0f)) continue;   // bounds [-0, 0]: lambda stays 0, nothing moves
                     const float hi = pass == 0 ? 1e10f : mu * ln, lo = pass == 0 ? 0.0f : -hi;
                     const int orb0 = robot ? L_ROB + (rslot * 3) * 22 + lj : lj;    // harmless address when no robot part
                     for (int r = r0; r < r1; r++) {
@@ -1325,7 +1329,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         unsigned *rgbp = (unsigned *)(D.rgb + pbase * 3);
         rgbp[0] = rgbw[0]; rgbp[1] = rgbw[1]; rgbp[2] = rgbw[2];
         *(float4 *)(D.depth + pbase) = make_float4(dep[0], dep[1], dep[2], dep[3]);
-        *(int4 *)(D.mask + pbase) = make_int4(msk[0], msk[1], msk[2], msk[3]);
+        if (D.mask) *(int4 *)(D.mask + pbase) = make_int4(msk[0], msk[1], msk[2], msk[3]);
     }
 }
 
@@ -1569,7 +1573,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     const size_t npx = (size_t)N * RM.W * RM.H;
     ALLOC(D.rgb, npx * 3);
     ALLOC(D.depth, npx);
-    ALLOC(D.mask, npx);
+    if (!(cfg->flags & RR_FLAG_NO_MASK)) ALLOC(D.mask, npx);
     ALLOC(e->state_aos, (size_t)N * NSTATE);
     ALLOC(e->mask_dev, (size_t)N);
     ALLOC(e->link_out, (size_t)N * nl * 7);
@@ -1602,7 +1606,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->field_ptr[RR_F_OBJ_POSE] = D.objpose; e->field_bytes[RR_F_OBJ_POSE] = (size_t)N * P.nobj * 7 * 4;
     e->field_ptr[RR_F_RGB] = D.rgb; e->field_bytes[RR_F_RGB] = npx * 3;
     e->field_ptr[RR_F_DEPTH] = D.depth; e->field_bytes[RR_F_DEPTH] = npx * 4;
-    e->field_ptr[RR_F_MASK] = D.mask; e->field_bytes[RR_F_MASK] = npx * 4;
+    e->field_ptr[RR_F_MASK] = D.mask; e->field_bytes[RR_F_MASK] = D.mask ? npx * 4 : 0;
     e->field_ptr[RR_F_TIMESTEP] = D.timestep; e->field_bytes[RR_F_TIMESTEP] = (size_t)N * 4;
     e->field_ptr[RR_F_ERRFLAGS] = D.errflags; e->field_bytes[RR_F_ERRFLAGS] = (size_t)N * 4;
     e->field_ptr[RR_F_STATE] = e->state_aos; e->field_bytes[RR_F_STATE] = (size_t)N * NSTATE * 4;
@@ -1720,6 +1724,7 @@ int rr_get_buffer(rr_env *e, int32_t field, void **dev_ptr, size_t *bytes) {
 
 int rr_copy_to_host(rr_env *e, int32_t field, void *dst, size_t bytes) {
     if (!e || !dst || field < 0 || field >= RR_F_COUNT) return fail(RR_EINVAL, "rr_copy_to_host: bad argument");
+    if (!e->field_ptr[field]) return fail(RR_EINVAL, "rr_copy_to_host: field not available (RR_FLAG_NO_MASK)");
     if (bytes != e->field_bytes[field]) return fail(RR_EINVAL, "rr_copy_to_host: size mismatch");
     HIPCHK(hipSetDevice(e->cfg.device));
     if (field == RR_F_STATE)
