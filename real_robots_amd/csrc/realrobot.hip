@@ -129,6 +129,7 @@ struct DevPtrs {
     const ShapeData *shapes;
     const unsigned long long *static_vis;   // [H*W] visibility keys of the never-moving instances (or nullptr)
     unsigned long long *static_vis_out;
+    unsigned char *static_rgb; float *static_depth; int *static_mask;   // [H*W] shaded static layer (shared by all envs)
 };
 
 // Kinematic tree of the 11 moving bodies (lbr_iiwa_link_1..7 [+gripper base], finger_00, finger_01, finger_10,
@@ -1256,20 +1257,42 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         }
     }
     __syncthreads();
-    if (pass == 1) {   // publish the static layer
+    if (pass == 1) {   // publish the static layer's keys; its shaded pixels are written by the resolve below
         unsigned long long *sv = D.static_vis_out + (size_t)row0 * W;
         for (int i = tid; i < npix; i += RASTER_THREADS) sv[i] = vis[i];
-        return;
     }
     // ---- resolve: 4 consecutive pixels per thread iteration (W % 4 == 0 enforced at create)
     const float Lx = -50.0f, Ly = 30.0f, Lz = 100.0f;
     const float linv = 1.0f / sqrtf(Lx * Lx + Ly * Ly + Lz * Lz);
     const float L0 = Lx * linv, L1 = Ly * linv, L2 = Lz * linv;
-    const size_t img_base = ((size_t)env * H + row0) * W;
+    const size_t img_base = (pass == 1) ? (size_t)row0 * W : ((size_t)env * H + row0) * W;
+    unsigned char *const out_rgb = (pass == 1) ? D.static_rgb : D.rgb;
+    float *const out_depth = (pass == 1) ? D.static_depth : D.depth;
+    int *const out_mask = (pass == 1) ? D.static_mask : D.mask;
+    const int first_dyn = RM.first_dynamic_tri;
     for (int g = tid; g < npix / 4; g += RASTER_THREADS) {
         unsigned rgbw[3] = {0, 0, 0};
         unsigned char rgb12[12];
         float dep[4]; int msk[4];
+        const size_t sbase = (size_t)row0 * W + (size_t)4 * g;      // pixel index in the shared static images
+        if (layered) {
+            // pixels still owned by the static layer (or background) were shaded once at creation: copy them
+            bool all_static = true;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                unsigned long long key = vis[4 * g + j];
+                all_static = all_static && (key == ~0ull || (int)(key & 0xffffffffu) < first_dyn);
+            }
+            if (all_static) {
+                const unsigned *srgb = (const unsigned *)(D.static_rgb + sbase * 3);
+                size_t pbase = img_base + (size_t)4 * g;
+                unsigned *rgbp = (unsigned *)(out_rgb + pbase * 3);
+                rgbp[0] = srgb[0]; rgbp[1] = srgb[1]; rgbp[2] = srgb[2];
+                *(float4 *)(out_depth + pbase) = *(const float4 *)(D.static_depth + sbase);
+                if (out_mask) *(int4 *)(out_mask + pbase) = *(const int4 *)(D.static_mask + sbase);
+                continue;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             int pi = 4 * g + j;
@@ -1279,6 +1302,12 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
             if (key == ~0ull || (P.ablate & 4)) {
                 rgb12[3 * j] = 255; rgb12[3 * j + 1] = 255; rgb12[3 * j + 2] = 255;
                 dep[j] = 1.0f; msk[j] = -1;
+                continue;
+            }
+            if (layered && (int)(key & 0xffffffffu) < first_dyn) {
+                const unsigned char *sp = D.static_rgb + (sbase + j) * 3;
+                rgb12[3 * j] = sp[0]; rgb12[3 * j + 1] = sp[1]; rgb12[3 * j + 2] = sp[2];
+                dep[j] = D.static_depth[sbase + j]; msk[j] = D.static_mask[sbase + j];
                 continue;
             }
             int t = (int)(key & 0xffffffffu);
@@ -1326,10 +1355,10 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         for (int k = 0; k < 3; k++)
             rgbw[k] = (unsigned)rgb12[4 * k] | ((unsigned)rgb12[4 * k + 1] << 8) | ((unsigned)rgb12[4 * k + 2] << 16) | ((unsigned)rgb12[4 * k + 3] << 24);
         size_t pbase = img_base + (size_t)4 * g;
-        unsigned *rgbp = (unsigned *)(D.rgb + pbase * 3);
+        unsigned *rgbp = (unsigned *)(out_rgb + pbase * 3);
         rgbp[0] = rgbw[0]; rgbp[1] = rgbw[1]; rgbp[2] = rgbw[2];
-        *(float4 *)(D.depth + pbase) = make_float4(dep[0], dep[1], dep[2], dep[3]);
-        if (D.mask) *(int4 *)(D.mask + pbase) = make_int4(msk[0], msk[1], msk[2], msk[3]);
+        *(float4 *)(out_depth + pbase) = make_float4(dep[0], dep[1], dep[2], dep[3]);
+        if (out_mask) *(int4 *)(out_mask + pbase) = make_int4(msk[0], msk[1], msk[2], msk[3]);
     }
 }
 
@@ -1618,6 +1647,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         unsigned long long *sv = nullptr;
         if ((r = dev_alloc(e, &sv, (size_t)RM.W * RM.H)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
         e->D.static_vis_out = sv;
+        if ((r = dev_alloc(e, &e->D.static_rgb, (size_t)RM.W * RM.H * 3)) != RR_OK || (r = dev_alloc(e, &e->D.static_depth, (size_t)RM.W * RM.H)) != RR_OK ||
+            (r = dev_alloc(e, &e->D.static_mask, (size_t)RM.W * RM.H)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
         hipLaunchKernelGGL(k_render_setup, dim3((N + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D);
         hipLaunchKernelGGL(k_raster, dim3(1, RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1);
         if (hipStreamSynchronize(e->stream) != hipSuccess) { rr_destroy(e); *out = nullptr; return fail(RR_EDEVICE, "rr_create: static layer pass failed"); }
