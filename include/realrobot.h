@@ -109,6 +109,20 @@ int rr_link_poses(rr_env *env, float *out_host);
  * {bodyA, bodyB, linkA, x,y,z, nx,ny,nz, distance, normal_force, mu}; *count receives the number written. */
 int rr_get_contacts(rr_env *env, int32_t env_index, float *out_host, int32_t max_contacts, int32_t *count);
 
+/* Batched damped-least-squares inverse kinematics for link 7 (gripper `base`), seeded with each env's current joints.
+ * Replaces pybullet.calculateInverseKinematics(0, 7, pos, orn, maxNumIterations=1000, residualThreshold=0.001) in
+ * step_cartesian (env.py:372-375).  targets: f32 [N, 7] (xyz + xyzw quaternion, host); q_out: f32 [N, 11] (all movable
+ * dofs like pybullet; the fingers keep their current values); err_out (nullable): f32 [N] final pose residual. */
+int rr_ik(rr_env *env, const float *targets_host, float *q_out_host, float *err_out_host);
+/* Replaces REALRobotEnv.generate_plan (env.py:388-454) for the envs selected by the mask (NULL: all): builds the
+ * 1000-step joint-space plan of a macro action [[x1, y1], [x2, y2]] on the device. macro: f32 [N, 4] host. */
+int rr_plan_macro(rr_env *env, const float *macro_host, const uint8_t *env_mask_host);
+/* Copies one env's plan to the host, f32 [1000, 9] (tests / debugging). */
+int rr_get_plan(rr_env *env, int32_t env_index, float *plan_host);
+/* Replaces step_macro's next_step() + step_joints (env.py:404-412, 463-467): every env consumes the next row of its
+ * plan (the last row repeats once the plan is exhausted; the host decides when to re-plan) and steps. */
+int rr_step_plan(rr_env *env, int32_t render_mode, const uint8_t *render_flags_host);
+
 /* Per-kernel device timing with HIP events on the library's stream (bench.py roofline leg).
  * After rr_set_timing(env, 1), each rr_step/rr_render records events; rr_get_timing returns accumulated
  * milliseconds and launch counts per kernel since the last call and resets them.

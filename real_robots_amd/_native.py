@@ -22,7 +22,8 @@ KERNEL_NAMES = ('k_prep', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster')
 # every symbol include/realrobot.h declares (tests check the library exports all of them)
 SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_object_pose', 'rr_step', 'rr_render',
            'rr_get_buffer', 'rr_copy_to_host', 'rr_set_state', 'rr_sync', 'rr_link_poses', 'rr_get_contacts',
-           'rr_set_timing', 'rr_get_timing', 'rr_last_error', 'rr_abi_version')
+           'rr_set_timing', 'rr_get_timing', 'rr_last_error', 'rr_abi_version', 'rr_ik', 'rr_plan_macro', 'rr_get_plan',
+           'rr_step_plan')
 
 
 class Config(C.Structure):
@@ -73,6 +74,10 @@ def load_library():
     L.rr_get_contacts.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
     L.rr_set_timing.argtypes = [vp, i32]
     L.rr_get_timing.argtypes = [vp, vp, vp]
+    L.rr_ik.argtypes = [vp, vp, vp, vp]
+    L.rr_plan_macro.argtypes = [vp, vp, vp]
+    L.rr_get_plan.argtypes = [vp, i32, vp]
+    L.rr_step_plan.argtypes = [vp, i32, vp]
     L.rr_last_error.restype = C.c_char_p
     L.rr_abi_version.restype = i32
     for name in SYMBOLS:

@@ -123,6 +123,55 @@ class BatchedREALRobotEnv:
         nat.check(self.L.rr_get_contacts(self.h, int(env), out.ctypes.data, 48, C.byref(n)))
         return out[:n.value]
 
+    # ------------------------------------------------------------------ IK / macro plans (K8)
+    def ik(self, targets):
+        """Batched DLS IK of the gripper base from every env's current joints. targets [N, 7] (xyz + xyzw quat).
+        Returns (q [N, 11], residual [N])."""
+        t = np.ascontiguousarray(targets, dtype=np.float32)
+        assert t.shape == (self.N, 7)
+        q = np.empty((self.N, 11), np.float32)
+        err = np.empty(self.N, np.float32)
+        nat.check(self.L.rr_ik(self.h, t.ctypes.data, q.ctypes.data, err.ctypes.data))
+        return q, err
+
+    def plan_macro(self, macro_actions, env_mask=None):
+        """Builds the 1000-step plans of macro actions [N, 2, 2] on the device (env.py:388-454)."""
+        m = np.ascontiguousarray(macro_actions, dtype=np.float32).reshape(self.N, 4)
+        mk = None
+        if env_mask is not None:
+            mk = np.ascontiguousarray(env_mask, dtype=np.uint8)
+            assert mk.shape == (self.N,)
+        nat.check(self.L.rr_plan_macro(self.h, m.ctypes.data, mk.ctypes.data if mk is not None else None))
+
+    def get_plan(self, env):
+        out = np.empty((1000, 9), np.float32)
+        nat.check(self.L.rr_get_plan(self.h, int(env), out.ctypes.data))
+        return out
+
+    def step_plan(self, render=False):
+        flags = None
+        if isinstance(render, np.ndarray) and render.size > 1:
+            flags = np.ascontiguousarray(render, dtype=np.uint8)
+            mode = 2
+        else:
+            mode = 1 if np.any(render) else 0
+        nat.check(self.L.rr_step_plan(self.h, mode, flags.ctypes.data if flags is not None else None))
+
+    def step_macro(self, macro_actions, render=False):
+        """Batched REALRobotEnv.step_macro (env.py:388-412): a new macro action (or an exhausted plan) triggers
+        re-planning for that env; every env then consumes the next row of its plan."""
+        m = np.ascontiguousarray(macro_actions, dtype=np.float64).reshape(self.N, 4)
+        if not hasattr(self, '_macro_req'):
+            self._macro_req = np.full((self.N, 4), np.nan)
+            self._macro_step = np.zeros(self.N, np.int64)
+        need = (~np.all(m == self._macro_req, axis=1)) | (self._macro_step >= 1000)
+        if need.any():
+            self.plan_macro(m, need.astype(np.uint8))
+            self._macro_req[need] = m[need]
+            self._macro_step[need] = 0
+        self.step_plan(render)
+        self._macro_step += 1
+
     def set_timing(self, on):
         nat.check(self.L.rr_set_timing(self.h, int(on)))
 

@@ -1100,6 +1100,237 @@ __global__ void __launch_bounds__(64) k_link_poses(BodyParams B, SimParams P, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------- inverse kinematics (K8)
+// Batched damped-least-squares IK for link 7 (gripper `base`): the device restatement of what step_cartesian /
+// generate_plan ask pybullet for (env.py:372-375, 422-427: calculateInverseKinematics(0, 7, pos, orn,
+// maxNumIterations=1000, residualThreshold=0.001)); same algorithm as real_robots_amd/kinematics.py (the checker in
+// tests): J^T (J J^T + 0.01 I)^-1 e steps clamped to 0.5 rad, wrapped to (-pi, pi], two or three seeds, branch choice
+// by (converged, continuity with the previous way-point | elbow height).
+struct IkModel {          // arm chain constants, passed by value
+    float jpos[7][3], jrot[7][9], axis[7][3], robot_pos[3];
+    float ee_pos[3], ee_rot[9];        // gripper base frame in body 6
+};
+
+__device__ void ik_fk(const IkModel &M, const float *q, v3 *p, v3 *ax, m3 &Re, v3 &pe, float &elbow_z) {
+    m3 R = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+    v3 pp = mk(M.robot_pos[0], M.robot_pos[1], M.robot_pos[2]);
+#pragma unroll
+    for (int b = 0; b < 7; b++) {
+        m3 jr;
+#pragma unroll
+        for (int k = 0; k < 9; k++) jr.m[k] = M.jrot[b][k];
+        m3 Rj = mul(R, jr);
+        v3 a = mk(M.axis[b][0], M.axis[b][1], M.axis[b][2]);
+        pp = pp + mulv(R, mk(M.jpos[b][0], M.jpos[b][1], M.jpos[b][2]));
+        p[b] = pp;
+        ax[b] = mulv(Rj, a);
+        R = mul(Rj, axis_angle(a, q[b]));
+        if (b == 3) elbow_z = pp.z;
+    }
+    m3 er;
+#pragma unroll
+    for (int k = 0; k < 9; k++) er.m[k] = M.ee_rot[k];
+    Re = mul(R, er);
+    pe = pp + mulv(R, mk(M.ee_pos[0], M.ee_pos[1], M.ee_pos[2]));
+}
+
+// one DLS run from q (in/out); returns the final residual norm
+__device__ float ik_dls(const IkModel &M, float *q, v3 tp, const m3 &Rt, int max_iters) {
+    float err = 1e30f;
+    for (int it = 0; it < max_iters; it++) {
+        v3 p[7], ax[7], pe; m3 Re; float ez;
+        ik_fk(M, q, p, ax, Re, pe, ez);
+        v3 dp = tp - pe;
+        m3 Rerr = mul(Rt, transpose(Re));
+        v3 w = mk(0.5f * (Rerr.m[7] - Rerr.m[5]), 0.5f * (Rerr.m[2] - Rerr.m[6]), 0.5f * (Rerr.m[3] - Rerr.m[1]));
+        float e[6] = {dp.x, dp.y, dp.z, w.x, w.y, w.z};
+        err = sqrtf(dot(dp, dp) + dot(w, w));
+        if (err < 1e-3f) break;
+        float J[6][7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            v3 jl = cross(ax[k], pe - p[k]);
+            J[0][k] = jl.x; J[1][k] = jl.y; J[2][k] = jl.z; J[3][k] = ax[k].x; J[4][k] = ax[k].y; J[5][k] = ax[k].z;
+        }
+        float A[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+                float s = (i == j) ? 0.01f : 0.0f;
+#pragma unroll
+                for (int k = 0; k < 7; k++) s += J[i][k] * J[j][k];
+                A[i][j] = s;
+            }
+        // Cholesky solve A x = e
+        float L[6][6], y[6], x[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+                float s = A[i][j];
+#pragma unroll
+                for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+                if (i == j) L[i][i] = sqrtf(s);
+                else L[i][j] = s / L[j][j];
+            }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            float s = e[i];
+#pragma unroll
+            for (int k = 0; k < i; k++) s -= L[i][k] * y[k];
+            y[i] = s / L[i][i];
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {
+            float s = y[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; k++) s -= L[k][i] * x[k];
+            x[i] = s / L[i][i];
+        }
+        float dq[7], mx = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            float s = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) s += J[i][k] * x[i];
+            dq[k] = s;
+            mx = fmaxf(mx, fabsf(s));
+        }
+        float sc = mx > 0.5f ? 0.5f / mx : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            float v = q[k] + dq[k] * sc;
+            v = v + 3.14159265358979f;
+            v = v - 6.28318530717959f * floorf(v * 0.159154943091895f);
+            q[k] = v - 3.14159265358979f;
+        }
+    }
+    return err;
+}
+
+// best of {current joints, elbow-up seed, previous way-point}; out7 receives the solution
+__device__ float ik_solve(const IkModel &M, const float *q_cur, const float *prefer /*nullable*/, v3 tp, const m3 &Rt, float *out7) {
+    const float elbow_up[7] = {0.0f, 0.6f, 0.0f, -1.3f, 0.0f, 1.2f, 0.0f};
+    bool have = false, best_conv = false;
+    float best_key = 0, best_err = 0;
+    const int nseeds = prefer ? 3 : 2;
+    for (int sidx = 0; sidx < nseeds; sidx++) {
+        float q[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) q[k] = sidx == 0 ? q_cur[k] : (sidx == 1 ? elbow_up[k] : prefer[k]);
+        float err = ik_dls(M, q, tp, Rt, 1000);
+        bool conv = err < 1e-2f;
+        float key;
+        if (prefer) {
+            float mxd = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) mxd = fmaxf(mxd, fabsf(q[k] - prefer[k]));
+            key = -mxd;
+        } else {
+            v3 p[7], ax[7], pe; m3 Re; float ez;
+            ik_fk(M, q, p, ax, Re, pe, ez);
+            key = ez;
+        }
+        bool better = !have || (conv && !best_conv) || (conv == best_conv && key > best_key);
+        if (better) {
+            have = true; best_conv = conv; best_key = key; best_err = err;
+#pragma unroll
+            for (int k = 0; k < 7; k++) out7[k] = q[k];
+        }
+    }
+    return best_err;
+}
+
+__device__ __forceinline__ m3 quat_target(const float *qt) {
+    float n = rsqrtf(qt[0] * qt[0] + qt[1] * qt[1] + qt[2] * qt[2] + qt[3] * qt[3]);
+    return quat_to_m3(qt[0] * n, qt[1] * n, qt[2] * n, qt[3] * n);
+}
+
+// single IK per env from the current joints: targets [N][7] (pos, quat xyzw) -> out [N][11] (fingers keep their values)
+__global__ void __launch_bounds__(64) k_ik(IkModel M, SimParams P, DevPtrs D, const float *targets, float *out_q, float *out_err) {
+    const int N = P.N;
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    const float *state = D.state;
+    float qc[7], o7[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) qc[k] = STT(ST_Q + k);
+    const float *t = targets + (size_t)env * 7;
+    m3 Rt = quat_target(t + 3);
+    float err = ik_solve(M, qc, nullptr, mk(t[0], t[1], t[2]), Rt, o7);
+    for (int k = 0; k < 7; k++) out_q[(size_t)env * 11 + k] = o7[k];
+    for (int k = 7; k < 11; k++) out_q[(size_t)env * 11 + k] = STT(ST_Q + k);
+    out_err[env] = err;
+}
+
+// 1000-step macro plan per env (env.py:388-454): rows 0-99 home2, 100-199 above p1 (z 0.6), 200-249 at p1 (z 0.46),
+// 250-749 p1 -> p2 at z 0.46 in <= 5 cm IK segments, 750-799 above p2, 800-899 home2, 900-999 home.
+#define PLAN_LEN 1000
+__global__ void __launch_bounds__(64) k_plan_macro(IkModel M, SimParams P, DevPtrs D, const float *macro /*[N][4]*/,
+                                                   const unsigned char *mask, float *plan /*[N][1000][9]*/, int *plan_step) {
+    const int N = P.N;
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    if (mask && !mask[env]) return;
+    const float *state = D.state;
+    float qc[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) qc[k] = STT(ST_Q + k);
+    const float f7 = STT(ST_Q + 7), f8 = STT(ST_Q + 8);       // env.py:427: first 9 of the 11 dofs
+    const float p1x = macro[(size_t)env * 4], p1y = macro[(size_t)env * 4 + 1], p2x = macro[(size_t)env * 4 + 2], p2y = macro[(size_t)env * 4 + 3];
+    // getQuaternionFromEuler([0, 3.14, -1.57])  (env.py:422)
+    float cr = 1.0f, sr = 0.0f, sp, cp, sy, cy;
+    sincosf(3.14f * 0.5f, &sp, &cp);
+    sincosf(-1.57f * 0.5f, &sy, &cy);
+    float qt[4] = {sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
+    m3 Rt = quat_target(qt);
+    float *pl = plan + (size_t)env * PLAN_LEN * 9;
+    auto fill = [&](int r0, int r1, const float *q7, bool ik) {
+        for (int r = r0; r < r1; r++) {
+            for (int k = 0; k < 7; k++) pl[r * 9 + k] = q7[k];
+            pl[r * 9 + 7] = ik ? f7 : q7[7];
+            pl[r * 9 + 8] = ik ? f8 : q7[8];
+        }
+    };
+    float home2[9] = {0, 0, 0, 0, 0, 1.57079632679f, 1.57079632679f, 0, 0}, home[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    fill(0, 100, home2, false);
+    fill(800, 900, home2, false);
+    fill(900, 1000, home, false);
+    float last[7], cur[7];
+    ik_solve(M, qc, nullptr, mk(p1x, p1y, 0.6f), Rt, last);
+    fill(100, 200, last, true);
+    ik_solve(M, qc, last, mk(p1x, p1y, 0.46f), Rt, cur);
+    for (int k = 0; k < 7; k++) last[k] = cur[k];
+    fill(200, 250, last, true);
+    // interpolate3D(p1, p2, 500) (env.py:430-441)
+    float dx = p2x - p1x, dy = p2y - p1y;
+    float dist = sqrtf(dx * dx + dy * dy);
+    int pieces = (int)(dist / 0.05f) + 1;
+    if (pieces > 500) pieces = 500;
+    int chunk = 500 / pieces;
+    for (int i = 0; i < pieces; i++) {
+        float f = (float)(i + 1) / (float)pieces;
+        ik_solve(M, qc, last, mk(p1x + dx * f, p1y + dy * f, 0.46f), Rt, cur);
+        for (int k = 0; k < 7; k++) last[k] = cur[k];
+        fill(250 + i * chunk, 750, last, true);
+    }
+    ik_solve(M, qc, last, mk(p2x, p2y, 0.6f), Rt, cur);
+    fill(750, 800, cur, true);
+    plan_step[env] = 0;
+}
+
+// command of this step = plan row plan_step (clamped to the last row); advances plan_step
+__global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *plan_step) {
+    const int N = P.N;
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    int st = plan_step[env];
+    int r = st < PLAN_LEN ? st : PLAN_LEN - 1;
+    for (int k = 0; k < 9; k++) D.cmd[(size_t)env * 9 + k] = plan[((size_t)env * PLAN_LEN + r) * 9 + k];
+    plan_step[env] = st + 1;
+}
+
 // ---------------------------------------------------------------------------------------------- rasteriser
 // One workgroup per (env, tile). Tile = full-width strip of tile_h rows (<= 16384 pixels -> 128 KiB of LDS keys).
 #define RASTER_THREADS 1024
@@ -1417,6 +1648,8 @@ struct rr_env {
     float *state_aos;        // [N][61] staging for RR_F_STATE
     unsigned char *mask_dev; // [N]
     float *link_out;         // [N][nl][7]
+    IkModel IK;
+    float *plan; int *plan_step; float *ik_in; float *ik_out; float *ik_err;   // lazily allocated (macro / cartesian adapters)
     std::vector<void *> allocs;
     bool timing;
     hipEvent_t ev[2 * RR_NUM_KERNELS];
@@ -1503,6 +1736,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     memset(&e->B, 0, sizeof e->B); memset(&e->RM, 0, sizeof e->RM); memset(&e->D, 0, sizeof e->D);
     memset(e->ev, 0, sizeof e->ev); memset(e->t_ms, 0, sizeof e->t_ms); memset(e->t_n, 0, sizeof e->t_n);
     e->timing = false;
+    e->plan = nullptr; e->plan_step = nullptr; e->ik_in = nullptr; e->ik_out = nullptr; e->ik_err = nullptr;
     e->cfg = *cfg;
     e->stream = (hipStream_t)stream;
     const int N = cfg->num_envs;
@@ -1529,6 +1763,17 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     NEED(f = b.f32("act_max", 9)); memcpy(B.act_max, f, sizeof B.act_max);
     NEED(f = b.f32("act_maxdiff", 9)); memcpy(B.act_maxdiff, f, sizeof B.act_maxdiff);
     NEED(ip = b.i32("touch_links", 4)); memcpy(B.touch_links, ip, sizeof B.touch_links);
+    {   // arm chain + gripper base frame (link id 8 = `base`, rigidly attached to body 6) for the IK kernels
+        IkModel &K = e->IK;
+        memset(&K, 0, sizeof K);
+        for (int j = 0; j < 7; j++) { memcpy(K.jpos[j], B.jpos[j], 12); memcpy(K.jrot[j], B.jrot[j], 36); memcpy(K.axis[j], B.axis[j], 12); }
+        memcpy(K.robot_pos, B.robot_pos, 12);
+        const float *lp, *lr; const int32_t *lb;
+        NEED(lb = b.i32("link_body", nl)); NEED(lp = b.f32("link_pos", nl * 3)); NEED(lr = b.f32("link_rot", nl * 9));
+        const int ee = 8;       // URDF depth-first id of the gripper `base` link (pybullet link index 7)
+        if (nl <= ee || lb[ee] != 6) { rr_destroy(e); return fail(RR_EMODEL, "rr_create: gripper base link not found"); }
+        memcpy(K.ee_pos, lp + 3 * ee, 12); memcpy(K.ee_rot, lr + 9 * ee, 36);
+    }
 
     SimParams &P = e->P;
     P.N = N; P.nobj = cfg->n_objects; P.iters = cfg->solver_iters > 0 ? cfg->solver_iters : 50;
@@ -1730,7 +1975,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     HIPCHK(hipSetDevice(e->cfg.device));
     const int N = e->P.N;
     if (!joint_cmd) HIPCHK(hipMemsetAsync(e->D.cmd, 0, (size_t)N * 36, e->stream));      // env.py:333-334
-    else HIPCHK(hipMemcpyAsync(e->D.cmd, joint_cmd, (size_t)N * 36, cmd_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    else if (joint_cmd != e->D.cmd) HIPCHK(hipMemcpyAsync(e->D.cmd, joint_cmd, (size_t)N * 36, cmd_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
     if (render_mode == 2) HIPCHK(hipMemcpyAsync(e->D.render_flags, render_flags_host, N, hipMemcpyHostToDevice, e->stream));
     TIMED(0, hipLaunchKernelGGL(k_prep, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, e->D));
     TIMED(1, hipLaunchKernelGGL(k_collide, dim3(((N + COLLIDE_THREADS - 1) / COLLIDE_THREADS) * e->P.npairs), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D, (N + COLLIDE_THREADS - 1) / COLLIDE_THREADS));
@@ -1806,6 +2051,67 @@ int rr_get_contacts(rr_env *e, int32_t env_index, float *out_host, int32_t max_c
     HIPCHK(hipStreamSynchronize(e->stream));
     *count = nc;
     return RR_OK;
+}
+
+static int ensure_plan_buffers(rr_env *e) {
+    if (e->plan) return RR_OK;
+    int rc;
+    const size_t N = e->P.N;
+    if ((rc = dev_alloc(e, &e->plan, N * PLAN_LEN * 9)) != RR_OK) return rc;
+    if ((rc = dev_alloc(e, &e->plan_step, N)) != RR_OK) return rc;
+    if ((rc = dev_alloc(e, &e->ik_in, N * 7)) != RR_OK) return rc;
+    if ((rc = dev_alloc(e, &e->ik_out, N * 11)) != RR_OK) return rc;
+    if ((rc = dev_alloc(e, &e->ik_err, N)) != RR_OK) return rc;
+    return RR_OK;
+}
+
+int rr_ik(rr_env *e, const float *targets_host, float *q_out_host, float *err_out_host) {
+    if (!e || !targets_host || !q_out_host) return fail(RR_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    int rc = ensure_plan_buffers(e);
+    if (rc != RR_OK) return rc;
+    const int N = e->P.N;
+    HIPCHK(hipMemcpyAsync(e->ik_in, targets_host, (size_t)N * 28, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_ik, dim3((N + 63) / 64), dim3(64), 0, e->stream, e->IK, e->P, e->D, e->ik_in, e->ik_out, e->ik_err);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(q_out_host, e->ik_out, (size_t)N * 44, hipMemcpyDeviceToHost, e->stream));
+    if (err_out_host) HIPCHK(hipMemcpyAsync(err_out_host, e->ik_err, (size_t)N * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return RR_OK;
+}
+
+int rr_plan_macro(rr_env *e, const float *macro_host, const uint8_t *env_mask_host) {
+    if (!e || !macro_host) return fail(RR_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    int rc = ensure_plan_buffers(e);
+    if (rc != RR_OK) return rc;
+    const int N = e->P.N;
+    // the macro targets travel through the (otherwise idle) ik_out staging buffer: [N][4]
+    HIPCHK(hipMemcpyAsync(e->ik_out, macro_host, (size_t)N * 16, hipMemcpyHostToDevice, e->stream));
+    const unsigned char *m = nullptr;
+    if (env_mask_host) { HIPCHK(hipMemcpyAsync(e->mask_dev, env_mask_host, N, hipMemcpyHostToDevice, e->stream)); m = e->mask_dev; }
+    hipLaunchKernelGGL(k_plan_macro, dim3((N + 63) / 64), dim3(64), 0, e->stream, e->IK, e->P, e->D, e->ik_out, m, e->plan, e->plan_step);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return RR_OK;
+}
+
+int rr_get_plan(rr_env *e, int32_t env_index, float *plan_host) {
+    if (!e || !plan_host) return fail(RR_EINVAL, "null argument");
+    if (!e->plan) return fail(RR_EINVAL, "rr_get_plan: no plan was generated");
+    if (env_index < 0 || env_index >= e->P.N) return fail(RR_EINVAL, "rr_get_plan: env out of range");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipMemcpyAsync(plan_host, e->plan + (size_t)env_index * PLAN_LEN * 9, PLAN_LEN * 36, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return RR_OK;
+}
+
+int rr_step_plan(rr_env *e, int32_t render_mode, const uint8_t *render_flags_host) {
+    if (!e) return fail(RR_EINVAL, "null env");
+    if (!e->plan) return fail(RR_EINVAL, "rr_step_plan: call rr_plan_macro first");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipLaunchKernelGGL(k_plan_fetch, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D, e->plan, e->plan_step);
+    return rr_step(e, e->D.cmd, 1, render_mode, render_flags_host);
 }
 
 int rr_set_timing(rr_env *e, int32_t enable) {

@@ -246,7 +246,8 @@ class REALRobotEnv:
             if same:
                 arm_joints = self.last_ik
             else:
-                arm_joints = inverse_kinematics(self._q11(), coords, orient)
+                target = np.concatenate([coords, orient]).reshape(1, 7)
+                arm_joints = self._backend().ik(target)[0][0].astype(np.float64)      # batched DLS IK on the device
                 self.last_ik = arm_joints
                 self.requested_coords = coords
                 self.requested_orient = orient
@@ -272,7 +273,9 @@ class REALRobotEnv:
     def generate_plan(self, macro_action):
         """1000-step plan of 9-vectors (env.py:388-454): home2, above p1, at p1, p1->p2 in <=5 cm IK segments,
         above p2, home2, home."""
-        self.planned_actions = generate_plan(self._q11(), macro_action)
+        be = self._backend()
+        be.plan_macro(np.asarray(macro_action, dtype=np.float64).reshape(1, 2, 2))     # IK + plan on the device
+        self.planned_actions = be.get_plan(0).astype(np.float64)
         self.plan_step = -1
 
     def next_step(self):

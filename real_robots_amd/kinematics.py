@@ -156,10 +156,11 @@ def generate_plan(q_seed11, macro_action):
             joints[i * chunk:, :] = goToPosXY(coord)
         return joints
 
+    # way-points are solved in path order so that each IK prefers the branch closest to the previous one
     point_1_h = goToPosXY(np.hstack([point_1, 0.6]))
     point_1_l = goToPosXY(np.hstack([point_1, 0.46]))
+    middle = interpolate3D(np.hstack([point_1, 0.46]), np.hstack([point_2, 0.46]), 500)
     point_2_h = goToPosXY(np.hstack([point_2, 0.6]))
-    parts = [np.tile(home2, (100, 1)), np.tile(point_1_h, (100, 1)), np.tile(point_1_l, (50, 1)),
-             interpolate3D(np.hstack([point_1, 0.46]), np.hstack([point_2, 0.46]), 500),
+    parts = [np.tile(home2, (100, 1)), np.tile(point_1_h, (100, 1)), np.tile(point_1_l, (50, 1)), middle,
              np.tile(point_2_h, (50, 1)), np.tile(home2, (100, 1)), np.tile(home, (100, 1))]
     return np.vstack(parts)

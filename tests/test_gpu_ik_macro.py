@@ -1,0 +1,91 @@
+"""GPU tests (-m gpu) of the K8 row: batched DLS IK and device-side macro plans, checked against the host numpy
+restatement (real_robots_amd/kinematics.py) and the reference's tracking known answers."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from real_robots_amd import _native as nat
+from real_robots_amd.batched import BatchedREALRobotEnv
+from real_robots_amd.kinematics import EE_LINK, generate_plan, inverse_kinematics, link_pose, quat_from_euler
+
+pytestmark = pytest.mark.gpu
+ORIENT = quat_from_euler(0, 3.14, -1.57)
+
+
+def test_batched_ik_reaches_cartesian_targets():
+    N = 64
+    env = BatchedREALRobotEnv(N, objects=1, width=64, height=64)
+    rng = np.random.default_rng(4)
+    pos = np.stack([rng.uniform(-0.25, 0.05, N), rng.uniform(-0.4, 0.4, N), rng.uniform(0.42, 0.6, N)], 1)
+    tg = np.concatenate([pos, np.tile(ORIENT, (N, 1))], 1)
+    q, err = env.ik(tg)
+    assert (err < 2e-3).mean() > 0.95
+    same = 0
+    for i in range(N):
+        if err[i] < 2e-3:
+            assert np.linalg.norm(link_pose(q[i].astype(np.float64), EE_LINK)[1] - pos[i]) < 3e-3
+        if i < 8:      # branch agreement with the host numpy IK (same seeds, same selection rule)
+            qh = inverse_kinematics(np.zeros(11), pos[i], ORIENT)
+            same += int(np.abs(qh[:7] - q[i][:7]).max() < 5e-2)
+    assert same >= 6
+    assert np.all(q[:, 7:] == 0)          # fingers keep their current values (pybullet returns all movable dofs)
+    env.close()
+
+
+def test_device_macro_plan_matches_host_plan_and_tracks_reference_checkpoints():
+    """reference tests/test_actions.py:69-71,147-152 on the HIP path: following the plan, gripper base within 0.01 m of
+    (p1, 0.6) @199, (p1, 0.46) @249, (p2, 0.46) @749 and home @999 (objects parked on the shelf)."""
+    pairs = [((-0.25, -0.5), (0.05, 0.0)), ((0.05, 0.0), (-0.25, 0.5)), ((-0.25, 0.5), (-0.25, -0.5)), ((0.05, 0.0), (0.05, 0.0))]
+    N = len(pairs)
+    env = BatchedREALRobotEnv(N, objects=1, width=64, height=64)
+    for i in range(N):
+        env.set_object_pose(i, 0, [0.2, 0.0, 0.45, 0, 0, 0, 1])
+    macro = np.array(pairs, dtype=np.float32)
+    env.plan_macro(macro)
+    plan0 = env.get_plan(0)
+    assert plan0.shape == (1000, 9)
+    host = generate_plan(np.zeros(11), pairs[0])
+    assert np.abs(plan0[:100] - host[:100]).max() < 1e-6                        # home2 segment
+    assert np.abs(plan0 - host).max() < 5e-2                                    # same IK branches along the path
+    base = nat.LINK_NAMES.index('base')
+    home = np.array([-0.55, 0.0, 1.27])
+    for t in range(1000):
+        env.step_plan()
+        if t in (199, 249, 749, 999):
+            lp = env.link_poses()[:, base, :3]
+            for i, (p1, p2) in enumerate(pairs):
+                tgt = {199: [p1[0], p1[1], 0.6], 249: [p1[0], p1[1], 0.46], 749: [p2[0], p2[1], 0.46], 999: home}[t]
+                assert np.linalg.norm(lp[i] - tgt) < 0.01, (t, i)
+    assert (env.host(nat.F_TIMESTEP) == 1000).all()
+    env.close()
+
+
+def test_step_macro_replans_on_new_action_and_facade_macro_env():
+    env = BatchedREALRobotEnv(2, objects=1, width=64, height=64)
+    a = np.array([[[-0.1, -0.2], [0.0, 0.2]], [[-0.2, 0.1], [0.0, -0.3]]])
+    for _ in range(5):
+        env.step_macro(a)
+    assert (env._macro_step == 5).all()
+    b = a.copy()
+    b[1, 0, 0] = -0.15
+    env.step_macro(b)
+    assert env._macro_step.tolist() == [6, 1]
+    env.close()
+    import real_robots_amd as rr
+    e = rr.make('REALRobot2020-R1M1-v0', eye_width=64, eye_height=64)
+    e.reset()
+    act = {'macro_action': np.array([[-0.1, -0.2], [0.0, 0.2]]), 'render': False}
+    for _ in range(3):
+        obs, r, done, info = e.step(act)
+    assert e.plan_step == 2 and e.planned_actions.shape == (1000, 9)
+    c = rr.make('REALRobot2020-R2C1-v0', eye_width=64, eye_height=64)
+    c.reset()
+    ca = {'cartesian_command': np.array([-0.1, 0.1, 0.5, *ORIENT]), 'gripper_command': np.array([0.2, 0.1]), 'render': False}
+    for _ in range(120):
+        obs, r, done, info = c.step(ca)
+    assert np.linalg.norm(c.get_part_pos('base') - np.array([-0.1, 0.1, 0.5])) < 0.01
+    assert abs(obs['joint_positions'][7] - 0.2) < 5e-3
+    e.close()
+    c.close()
