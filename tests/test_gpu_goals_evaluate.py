@@ -1,0 +1,58 @@
+"""GPU tests (-m gpu) of the callers either side of the path: goal dataset generation on the
+batched simulator, the reference-compatible dataset format, and real_robots.evaluate() end to end."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_generate_goals_and_evaluate_end_to_end(tmp_path):
+    import real_robots            # the alias package: existing agents import this name
+    from real_robots.policy import BasePolicy
+    from real_robots_amd.generate_goals import generate_goals, is_on_table, save_goals
+    goals = generate_goals(n_2d_goals=2, n_25d_goals=1, n_3d_goals=1, n_obj=1, seed=7, batch=32, width=64, height=64)
+    assert [g.challenge for g in goals] == ['2D', '2D', '2.5D', '3D']
+    g = goals[0]
+    assert set(g.initial_state) == {'cube'} and g.retina.shape == (64, 64, 3) and g.mask.shape == (64, 64)
+    assert is_on_table('cube', g.final_state['cube'][2]) and is_on_table('cube', g.initial_state['cube'][2])
+    assert np.linalg.norm(g.final_state['cube'][:2] - g.initial_state['cube'][:2]) >= 0.2
+    assert (g.mask == 2).sum() > 0 and g.retina.any()
+    path = str(tmp_path / 'goals.npy.npz')
+    save_goals(path, goals)
+
+    calls = []
+
+    class Pusher(BasePolicy):
+        def start_intrinsic_phase(self):
+            calls.append('si')
+
+        def start_extrinsic_trial(self):
+            calls.append('st')
+
+        def end_extrinsic_trial(self, observation, reward, done):
+            calls.append('et')
+
+        def step(self, observation, reward, done):
+            assert set(observation) >= {'joint_positions', 'touch_sensors', 'retina', 'goal', 'object_positions', 'goal_positions'}
+            return {'macro_action': np.array([[-0.1, -0.2], [0.0, 0.2]]), 'render': False}
+
+    result, scores = real_robots.evaluate(Pusher, environment='R1', action_type='macro_action', n_objects=1,
+                                          intrinsic_timesteps=30, extrinsic_timesteps=40, extrinsic_trials=3,
+                                          visualize=False, goals_dataset_path=path,
+                                          env_kwargs=dict(eye_width=64, eye_height=64))
+    assert calls == ['si', 'st', 'et', 'st', 'et', 'st', 'et']
+    assert set(result) == {'score_2D', 'score_2.5D', 'score_3D', 'score_total'}
+    assert len(scores['2D']) == 2 and len(scores['2.5D']) == 1
+    assert 0 <= result['score_total'] <= 1          # one object: exp(-ln4/0.1 * dist) in (0, 1]
+    # the goal image shown during the extrinsic phase is the dataset's final-state retina
+    env = real_robots.make('REALRobot2020-R1J1-v0', eye_width=64, eye_height=64)
+    env.set_goals_dataset_path(path)
+    env.reset()
+    obs = env.set_goal()
+    assert (obs['goal'] == goals[0].retina).all() and env.goal_idx == 0
+    p = env.get_obj_pos('cube')
+    assert np.allclose(p, goals[0].initial_state['cube'][:3], atol=1e-3)
+    challenge, score = env.evaluateGoal()
+    d = np.linalg.norm(goals[0].final_state['cube'][:3] - p)
+    assert challenge == '2D' and abs(score - np.exp(np.log(0.25) / 0.10 * d)) < 1e-3     # env.py:181-200
+    env.close()
