@@ -11,7 +11,7 @@ from .registry import register, make, registered_ids  # noqa: F401
 from .policy import BasePolicy  # noqa: F401
 from .batched import BatchedREALRobotEnv  # noqa: F401
 from .envs import REALRobotEnv  # noqa: F401
-from .evaluate import evaluate  # noqa: F401
+from .evaluate import evaluate, evaluate_batched  # noqa: F401
 
 # the 18 environment ids of the reference (real_robots/__init__.py:16-28)
 for _n_obj in [1, 2, 3]:

@@ -163,3 +163,112 @@ def evaluate(Controller, environment='R1', action_type='macro_action', n_objects
     service.run_intrinsic_phase()
     service.run_extrinsic_phase()
     return service.build_score_object(), service.scores
+
+
+def evaluate_batched(Controller, num_envs, environment='R1', action_type='macro_action', n_objects=1,
+                     intrinsic_timesteps=1000, extrinsic_timesteps=1000, extrinsic_trials=5,
+                     goals_dataset_path="./goals.npy.npz", eye_width=320, eye_height=240, device=0, render_every=0):
+    """`evaluate()` for `num_envs` independent agents stepped in lock-step on one GPU (BASELINE config 5): env i owns
+    its own `Controller` instance and walks the goal list from goal i (cyclically), so every env sees
+    `extrinsic_trials` different goals. Phases, callbacks and the scoring formula are those of the single-env harness
+    (evaluate.py:249-259, 282-324; env.py:181-200). Observations are assembled on the host per env; the retina is
+    only rendered/fetched on the steps where `render_every` divides the step index (0: never) -- policies that need
+    images every step should consume the device buffers of `BatchedREALRobotEnv` instead.
+    Returns (score_object, scores) aggregated over all envs and trials."""
+    from . import _native as nat
+    from .batched import BatchedREALRobotEnv, OBJECT_NAMES
+    from .envs.env import REALRobotEnv
+    if environment not in ("R1", "R2"):
+        raise Exception("Environment type has to be either R1 or R2")
+    if action_type == 'macro_action' and environment == 'R2':
+        raise Exception("Action type cannot be macro_action in Round 2")
+    if action_type not in ('joints', 'macro_action'):
+        raise Exception("evaluate_batched supports 'joints' and 'macro_action'")
+    if not issubclass(Controller, BasePolicy):
+        raise Exception("Supplied Controller is not a Sub-Class of real_robots.policy.BasePolicy")
+    proto = REALRobotEnv(objects=n_objects, action_type=action_type, additional_obs=(environment == 'R1'),
+                         eye_width=eye_width, eye_height=eye_height)
+    proto.set_goals_dataset_path(goals_dataset_path)
+    proto.load_goals()
+    goals = list(proto.goals)
+    names = OBJECT_NAMES[:n_objects]
+    N = int(num_envs)
+    env = BatchedREALRobotEnv(N, objects=n_objects, width=eye_width, height=eye_height, device=device,
+                              want_mask=(environment == 'R1'))
+    ctrls = [Controller(proto.action_space, proto.observation_space) for _ in range(N)]
+    zero_img = np.zeros((eye_height, eye_width, 3), np.uint8)
+    zero_depth = np.zeros((eye_height, eye_width))
+    zero_mask = np.zeros((eye_height, eye_width), np.int32)
+
+    def observations(goal_of_env, rendered):
+        joints, touch = env.host(nat.F_JOINTS).astype(np.float64), env.host(nat.F_TOUCH).astype(np.float64)
+        poses = env.host(nat.F_OBJ_POSE).astype(np.float64)
+        rgb = env.host(nat.F_RGB) if rendered else None
+        dep = env.host(nat.F_DEPTH) if rendered else None
+        msk = env.host(nat.F_MASK) if rendered and environment == 'R1' else None
+        out = []
+        for i in range(N):
+            g = goal_of_env[i]
+            o = {"joint_positions": list(joints[i]), "touch_sensors": touch[i],
+                 "retina": rgb[i] if rendered else zero_img, "depth": dep[i].astype(np.float64) if rendered else zero_depth,
+                 "goal": g.retina if g is not None else zero_img}
+            if environment == 'R1':
+                o["mask"] = msk[i] if rendered else zero_mask
+                o["object_positions"] = {n: poses[i, k, :3] for k, n in enumerate(names)}
+                o["goal_mask"] = g.mask if g is not None else zero_mask
+                o["goal_positions"] = {n: np.asarray(g.final_state[n])[:3] for n in g.final_state} if g is not None else None
+            out.append(o)
+        return out
+
+    def run_phase(n_steps, goal_of_env):
+        obs = observations(goal_of_env, False)
+        done = False
+        for t in range(int(n_steps)):
+            acts = [c.step(o, 0, done) for c, o in zip(ctrls, obs)]
+            rendered = bool(render_every) and (t % render_every == 0)
+            if action_type == 'macro_action':
+                env.step_macro(np.array([a['macro_action'] for a in acts], dtype=np.float64), render=rendered)
+            else:
+                env.step(np.array([np.zeros(9) if a['joint_command'] is None else a['joint_command'] for a in acts],
+                                  dtype=np.float32), render=rendered)
+            done = (t + 1) >= n_steps
+            obs = observations(goal_of_env, rendered)
+        return obs
+
+    scores = {}
+    if intrinsic_timesteps and intrinsic_timesteps > 0:
+        env.reset()
+        for c in ctrls:
+            c.start_intrinsic_phase()
+        obs = run_phase(intrinsic_timesteps, [None] * N)
+        for c, o in zip(ctrls, obs):
+            c.end_intrinsic_phase(o, 0, True)
+    for c in ctrls:
+        c.start_extrinsic_phase()
+    pos_const = -np.log(0.25) / 0.10
+    for trial in range(int(extrinsic_trials)):
+        env.reset()
+        goal_of_env = [goals[(i + trial) % len(goals)] for i in range(N)]
+        for i, g in enumerate(goal_of_env):
+            for n in g.initial_state:
+                env.set_object_pose(i, names.index(n), np.asarray(g.initial_state[n], dtype=np.float32))
+        for c in ctrls:
+            c.start_extrinsic_trial()
+        obs = run_phase(extrinsic_timesteps, goal_of_env)
+        poses = env.host(nat.F_OBJ_POSE).astype(np.float64)
+        for i, g in enumerate(goal_of_env):
+            sc = sum(np.exp(-pos_const * np.linalg.norm(np.asarray(g.final_state[n])[:3] - poses[i, names.index(n), :3]))
+                     for n in g.final_state)
+            scores.setdefault(g.challenge, []).append(sc)
+        for c, o in zip(ctrls, obs):
+            c.end_extrinsic_trial(o, 0, True)
+    for c in ctrls:
+        c.end_extrinsic_phase()
+    env.close()
+    total, score_object = [], {}
+    for key in ['2D', '2.5D', '3D']:
+        r = scores.get(key, [])
+        score_object["score_{}".format(key)] = np.mean(r) if r else 0
+        total += r
+    score_object["score_total"] = np.mean(total) if total else float('nan')
+    return score_object, scores

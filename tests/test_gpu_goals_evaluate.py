@@ -56,3 +56,26 @@ def test_generate_goals_and_evaluate_end_to_end(tmp_path):
     d = np.linalg.norm(goals[0].final_state['cube'][:3] - p)
     assert challenge == '2D' and abs(score - np.exp(np.log(0.25) / 0.10 * d)) < 1e-3     # env.py:181-200
     env.close()
+
+
+def test_evaluate_batched_matches_single_env_scores(tmp_path):
+    """N envs with identical scripted controllers: every env reproduces the single-env harness' score for the goal
+    it is given (same physics, same scoring), and the per-challenge aggregation has N x trials entries."""
+    import real_robots_amd as rr
+    from real_robots_amd.generate_goals import generate_goals, save_goals
+    goals = generate_goals(n_2d_goals=2, n_25d_goals=0, n_3d_goals=0, n_obj=1, seed=3, batch=16, width=64, height=64)
+    path = str(tmp_path / 'g.npy.npz')
+    save_goals(path, goals)
+
+    class Scripted(rr.BasePolicy):
+        def step(self, observation, reward, done):
+            return {'macro_action': np.array([[-0.1, -0.25], [-0.1, 0.25]]), 'render': False}
+
+    kw = dict(environment='R1', action_type='macro_action', n_objects=1, intrinsic_timesteps=20,
+              extrinsic_timesteps=60, extrinsic_trials=2, goals_dataset_path=path)
+    res_b, scores_b = rr.evaluate_batched(Scripted, 6, eye_width=64, eye_height=64, **kw)
+    res_s, scores_s = rr.evaluate(Scripted, visualize=False, env_kwargs=dict(eye_width=64, eye_height=64), **kw)
+    assert len(scores_b['2D']) == 12
+    # env 0 walks the goals in the same order as the single env: trial 0 -> goal 0, trial 1 -> goal 1
+    assert abs(scores_b['2D'][0] - scores_s['2D'][0]) < 1e-3 and abs(scores_b['2D'][6] - scores_s['2D'][1]) < 1e-3
+    assert 0 < res_b['score_total'] <= 1
