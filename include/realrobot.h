@@ -94,6 +94,11 @@ int rr_step(rr_env *env, const float *joint_cmd, int32_t cmd_on_device, int32_t 
 /* Replaces EyeCamera.render (env.py:536-567) for all envs at the current state (used by reset()/set_goal()). */
 int rr_render(rr_env *env);
 
+/* Replaces the camera of this rr_env (row-major 4x4 OpenGL view and projection matrices, host). The default is the
+ * reference's eye camera; the facade uses a second rr_env with EnvCamera's matrices for render('rgb_array')
+ * (computeViewMatrixFromYawPitchRoll / computeProjectionMatrixFOV, env.py:480-499). */
+int rr_set_camera(rr_env *env, const float *view16, const float *proj16);
+
 /* Device pointer + size of an observation/state buffer (valid until rr_destroy). */
 int rr_get_buffer(rr_env *env, int32_t field, void **dev_ptr, size_t *bytes);
 /* Synchronising copy of a whole field to host memory. */

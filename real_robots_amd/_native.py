@@ -23,7 +23,7 @@ KERNEL_NAMES = ('k_prep', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster')
 SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_object_pose', 'rr_step', 'rr_render',
            'rr_get_buffer', 'rr_copy_to_host', 'rr_set_state', 'rr_sync', 'rr_link_poses', 'rr_get_contacts',
            'rr_set_timing', 'rr_get_timing', 'rr_last_error', 'rr_abi_version', 'rr_ik', 'rr_plan_macro', 'rr_get_plan',
-           'rr_step_plan')
+           'rr_step_plan', 'rr_set_camera')
 
 
 class Config(C.Structure):
@@ -78,6 +78,7 @@ def load_library():
     L.rr_plan_macro.argtypes = [vp, vp, vp]
     L.rr_get_plan.argtypes = [vp, i32, vp]
     L.rr_step_plan.argtypes = [vp, i32, vp]
+    L.rr_set_camera.argtypes = [vp, vp, vp]
     L.rr_last_error.restype = C.c_char_p
     L.rr_abi_version.restype = i32
     for name in SYMBOLS:

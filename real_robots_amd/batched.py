@@ -172,6 +172,12 @@ class BatchedREALRobotEnv:
         self.step_plan(render)
         self._macro_step += 1
 
+    def set_camera(self, view, proj):
+        """Row-major 4x4 OpenGL view / projection matrices replacing the eye camera of this batch."""
+        v = np.ascontiguousarray(view, dtype=np.float32).reshape(16)
+        p = np.ascontiguousarray(proj, dtype=np.float32).reshape(16)
+        nat.check(self.L.rr_set_camera(self.h, v.ctypes.data, p.ctypes.data))
+
     def set_timing(self, on):
         nat.check(self.L.rr_set_timing(self.h, int(on)))
 

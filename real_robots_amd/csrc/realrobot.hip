@@ -2114,6 +2114,30 @@ int rr_step_plan(rr_env *e, int32_t render_mode, const uint8_t *render_flags_hos
     return rr_step(e, e->D.cmd, 1, render_mode, render_flags_host);
 }
 
+// Replaces the fixed eye camera by an arbitrary one (row-major 4x4 view and projection, OpenGL conventions) and rebuilds
+// the static layer. Used for the debug camera of render('rgb_array') (EnvCamera, env.py:470-513).
+int rr_set_camera(rr_env *e, const float *view16, const float *proj16) {
+    if (!e || !view16 || !proj16) return fail(RR_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float a = 0;
+            for (int k = 0; k < 4; k++) a += proj16[4 * i + k] * view16[4 * k + j];
+            e->RM.VP[4 * i + j] = a;
+        }
+    HIPCHK(hipMemcpy(e->RM_dev, &e->RM, sizeof e->RM, hipMemcpyHostToDevice));
+    if (e->D.static_vis_out) {
+        const unsigned long long *keep = e->D.static_vis;
+        e->D.static_vis = nullptr;
+        hipLaunchKernelGGL(k_render_setup, dim3((e->P.N + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D);
+        hipLaunchKernelGGL(k_raster, dim3(1, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1);
+        HIPCHK(hipStreamSynchronize(e->stream));
+        e->D.static_vis = keep ? keep : e->D.static_vis_out;
+    }
+    return RR_OK;
+}
+
 int rr_set_timing(rr_env *e, int32_t enable) {
     if (!e) return fail(RR_EINVAL, "null env");
     e->timing = enable != 0;

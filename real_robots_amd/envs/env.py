@@ -34,12 +34,24 @@ class Goal:
 
 
 class EnvCamera:
-    """Debug camera parameters of render('rgb_array') (env.py:470-513). Rendering it on the GPU is a "next" row
-    (SURVEY.md 8f-3); render() currently returns the eye camera frame."""
+    """Debug camera of render('rgb_array') (env.py:470-513): yaw/pitch/roll view at `distance` from `pos`, fov 80,
+    rendered by the same HIP rasteriser through a second single-env backend that mirrors the simulation state."""
 
     def __init__(self, distance, yaw, pitch, roll, pos, fov=80, width=320, height=240):
         self.dist, self.yaw, self.pitch, self.roll, self.pos = distance, yaw, pitch, roll, pos
         self.fov, self.render_width, self.render_height = fov, width, height
+        self._be = None
+
+    def render(self, env):
+        from ..kinematics import perspective, view_from_yaw_pitch_roll
+        if self._be is None:
+            self._be = BatchedREALRobotEnv(1, objects=env._n_objects, width=self.render_width, height=self.render_height,
+                                           device=env._device)
+            self._be.set_camera(view_from_yaw_pitch_roll(self.pos, self.dist, self.yaw, self.pitch, self.roll),
+                                perspective(self.fov, float(self.render_width) / self.render_height, 0.1, 100.0))
+        self._be.state = env._backend().state
+        self._be.render()
+        return self._be.host(nat.F_RGB)[0]
 
 
 class REALRobotEnv:
@@ -154,8 +166,7 @@ class REALRobotEnv:
             self.isRender = True
         if mode != "rgb_array":
             return np.array([])
-        retina, _, _ = self.get_retina()
-        return retina
+        return self.envCamera.render(self)
 
     def seed(self, seed=None):
         return [seed]

@@ -233,3 +233,20 @@ def test_gym_facade_step_contract():
         env.step({'joint_command': np.zeros(8), 'render': False})
     assert np.allclose(env.get_part_pos('base'), [-0.55, 0, 1.27], atol=0.05)
     env.close()
+
+
+def test_env_camera_rgb_array():
+    """render('rgb_array'): EnvCamera (distance 1.2, yaw 30, pitch -30, target [0,0,.4], 320x240; env.py:83-90,470-513)."""
+    import real_robots_amd as rr
+    env = rr.make('REALRobot2020-R2J3-v0', eye_width=64, eye_height=64)
+    env.reset()
+    assert env.render('human').size == 0
+    img = env.render('rgb_array')
+    assert img.shape == (240, 320, 3) and img.dtype == np.uint8
+    frac_bg = (img == 255).all(-1).mean()
+    assert 0.3 < frac_bg < 0.95                     # an oblique view of robot + table, not an empty or full frame
+    for _ in range(60):
+        env.step({'joint_command': np.array([0.8, 0.6, 0, -1.0, 0, 0.5, 0, 0, 0]), 'render': False})
+    img2 = env.render('rgb_array')
+    assert (img2 != img).any()                       # follows the simulation state
+    env.close()
