@@ -94,7 +94,7 @@ int rr_step(rr_env *env, const float *joint_cmd, int32_t cmd_on_device, int32_t 
 /* Replaces EyeCamera.render (env.py:536-567) for all envs at the current state (used by reset()/set_goal()). */
 int rr_render(rr_env *env);
 
-/* Replaces the camera of this rr_env (row-major 4x4 OpenGL view and projection matrices, host). The default is the
+/* Replaces the camera of this env handle (row-major 4x4 OpenGL view and projection matrices, host). The default is the
  * reference's eye camera; the facade uses a second env handle with EnvCamera's matrices for render('rgb_array')
  * (computeViewMatrixFromYawPitchRoll / computeProjectionMatrixFOV, env.py:480-499). */
 int rr_set_camera(rr_env *env, const float *view16, const float *proj16);
