@@ -808,17 +808,36 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     v3 dv = mk(0, 0, 0), dw = mk(0, 0, 0);
     const float inv_mass = lo_ >= 0 ? 1.0f / B.obj_mass[lo_ >= 0 ? lo_ : 0] : 0.0f;
     const float max_imp = P.max_impulse;
+    // Motor row j lives in the registers of lane j (rhs, dinv, lambda) and row l of Minv in the registers of lane l:
+    // lane j computes its impulse change from its own dq, one DPP sum broadcasts it, every joint lane applies
+    // Minv[l][j] * dl -- no LDS traffic on the 11 motor rows.
+    float minv_l[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) minv_l[j] = l < NB ? LD(L_MINV + lj * NB + j) : 0.0f;
+    const float m_rhs = l < NB ? LD(L_MOT + 3 * lj) : 0.0f, m_dinv = l < NB ? LD(L_MOT + 3 * lj + 1) : 0.0f;
+    float m_lam = 0.0f;
+    // Leading object-vs-static contacts (the common case: objects resting on the table) get a specialised sweep:
+    // ownership of contact c by this lane is one bit of `own_os`, rows are prefetched one step ahead.
+    int n_os = 0;
+    unsigned own_os = 0;
+    for (int c = 0; c < nc && c < LC; c++) {
+        const int meta = *(const int *)&LD(L_META + c);
+        if (!(meta_bodyA(meta) >= 16 && meta_bodyB(meta) < 0)) break;
+        if (lo_ >= 0 && meta_bodyA(meta) == 16 + lo_) own_os |= 1u << c;
+        n_os = c + 1;
+    }
+#define LDB4(r, off) (*(const float4 *)&LD(L_BASE + (r) * 12 + (off)))
     for (int it = 0; it < P.iters; it++) {
-#pragma unroll 1
+#pragma unroll
         for (int j = 0; j < NB; j++) {          // motors
-            float dqj = group_sum(l == j ? dq : 0.0f);
-            float mdinv = LD(L_MOT + 3 * j + 1), mlam = LD(L_MOT + 3 * j + 2);
-            float dl = LD(L_MOT + 3 * j) - dqj * mdinv;
-            float sum = mlam + dl;
-            if (sum < -max_imp) { dl = -max_imp - mlam; sum = -max_imp; }
-            else if (sum > max_imp) { dl = max_imp - mlam; sum = max_imp; }
-            if (l == 0) LD(L_MOT + 3 * j + 2) = sum;
-            if (l < NB) dq += LD(L_MINV + l * NB + j) * dl;
+            float dl = m_rhs - dq * m_dinv;
+            float sum = m_lam + dl;
+            if (sum < -max_imp) { dl = -max_imp - m_lam; sum = -max_imp; }
+            else if (sum > max_imp) { dl = max_imp - m_lam; sum = max_imp; }
+            const bool is_j = l == j;
+            m_lam = is_j ? sum : m_lam;
+            const float dlj = group_sum(is_j ? dl : 0.0f);
+            dq += minv_l[j] * dlj;
         }
 #pragma unroll 1
         for (unsigned rem = limmask; rem; rem &= rem - 1) {   // joint limits (existing rows only)
@@ -835,8 +854,60 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             if (l == 0) LD(L_LIM + 2 * js + 1) = sum;
             if (l < NB) dq += LD(L_MINV + l * NB + j) * (sg * dl);
         }
+        // ---- object-vs-static contacts, normals (rows 3c)
+        if (n_os > 0) {
+            float4 n0 = LDB4(0, 0), n1 = LDB4(0, 4), n2 = LDB4(0, 8);
+            for (int c = 0; c < n_os; c++) {
+                const float4 b0 = n0, b1 = n1, b2 = n2;
+                if (c + 1 < n_os) { n0 = LDB4(3 * (c + 1), 0); n1 = LDB4(3 * (c + 1), 4); n2 = LDB4(3 * (c + 1), 8); }
+                const bool own = (own_os >> c) & 1u;
+                const v3 dir = mk(b0.x, b0.y, b0.z), ang = mk(b0.w, b1.x, b1.y), mang = mk(b1.z, b1.w, b2.x);
+                const float jv = group_sum(own ? dot(dir, dv) + dot(ang, dw) : 0.0f);
+                const float lam = b2.w;
+                float dl = b2.y - jv * b2.z;
+                float sum = lam + dl;
+                if (sum < 0.0f) { dl = -lam; sum = 0.0f; }
+                else if (sum > 1e10f) { dl = 1e10f - lam; sum = 1e10f; }
+                if (l == 0) LD(L_BASE + (3 * c) * 12 + 11) = sum;
+                if (own) { dv = dv + dir * (dl * inv_mass); dw = dw + mang * dl; }
+            }
+        }
+        // ---- object-vs-static contacts, frictions (rows 3c+1, 3c+2) are swept after ALL normals (Bullet's order),
+        //      i.e. after the generic normals below; see the friction pass.
         for (int pass = 0; pass < 2; pass++) {  // all normals, then all frictions
-            for (int c = 0; c < nc; c++) {
+            if (pass == 1) {
+                for (int c = 0; c < n_os; c++) {
+                    const float ln = LD(L_BASE + (3 * c) * 12 + 11), mu = LD(L_MU + c);
+                    const float hi = mu * ln;
+                    if (!(hi > 0.0f)) continue;          // bounds [-0, 0]: lambda stays 0, nothing moves
+                    const float4 a0 = LDB4(3 * c + 1, 0), a1 = LDB4(3 * c + 1, 4), a2 = LDB4(3 * c + 1, 8);
+                    const float4 c0 = LDB4(3 * c + 2, 0), c1 = LDB4(3 * c + 2, 4), c2 = LDB4(3 * c + 2, 8);
+                    const bool own = (own_os >> c) & 1u;
+                    {
+                        const v3 dir = mk(a0.x, a0.y, a0.z), ang = mk(a0.w, a1.x, a1.y), mang = mk(a1.z, a1.w, a2.x);
+                        const float jv = group_sum(own ? dot(dir, dv) + dot(ang, dw) : 0.0f);
+                        const float lam = a2.w;
+                        float dl = a2.y - jv * a2.z;
+                        float sum = lam + dl;
+                        if (sum < -hi) { dl = -hi - lam; sum = -hi; }
+                        else if (sum > hi) { dl = hi - lam; sum = hi; }
+                        if (l == 0) LD(L_BASE + (3 * c + 1) * 12 + 11) = sum;
+                        if (own) { dv = dv + dir * (dl * inv_mass); dw = dw + mang * dl; }
+                    }
+                    {
+                        const v3 dir = mk(c0.x, c0.y, c0.z), ang = mk(c0.w, c1.x, c1.y), mang = mk(c1.z, c1.w, c2.x);
+                        const float jv = group_sum(own ? dot(dir, dv) + dot(ang, dw) : 0.0f);
+                        const float lam = c2.w;
+                        float dl = c2.y - jv * c2.z;
+                        float sum = lam + dl;
+                        if (sum < -hi) { dl = -hi - lam; sum = -hi; }
+                        else if (sum > hi) { dl = hi - lam; sum = hi; }
+                        if (l == 0) LD(L_BASE + (3 * c + 2) * 12 + 11) = sum;
+                        if (own) { dv = dv + dir * (dl * inv_mass); dw = dw + mang * dl; }
+                    }
+                }
+            }
+            for (int c = n_os; c < nc; c++) {
                 const int meta = *(const int *)&LD(L_META + c);
                 const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta), rslot = meta_rslot(meta), bslot = meta_bslot(meta);
                 const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
