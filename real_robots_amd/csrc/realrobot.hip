@@ -1407,7 +1407,7 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 #define RASTER_THREADS 1024
 #define TILE_PIX 16384
 #define QCAP 512         // queued (non-tiny) triangles per tile; overflow falls back to the serial path
-#define SMALL_AREA 4     // bbox area (pixels) up to which the owning thread rasterises a triangle itself
+#define SMALL_AREA 64    // bbox area (pixels) up to which the owning thread rasterises a triangle itself (measured optimum)
 
 struct STri { float sx[3], sy[3], sz[3], w[3]; };
 
@@ -1457,6 +1457,32 @@ __device__ __forceinline__ void raster_pixel(const STri &s, int t, int px, int p
     if (!(d >= 0.0f && d <= 1.0f)) return;
     unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
     atomicMin(&vis[(row - row0) * W + px], key);
+}
+
+// Same arithmetic as bary()/raster_pixel() with the per-triangle part (signed area, its reciprocal) hoisted out of the
+// pixel loop; (px, py) must already lie inside the tile.
+struct TriEdge { float ia; bool ok; };
+__device__ __forceinline__ TriEdge tri_edge(const STri &s) {
+#pragma clang fp contract(off)
+    float area = (s.sx[1] - s.sx[0]) * (s.sy[2] - s.sy[0]) - (s.sx[2] - s.sx[0]) * (s.sy[1] - s.sy[0]);
+    TriEdge e;
+    e.ok = !(fabsf(area) < 1e-12f);
+    e.ia = 1.0f / area;
+    return e;
+}
+__device__ __forceinline__ void raster_pixel_hoisted(const STri &s, float ia, int t, int px, int py, int H, int W, int row0,
+                                                     unsigned long long *vis) {
+#pragma clang fp contract(off)
+    const float fx = (float)px, fy = (float)py;
+    const float b0 = ((s.sx[1] - fx) * (s.sy[2] - fy) - (s.sx[2] - fx) * (s.sy[1] - fy)) * ia;
+    const float b1 = ((s.sx[2] - fx) * (s.sy[0] - fy) - (s.sx[0] - fx) * (s.sy[2] - fy)) * ia;
+    const float b2 = 1.0f - b0 - b1;
+    if (!(b0 >= 0 && b1 >= 0 && b2 >= 0)) return;
+    const float z = b0 * s.sz[0] + b1 * s.sz[1] + b2 * s.sz[2];
+    const float d = 0.5f * z + 0.5f;
+    if (!(d >= 0.0f && d <= 1.0f)) return;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
+    atomicMin(&vis[(H - 1 - py - row0) * W + px], key);
 }
 
 // pass: 0 = per-env frame (starts from the static layer when D.static_vis != nullptr and rasterises only the
@@ -1536,8 +1562,17 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
             // queue overflow: fall through and rasterise serially (still correct)
         }
         if (P.ablate & 1) continue;
-        for (int py = y0; py <= y1; py++)
-            for (int px = x0; px <= x1; px++) raster_pixel(s, t, px, py, H, W, row0, rows, vis);
+        {   // tiny triangle: <= SMALL_AREA candidate samples, one flat loop
+            const TriEdge te = tri_edge(s);
+            if (!te.ok) continue;
+            const int bw = x1 - x0 + 1;
+            int px = x0, py = y0;
+            for (int i = 0; i < area; i++) {
+                raster_pixel_hoisted(s, te.ia, t, px, py, H, W, row0, vis);
+                if (++px > x1) { px = x0; py++; }
+            }
+            (void)bw;
+        }
     }
     __syncthreads();
     // queued triangles: one wave per triangle, lanes sweep the bbox in 8x8 pixel blocks
