@@ -1406,8 +1406,8 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 // One workgroup per (env, tile). Tile = full-width strip of tile_h rows (<= 16384 pixels -> 128 KiB of LDS keys).
 #define RASTER_THREADS 1024
 #define TILE_PIX 16384
-#define QCAP 512         // queued (non-tiny) triangles per tile; overflow falls back to the serial path
-#define SMALL_AREA 64    // bbox area (pixels) up to which the owning thread rasterises a triangle itself (measured optimum)
+#define PIXLIST_CAP 6144 // LDS list of pixels to shade per tile (overflow is shaded in place)
+#define SMALL_AREA 32    // bbox area (pixels) up to which the owning lane rasterises a triangle itself (measured optimum 16..64)
 
 struct STri { float sx[3], sy[3], sz[3], w[3]; };
 
@@ -1485,6 +1485,61 @@ __device__ __forceinline__ void raster_pixel_hoisted(const STri &s, float ia, in
     atomicMin(&vis[(H - 1 - py - row0) * W + px], key);
 }
 
+// Deferred shading of one pixel from its visibility key (depth bits | triangle id): re-projects the winning triangle,
+// perspective-correct barycentrics, interpolated normal -> Phong-like TinyRenderer shading, nearest texel.
+struct ShadeCtx { const SimParams *P; const RenderModel *RM; const DevPtrs *D; const float *mvp; int env, W, H, NT; };
+__device__ __forceinline__ void shade_pixel(const ShadeCtx &c, unsigned long long key, int pi, int row0, unsigned char *rgb3,
+                                            float &depth, int &mask) {
+    const RenderModel &RM = *c.RM;
+    const DevPtrs &D = *c.D;
+    const int W = c.W, H = c.H, NT = c.NT;
+    const float Lx = -50.0f, Ly = 30.0f, Lz = 100.0f;
+    const float linv = 1.0f / sqrtf(Lx * Lx + Ly * Ly + Lz * Lz);
+    const float L0 = Lx * linv, L1 = Ly * linv, L2 = Lz * linv;
+    const int lrow = pi / W, px = pi - lrow * W, row = row0 + lrow;
+    const int t = (int)(key & 0xffffffffu);
+    const float d = __uint_as_float((unsigned)(key >> 32));
+    const int inst = D.tri_inst[t];
+    float tp[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) tp[k] = D.tri_pos[(size_t)k * NT + t];
+    STri s;
+    project_tri(c.mvp + inst * 16, tp, W, H, s);
+    float b[3] = {0, 0, 0};
+    bary(s, (float)px, (float)(H - 1 - row), b);
+    float c0 = b[0] / s.w[0], c1 = b[1] / s.w[1], c2 = b[2] / s.w[2];
+    float cs = 1.0f / (c0 + c1 + c2);
+    c0 *= cs; c1 *= cs; c2 *= cs;
+    const float *nn = D.tri_nrm + (size_t)9 * t, *uv = D.tri_uv + (size_t)6 * t;
+    float n0 = c0 * nn[0] + c1 * nn[3] + c2 * nn[6], n1 = c0 * nn[1] + c1 * nn[4] + c2 * nn[7], n2 = c0 * nn[2] + c1 * nn[5] + c2 * nn[8];
+    const float *xf = D.inst_xf + ((size_t)c.env * MAXINST + inst) * 12;
+    float w0 = xf[0] * n0 + xf[1] * n1 + xf[2] * n2, w1 = xf[3] * n0 + xf[4] * n1 + xf[5] * n2, w2 = xf[6] * n0 + xf[7] * n1 + xf[8] * n2;
+    float nlen = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
+    if (nlen > 0) { w0 /= nlen; w1 /= nlen; w2 /= nlen; }
+    float ndl = w0 * L0 + w1 * L1 + w2 * L2;
+    float diff = fmaxf(ndl, 0.0f);
+    float r0 = w0 * (2 * ndl) - L0, r1 = w1 * (2 * ndl) - L1, r2 = w2 * (2 * ndl) - L2;
+    float rl = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+    float rz = rl > 0 ? fmaxf(r2 / rl, 0.0f) : 0.0f;
+    float spec = rz * rz;
+    float tex0 = 255.0f, tex1 = 255.0f, tex2 = 255.0f;
+    int tidx = RM.in_tex[inst];
+    if (tidx >= 0) {
+        float u = c0 * uv[0] + c1 * uv[2] + c2 * uv[4], v = c0 * uv[1] + c1 * uv[3] + c2 * uv[5];
+        u = u - floorf(u); v = v - floorf(v);
+        int tw = RM.tex_w[tidx], th = RM.tex_h[tidx];
+        int tx = min((int)(u * (float)tw), tw - 1), ty = min((int)(v * (float)th), th - 1);
+        unsigned px4 = D.tex[(size_t)RM.tex_off[tidx] + (size_t)(th - 1 - ty) * tw + tx];
+        tex0 = (float)(px4 & 255); tex1 = (float)((px4 >> 8) & 255); tex2 = (float)((px4 >> 16) & 255);
+    }
+    float shade = 0.6f + 0.35f * diff + 0.05f * spec;
+    rgb3[0] = (unsigned char)min((int)(tex0 * RM.in_color[inst][0] * shade), 255);
+    rgb3[1] = (unsigned char)min((int)(tex1 * RM.in_color[inst][1] * shade), 255);
+    rgb3[2] = (unsigned char)min((int)(tex2 * RM.in_color[inst][2] * shade), 255);
+    depth = d;
+    mask = RM.in_uid[inst];
+}
+
 // pass: 0 = per-env frame (starts from the static layer when D.static_vis != nullptr and rasterises only the
 // triangles of moving instances), 1 = static layer (instances that never move: table, shelf, robot base link_0;
 // one launch at creation, result shared by all envs).
@@ -1492,11 +1547,8 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     const RenderModel &RM = *RMp;
     __shared__ unsigned long long vis[TILE_PIX];
     __shared__ float mvp[MAXINST][16];
-    __shared__ float qf[9][QCAP];        // queued triangles: screen x[3], y[3], z[3]
-    __shared__ int qid[QCAP];            // triangle id
-    __shared__ unsigned qbb[QCAP];       // bbox packed x0 | y0<<8 | (x1-x0)<<16 | (y1-y0)<<24  (tile-local, W,H <= 16384 -> use 2 words)
-    __shared__ unsigned qbb2[QCAP];
-    __shared__ int nq;
+    __shared__ int pixlist[PIXLIST_CAP];   // pixels won by moving triangles (deferred shading, pass B)
+    __shared__ int nlist;
     const int env = blockIdx.x, tile = blockIdx.y;
     if (pass == 0 && D.render_flags && !D.render_flags[env]) return;
     const int W = RM.W, H = RM.H;
@@ -1511,7 +1563,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     } else {
         for (int i = tid; i < npix; i += RASTER_THREADS) vis[i] = ~0ull;
     }
-    if (tid == 0) nq = 0;
+    if (tid == 0) nlist = 0;
     if (tid < RM.ni * 16) {
         int inst = tid >> 4, e = tid & 15, r = e >> 2, c = e & 3;
         const float *xf = D.inst_xf + ((size_t)env * MAXINST + inst) * 12;
@@ -1532,64 +1584,73 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     const int NT = RM.nt;
     const int t_begin = layered ? RM.first_dynamic_tri : 0;
     const int t_end = (pass == 1) ? RM.first_dynamic_tri : NT;
-    for (int t = t_begin + tid; t < ((P.ablate & 8) ? 0 : t_end); t += RASTER_THREADS) {
-        int inst = D.tri_inst[t];
-        if (inst >= n_inst_used) continue;
-        float tp[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) tp[k] = D.tri_pos[(size_t)k * NT + t];
+    // Triangle stream: every wave takes 64 consecutive triangles per iteration.  A triangle whose clipped bounding box
+    // holds <= small_area sample points is rasterised by its own lane; bigger ones are handed to the whole wave (ballot,
+    // v_readlane broadcast of the projected triangle, 64 sample points per step in 8x8 blocks) so that one large
+    // triangle does not make 63 lanes wait -- no LDS queue, no atomic counters.
+    const int t_stop = (P.ablate & 8) ? 0 : t_end;
+    const int lane = tid & 63, lx = lane & 7, ly = lane >> 3;
+    for (int tb = t_begin + (tid & ~63); tb < t_stop; tb += RASTER_THREADS) {
+        const int t = tb + lane;
+        bool live = t < t_stop;
+        int inst = live ? D.tri_inst[t] : 0;
+        live = live && inst < n_inst_used;
         STri s;
-        if (!project_tri(mvp[inst], tp, W, H, s)) continue;
-        float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
-        float ymin = fminf(s.sy[0], fminf(s.sy[1], s.sy[2])), ymax = fmaxf(s.sy[0], fmaxf(s.sy[1], s.sy[2]));
-        if (xmax < 0 || ymax < ty0 || xmin > (float)(W - 1) || ymin > ty1) continue;
-        // back faces of closed, consistently wound meshes can never win the depth test
-        if (RM.in_cull[inst] && (s.sx[1] - s.sx[0]) * (s.sy[2] - s.sy[0]) - (s.sx[2] - s.sx[0]) * (s.sy[1] - s.sy[0]) <= 0.0f) continue;
-        int x0 = (int)ceilf(fmaxf(xmin, 0.0f)), x1 = (int)floorf(fminf(xmax, (float)(W - 1)));
-        int y0 = (int)ceilf(fmaxf(ymin, ty0)), y1 = (int)floorf(fminf(ymax, ty1));
-        if (x1 < x0 || y1 < y0) continue;
-        int area = (x1 - x0 + 1) * (y1 - y0 + 1);
-        if (area > P.small_area) {
-            int slot = atomicAdd(&nq, 1);
-            if (slot < QCAP) {
+        int x0 = 0, y0 = 0, x1 = -1, y1 = -1, area = 0;
+        float ia = 0.0f;
+        if (live) {
+            float tp[9];
 #pragma unroll
-                for (int k = 0; k < 3; k++) { qf[k][slot] = s.sx[k]; qf[3 + k][slot] = s.sy[k]; qf[6 + k][slot] = s.sz[k]; }
-                qid[slot] = t;
-                qbb[slot] = (unsigned)x0 | ((unsigned)y0 << 16);
-                qbb2[slot] = (unsigned)(x1 - x0) | ((unsigned)(y1 - y0) << 16);
-                continue;
+            for (int k = 0; k < 9; k++) tp[k] = D.tri_pos[(size_t)k * NT + t];
+            live = project_tri(mvp[inst], tp, W, H, s);
+        }
+        if (live) {
+            float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
+            float ymin = fminf(s.sy[0], fminf(s.sy[1], s.sy[2])), ymax = fmaxf(s.sy[0], fmaxf(s.sy[1], s.sy[2]));
+            live = !(xmax < 0 || ymax < ty0 || xmin > (float)(W - 1) || ymin > ty1);
+            // back faces of closed, consistently wound meshes can never win the depth test (opt-in, RR_CULL)
+            if (live && RM.in_cull[inst] && (s.sx[1] - s.sx[0]) * (s.sy[2] - s.sy[0]) - (s.sx[2] - s.sx[0]) * (s.sy[1] - s.sy[0]) <= 0.0f) live = false;
+            if (live) {
+                x0 = (int)ceilf(fmaxf(xmin, 0.0f)); x1 = (int)floorf(fminf(xmax, (float)(W - 1)));
+                y0 = (int)ceilf(fmaxf(ymin, ty0)); y1 = (int)floorf(fminf(ymax, ty1));
+                live = !(x1 < x0 || y1 < y0);
             }
-            // queue overflow: fall through and rasterise serially (still correct)
+            if (live) {
+                const TriEdge te = tri_edge(s);
+                live = te.ok;
+                ia = te.ia;
+                area = (x1 - x0 + 1) * (y1 - y0 + 1);
+            }
         }
         if (P.ablate & 1) continue;
-        {   // tiny triangle: <= SMALL_AREA candidate samples, one flat loop
-            const TriEdge te = tri_edge(s);
-            if (!te.ok) continue;
-            const int bw = x1 - x0 + 1;
+        const bool big = live && area > P.small_area;
+        if (live && !big) {   // small: the owning lane walks its <= small_area sample points
             int px = x0, py = y0;
             for (int i = 0; i < area; i++) {
-                raster_pixel_hoisted(s, te.ia, t, px, py, H, W, row0, vis);
+                raster_pixel_hoisted(s, ia, t, px, py, H, W, row0, vis);
                 if (++px > x1) { px = x0; py++; }
             }
-            (void)bw;
         }
-    }
-    __syncthreads();
-    // queued triangles: one wave per triangle, lanes sweep the bbox in 8x8 pixel blocks
-    {
-        const int nb = (P.ablate & 2) ? 0 : min(nq, QCAP);
-        const int wave = tid >> 6, lane = tid & 63, lx = lane & 7, ly = lane >> 3;
-        for (int qi = wave; qi < nb; qi += RASTER_THREADS / 64) {
-            STri s;
+        unsigned long long todo = (P.ablate & 2) ? 0ull : __ballot(big);
+        while (todo) {        // wave-cooperative: all 64 lanes rasterise the triangle of lane `src`
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            STri bs;
 #pragma unroll
-            for (int k = 0; k < 3; k++) { s.sx[k] = qf[k][qi]; s.sy[k] = qf[3 + k][qi]; s.sz[k] = qf[6 + k][qi]; s.w[k] = 1.0f; }
-            const int t = qid[qi];
-            const unsigned b1 = qbb[qi], b2 = qbb2[qi];
-            const int x0 = b1 & 0xffff, y0 = b1 >> 16, bw = (b2 & 0xffff) + 1, bh = (b2 >> 16) + 1;
+            for (int k = 0; k < 3; k++) {
+                bs.sx[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.sx[k]), src));
+                bs.sy[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.sy[k]), src));
+                bs.sz[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.sz[k]), src));
+                bs.w[k] = 1.0f;
+            }
+            const float bia = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ia), src));
+            const int bt = tb + src;
+            const int bx0 = __builtin_amdgcn_readlane(x0, src), by0 = __builtin_amdgcn_readlane(y0, src);
+            const int bw = __builtin_amdgcn_readlane(x1, src) - bx0 + 1, bh = __builtin_amdgcn_readlane(y1, src) - by0 + 1;
             for (int by = 0; by < bh; by += 8)
                 for (int bx = 0; bx < bw; bx += 8) {
-                    int ox = bx + lx, oy = by + ly;
-                    if (ox < bw && oy < bh) raster_pixel(s, t, x0 + ox, y0 + oy, H, W, row0, rows, vis);
+                    const int ox = bx + lx, oy = by + ly;
+                    if (ox < bw && oy < bh) raster_pixel_hoisted(bs, bia, bt, bx0 + ox, by0 + oy, H, W, row0, vis);
                 }
         }
     }
@@ -1598,10 +1659,12 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         unsigned long long *sv = D.static_vis_out + (size_t)row0 * W;
         for (int i = tid; i < npix; i += RASTER_THREADS) sv[i] = vis[i];
     }
-    // ---- resolve: 4 consecutive pixels per thread iteration (W % 4 == 0 enforced at create)
-    const float Lx = -50.0f, Ly = 30.0f, Lz = 100.0f;
-    const float linv = 1.0f / sqrtf(Lx * Lx + Ly * Ly + Lz * Lz);
-    const float L0 = Lx * linv, L1 = Ly * linv, L2 = Lz * linv;
+    // ---- resolve.  Pass A: 4 consecutive pixels per thread (W % 4 == 0 enforced at create): pixels still owned by the
+    // static layer / background are copied from the images shaded once at creation; pixels won by a moving triangle are
+    // appended to an LDS list.  Pass B: the list is shaded densely, one lane per pixel (the deferred shading of a
+    // pixel is ~300 instructions; doing it inside pass A would make whole waves wait for a few lanes).
+    ShadeCtx ctx;
+    ctx.P = &P; ctx.RM = &RM; ctx.D = &D; ctx.mvp = &mvp[0][0]; ctx.env = env; ctx.W = W; ctx.H = H; ctx.NT = NT;
     const size_t img_base = (pass == 1) ? (size_t)row0 * W : ((size_t)env * H + row0) * W;
     unsigned char *const out_rgb = (pass == 1) ? D.static_rgb : D.rgb;
     float *const out_depth = (pass == 1) ? D.static_depth : D.depth;
@@ -1613,7 +1676,6 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         float dep[4]; int msk[4];
         const size_t sbase = (size_t)row0 * W + (size_t)4 * g;      // pixel index in the shared static images
         if (layered) {
-            // pixels still owned by the static layer (or background) were shaded once at creation: copy them
             bool all_static = true;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1634,8 +1696,6 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         for (int j = 0; j < 4; j++) {
             int pi = 4 * g + j;
             unsigned long long key = vis[pi];
-            int lrow = pi / W, px = pi - lrow * W;
-            int row = row0 + lrow;
             if (key == ~0ull || (P.ablate & 4)) {
                 rgb12[3 * j] = 255; rgb12[3 * j + 1] = 255; rgb12[3 * j + 2] = 255;
                 dep[j] = 1.0f; msk[j] = -1;
@@ -1647,46 +1707,15 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
                 dep[j] = D.static_depth[sbase + j]; msk[j] = D.static_mask[sbase + j];
                 continue;
             }
-            int t = (int)(key & 0xffffffffu);
-            float d = __uint_as_float((unsigned)(key >> 32));
-            int inst = D.tri_inst[t];
-            float tp[9];
-#pragma unroll
-            for (int k = 0; k < 9; k++) tp[k] = D.tri_pos[(size_t)k * NT + t];
-            STri s;
-            project_tri(mvp[inst], tp, W, H, s);
-            float b[3] = {0, 0, 0};
-            bary(s, (float)px, (float)(H - 1 - row), b);
-            float c0 = b[0] / s.w[0], c1 = b[1] / s.w[1], c2 = b[2] / s.w[2];
-            float cs = 1.0f / (c0 + c1 + c2);
-            c0 *= cs; c1 *= cs; c2 *= cs;
-            const float *nn = D.tri_nrm + (size_t)9 * t, *uv = D.tri_uv + (size_t)6 * t;
-            float n0 = c0 * nn[0] + c1 * nn[3] + c2 * nn[6], n1 = c0 * nn[1] + c1 * nn[4] + c2 * nn[7], n2 = c0 * nn[2] + c1 * nn[5] + c2 * nn[8];
-            const float *xf = D.inst_xf + ((size_t)env * MAXINST + inst) * 12;
-            float w0 = xf[0] * n0 + xf[1] * n1 + xf[2] * n2, w1 = xf[3] * n0 + xf[4] * n1 + xf[5] * n2, w2 = xf[6] * n0 + xf[7] * n1 + xf[8] * n2;
-            float nlen = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
-            if (nlen > 0) { w0 /= nlen; w1 /= nlen; w2 /= nlen; }
-            float ndl = w0 * L0 + w1 * L1 + w2 * L2;
-            float diff = fmaxf(ndl, 0.0f);
-            float r0 = w0 * (2 * ndl) - L0, r1 = w1 * (2 * ndl) - L1, r2 = w2 * (2 * ndl) - L2;
-            float rl = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
-            float rz = rl > 0 ? fmaxf(r2 / rl, 0.0f) : 0.0f;
-            float spec = rz * rz;
-            float tex0 = 255.0f, tex1 = 255.0f, tex2 = 255.0f;
-            int tidx = RM.in_tex[inst];
-            if (tidx >= 0) {
-                float u = c0 * uv[0] + c1 * uv[2] + c2 * uv[4], v = c0 * uv[1] + c1 * uv[3] + c2 * uv[5];
-                u = u - floorf(u); v = v - floorf(v);
-                int tw = RM.tex_w[tidx], th = RM.tex_h[tidx];
-                int tx = min((int)(u * (float)tw), tw - 1), ty = min((int)(v * (float)th), th - 1);
-                unsigned px4 = D.tex[(size_t)RM.tex_off[tidx] + (size_t)(th - 1 - ty) * tw + tx];
-                tex0 = (float)(px4 & 255); tex1 = (float)((px4 >> 8) & 255); tex2 = (float)((px4 >> 16) & 255);
+            if (layered) {
+                int slot = atomicAdd(&nlist, 1);
+                if (slot < PIXLIST_CAP) {      // shaded in pass B; the placeholder written below is overwritten
+                    pixlist[slot] = pi;
+                    rgb12[3 * j] = 0; rgb12[3 * j + 1] = 0; rgb12[3 * j + 2] = 0; dep[j] = 0.0f; msk[j] = 0;
+                    continue;
+                }
             }
-            float shade = 0.6f + 0.35f * diff + 0.05f * spec;
-            rgb12[3 * j] = (unsigned char)min((int)(tex0 * RM.in_color[inst][0] * shade), 255);
-            rgb12[3 * j + 1] = (unsigned char)min((int)(tex1 * RM.in_color[inst][1] * shade), 255);
-            rgb12[3 * j + 2] = (unsigned char)min((int)(tex2 * RM.in_color[inst][2] * shade), 255);
-            dep[j] = d; msk[j] = RM.in_uid[inst];
+            shade_pixel(ctx, key, pi, row0, &rgb12[3 * j], dep[j], msk[j]);
         }
 #pragma unroll
         for (int k = 0; k < 3; k++)
@@ -1696,6 +1725,18 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         rgbp[0] = rgbw[0]; rgbp[1] = rgbw[1]; rgbp[2] = rgbw[2];
         *(float4 *)(out_depth + pbase) = make_float4(dep[0], dep[1], dep[2], dep[3]);
         if (out_mask) *(int4 *)(out_mask + pbase) = make_int4(msk[0], msk[1], msk[2], msk[3]);
+    }
+    if (!layered) return;
+    __syncthreads();     // pass A's placeholder stores are complete (workgroup release) before pass B overwrites them
+    const int nl = min(nlist, PIXLIST_CAP);
+    for (int i = tid; i < nl; i += RASTER_THREADS) {
+        const int pi = pixlist[i];
+        unsigned char c3[3]; float d; int m;
+        shade_pixel(ctx, vis[pi], pi, row0, c3, d, m);
+        const size_t o = img_base + (size_t)pi;
+        out_rgb[o * 3] = c3[0]; out_rgb[o * 3 + 1] = c3[1]; out_rgb[o * 3 + 2] = c3[2];
+        out_depth[o] = d;
+        if (out_mask) out_mask[o] = m;
     }
 }
 
