@@ -57,6 +57,15 @@ def load_library():
         raise RuntimeError(
             "real_robots_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C real_robots_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime. If torch is going to be used in this process (zero-copy
+    # views of the observation buffers, torch.distributed), its runtime stack has to be loaded before this library's
+    # (/opt/rocm) one, otherwise torch later reports "No HIP GPUs are available". Importing torch first is harmless
+    # when it is not needed and is skipped when it is not installed.
+    if os.environ.get('RR_NO_TORCH_PRELOAD') is None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32 = C.c_void_p, C.c_int32
     L.rr_create.argtypes = [C.POINTER(Config), C.c_char_p, C.c_size_t, vp, C.POINTER(vp)]

@@ -250,3 +250,45 @@ def test_env_camera_rgb_array():
     img2 = env.render('rgb_array')
     assert (img2 != img).any()                       # follows the simulation state
     env.close()
+
+
+@pytest.mark.parametrize("N,nobj", [(1, 1), (5, 2), (37, 3), (130, 3)])
+def test_odd_batch_sizes_and_object_counts(N, nobj):
+    """Batch sizes that are not multiples of the 4-env solver groups / 32-64 thread blocks; 1-3 objects."""
+    env = BatchedREALRobotEnv(N, objects=nobj, width=64, height=64)
+    o = Oracle(nobj, 64, 64)
+    for t in range(80):
+        act = synthetic_actions(range(N), t, seed=9) * 0.4
+        env.step(act, render=(t == 79))
+        o.step(act[N - 1].astype(np.float64))
+    st = env.state
+    assert np.isfinite(st).all()
+    assert np.abs(st[N - 1][:11] - o.state[:11]).max() < 1e-4          # the last env of a ragged block is right
+    assert np.abs(_objs(st[N - 1])[:nobj, :3] - _objs(o.state)[:nobj, :3]).max() < 1e-3
+    o.state = st[N - 1].astype(np.float64)
+    r, d, m = o.render()
+    assert (m == env.host(nat.F_MASK)[N - 1]).all()
+    assert set(np.unique(m).tolist()) <= set([-1, 0, 1] + list(range(2, 2 + nobj)))
+    env.close()
+
+
+def test_device_side_nonfinite_command_is_flagged_and_skipped():
+    """robot.py:189 asserts on the host; a device-resident command cannot be asserted, so the env is flagged
+    (RR_F_ERRFLAGS bit 1) and its step is skipped while the other envs advance."""
+    import torch
+    N = 4
+    env = BatchedREALRobotEnv(N, objects=1, width=64, height=64)
+    cmd = torch.zeros(N, 9, device='cuda')
+    cmd[2, 3] = float('nan')
+    env.step(device_ptr=cmd.data_ptr())
+    torch.cuda.synchronize()
+    flags = env.host(nat.F_ERRFLAGS)
+    ts = env.host(nat.F_TIMESTEP)
+    assert flags.tolist() == [0, 0, 2, 0] and ts.tolist() == [1, 1, 0, 1]
+    cmd[2, 3] = 0.0
+    env.step(device_ptr=cmd.data_ptr())
+    assert env.host(nat.F_ERRFLAGS).tolist() == [0, 0, 0, 0] and env.host(nat.F_TIMESTEP).tolist() == [2, 2, 1, 2]
+    # zero-copy view of an observation buffer as a torch tensor
+    j = torch.as_tensor(env.device_buffer(nat.F_JOINTS), device='cuda')
+    assert j.shape == (N, 9) and torch.isfinite(j).all()
+    env.close()
