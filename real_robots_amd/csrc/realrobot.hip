@@ -80,6 +80,7 @@ struct RenderModel {
     float link_pos[NLINK_MAX][3], link_rot[NLINK_MAX][9];
     int nl;
     float VP[16];
+    float plane_norm[5];     // |xyz| of the frustum planes w+x, w-x, w+y, w-y, w (near) -- invariant under the rigid model matrices
 };
 
 // scratch slots (floats per env), SoA [slot][N]
@@ -125,6 +126,7 @@ struct DevPtrs {
     const float *tri_nrm;   // AoS [NT][9]
     const float *tri_uv;    // AoS [NT][6]
     const int *tri_inst;    // [NT]
+    const float4 *cluster_sphere; // [NT/64] bounding sphere (instance frame) of each 64-triangle raster cluster
     const unsigned *tex;    // RGBX texels
     const ShapeData *shapes;
     const unsigned long long *static_vis;   // [H*W] visibility keys of the never-moving instances (or nullptr)
@@ -1591,6 +1593,15 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     const int t_stop = (P.ablate & 8) ? 0 : t_end;
     const int lane = tid & 63, lx = lane & 7, ly = lane >> 3;
     for (int tb = t_begin + (tid & ~63); tb < t_stop; tb += RASTER_THREADS) {
+        {   // wave-uniform frustum test of the window's cluster sphere (a window never spans two instances)
+            const float4 cs = D.cluster_sphere[tb >> 6];
+            const float *m = mvp[D.tri_inst[tb]];
+            const float cx = m[0] * cs.x + m[1] * cs.y + m[2] * cs.z + m[3], cy = m[4] * cs.x + m[5] * cs.y + m[6] * cs.z + m[7];
+            const float cw = m[12] * cs.x + m[13] * cs.y + m[14] * cs.z + m[15];
+            const float r = cs.w * 1.001f + 1e-4f;      // conservative
+            if ((cw + cx) < -r * RM.plane_norm[0] || (cw - cx) < -r * RM.plane_norm[1] || (cw + cy) < -r * RM.plane_norm[2] ||
+                (cw - cy) < -r * RM.plane_norm[3] || (cw - 0.1f) < -r * RM.plane_norm[4]) continue;
+        }
         const int t = tb + lane;
         bool live = t < t_stop;
         int inst = live ? D.tri_inst[t] : 0;
@@ -1843,6 +1854,17 @@ static void look_at_persp(float *VP, const float *table_pos, int W, int H) {
         }
 }
 
+static void frustum_plane_norms(RenderModel &RM) {
+    const float *V = RM.VP;
+    const float sg[4] = {1, -1, 1, -1};
+    const int row[4] = {0, 0, 1, 1};
+    for (int k = 0; k < 4; k++) {
+        float a = V[12] + sg[k] * V[4 * row[k]], b = V[13] + sg[k] * V[4 * row[k] + 1], c = V[14] + sg[k] * V[4 * row[k] + 2];
+        RM.plane_norm[k] = sqrtf(a * a + b * b + c * c);
+    }
+    RM.plane_norm[4] = sqrtf(V[12] * V[12] + V[13] * V[13] + V[14] * V[14]);
+}
+
 extern "C" {
 
 const char *rr_last_error(void) { return g_err.c_str(); }
@@ -1975,6 +1997,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         RM.first_dynamic_tri = (n_static_inst < ni) ? ir[2 * n_static_inst] : nt;
     }
     look_at_persp(RM.VP, table_pos, RM.W, RM.H);
+    frustum_plane_norms(RM);
     e->n_inst_used = ni - (NOBJ - P.nobj);
 
     // device allocations
@@ -2020,6 +2043,15 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         ALLOC(e->RM_dev, 1);
         hipMemcpy(e->RM_dev, &e->RM, sizeof e->RM, hipMemcpyHostToDevice);
         D.tri_pos = dp; D.tri_nrm = dn; D.tri_uv = du; D.tri_inst = di; D.tex = dt_; D.shapes = ds;
+        {
+            const float *cs;
+            if (nt % 64 != 0) { rr_destroy(e); return fail(RR_EMODEL, "rr_create: triangle count is not a multiple of the cluster size"); }
+            NEED(cs = b.f32("cluster_sphere", (size_t)(nt / 64) * 4));
+            float4 *dcs;
+            ALLOC(dcs, (size_t)nt / 64);
+            hipMemcpy(dcs, cs, (size_t)(nt / 64) * 16, hipMemcpyHostToDevice);
+            D.cluster_sphere = dcs;
+        }
     }
     for (int i = 0; i < 2 * RR_NUM_KERNELS; i++) hipEventCreate(&e->ev[i]);
     e->field_ptr[RR_F_JOINTS] = D.joints; e->field_bytes[RR_F_JOINTS] = (size_t)N * 9 * 4;
@@ -2273,6 +2305,7 @@ int rr_set_camera(rr_env *e, const float *view16, const float *proj16) {
             for (int k = 0; k < 4; k++) a += proj16[4 * i + k] * view16[4 * k + j];
             e->RM.VP[4 * i + j] = a;
         }
+    frustum_plane_norms(e->RM);
     HIPCHK(hipMemcpy(e->RM_dev, &e->RM, sizeof e->RM, hipMemcpyHostToDevice));
     if (e->D.static_vis_out) {
         const unsigned long long *keep = e->D.static_vis;

@@ -35,6 +35,7 @@ REF = os.environ.get("RR_REFERENCE_DATA",
 VMAX = 32     # collision vertices per shape
 FMAX = 32     # collision planes per shape
 MARGIN = 0.001  # Bullet gUrdfDefaultCollisionMargin, used for the inertia AABB only
+CLUSTER = 64    # triangles per raster cluster (= one wavefront iteration)
 
 
 # ----------------------------------------------------------------------------- math
@@ -554,6 +555,13 @@ def main(out_path):
         tid = get_tex(texpath)
         # colour: textured meshes show the texel unmodified; untextured use the MTL Kd (skin: 0.8)
         col = (1.0, 1.0, 1.0) if tid >= 0 else kd
+        # pad every instance to a multiple of CLUSTER triangles with degenerate (zero-area) triangles so that a
+        # 64-triangle window of the rasteriser never spans two instances (wave-uniform cluster culling)
+        pad = (-len(P)) % CLUSTER
+        if pad:
+            P = np.concatenate([P, np.repeat(P[:1, :1, :], 3, axis=1).repeat(pad, axis=0)])
+            Nn = np.concatenate([Nn, np.repeat(Nn[:1], pad, axis=0)])
+            tu = np.concatenate([tu, np.repeat(tu[:1], pad, axis=0)])
         start = sum(len(x) for x in tri_pos)
         tri_pos.append(P)
         tri_nrm.append(Nn)
@@ -603,6 +611,15 @@ def main(out_path):
         closed = float(np.mean([c == 2 for c in edges.values()]))
         in_cull[i] = int(agree >= 0.999 and vol > 0 and closed >= 0.9999)   # arm links are open at the joints: not culled
         print('cull %-16s agree %.3f closed %.3f vol %+.2e -> %d' % (I['name'], agree, closed, vol, in_cull[i]))
+    # bounding sphere of every 64-triangle cluster in its instance's frame (centre of the AABB, max vertex distance)
+    assert len(tri_pos) % CLUSTER == 0
+    ncl = len(tri_pos) // CLUSTER
+    cl_sphere = np.zeros((ncl, 4))
+    for k in range(ncl):
+        pts = tri_pos[k * CLUSTER:(k + 1) * CLUSTER].reshape(-1, 3)
+        c = 0.5 * (pts.min(0) + pts.max(0))
+        cl_sphere[k, :3] = c
+        cl_sphere[k, 3] = np.linalg.norm(pts - c, axis=1).max()
     tri_inst = np.zeros(len(tri_pos), np.int32)
     for i, I in enumerate(inst):
         tri_inst[I['start']:I['start'] + I['count']] = i
@@ -671,6 +688,7 @@ def main(out_path):
     B.add('tri_nrm', tri_nrm, F)
     B.add('tri_uv', tri_uv, F)
     B.add('tri_inst', tri_inst, I32)
+    B.add('cluster_sphere', cl_sphere, F)
     B.add('tex_info', tex_info, I32)
     B.add('tex_data', tex_data, U8)
     B.add('act_min', min_j, F)
