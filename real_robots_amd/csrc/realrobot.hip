@@ -709,6 +709,23 @@ __device__ float build_row(const BodyParams &B, const SimParams &P, const DevPtr
     return rel;
 }
 
+// Branch-free row step of an object-vs-static contact row for the 16 lanes of an env: b0,b1,b2 = the row's base part
+// (dir.xyz ang.x | ang.yz mang.xy | mang.z rhs dinv lambda), bounds [lo, hi]; `own` lanes hold the object's (dv, dw).
+#define OS_ROW_STEP(b0, b1, b2, lo, hi, rowidx)                                                                   \
+    do {                                                                                                          \
+        const float part_ = (b0).x * dvx + (b0).y * dvy + (b0).z * dvz + (b0).w * dwx + (b1).x * dwy + (b1).y * dwz;  \
+        const float jv_ = group_sum(own ? part_ : 0.0f);                                                          \
+        const float lam_ = (b2).w;                                                                                \
+        const float dl0_ = (b2).y - jv_ * (b2).z;                                                                 \
+        const float s0_ = lam_ + dl0_;                                                                            \
+        const float sum_ = fminf(fmaxf(s0_, (lo)), (hi));                                                         \
+        const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - lam_;                                                     \
+        LD(L_BASE + (rowidx) * 12 + 11) = sum_;       /* every lane writes the same value */                     \
+        const float so_ = own ? dl_ : 0.0f, sm_ = so_ * inv_mass;                                                 \
+        dvx += (b0).x * sm_; dvy += (b0).y * sm_; dvz += (b0).z * sm_;                                            \
+        dwx += (b1).z * so_; dwy += (b1).w * so_; dwz += (b2).x * so_;                                            \
+    } while (0)
+
 __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs D) {
     const int N = P.N;
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
@@ -858,56 +875,38 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         }
         // ---- object-vs-static contacts, normals (rows 3c)
         if (n_os > 0) {
+            float dvx = dv.x, dvy = dv.y, dvz = dv.z, dwx = dw.x, dwy = dw.y, dwz = dw.z;
             float4 n0 = LDB4(0, 0), n1 = LDB4(0, 4), n2 = LDB4(0, 8);
             for (int c = 0; c < n_os; c++) {
                 const float4 b0 = n0, b1 = n1, b2 = n2;
                 if (c + 1 < n_os) { n0 = LDB4(3 * (c + 1), 0); n1 = LDB4(3 * (c + 1), 4); n2 = LDB4(3 * (c + 1), 8); }
                 const bool own = (own_os >> c) & 1u;
-                const v3 dir = mk(b0.x, b0.y, b0.z), ang = mk(b0.w, b1.x, b1.y), mang = mk(b1.z, b1.w, b2.x);
-                const float jv = group_sum(own ? dot(dir, dv) + dot(ang, dw) : 0.0f);
-                const float lam = b2.w;
-                float dl = b2.y - jv * b2.z;
-                float sum = lam + dl;
-                if (sum < 0.0f) { dl = -lam; sum = 0.0f; }
-                else if (sum > 1e10f) { dl = 1e10f - lam; sum = 1e10f; }
-                if (l == 0) LD(L_BASE + (3 * c) * 12 + 11) = sum;
-                if (own) { dv = dv + dir * (dl * inv_mass); dw = dw + mang * dl; }
+                OS_ROW_STEP(b0, b1, b2, 0.0f, 1e10f, 3 * c);
             }
+            dv = mk(dvx, dvy, dvz); dw = mk(dwx, dwy, dwz);
         }
         // ---- object-vs-static contacts, frictions (rows 3c+1, 3c+2) are swept after ALL normals (Bullet's order),
         //      i.e. after the generic normals below; see the friction pass.
         for (int pass = 0; pass < 2; pass++) {  // all normals, then all frictions
-            if (pass == 1) {
+            if (pass == 1 && n_os > 0) {
+                // frictions of the object-vs-static contacts; the rows of contact c+1 are prefetched while c is swept
+                float dvx = dv.x, dvy = dv.y, dvz = dv.z, dwx = dw.x, dwy = dw.y, dwz = dw.z;
+                float nln = LD(L_BASE + 11), nmu = LD(L_MU);
+                float4 na0 = LDB4(1, 0), na1 = LDB4(1, 4), na2 = LDB4(1, 8), nc0 = LDB4(2, 0), nc1 = LDB4(2, 4), nc2 = LDB4(2, 8);
                 for (int c = 0; c < n_os; c++) {
-                    const float ln = LD(L_BASE + (3 * c) * 12 + 11), mu = LD(L_MU + c);
-                    const float hi = mu * ln;
+                    const float hi = nmu * nln;
+                    const float4 a0 = na0, a1 = na1, a2 = na2, c0 = nc0, c1 = nc1, c2 = nc2;
+                    if (c + 1 < n_os) {
+                        nln = LD(L_BASE + (3 * c + 3) * 12 + 11); nmu = LD(L_MU + c + 1);
+                        na0 = LDB4(3 * c + 4, 0); na1 = LDB4(3 * c + 4, 4); na2 = LDB4(3 * c + 4, 8);
+                        nc0 = LDB4(3 * c + 5, 0); nc1 = LDB4(3 * c + 5, 4); nc2 = LDB4(3 * c + 5, 8);
+                    }
                     if (!(hi > 0.0f)) continue;          // bounds [-0, 0]: lambda stays 0, nothing moves
-                    const float4 a0 = LDB4(3 * c + 1, 0), a1 = LDB4(3 * c + 1, 4), a2 = LDB4(3 * c + 1, 8);
-                    const float4 c0 = LDB4(3 * c + 2, 0), c1 = LDB4(3 * c + 2, 4), c2 = LDB4(3 * c + 2, 8);
                     const bool own = (own_os >> c) & 1u;
-                    {
-                        const v3 dir = mk(a0.x, a0.y, a0.z), ang = mk(a0.w, a1.x, a1.y), mang = mk(a1.z, a1.w, a2.x);
-                        const float jv = group_sum(own ? dot(dir, dv) + dot(ang, dw) : 0.0f);
-                        const float lam = a2.w;
-                        float dl = a2.y - jv * a2.z;
-                        float sum = lam + dl;
-                        if (sum < -hi) { dl = -hi - lam; sum = -hi; }
-                        else if (sum > hi) { dl = hi - lam; sum = hi; }
-                        if (l == 0) LD(L_BASE + (3 * c + 1) * 12 + 11) = sum;
-                        if (own) { dv = dv + dir * (dl * inv_mass); dw = dw + mang * dl; }
-                    }
-                    {
-                        const v3 dir = mk(c0.x, c0.y, c0.z), ang = mk(c0.w, c1.x, c1.y), mang = mk(c1.z, c1.w, c2.x);
-                        const float jv = group_sum(own ? dot(dir, dv) + dot(ang, dw) : 0.0f);
-                        const float lam = c2.w;
-                        float dl = c2.y - jv * c2.z;
-                        float sum = lam + dl;
-                        if (sum < -hi) { dl = -hi - lam; sum = -hi; }
-                        else if (sum > hi) { dl = hi - lam; sum = hi; }
-                        if (l == 0) LD(L_BASE + (3 * c + 2) * 12 + 11) = sum;
-                        if (own) { dv = dv + dir * (dl * inv_mass); dw = dw + mang * dl; }
-                    }
+                    OS_ROW_STEP(a0, a1, a2, -hi, hi, 3 * c + 1);
+                    OS_ROW_STEP(c0, c1, c2, -hi, hi, 3 * c + 2);
                 }
+                dv = mk(dvx, dvy, dvz); dw = mk(dwx, dwy, dwz);
             }
             for (int c = n_os; c < nc; c++) {
                 const int meta = *(const int *)&LD(L_META + c);
