@@ -740,10 +740,22 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     // ---- stage Minv in LDS
     for (int i = l; i < NB * NB; i += 16) LD(L_MINV + i) = SCR(S_MINV + i);
     // ---- gather contacts in pair order, build rows (all lanes of the group run the control flow redundantly)
+    // The 92 per-pair candidate counts are fetched in one go: lane l loads the counts of pairs l, l+16, ... and the
+    // non-empty pairs are collected into per-group bit masks with wave ballots (no chain of dependent global loads).
+    unsigned pmask[MAXPAIRS / 16];
+#pragma unroll
+    for (int k = 0; k < MAXPAIRS / 16; k++) {
+        const int pr = 16 * k + l;
+        const int cntl = pr < P.npairs ? *(const int *)&SCR(S_PCOUNT + pr) : 0;
+        const unsigned long long bal = __ballot(cntl > 0);
+        pmask[k] = (unsigned)(bal >> (16 * grp)) & 0xffffu;
+    }
     int nc = 0, nrob = 0, nbs = 0;
-    for (int pair = 0; pair < P.npairs && nc < MAXC; pair++) {
-        int cnt = *(const int *)&SCR(S_PCOUNT + pair);
-        if (cnt == 0) continue;
+#pragma unroll
+    for (int k = 0; k < MAXPAIRS / 16; k++)
+    for (unsigned rem = pmask[k]; rem && nc < MAXC; rem &= rem - 1) {
+        const int pair = 16 * k + __ffs(rem) - 1;
+        const int cnt = *(const int *)&SCR(S_PCOUNT + pair);
         int sa = S->pair_a[pair], sb = S->pair_b[pair];
         int bodyA = S->otype[sa] == 0 ? -1 : (S->otype[sa] == 1 ? S->oidx[sa] : 16 + S->oidx[sa]);
         int bodyB = S->otype[sb] == 0 ? -1 : (S->otype[sb] == 1 ? S->oidx[sb] : 16 + S->oidx[sb]);
@@ -770,6 +782,37 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                 ct[0] = (float)bodyA; ct[Ns] = (float)bodyB; ct[2 * Ns] = (float)S->link[sa];
                 ct[3 * Ns] = x.x; ct[4 * Ns] = x.y; ct[5 * Ns] = x.z; ct[6 * Ns] = n.x; ct[7 * Ns] = n.y; ct[8 * Ns] = n.z;
                 ct[9 * Ns] = dist; ct[10 * Ns] = 0; ct[11 * Ns] = mu;
+            }
+            if (fast && bodyA >= 16 && bodyB < 0) {
+                // object-vs-static contact: the three rows (n, t1, t2) are built by lanes 0, 1, 2 in parallel
+                const int ob = bodyA - 16;
+                v3 t1, t2;
+                plane_space(n, t1, t2);
+                const v3 dir = l == 0 ? n : (l == 1 ? t1 : t2);
+                const v3 op = mk(STT(ST_OPOS + 3 * ob), STT(ST_OPOS + 3 * ob + 1), STT(ST_OPOS + 3 * ob + 2));
+                const v3 ang = cross(x - op, dir);
+                m3 Iinv;
+#pragma unroll
+                for (int kk = 0; kk < 9; kk++) Iinv.m[kk] = SCR(S_OIINV + 9 * ob + kk);
+                const v3 mang = mulv(Iinv, ang);
+                const v3 vs = mk(SCR(S_OVS + 3 * ob), SCR(S_OVS + 3 * ob + 1), SCR(S_OVS + 3 * ob + 2));
+                const v3 ws = mk(SCR(S_OWS + 3 * ob), SCR(S_OWS + 3 * ob + 1), SCR(S_OWS + 3 * ob + 2));
+                const float diag = dot(dir, dir) * (1.0f / B.obj_mass[ob]) + dot(ang, mang);
+                const float rel = dot(dir, vs) + dot(ang, ws);
+                const float dinv = diag > 0 ? 1.0f / diag : 0.0f;
+                float rr = 0;
+                if (fabsf(rel) >= P.rest_thresh) { rr = rest * -rel; if (rr < 0) rr = 0; }
+                float verr = rr - rel, perr = 0;
+                if (dist > 0) verr -= dist / dt;
+                else perr = -dist * P.erp / dt;
+                const float rhs = l == 0 ? (perr + verr) * dinv : -rel * dinv;
+                if (l < 3) {
+                    float4 *bp4 = (float4 *)&LD(L_BASE + (3 * nc + l) * 12);
+                    bp4[0] = make_float4(dir.x, dir.y, dir.z, ang.x);
+                    bp4[1] = make_float4(ang.y, ang.z, mang.x, mang.y);
+                    bp4[2] = make_float4(mang.z, rhs, dinv, 0.0f);
+                }
+                continue;
             }
             // normal row
             float rel = build_row(B, P, D, env, grp, l, nc, 0, fast, rslot, bslot, bodyA, bodyB, x, n);
