@@ -44,7 +44,8 @@ enum {
     RR_F_TIMESTEP = 6,  /* i32 [N]           env.timestep                 env.py:217,346 */
     RR_F_ERRFLAGS = 7,  /* u32 [N]           bit0: non-finite state detected (env auto-frozen) */
     RR_F_STATE = 8,     /* f32 [N, 61]       q[11] qd[11] 3x(pos3 quat4 lin3 ang3)  (checkpoint / parity) */
-    RR_F_COUNT = 9
+    RR_F_FRAG_COUNT = 9,/* u32 [N, tiles]    diagnostic: pixels won by moving geometry in the last render (k_shade's work list) */
+    RR_F_COUNT = 10
 };
 
 /* rr_config.flags */
@@ -131,8 +132,8 @@ int rr_step_plan(rr_env *env, int32_t render_mode, const uint8_t *render_flags_h
 /* Per-kernel device timing with HIP events on the library's stream (bench.py roofline leg).
  * After rr_set_timing(env, 1), each rr_step/rr_render records events; rr_get_timing returns accumulated
  * milliseconds and launch counts per kernel since the last call and resets them.
- * kernel ids: 0 prep, 1 collide, 2 solve, 3 render_setup, 4 raster. */
-#define RR_NUM_KERNELS 5
+ * kernel ids: 0 prep, 1 collide, 2 solve, 3 render_setup, 4 raster, 5 static_copy, 6 shade. */
+#define RR_NUM_KERNELS 7
 int rr_set_timing(rr_env *env, int32_t enable);
 int rr_get_timing(rr_env *env, float *ms_out /*[RR_NUM_KERNELS]*/, int32_t *launches_out /*[RR_NUM_KERNELS]*/);
 

@@ -35,7 +35,8 @@ class BatchedREALRobotEnv:
             nat.F_OBJ_POSE: ((self.N, self.n_objects, 7), np.float32),
             nat.F_RGB: ((self.N, self.H, self.W, 3), np.uint8), nat.F_DEPTH: ((self.N, self.H, self.W), np.float32),
             nat.F_MASK: ((self.N, self.H, self.W), np.int32), nat.F_TIMESTEP: ((self.N,), np.int32),
-            nat.F_ERRFLAGS: ((self.N,), np.uint32), nat.F_STATE: ((self.N, 61), np.float32)}
+            nat.F_ERRFLAGS: ((self.N,), np.uint32), nat.F_STATE: ((self.N, 61), np.float32),
+            nat.F_FRAG_COUNT: ((self.N, -(-self.H // max(1, 16384 // self.W))), np.uint32)}
 
     def close(self):
         if getattr(self, 'h', None):

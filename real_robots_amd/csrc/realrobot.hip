@@ -123,8 +123,7 @@ struct DevPtrs {
     unsigned char *render_flags; // [N]
     unsigned char *rgb; float *depth; int *mask;
     const float *tri_pos;   // SoA [9][NT]
-    const float *tri_nrm;   // AoS [NT][9]
-    const float *tri_uv;    // AoS [NT][6]
+    const float4 *tri_rec;  // AoS [NT][8]: one 128-byte shading record per triangle {pos[9], nrm[9], uv[6], inst, pad}
     const int *tri_inst;    // [NT]
     const float4 *cluster_sphere; // [NT/64] bounding sphere (instance frame) of each 64-triangle raster cluster
     const unsigned *tex;    // RGBX texels
@@ -132,6 +131,8 @@ struct DevPtrs {
     const unsigned long long *static_vis;   // [H*W] visibility keys of the never-moving instances (or nullptr)
     unsigned long long *static_vis_out;
     unsigned char *static_rgb; float *static_depth; int *static_mask;   // [H*W] shaded static layer (shared by all envs)
+    uint2 *frag_list;       // [N*ntiles][TILE_PIX] pixels won by moving triangles: {depth bits, pixel-in-tile << 18 | triangle}
+    unsigned *frag_count;   // [N*ntiles]
 };
 
 // Kinematic tree of the 11 moving bodies (lbr_iiwa_link_1..7 [+gripper base], finger_00, finger_01, finger_10,
@@ -1450,7 +1451,6 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 // One workgroup per (env, tile). Tile = full-width strip of tile_h rows (<= 16384 pixels -> 128 KiB of LDS keys).
 #define RASTER_THREADS 1024
 #define TILE_PIX 16384
-#define PIXLIST_CAP 6144 // LDS list of pixels to shade per tile (overflow is shaded in place)
 #define SMALL_AREA 32    // bbox area (pixels) up to which the owning lane rasterises a triangle itself (measured optimum 16..64)
 
 struct STri { float sx[3], sy[3], sz[3], w[3]; };
@@ -1529,24 +1529,46 @@ __device__ __forceinline__ void raster_pixel_hoisted(const STri &s, float ia, in
     atomicMin(&vis[(H - 1 - py - row0) * W + px], key);
 }
 
+// Conservative test "can any sample point of the pixel rectangle [px0,px1]x[py0,py1] pass raster_pixel_hoisted's
+// inside test?".  Exact barycentrics are affine in (px, py), so their maximum over the rectangle is at a corner; the
+// float evaluation of raster_pixel_hoisted differs from the exact value by at most delta (see the caller), hence a
+// rectangle whose four corner values of some barycentric are all < -2*delta cannot contain a covered sample point.
+__device__ __forceinline__ bool block_may_overlap(const STri &s, float ia, int px0, int px1, int py0, int py1, float delta2) {
+#pragma clang fp contract(off)
+    float m0 = -3.0e38f, m1 = -3.0e38f, m2 = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float fx = (float)((c & 1) ? px1 : px0), fy = (float)((c & 2) ? py1 : py0);
+        const float b0 = ((s.sx[1] - fx) * (s.sy[2] - fy) - (s.sx[2] - fx) * (s.sy[1] - fy)) * ia;
+        const float b1 = ((s.sx[2] - fx) * (s.sy[0] - fy) - (s.sx[0] - fx) * (s.sy[2] - fy)) * ia;
+        const float b2 = 1.0f - b0 - b1;
+        m0 = fmaxf(m0, b0); m1 = fmaxf(m1, b1); m2 = fmaxf(m2, b2);
+    }
+    return !(m0 < -delta2 || m1 < -delta2 || m2 < -delta2);
+}
+
 // Deferred shading of one pixel from its visibility key (depth bits | triangle id): re-projects the winning triangle,
 // perspective-correct barycentrics, interpolated normal -> Phong-like TinyRenderer shading, nearest texel.
-struct ShadeCtx { const SimParams *P; const RenderModel *RM; const DevPtrs *D; const float *mvp; int env, W, H, NT; };
-__device__ __forceinline__ void shade_pixel(const ShadeCtx &c, unsigned long long key, int pi, int row0, unsigned char *rgb3,
-                                            float &depth, int &mask) {
-    const RenderModel &RM = *c.RM;
+// mvp / sinst: per-instance constants of this env staged in LDS by stage_instances(); sinst holds 16 floats per instance
+// {R[9], colour[3], tex_off, tex_w (0: untextured), tex_h, uid}, which keeps the chain of dependent global loads of a
+// shaded pixel at two (triangle record, texel).
+struct ShadeCtx { const DevPtrs *D; const float *mvp; const float *sinst; int W, H; };
+__device__ __forceinline__ void shade_pixel(const ShadeCtx &c, int t, int px, int row, unsigned char *rgb3, int &mask) {
     const DevPtrs &D = *c.D;
-    const int W = c.W, H = c.H, NT = c.NT;
+    const int W = c.W, H = c.H;
     const float Lx = -50.0f, Ly = 30.0f, Lz = 100.0f;
     const float linv = 1.0f / sqrtf(Lx * Lx + Ly * Ly + Lz * Lz);
     const float L0 = Lx * linv, L1 = Ly * linv, L2 = Lz * linv;
-    const int lrow = pi / W, px = pi - lrow * W, row = row0 + lrow;
-    const int t = (int)(key & 0xffffffffu);
-    const float d = __uint_as_float((unsigned)(key >> 32));
-    const int inst = D.tri_inst[t];
-    float tp[9];
+    // one 128-byte record per triangle: 7 x 16-byte loads from a single cache line instead of 26 scattered dwords
+    // (every lane shades a different triangle, so the cost of a load is its number of distinct lines)
+    float rec[28];
+    {
+        const float4 *rp = D.tri_rec + (size_t)8 * t;
 #pragma unroll
-    for (int k = 0; k < 9; k++) tp[k] = D.tri_pos[(size_t)k * NT + t];
+        for (int k = 0; k < 7; k++) { const float4 v = rp[k]; rec[4 * k] = v.x; rec[4 * k + 1] = v.y; rec[4 * k + 2] = v.z; rec[4 * k + 3] = v.w; }
+    }
+    const float *tp = rec, *nn = rec + 9, *uv = rec + 18;
+    const int inst = __float_as_int(rec[24]);
     STri s;
     project_tri(c.mvp + inst * 16, tp, W, H, s);
     float b[3] = {0, 0, 0};
@@ -1554,9 +1576,8 @@ __device__ __forceinline__ void shade_pixel(const ShadeCtx &c, unsigned long lon
     float c0 = b[0] / s.w[0], c1 = b[1] / s.w[1], c2 = b[2] / s.w[2];
     float cs = 1.0f / (c0 + c1 + c2);
     c0 *= cs; c1 *= cs; c2 *= cs;
-    const float *nn = D.tri_nrm + (size_t)9 * t, *uv = D.tri_uv + (size_t)6 * t;
     float n0 = c0 * nn[0] + c1 * nn[3] + c2 * nn[6], n1 = c0 * nn[1] + c1 * nn[4] + c2 * nn[7], n2 = c0 * nn[2] + c1 * nn[5] + c2 * nn[8];
-    const float *xf = D.inst_xf + ((size_t)c.env * MAXINST + inst) * 12;
+    const float *xf = c.sinst + inst * 16;
     float w0 = xf[0] * n0 + xf[1] * n1 + xf[2] * n2, w1 = xf[3] * n0 + xf[4] * n1 + xf[5] * n2, w2 = xf[6] * n0 + xf[7] * n1 + xf[8] * n2;
     float nlen = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
     if (nlen > 0) { w0 /= nlen; w1 /= nlen; w2 /= nlen; }
@@ -1567,32 +1588,74 @@ __device__ __forceinline__ void shade_pixel(const ShadeCtx &c, unsigned long lon
     float rz = rl > 0 ? fmaxf(r2 / rl, 0.0f) : 0.0f;
     float spec = rz * rz;
     float tex0 = 255.0f, tex1 = 255.0f, tex2 = 255.0f;
-    int tidx = RM.in_tex[inst];
-    if (tidx >= 0) {
+    const int tw = __float_as_int(xf[13]);
+    if (tw > 0) {
         float u = c0 * uv[0] + c1 * uv[2] + c2 * uv[4], v = c0 * uv[1] + c1 * uv[3] + c2 * uv[5];
         u = u - floorf(u); v = v - floorf(v);
-        int tw = RM.tex_w[tidx], th = RM.tex_h[tidx];
+        const int th = __float_as_int(xf[14]);
         int tx = min((int)(u * (float)tw), tw - 1), ty = min((int)(v * (float)th), th - 1);
-        unsigned px4 = D.tex[(size_t)RM.tex_off[tidx] + (size_t)(th - 1 - ty) * tw + tx];
+        unsigned px4 = D.tex[(size_t)__float_as_int(xf[12]) + (size_t)(th - 1 - ty) * tw + tx];
         tex0 = (float)(px4 & 255); tex1 = (float)((px4 >> 8) & 255); tex2 = (float)((px4 >> 16) & 255);
     }
     float shade = 0.6f + 0.35f * diff + 0.05f * spec;
-    rgb3[0] = (unsigned char)min((int)(tex0 * RM.in_color[inst][0] * shade), 255);
-    rgb3[1] = (unsigned char)min((int)(tex1 * RM.in_color[inst][1] * shade), 255);
-    rgb3[2] = (unsigned char)min((int)(tex2 * RM.in_color[inst][2] * shade), 255);
-    depth = d;
-    mask = RM.in_uid[inst];
+    rgb3[0] = (unsigned char)min((int)(tex0 * xf[9] * shade), 255);
+    rgb3[1] = (unsigned char)min((int)(tex1 * xf[10] * shade), 255);
+    rgb3[2] = (unsigned char)min((int)(tex2 * xf[11] * shade), 255);
+    mask = __float_as_int(xf[15]);
 }
 
-// pass: 0 = per-env frame (starts from the static layer when D.static_vis != nullptr and rasterises only the
-// triangles of moving instances), 1 = static layer (instances that never move: table, shelf, robot base link_0;
-// one launch at creation, result shared by all envs).
+// Stages the per-instance constants of one env in LDS: mvp = VP * [R p; 0 1] (same summation order as the oracle's 4x4
+// product, no FMA contraction) and, when sinst != nullptr, the shading constants. Caller synchronises.
+__device__ __forceinline__ void stage_instances(const RenderModel &RM, const DevPtrs &D, int env, int tid, int nthreads,
+                                                float (*mvp)[16], float (*sinst)[16]) {
+    for (int i = tid; i < RM.ni * 16; i += nthreads) {
+        const int inst = i >> 4, e = i & 15, r = e >> 2, c = e & 3;
+        const float *xf = D.inst_xf + ((size_t)env * MAXINST + inst) * 12;
+        {
+#pragma clang fp contract(off)
+            float a = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) a += RM.VP[4 * r + k] * (c < 3 ? xf[3 * k + c] : xf[9 + k]);
+            a += RM.VP[4 * r + 3] * (c == 3 ? 1.0f : 0.0f);
+            mvp[inst][e] = a;
+        }
+        if (sinst) {
+            const int tidx = RM.in_tex[inst];
+            float sv;
+            if (e < 9) sv = xf[e];
+            else if (e < 12) sv = RM.in_color[inst][e - 9];
+            else if (e == 12) sv = __int_as_float(tidx >= 0 ? RM.tex_off[tidx] : 0);
+            else if (e == 13) sv = __int_as_float(tidx >= 0 ? RM.tex_w[tidx] : 0);
+            else if (e == 14) sv = __int_as_float(tidx >= 0 ? RM.tex_h[tidx] : 0);
+            else sv = __int_as_float(RM.in_uid[inst]);
+            sinst[inst][e] = sv;
+        }
+    }
+}
+
+#ifdef RR_RASTER_STATS
+// Development-only work counters (librealrobot_hip_stats.so, `make stats`; never part of the shipped library).
+__device__ unsigned long long g_rstats[16];
+#define RSTAT(i, v) atomicAdd(&g_rstats[i], (unsigned long long)(v))
+extern "C" int rr_debug_raster_stats(unsigned long long *out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rstats), sizeof(g_rstats)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rstats), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define RSTAT(i, v)
+#endif
+
+// Visibility pass of one (env, tile).  pass 0 = per-env frame: starts from the static layer's keys when D.static_vis !=
+// nullptr and rasterises only the triangles of moving instances; pass 1 = static layer (instances that never move: table,
+// shelf, robot base link_0; one launch at creation, result shared by all envs).  Output: the list of pixels won by a
+// rasterised triangle {depth bits, pixel-in-tile << 18 | triangle}, shaded by k_shade; everything else in the image is the
+// static layer, copied by k_static_copy.
 __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int pass) {
     const RenderModel &RM = *RMp;
     __shared__ unsigned long long vis[TILE_PIX];
     __shared__ float mvp[MAXINST][16];
-    __shared__ int pixlist[PIXLIST_CAP];   // pixels won by moving triangles (deferred shading, pass B)
-    __shared__ int nlist;
+    __shared__ unsigned nlist;
     const int env = blockIdx.x, tile = blockIdx.y;
     if (pass == 0 && D.render_flags && !D.render_flags[env]) return;
     const int W = RM.W, H = RM.H;
@@ -1608,20 +1671,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         for (int i = tid; i < npix; i += RASTER_THREADS) vis[i] = ~0ull;
     }
     if (tid == 0) nlist = 0;
-    if (tid < RM.ni * 16) {
-        int inst = tid >> 4, e = tid & 15, r = e >> 2, c = e & 3;
-        const float *xf = D.inst_xf + ((size_t)env * MAXINST + inst) * 12;
-        // MVP = VP * [R p; 0 1]
-        {
-#pragma clang fp contract(off)
-            // same summation order as the oracle's 4x4 product: k = 0..3 with the implicit [0 0 0 1] row
-            float a = 0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) a += RM.VP[4 * r + k] * (c < 3 ? xf[3 * k + c] : xf[9 + k]);
-            a += RM.VP[4 * r + 3] * (c == 3 ? 1.0f : 0.0f);
-            mvp[inst][e] = a;
-        }
-    }
+    stage_instances(RM, D, env, tid, RASTER_THREADS, mvp, nullptr);
     __syncthreads();
     // tile bounds in screen y (py = H-1-row)
     const float ty0 = (float)(H - 1 - (row0 + rows - 1)), ty1 = (float)(H - 1 - row0);
@@ -1635,6 +1685,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     const int t_stop = (P.ablate & 8) ? 0 : t_end;
     const int lane = tid & 63, lx = lane & 7, ly = lane >> 3;
     for (int tb = t_begin + (tid & ~63); tb < t_stop; tb += RASTER_THREADS) {
+        if (lane == 0) RSTAT(0, 1);                 // windows
         {   // wave-uniform frustum test of the window's cluster sphere (a window never spans two instances)
             const float4 cs = D.cluster_sphere[tb >> 6];
             const float *m = mvp[D.tri_inst[tb]];
@@ -1644,6 +1695,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
             if ((cw + cx) < -r * RM.plane_norm[0] || (cw - cx) < -r * RM.plane_norm[1] || (cw + cy) < -r * RM.plane_norm[2] ||
                 (cw - cy) < -r * RM.plane_norm[3] || (cw - 0.1f) < -r * RM.plane_norm[4]) continue;
         }
+        if (lane == 0) RSTAT(1, 1);                 // windows that pass the cluster test
         const int t = tb + lane;
         bool live = t < t_stop;
         int inst = live ? D.tri_inst[t] : 0;
@@ -1677,8 +1729,40 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         }
         if (P.ablate & 1) continue;
         const bool big = live && area > P.small_area;
+#ifdef RR_RASTER_STATS
+        {
+            const unsigned long long lm = __ballot(live), bm = __ballot(big);
+            int sa_ = (live && !big) ? area : 0, mx = sa_, sm = sa_;
+            for (int o = 32; o; o >>= 1) { mx = max(mx, __shfl_xor(mx, o)); sm += __shfl_xor(sm, o); }
+            if (lane == 0) {
+                RSTAT(2, __popcll(lm)); RSTAT(3, __popcll(bm)); RSTAT(4, sm); RSTAT(5, mx);
+                if (lm) RSTAT(6, 1);
+                if (lm & ~bm) RSTAT(7, 1);
+            }
+            if (big) RSTAT(8, area);
+        }
+#endif
         if (live && !big) {   // small: the owning lane walks its <= small_area sample points
             int px = x0, py = y0;
+            if (P.ablate & 0xe0) {      // EXPERIMENT (timing only)
+                for (int i = 0; i < area; i++) {
+#pragma clang fp contract(off)
+                    const float fx = (float)px, fy = (float)py;
+                    const float b0 = ((s.sx[1] - fx) * (s.sy[2] - fy) - (s.sx[2] - fx) * (s.sy[1] - fy)) * ia;
+                    const float b1 = ((s.sx[2] - fx) * (s.sy[0] - fy) - (s.sx[0] - fx) * (s.sy[2] - fy)) * ia;
+                    const float b2 = 1.0f - b0 - b1;
+                    const float z = b0 * s.sz[0] + b1 * s.sz[1] + b2 * s.sz[2];
+                    const float d = 0.5f * z + 0.5f;
+                    if ((b0 >= 0 && b1 >= 0 && b2 >= 0) && (d >= 0.0f && d <= 1.0f)) {
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
+                        const int r_ = H - 1 - py - row0;
+                        if (P.ablate & 32) { if (key == 12345ull) vis[0] = key; }
+                        else if (P.ablate & 64) { if (key < vis[r_ * W + px]) vis[r_ * W + px] = key; }
+                        else atomicMin(&vis[r_ * W + ((px + 2 * r_) & (W - 1))], key);
+                    }
+                    if (++px > x1) { px = x0; py++; }
+                }
+            } else
             for (int i = 0; i < area; i++) {
                 raster_pixel_hoisted(s, ia, t, px, py, H, W, row0, vis);
                 if (++px > x1) { px = x0; py++; }
@@ -1700,96 +1784,126 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
             const int bt = tb + src;
             const int bx0 = __builtin_amdgcn_readlane(x0, src), by0 = __builtin_amdgcn_readlane(y0, src);
             const int bw = __builtin_amdgcn_readlane(x1, src) - bx0 + 1, bh = __builtin_amdgcn_readlane(y1, src) - by0 + 1;
-            for (int by = 0; by < bh; by += 8)
-                for (int bx = 0; bx < bw; bx += 8) {
-                    const int ox = bx + lx, oy = by + ly;
+            const int nbx = (bw + 7) >> 3, nby = (bh + 7) >> 3, nblk = nbx * nby;
+            if (nblk <= 4 || (P.ablate & 16)) {
+                for (int by = 0; by < bh; by += 8)
+                    for (int bx = 0; bx < bw; bx += 8) {
+                        const int ox = bx + lx, oy = by + ly;
+                        if (ox < bw && oy < bh) raster_pixel_hoisted(bs, bia, bt, bx0 + ox, by0 + oy, H, W, row0, vis);
+                    }
+                continue;
+            }
+            // Hierarchical: each lane first classifies one 8x8 block (64 blocks per step) with the conservative corner
+            // test; only blocks that may hold covered sample points are rasterised.  Triangles close to the near plane
+            // project to slivers whose clipped bounding box is the whole image -- without this they dominate the kernel.
+            // delta bounds |float - exact| of a barycentric anywhere in the tile: each edge function is a difference of
+            // two products of magnitude <= X*Y (X = max|sx|+W, Y = max|sy|+H), evaluated with <= 4 roundings.
+            const float X = fmaxf(fabsf(bs.sx[0]), fmaxf(fabsf(bs.sx[1]), fabsf(bs.sx[2]))) + (float)W;
+            const float Y = fmaxf(fabsf(bs.sy[0]), fmaxf(fabsf(bs.sy[1]), fabsf(bs.sy[2]))) + (float)H;
+            const float delta2 = 2.0f * (8.0e-6f * X * Y * fabsf(bia) + 1.0e-6f);
+            const float inbx = 1.0f / (float)nbx;
+            if (lane == 0) { RSTAT(10, 1); RSTAT(11, nblk); }
+            for (int c0 = 0; c0 < nblk; c0 += 64) {
+                const int bi = c0 + lane;
+                bool keep = false;
+                if (bi < nblk) {
+                    const int byi = (int)(((float)bi + 0.5f) * inbx), bxi = bi - byi * nbx;
+                    const int px0 = bx0 + 8 * bxi, py0 = by0 + 8 * byi;
+                    keep = block_may_overlap(bs, bia, px0, min(px0 + 7, bx0 + bw - 1), py0, min(py0 + 7, by0 + bh - 1), delta2);
+                }
+                unsigned long long km = __ballot(keep);
+                while (km) {
+                    const int j = c0 + __ffsll((long long)km) - 1;
+                    km &= km - 1;
+                    const int byi = (int)(((float)j + 0.5f) * inbx), bxi = j - byi * nbx;
+                    const int ox = 8 * bxi + lx, oy = 8 * byi + ly;
+                    if (lane == 0) RSTAT(9, 1);     // 8x8 blocks rasterised by the hierarchical path
                     if (ox < bw && oy < bh) raster_pixel_hoisted(bs, bia, bt, bx0 + ox, by0 + oy, H, W, row0, vis);
                 }
+            }
         }
     }
     __syncthreads();
-    if (pass == 1) {   // publish the static layer's keys; its shaded pixels are written by the resolve below
+    if (pass == 1) {   // publish the static layer's keys
         unsigned long long *sv = D.static_vis_out + (size_t)row0 * W;
         for (int i = tid; i < npix; i += RASTER_THREADS) sv[i] = vis[i];
     }
-    // ---- resolve.  Pass A: 4 consecutive pixels per thread (W % 4 == 0 enforced at create): pixels still owned by the
-    // static layer / background are copied from the images shaded once at creation; pixels won by a moving triangle are
-    // appended to an LDS list.  Pass B: the list is shaded densely, one lane per pixel (the deferred shading of a
-    // pixel is ~300 instructions; doing it inside pass A would make whole waves wait for a few lanes).
-    ShadeCtx ctx;
-    ctx.P = &P; ctx.RM = &RM; ctx.D = &D; ctx.mvp = &mvp[0][0]; ctx.env = env; ctx.W = W; ctx.H = H; ctx.NT = NT;
-    const size_t img_base = (pass == 1) ? (size_t)row0 * W : ((size_t)env * H + row0) * W;
-    unsigned char *const out_rgb = (pass == 1) ? D.static_rgb : D.rgb;
-    float *const out_depth = (pass == 1) ? D.static_depth : D.depth;
-    int *const out_mask = (pass == 1) ? D.static_mask : D.mask;
-    const int first_dyn = RM.first_dynamic_tri;
-    for (int g = tid; g < npix / 4; g += RASTER_THREADS) {
-        unsigned rgbw[3] = {0, 0, 0};
-        unsigned char rgb12[12];
-        float dep[4]; int msk[4];
-        const size_t sbase = (size_t)row0 * W + (size_t)4 * g;      // pixel index in the shared static images
-        if (layered) {
-            bool all_static = true;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                unsigned long long key = vis[4 * g + j];
-                all_static = all_static && (key == ~0ull || (int)(key & 0xffffffffu) < first_dyn);
-            }
-            if (all_static) {
-                const unsigned *srgb = (const unsigned *)(D.static_rgb + sbase * 3);
-                size_t pbase = img_base + (size_t)4 * g;
-                unsigned *rgbp = (unsigned *)(out_rgb + pbase * 3);
-                rgbp[0] = srgb[0]; rgbp[1] = srgb[1]; rgbp[2] = srgb[2];
-                *(float4 *)(out_depth + pbase) = *(const float4 *)(D.static_depth + sbase);
-                if (out_mask) *(int4 *)(out_mask + pbase) = *(const int4 *)(D.static_mask + sbase);
-                continue;
-            }
+    // ---- compaction: pixels owned by a triangle rasterised in this pass go to the fragment list of this (env, tile)
+    const unsigned first_dyn = layered ? (unsigned)RM.first_dynamic_tri : 0u;
+    uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
+    for (int i = tid; i < npix; i += RASTER_THREADS) {
+        const unsigned long long key = vis[i];
+        const unsigned tri = (unsigned)(key & 0xffffffffu);
+        if (key != ~0ull && tri >= first_dyn) {
+            const unsigned slot = atomicAdd(&nlist, 1u);
+            lst[slot] = make_uint2((unsigned)(key >> 32), ((unsigned)i << 18) | tri);
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            int pi = 4 * g + j;
-            unsigned long long key = vis[pi];
-            if (key == ~0ull || (P.ablate & 4)) {
-                rgb12[3 * j] = 255; rgb12[3 * j + 1] = 255; rgb12[3 * j + 2] = 255;
-                dep[j] = 1.0f; msk[j] = -1;
-                continue;
-            }
-            if (layered && (int)(key & 0xffffffffu) < first_dyn) {
-                const unsigned char *sp = D.static_rgb + (sbase + j) * 3;
-                rgb12[3 * j] = sp[0]; rgb12[3 * j + 1] = sp[1]; rgb12[3 * j + 2] = sp[2];
-                dep[j] = D.static_depth[sbase + j]; msk[j] = D.static_mask[sbase + j];
-                continue;
-            }
-            if (layered) {
-                int slot = atomicAdd(&nlist, 1);
-                if (slot < PIXLIST_CAP) {      // shaded in pass B; the placeholder written below is overwritten
-                    pixlist[slot] = pi;
-                    rgb12[3 * j] = 0; rgb12[3 * j + 1] = 0; rgb12[3 * j + 2] = 0; dep[j] = 0.0f; msk[j] = 0;
-                    continue;
-                }
-            }
-            shade_pixel(ctx, key, pi, row0, &rgb12[3 * j], dep[j], msk[j]);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-            rgbw[k] = (unsigned)rgb12[4 * k] | ((unsigned)rgb12[4 * k + 1] << 8) | ((unsigned)rgb12[4 * k + 2] << 16) | ((unsigned)rgb12[4 * k + 3] << 24);
-        size_t pbase = img_base + (size_t)4 * g;
-        unsigned *rgbp = (unsigned *)(out_rgb + pbase * 3);
-        rgbp[0] = rgbw[0]; rgbp[1] = rgbw[1]; rgbp[2] = rgbw[2];
-        *(float4 *)(out_depth + pbase) = make_float4(dep[0], dep[1], dep[2], dep[3]);
-        if (out_mask) *(int4 *)(out_mask + pbase) = make_int4(msk[0], msk[1], msk[2], msk[3]);
     }
-    if (!layered) return;
-    __syncthreads();     // pass A's placeholder stores are complete (workgroup release) before pass B overwrites them
-    const int nl = min(nlist, PIXLIST_CAP);
-    for (int i = tid; i < nl; i += RASTER_THREADS) {
-        const int pi = pixlist[i];
-        unsigned char c3[3]; float d; int m;
-        shade_pixel(ctx, vis[pi], pi, row0, c3, d, m);
-        const size_t o = img_base + (size_t)pi;
-        out_rgb[o * 3] = c3[0]; out_rgb[o * 3 + 1] = c3[1]; out_rgb[o * 3 + 2] = c3[2];
-        out_depth[o] = d;
-        if (out_mask) out_mask[o] = m;
+    __syncthreads();
+    if (tid == 0) { D.frag_count[(size_t)env * RM.ntiles + tile] = nlist; RSTAT(12, nlist); RSTAT(13, 1); }
+}
+
+// Image targets of k_static_copy / k_shade: the per-env observation buffers (pass 0) or the shared static layer (pass 1).
+struct ImageOut { unsigned char *rgb; float *depth; int *mask; size_t env_stride; /* pixels between envs */ };
+
+// Copies the static layer (or the background when there is none) into the images of every rendered env: 4 pixels per
+// thread (W % 4 == 0 enforced at create).  Pure streaming: reads hit L2, writes are the obs bytes of SURVEY 8(d).
+#define COPY_THREADS 256
+__global__ void __launch_bounds__(COPY_THREADS) k_static_copy(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags) {
+    const int env = blockIdx.y;
+    if (use_flags && D.render_flags && !D.render_flags[env]) return;
+    const int ngroups = (RMp->W * RMp->H) >> 2;
+    const size_t base = (size_t)env * out.env_stride;
+    for (int g = blockIdx.x * COPY_THREADS + threadIdx.x; g < ngroups; g += gridDim.x * COPY_THREADS) {
+        const unsigned *srgb = (const unsigned *)(D.static_rgb) + (size_t)3 * g;
+        const unsigned r0 = srgb[0], r1 = srgb[1], r2 = srgb[2];
+        const float4 dv = *(const float4 *)(D.static_depth + (size_t)4 * g);
+        unsigned *rgbp = (unsigned *)(out.rgb + (base + (size_t)4 * g) * 3);
+        rgbp[0] = r0; rgbp[1] = r1; rgbp[2] = r2;
+        *(float4 *)(out.depth + base + (size_t)4 * g) = dv;
+        if (out.mask) *(int4 *)(out.mask + base + (size_t)4 * g) = *(const int4 *)(D.static_mask + (size_t)4 * g);
+    }
+}
+
+// Background fill of the shared static images (before the static layer is shaded, and when there is no static layer).
+__global__ void k_background(const RenderModel *RMp, DevPtrs D) {
+    const int npx = RMp->W * RMp->H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+        D.static_rgb[3 * i] = 255; D.static_rgb[3 * i + 1] = 255; D.static_rgb[3 * i + 2] = 255;
+        D.static_depth[i] = 1.0f; D.static_mask[i] = -1;
+    }
+}
+
+// Deferred shading of the fragment lists, one lane per listed pixel.  Fragment counts vary from 0 to the whole tile
+// between envs, so every (env, tile) list is dealt out in 256-entry chunks to SHADE_SPLIT workgroups (blocks whose first
+// chunk lies beyond the list exit at once): the longest list no longer sets the tail of the launch.
+#define SHADE_THREADS 256
+#define SHADE_SPLIT 8
+__global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags) {
+    const RenderModel &RM = *RMp;
+    __shared__ float mvp[MAXINST][16];
+    __shared__ float sinst[MAXINST][16];
+    const int env = blockIdx.x, tile = blockIdx.y;
+    if (use_flags && D.render_flags && !D.render_flags[env]) return;
+    const unsigned n = D.frag_count[(size_t)env * RM.ntiles + tile];
+    if (blockIdx.z * SHADE_THREADS >= n) return;
+    stage_instances(RM, D, env, threadIdx.x, SHADE_THREADS, mvp, sinst);
+    __syncthreads();
+    ShadeCtx ctx;
+    ctx.D = &D; ctx.mvp = &mvp[0][0]; ctx.sinst = &sinst[0][0]; ctx.W = RM.W; ctx.H = RM.H;
+    const uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
+    const int row0 = tile * RM.tile_h;
+    const size_t base = (size_t)env * out.env_stride + (size_t)row0 * RM.W;
+    for (unsigned i = blockIdx.z * SHADE_THREADS + threadIdx.x; i < n; i += gridDim.z * SHADE_THREADS) {
+        const uint2 f = lst[i];
+        const int pi = (int)(f.y >> 18), t = (int)(f.y & 0x3ffffu);
+        const int lrow = pi / RM.W, px = pi - lrow * RM.W;
+        unsigned char c3[3]; int m;
+        shade_pixel(ctx, t, px, row0 + lrow, c3, m);
+        const size_t o = base + (size_t)pi;
+        out.rgb[o * 3] = c3[0]; out.rgb[o * 3 + 1] = c3[1]; out.rgb[o * 3 + 2] = c3[2];
+        out.depth[o] = __uint_as_float(f.x);
+        if (out.mask) out.mask[o] = m;
     }
 }
 
@@ -1853,6 +1967,9 @@ struct rr_env {
     std::vector<void *> allocs;
     bool timing;
     hipEvent_t ev[2 * RR_NUM_KERNELS];
+    hipStream_t aux;         // side stream: the HBM-bound static-layer copy runs beside the VALU-bound physics / visibility kernels
+    hipEvent_t ev_fork, ev_join;
+    bool copy_in_flight;
     float t_ms[RR_NUM_KERNELS];
     int t_n[RR_NUM_KERNELS];
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -1918,7 +2035,34 @@ int rr_destroy(rr_env *e) {
     hipStreamSynchronize(e->stream);
     for (void *p : e->allocs) hipFree(p);
     for (int i = 0; i < 2 * RR_NUM_KERNELS; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
+    if (e->aux) { hipStreamSynchronize(e->aux); hipStreamDestroy(e->aux); }
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->ev_join) hipEventDestroy(e->ev_join);
     delete e;
+    return RR_OK;
+}
+
+static ImageOut env_images(const rr_env *e) {
+    ImageOut o;
+    o.rgb = e->D.rgb; o.depth = e->D.depth; o.mask = e->D.mask; o.env_stride = (size_t)e->RM.W * e->RM.H;
+    return o;
+}
+
+// (Re)builds the shared static layer for the current camera: background everywhere, then -- unless disabled with
+// RR_NO_STATIC_LAYER -- the never-moving instances (table, shelf, robot base; the eye camera is fixed, env.py:136-141,
+// 253-255) are rasterised and shaded once; their visibility keys seed every env's frame.
+static int build_static_layer(rr_env *e) {
+    hipLaunchKernelGGL(k_background, dim3(64), dim3(256), 0, e->stream, e->RM_dev, e->D);
+    if (e->D.static_vis_out) {
+        ImageOut so;
+        so.rgb = e->D.static_rgb; so.depth = e->D.static_depth; so.mask = e->D.static_mask; so.env_stride = 0;
+        e->D.static_vis = nullptr;
+        hipLaunchKernelGGL(k_render_setup, dim3((e->P.N + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D);
+        hipLaunchKernelGGL(k_raster, dim3(1, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1);
+        hipLaunchKernelGGL(k_shade, dim3(1, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, e->D, so, 0);
+    }
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(RR_EDEVICE, "static layer pass failed");
+    e->D.static_vis = e->D.static_vis_out;
     return RR_OK;
 }
 
@@ -2069,11 +2213,16 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         NEED(tu = b.f32("tri_uv", (size_t)nt * 6)); NEED(ti = b.i32("tri_inst", nt));
         std::vector<float> soa((size_t)nt * 9);
         for (int t = 0; t < nt; t++) for (int k = 0; k < 9; k++) soa[(size_t)k * nt + t] = tp[(size_t)t * 9 + k];
-        float *dp, *dn, *du; int *di; unsigned *dt_; ShapeData *ds;
-        ALLOC(dp, (size_t)nt * 9); ALLOC(dn, (size_t)nt * 9); ALLOC(du, (size_t)nt * 6); ALLOC(di, (size_t)nt);
+        std::vector<float> rec((size_t)nt * 32, 0.0f);
+        for (int t = 0; t < nt; t++) {
+            float *r = &rec[(size_t)t * 32];
+            memcpy(r, tp + (size_t)t * 9, 36); memcpy(r + 9, tn + (size_t)t * 9, 36); memcpy(r + 18, tu + (size_t)t * 6, 24);
+            memcpy(r + 24, ti + t, 4);
+        }
+        float *dp; float4 *drec; int *di; unsigned *dt_; ShapeData *ds;
+        ALLOC(dp, (size_t)nt * 9); ALLOC(drec, (size_t)nt * 8); ALLOC(di, (size_t)nt);
         hipMemcpy(dp, soa.data(), (size_t)nt * 36, hipMemcpyHostToDevice);
-        hipMemcpy(dn, tn, (size_t)nt * 36, hipMemcpyHostToDevice);
-        hipMemcpy(du, tu, (size_t)nt * 24, hipMemcpyHostToDevice);
+        hipMemcpy(drec, rec.data(), (size_t)nt * 128, hipMemcpyHostToDevice);
         hipMemcpy(di, ti, (size_t)nt * 4, hipMemcpyHostToDevice);
         size_t texbytes = 0;
         const uint8_t *tex = b.u8("tex_data", &texbytes);
@@ -2084,7 +2233,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         hipMemcpy(ds, &S, sizeof S, hipMemcpyHostToDevice);
         ALLOC(e->RM_dev, 1);
         hipMemcpy(e->RM_dev, &e->RM, sizeof e->RM, hipMemcpyHostToDevice);
-        D.tri_pos = dp; D.tri_nrm = dn; D.tri_uv = du; D.tri_inst = di; D.tex = dt_; D.shapes = ds;
+        D.tri_pos = dp; D.tri_rec = drec; D.tri_inst = di; D.tex = dt_; D.shapes = ds;
         {
             const float *cs;
             if (nt % 64 != 0) { rr_destroy(e); return fail(RR_EMODEL, "rr_create: triangle count is not a multiple of the cluster size"); }
@@ -2096,6 +2245,10 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         }
     }
     for (int i = 0; i < 2 * RR_NUM_KERNELS; i++) hipEventCreate(&e->ev[i]);
+    if (!getenv("RR_NO_AUX_STREAM")) {
+        if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
+    }
     e->field_ptr[RR_F_JOINTS] = D.joints; e->field_bytes[RR_F_JOINTS] = (size_t)N * 9 * 4;
     e->field_ptr[RR_F_TOUCH] = D.touch; e->field_bytes[RR_F_TOUCH] = (size_t)N * 4 * 4;
     e->field_ptr[RR_F_OBJ_POSE] = D.objpose; e->field_bytes[RR_F_OBJ_POSE] = (size_t)N * P.nobj * 7 * 4;
@@ -2105,20 +2258,22 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->field_ptr[RR_F_TIMESTEP] = D.timestep; e->field_bytes[RR_F_TIMESTEP] = (size_t)N * 4;
     e->field_ptr[RR_F_ERRFLAGS] = D.errflags; e->field_bytes[RR_F_ERRFLAGS] = (size_t)N * 4;
     e->field_ptr[RR_F_STATE] = e->state_aos; e->field_bytes[RR_F_STATE] = (size_t)N * NSTATE * 4;
+    e->field_bytes[RR_F_FRAG_COUNT] = (size_t)N * RM.ntiles * 4;     // pointer set once the list is allocated
     *out = e;
     int r = rr_reset(e, nullptr);
     if (r != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
-    if (!getenv("RR_NO_STATIC_LAYER")) {
-        // static layer: table, shelf and robot base never move and the eye camera is fixed (env.py:136-141, 253-255)
-        unsigned long long *sv = nullptr;
-        if ((r = dev_alloc(e, &sv, (size_t)RM.W * RM.H)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
-        e->D.static_vis_out = sv;
-        if ((r = dev_alloc(e, &e->D.static_rgb, (size_t)RM.W * RM.H * 3)) != RR_OK || (r = dev_alloc(e, &e->D.static_depth, (size_t)RM.W * RM.H)) != RR_OK ||
-            (r = dev_alloc(e, &e->D.static_mask, (size_t)RM.W * RM.H)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
-        hipLaunchKernelGGL(k_render_setup, dim3((N + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D);
-        hipLaunchKernelGGL(k_raster, dim3(1, RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1);
-        if (hipStreamSynchronize(e->stream) != hipSuccess) { rr_destroy(e); *out = nullptr; return fail(RR_EDEVICE, "rr_create: static layer pass failed"); }
-        e->D.static_vis = sv;
+    {
+        const size_t spx = (size_t)RM.W * RM.H;
+        if ((r = dev_alloc(e, &e->D.static_rgb, spx * 3)) != RR_OK || (r = dev_alloc(e, &e->D.static_depth, spx)) != RR_OK ||
+            (r = dev_alloc(e, &e->D.static_mask, spx)) != RR_OK || (r = dev_alloc(e, &e->D.frag_count, (size_t)N * RM.ntiles)) != RR_OK ||
+            (r = dev_alloc(e, &e->D.frag_list, (size_t)N * RM.ntiles * TILE_PIX, false)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
+        if (!getenv("RR_NO_STATIC_LAYER")) {
+            unsigned long long *sv = nullptr;
+            if ((r = dev_alloc(e, &sv, spx)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
+            e->D.static_vis_out = sv;
+        }
+        e->field_ptr[RR_F_FRAG_COUNT] = e->D.frag_count;
+        if ((r = build_static_layer(e)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
     }
     return RR_OK;
 }
@@ -2181,11 +2336,36 @@ static int g_skip = getenv("RR_SKIP") ? atoi(getenv("RR_SKIP")) : 0;
         }                                                                   \
     } while (0)
 
+// The static-layer copy only depends on work already enqueued on the main stream (the previous frame's consumers and the
+// render flags), not on this step's physics: it is forked to the side stream at the start of the step and joined before
+// k_shade.  In timing mode every kernel runs alone on the main stream.
+static void fork_static_copy(rr_env *e, bool use_flags) {
+    e->copy_in_flight = false;
+    if (!e->aux || e->timing || ((g_skip >> 5) & 1)) return;
+    DevPtrs D = e->D;
+    if (!use_flags) D.render_flags = nullptr;
+    const int copy_blocks = std::min(16, (e->RM.W * e->RM.H / 4 + COPY_THREADS - 1) / COPY_THREADS);
+    hipEventRecord(e->ev_fork, e->stream);
+    hipStreamWaitEvent(e->aux, e->ev_fork, 0);
+    hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, e->P.N), dim3(COPY_THREADS), 0, e->aux, e->RM_dev, D, env_images(e), 1);
+    hipEventRecord(e->ev_join, e->aux);
+    e->copy_in_flight = true;
+}
+
 static int do_render(rr_env *e, bool use_flags) {
     DevPtrs D = e->D;
     if (!use_flags) D.render_flags = nullptr;
     TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((e->P.N + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, D));
     TIMED(4, hipLaunchKernelGGL(k_raster, dim3(e->P.N, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, D, e->n_inst_used, 0));
+    const ImageOut io = env_images(e);
+    if (e->copy_in_flight) {
+        hipStreamWaitEvent(e->stream, e->ev_join, 0);
+        e->copy_in_flight = false;
+    } else {
+        const int copy_blocks = std::min(16, (e->RM.W * e->RM.H / 4 + COPY_THREADS - 1) / COPY_THREADS);
+        TIMED(5, hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, e->P.N), dim3(COPY_THREADS), 0, e->stream, e->RM_dev, D, io, 1));
+    }
+    TIMED(6, hipLaunchKernelGGL(k_shade, dim3(e->P.N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, D, io, 1));
     HIPCHK(hipGetLastError());
     return RR_OK;
 }
@@ -2198,6 +2378,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     if (!joint_cmd) HIPCHK(hipMemsetAsync(e->D.cmd, 0, (size_t)N * 36, e->stream));      // env.py:333-334
     else if (joint_cmd != e->D.cmd) HIPCHK(hipMemcpyAsync(e->D.cmd, joint_cmd, (size_t)N * 36, cmd_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
     if (render_mode == 2) HIPCHK(hipMemcpyAsync(e->D.render_flags, render_flags_host, N, hipMemcpyHostToDevice, e->stream));
+    if (render_mode) fork_static_copy(e, render_mode == 2);
     TIMED(0, hipLaunchKernelGGL(k_prep, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, e->D));
     TIMED(1, hipLaunchKernelGGL(k_collide, dim3(((N + COLLIDE_THREADS - 1) / COLLIDE_THREADS) * e->P.npairs), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D, (N + COLLIDE_THREADS - 1) / COLLIDE_THREADS));
     TIMED(2, hipLaunchKernelGGL(k_solve, dim3((N + SGRP - 1) / SGRP), dim3(SGRP * 16), 0, e->stream, e->B, e->P, e->D));
@@ -2209,6 +2390,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
 int rr_render(rr_env *e) {
     if (!e) return fail(RR_EINVAL, "null env");
     HIPCHK(hipSetDevice(e->cfg.device));
+    fork_static_copy(e, false);
     return do_render(e, false);
 }
 
@@ -2349,14 +2531,8 @@ int rr_set_camera(rr_env *e, const float *view16, const float *proj16) {
         }
     frustum_plane_norms(e->RM);
     HIPCHK(hipMemcpy(e->RM_dev, &e->RM, sizeof e->RM, hipMemcpyHostToDevice));
-    if (e->D.static_vis_out) {
-        const unsigned long long *keep = e->D.static_vis;
-        e->D.static_vis = nullptr;
-        hipLaunchKernelGGL(k_render_setup, dim3((e->P.N + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D);
-        hipLaunchKernelGGL(k_raster, dim3(1, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1);
-        HIPCHK(hipStreamSynchronize(e->stream));
-        e->D.static_vis = keep ? keep : e->D.static_vis_out;
-    }
+    int rc = build_static_layer(e);
+    if (rc != RR_OK) return rc;
     return RR_OK;
 }
 

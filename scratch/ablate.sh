@@ -1,4 +1,4 @@
 #!/bin/bash
-for a in 0 1 2 4 8; do
+for a in ${ABL:-0 1 2 3 4 8 16}; do
   echo "ablate=$a: $(RR_ABLATE=$a python bench.py --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['ms_per_step'], {k:v['avg_ms'] for k,v in d['roofline']['kernels'].items() if k=='k_raster'})")"
 done
