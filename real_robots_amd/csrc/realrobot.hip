@@ -1451,6 +1451,7 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 // One workgroup per (env, tile). Tile = full-width strip of tile_h rows (<= 16384 pixels -> 128 KiB of LDS keys).
 #define RASTER_THREADS 1024
 #define TILE_PIX 16384
+#define MAXWIN 1024      // 64-triangle windows per model (rr_create checks nt)
 #define SMALL_AREA 32    // bbox area (pixels) up to which the owning lane rasterises a triangle itself (measured optimum 16..64)
 
 struct STri { float sx[3], sy[3], sz[3], w[3]; };
@@ -1655,7 +1656,8 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     const RenderModel &RM = *RMp;
     __shared__ unsigned long long vis[TILE_PIX];
     __shared__ float mvp[MAXINST][16];
-    __shared__ unsigned nlist;
+    __shared__ unsigned nlist, wcount, wnext;
+    __shared__ unsigned short wlist[MAXWIN];
     const int env = blockIdx.x, tile = blockIdx.y;
     if (pass == 0 && D.render_flags && !D.render_flags[env]) return;
     const int W = RM.W, H = RM.H;
@@ -1670,7 +1672,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     } else {
         for (int i = tid; i < npix; i += RASTER_THREADS) vis[i] = ~0ull;
     }
-    if (tid == 0) nlist = 0;
+    if (tid == 0) { nlist = 0; wcount = 0; wnext = 0; }
     stage_instances(RM, D, env, tid, RASTER_THREADS, mvp, nullptr);
     __syncthreads();
     // tile bounds in screen y (py = H-1-row)
@@ -1678,28 +1680,41 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     const int NT = RM.nt;
     const int t_begin = layered ? RM.first_dynamic_tri : 0;
     const int t_end = (pass == 1) ? RM.first_dynamic_tri : NT;
-    // Triangle stream: every wave takes 64 consecutive triangles per iteration.  A triangle whose clipped bounding box
-    // holds <= small_area sample points is rasterised by its own lane; bigger ones are handed to the whole wave (ballot,
-    // v_readlane broadcast of the projected triangle, 64 sample points per step in 8x8 blocks) so that one large
-    // triangle does not make 63 lanes wait -- no LDS queue, no atomic counters.
+    // Window queue: one thread per 64-triangle cluster ("window"; never spans two instances) runs the frustum test of the
+    // cluster's bounding sphere and appends survivors to an LDS list; the waves then pull windows from that list with an
+    // LDS counter, so culled windows cost nothing in the wave loops and waves that drew cheap windows take more of them.
     const int t_stop = (P.ablate & 8) ? 0 : t_end;
     const int lane = tid & 63, lx = lane & 7, ly = lane >> 3;
-    for (int tb = t_begin + (tid & ~63); tb < t_stop; tb += RASTER_THREADS) {
-        if (lane == 0) RSTAT(0, 1);                 // windows
-        {   // wave-uniform frustum test of the window's cluster sphere (a window never spans two instances)
-            const float4 cs = D.cluster_sphere[tb >> 6];
-            const float *m = mvp[D.tri_inst[tb]];
-            const float cx = m[0] * cs.x + m[1] * cs.y + m[2] * cs.z + m[3], cy = m[4] * cs.x + m[5] * cs.y + m[6] * cs.z + m[7];
-            const float cw = m[12] * cs.x + m[13] * cs.y + m[14] * cs.z + m[15];
-            const float r = cs.w * 1.001f + 1e-4f;      // conservative
-            if ((cw + cx) < -r * RM.plane_norm[0] || (cw - cx) < -r * RM.plane_norm[1] || (cw + cy) < -r * RM.plane_norm[2] ||
-                (cw - cy) < -r * RM.plane_norm[3] || (cw - 0.1f) < -r * RM.plane_norm[4]) continue;
-        }
+    const int nwin = (t_stop - t_begin + 63) >> 6;
+    for (int wi = tid; wi < nwin; wi += RASTER_THREADS) {
+        const int tb = t_begin + (wi << 6);
+        const int inst = D.tri_inst[tb];
+        const float4 cs = D.cluster_sphere[tb >> 6];
+        const float *m = mvp[inst];
+        const float cx = m[0] * cs.x + m[1] * cs.y + m[2] * cs.z + m[3], cy = m[4] * cs.x + m[5] * cs.y + m[6] * cs.z + m[7];
+        const float cw = m[12] * cs.x + m[13] * cs.y + m[14] * cs.z + m[15];
+        const float r = cs.w * 1.001f + 1e-4f;      // conservative
+        const bool out = (cw + cx) < -r * RM.plane_norm[0] || (cw - cx) < -r * RM.plane_norm[1] || (cw + cy) < -r * RM.plane_norm[2] ||
+                         (cw - cy) < -r * RM.plane_norm[3] || (cw - 0.1f) < -r * RM.plane_norm[4];
+        RSTAT(0, 1);                                // windows
+        if (!out && inst < n_inst_used) wlist[atomicAdd(&wcount, 1u)] = (unsigned short)wi;
+    }
+    __syncthreads();
+    // Every wave takes 64 consecutive triangles per window.  A triangle whose clipped bounding box holds <= small_area
+    // sample points is rasterised by its own lane; bigger ones are handed to the whole wave (ballot, v_readlane broadcast
+    // of the projected triangle, 64 sample points per step in 8x8 blocks) so that one large triangle does not make 63
+    // lanes wait.
+    const unsigned nw = wcount;
+    for (;;) {
+        unsigned k = 0;
+        if (lane == 0) k = atomicAdd(&wnext, 1u);
+        k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+        if (k >= nw) break;
+        const int tb = t_begin + ((int)wlist[k] << 6);
         if (lane == 0) RSTAT(1, 1);                 // windows that pass the cluster test
         const int t = tb + lane;
         bool live = t < t_stop;
-        int inst = live ? D.tri_inst[t] : 0;
-        live = live && inst < n_inst_used;
+        const int inst = D.tri_inst[tb];
         STri s;
         int x0 = 0, y0 = 0, x1 = -1, y1 = -1, area = 0;
         float ia = 0.0f;
@@ -2236,7 +2251,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         D.tri_pos = dp; D.tri_rec = drec; D.tri_inst = di; D.tex = dt_; D.shapes = ds;
         {
             const float *cs;
-            if (nt % 64 != 0) { rr_destroy(e); return fail(RR_EMODEL, "rr_create: triangle count is not a multiple of the cluster size"); }
+            if (nt % 64 != 0 || nt / 64 > MAXWIN || nt >= (1 << 18)) { rr_destroy(e); return fail(RR_EMODEL, "rr_create: triangle count must be a multiple of the cluster size 64 and below 65536"); }
             NEED(cs = b.f32("cluster_sphere", (size_t)(nt / 64) * 4));
             float4 *dcs;
             ALLOC(dcs, (size_t)nt / 64);
