@@ -710,21 +710,21 @@ __device__ float build_row(const BodyParams &B, const SimParams &P, const DevPtr
     return rel;
 }
 
-// Branch-free row step of an object-vs-static contact row for the 16 lanes of an env: b0,b1,b2 = the row's base part
-// (dir.xyz ang.x | ang.yz mang.xy | mang.z rhs dinv lambda), bounds [lo, hi]; `own` lanes hold the object's (dv, dw).
+// Row step of an object-vs-static contact row, executed by the lane that owns the object only (such a row touches no
+// other body, so the three object lanes sweep their own contacts side by side and no cross-lane sum is needed):
+// b0,b1,b2 = the row's base part (dir.xyz ang.x | ang.yz mang.xy | mang.z rhs dinv lambda), bounds [lo, hi].
 #define OS_ROW_STEP(b0, b1, b2, lo, hi, rowidx)                                                                   \
     do {                                                                                                          \
-        const float part_ = (b0).x * dvx + (b0).y * dvy + (b0).z * dvz + (b0).w * dwx + (b1).x * dwy + (b1).y * dwz;  \
-        const float jv_ = group_sum(own ? part_ : 0.0f);                                                          \
+        const float jv_ = (b0).x * dvx + (b0).y * dvy + (b0).z * dvz + (b0).w * dwx + (b1).x * dwy + (b1).y * dwz;    \
         const float lam_ = (b2).w;                                                                                \
         const float dl0_ = (b2).y - jv_ * (b2).z;                                                                 \
         const float s0_ = lam_ + dl0_;                                                                            \
         const float sum_ = fminf(fmaxf(s0_, (lo)), (hi));                                                         \
         const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - lam_;                                                     \
-        LD(L_BASE + (rowidx) * 12 + 11) = sum_;       /* every lane writes the same value */                     \
-        const float so_ = own ? dl_ : 0.0f, sm_ = so_ * inv_mass;                                                 \
+        LD(L_BASE + (rowidx) * 12 + 11) = sum_;                                                                   \
+        const float sm_ = dl_ * inv_mass;                                                                         \
         dvx += (b0).x * sm_; dvy += (b0).y * sm_; dvz += (b0).z * sm_;                                            \
-        dwx += (b1).z * so_; dwy += (b1).w * so_; dwz += (b2).x * so_;                                            \
+        dwx += (b1).z * dl_; dwy += (b1).w * dl_; dwz += (b2).x * dl_;                                            \
     } while (0)
 
 __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs D) {
@@ -917,38 +917,47 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             if (l == 0) LD(L_LIM + 2 * js + 1) = sum;
             if (l < NB) dq += LD(L_MINV + l * NB + j) * (sg * dl);
         }
-        // ---- object-vs-static contacts, normals (rows 3c)
-        if (n_os > 0) {
+        // ---- object-vs-static contacts, normals (rows 3c): every object lane walks its own contacts in contact order
+        //      (divergent loop; rows of different objects are independent, so this equals the sequential sweep)
+        if (own_os) {
             float dvx = dv.x, dvy = dv.y, dvz = dv.z, dwx = dw.x, dwy = dw.y, dwz = dw.z;
-            float4 n0 = LDB4(0, 0), n1 = LDB4(0, 4), n2 = LDB4(0, 8);
-            for (int c = 0; c < n_os; c++) {
+            unsigned rem = own_os;
+            int c = __ffs(rem) - 1;
+            float4 n0 = LDB4(3 * c, 0), n1 = LDB4(3 * c, 4), n2 = LDB4(3 * c, 8);
+            while (rem) {
                 const float4 b0 = n0, b1 = n1, b2 = n2;
-                if (c + 1 < n_os) { n0 = LDB4(3 * (c + 1), 0); n1 = LDB4(3 * (c + 1), 4); n2 = LDB4(3 * (c + 1), 8); }
-                const bool own = (own_os >> c) & 1u;
-                OS_ROW_STEP(b0, b1, b2, 0.0f, 1e10f, 3 * c);
+                const int cc = c;
+                rem &= rem - 1;
+                if (rem) { c = __ffs(rem) - 1; n0 = LDB4(3 * c, 0); n1 = LDB4(3 * c, 4); n2 = LDB4(3 * c, 8); }
+                OS_ROW_STEP(b0, b1, b2, 0.0f, 1e10f, 3 * cc);
             }
             dv = mk(dvx, dvy, dvz); dw = mk(dwx, dwy, dwz);
         }
         // ---- object-vs-static contacts, frictions (rows 3c+1, 3c+2) are swept after ALL normals (Bullet's order),
         //      i.e. after the generic normals below; see the friction pass.
         for (int pass = 0; pass < 2; pass++) {  // all normals, then all frictions
-            if (pass == 1 && n_os > 0) {
-                // frictions of the object-vs-static contacts; the rows of contact c+1 are prefetched while c is swept
+            if (pass == 1 && own_os) {
+                // frictions of this lane's object-vs-static contacts; the rows of the next one are prefetched
                 float dvx = dv.x, dvy = dv.y, dvz = dv.z, dwx = dw.x, dwy = dw.y, dwz = dw.z;
-                float nln = LD(L_BASE + 11), nmu = LD(L_MU);
-                float4 na0 = LDB4(1, 0), na1 = LDB4(1, 4), na2 = LDB4(1, 8), nc0 = LDB4(2, 0), nc1 = LDB4(2, 4), nc2 = LDB4(2, 8);
-                for (int c = 0; c < n_os; c++) {
+                unsigned rem = own_os;
+                int c = __ffs(rem) - 1;
+                float nln = LD(L_BASE + (3 * c) * 12 + 11), nmu = LD(L_MU + c);
+                float4 na0 = LDB4(3 * c + 1, 0), na1 = LDB4(3 * c + 1, 4), na2 = LDB4(3 * c + 1, 8);
+                float4 nc0 = LDB4(3 * c + 2, 0), nc1 = LDB4(3 * c + 2, 4), nc2 = LDB4(3 * c + 2, 8);
+                while (rem) {
                     const float hi = nmu * nln;
                     const float4 a0 = na0, a1 = na1, a2 = na2, c0 = nc0, c1 = nc1, c2 = nc2;
-                    if (c + 1 < n_os) {
-                        nln = LD(L_BASE + (3 * c + 3) * 12 + 11); nmu = LD(L_MU + c + 1);
-                        na0 = LDB4(3 * c + 4, 0); na1 = LDB4(3 * c + 4, 4); na2 = LDB4(3 * c + 4, 8);
-                        nc0 = LDB4(3 * c + 5, 0); nc1 = LDB4(3 * c + 5, 4); nc2 = LDB4(3 * c + 5, 8);
+                    const int cc = c;
+                    rem &= rem - 1;
+                    if (rem) {
+                        c = __ffs(rem) - 1;
+                        nln = LD(L_BASE + (3 * c) * 12 + 11); nmu = LD(L_MU + c);
+                        na0 = LDB4(3 * c + 1, 0); na1 = LDB4(3 * c + 1, 4); na2 = LDB4(3 * c + 1, 8);
+                        nc0 = LDB4(3 * c + 2, 0); nc1 = LDB4(3 * c + 2, 4); nc2 = LDB4(3 * c + 2, 8);
                     }
                     if (!(hi > 0.0f)) continue;          // bounds [-0, 0]: lambda stays 0, nothing moves
-                    const bool own = (own_os >> c) & 1u;
-                    OS_ROW_STEP(a0, a1, a2, -hi, hi, 3 * c + 1);
-                    OS_ROW_STEP(c0, c1, c2, -hi, hi, 3 * c + 2);
+                    OS_ROW_STEP(a0, a1, a2, -hi, hi, 3 * cc + 1);
+                    OS_ROW_STEP(c0, c1, c2, -hi, hi, 3 * cc + 2);
                 }
                 dv = mk(dvx, dvy, dvz); dw = mk(dwx, dwy, dwz);
             }
@@ -1722,6 +1731,9 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
             float tp[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) tp[k] = D.tri_pos[(size_t)k * NT + t];
+            // all nine loads are issued back to back and waited for once (otherwise the compiler sinks the loads of
+            // vertices 1 and 2 below project_tri's near-plane early-outs: three dependent round trips per window)
+            asm volatile("" : "+v"(tp[0]), "+v"(tp[1]), "+v"(tp[2]), "+v"(tp[3]), "+v"(tp[4]), "+v"(tp[5]), "+v"(tp[6]), "+v"(tp[7]), "+v"(tp[8]));
             live = project_tri(mvp[inst], tp, W, H, s);
         }
         if (live) {
