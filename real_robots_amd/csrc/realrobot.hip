@@ -727,6 +727,27 @@ __device__ float build_row(const BodyParams &B, const SimParams &P, const DevPtr
         dwx += (b1).z * dl_; dwy += (b1).w * dl_; dwz += (b2).x * dl_;                                            \
     } while (0)
 
+// Same step for a row held in registers (b0, b1, b2 as above but lambda in `lam`).  An all-zero row with lam = 0 is a
+// no-op (dl = 0), which is how absent rows are represented -- no predicates, no scalar mask registers.
+#define REG_ROW_STEP(b0, b1, b2, lam, lo, hi)                                                                     \
+    do {                                                                                                          \
+        const float jv_ = (b0).x * dvx + (b0).y * dvy + (b0).z * dvz + (b0).w * dwx + (b1).x * dwy + (b1).y * dwz;    \
+        const float dl0_ = (b2).y - jv_ * (b2).z;                                                                 \
+        const float s0_ = (lam) + dl0_;                                                                           \
+        const float sum_ = fminf(fmaxf(s0_, (lo)), (hi));                                                         \
+        const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - (lam);                                                    \
+        (lam) = sum_;                                                                                             \
+        const float sm_ = dl_ * inv_mass;                                                                         \
+        dvx += (b0).x * sm_; dvy += (b0).y * sm_; dvz += (b0).z * sm_;                                            \
+        dwx += (b1).z * dl_; dwy += (b1).w * dl_; dwz += (b2).x * dl_;                                            \
+    } while (0)
+#define KLIM 4           // joint-limit rows kept in registers (usually two: the finger lower limits)
+#define KOS 4            // object-vs-static contacts per object kept in registers (a resting object has <= 4)
+
+__device__ __forceinline__ float4 sel4(bool has, float4 v) {
+    return make_float4(has ? v.x : 0.0f, has ? v.y : 0.0f, has ? v.z : 0.0f, has ? v.w : 0.0f);
+}
+
 __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs D) {
     const int N = P.N;
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
@@ -890,6 +911,44 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         n_os = c + 1;
     }
 #define LDB4(r, off) (*(const float4 *)&LD(L_BASE + (r) * 12 + (off)))
+    // Each SIMD runs a single wave of this kernel (4 envs), so the sweep is a chain of dependent operations and its LDS
+    // round trips are fully exposed.  Rows that are the same in every iteration are therefore lifted into registers
+    // (occupancy cannot drop below the one wave there is): the first KLIM joint-limit rows and, on the object lanes, the
+    // rows of the object's first KOS object-vs-static contacts.  Anything beyond stays in LDS and uses the loops below.
+#define LDZ4(has, r, off) sel4((has), LDB4((r), (off)))
+    int lim_j[KLIM]; float lim_sg[KLIM], lim_rhs[KLIM], lim_dinv[KLIM], lim_col[KLIM], lim_lam[KLIM];
+    {
+        unsigned rem = limmask;
+#pragma unroll
+        for (int k = 0; k < KLIM; k++) {
+            const bool has = rem != 0;
+            const int js = has ? __ffs(rem) - 1 : 0;
+            rem &= rem - 1;
+            lim_j[k] = js >> 1; lim_sg[k] = (js & 1) == 0 ? 1.0f : -1.0f;
+            lim_rhs[k] = has ? LD(L_LIM + 2 * js) : 0.0f; lim_dinv[k] = has ? LD(L_MOT + 3 * (js >> 1) + 1) : 0.0f;
+            lim_col[k] = (has && l < NB) ? LD(L_MINV + lj * NB + (js >> 1)) : 0.0f;
+            lim_lam[k] = 0.0f;
+        }
+        limmask = rem;                                   // rows left for the LDS loop
+    }
+    unsigned os_cs = 0;                                  // contact indices of the register rows, one byte each
+    float os_mu[KOS], os_ln[KOS], os_l1[KOS], os_l2[KOS];
+    float4 os_n0[KOS], os_n1[KOS], os_n2[KOS], os_a0[KOS], os_a1[KOS], os_a2[KOS], os_b0[KOS], os_b1[KOS], os_b2[KOS];
+    {
+        unsigned rem = own_os;
+#pragma unroll
+        for (int i = 0; i < KOS; i++) {
+            const bool has = rem != 0;
+            const int c = has ? __ffs(rem) - 1 : 0;
+            rem &= rem - 1;
+            os_cs |= (has ? (unsigned)c : 255u) << (8 * i);
+            os_mu[i] = has ? LD(L_MU + c) : 0.0f; os_ln[i] = 0.0f; os_l1[i] = 0.0f; os_l2[i] = 0.0f;
+            os_n0[i] = LDZ4(has, 3 * c, 0); os_n1[i] = LDZ4(has, 3 * c, 4); os_n2[i] = LDZ4(has, 3 * c, 8);
+            os_a0[i] = LDZ4(has, 3 * c + 1, 0); os_a1[i] = LDZ4(has, 3 * c + 1, 4); os_a2[i] = LDZ4(has, 3 * c + 1, 8);
+            os_b0[i] = LDZ4(has, 3 * c + 2, 0); os_b1[i] = LDZ4(has, 3 * c + 2, 4); os_b2[i] = LDZ4(has, 3 * c + 2, 8);
+        }
+        own_os = rem;                                    // contacts left for the LDS loops
+    }
     for (int it = 0; it < P.iters; it++) {
 #pragma unroll
         for (int j = 0; j < NB; j++) {          // motors
@@ -902,8 +961,18 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             const float dlj = group_sum(is_j ? dl : 0.0f);
             dq += minv_l[j] * dlj;
         }
+#pragma unroll
+        for (int k = 0; k < KLIM; k++) {        // joint limits held in registers
+            const float dqj = group_sum(l == lim_j[k] ? dq : 0.0f);
+            float dl = lim_rhs[k] - lim_sg[k] * dqj * lim_dinv[k];
+            float sum = lim_lam[k] + dl;
+            if (sum < 0) { dl = -lim_lam[k]; sum = 0; }
+            else if (sum > 100.0f) { dl = 100.0f - lim_lam[k]; sum = 100.0f; }
+            lim_lam[k] = sum;
+            dq += lim_col[k] * (lim_sg[k] * dl);           // absent rows are all-zero: dl = 0
+        }
 #pragma unroll 1
-        for (unsigned rem = limmask; rem; rem &= rem - 1) {   // joint limits (existing rows only)
+        for (unsigned rem = limmask; rem; rem &= rem - 1) {   // further joint limits (existing rows only)
             const int js = __ffs(rem) - 1;
             float lr = LD(L_LIM + 2 * js);
             int j = js >> 1;
@@ -919,6 +988,12 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         }
         // ---- object-vs-static contacts, normals (rows 3c): every object lane walks its own contacts in contact order
         //      (divergent loop; rows of different objects are independent, so this equals the sequential sweep)
+        {
+            float dvx = dv.x, dvy = dv.y, dvz = dv.z, dwx = dw.x, dwy = dw.y, dwz = dw.z;
+#pragma unroll
+            for (int i = 0; i < KOS; i++) REG_ROW_STEP(os_n0[i], os_n1[i], os_n2[i], os_ln[i], 0.0f, 1e10f);
+            dv = mk(dvx, dvy, dvz); dw = mk(dwx, dwy, dwz);
+        }
         if (own_os) {
             float dvx = dv.x, dvy = dv.y, dvz = dv.z, dwx = dw.x, dwy = dw.y, dwz = dw.z;
             unsigned rem = own_os;
@@ -936,8 +1011,18 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         // ---- object-vs-static contacts, frictions (rows 3c+1, 3c+2) are swept after ALL normals (Bullet's order),
         //      i.e. after the generic normals below; see the friction pass.
         for (int pass = 0; pass < 2; pass++) {  // all normals, then all frictions
+            if (pass == 1) {
+                float dvx = dv.x, dvy = dv.y, dvz = dv.z, dwx = dw.x, dwy = dw.y, dwz = dw.z;
+#pragma unroll
+                for (int i = 0; i < KOS; i++) {
+                    const float hi = os_mu[i] * os_ln[i];
+                    REG_ROW_STEP(os_a0[i], os_a1[i], os_a2[i], os_l1[i], -hi, hi);
+                    REG_ROW_STEP(os_b0[i], os_b1[i], os_b2[i], os_l2[i], -hi, hi);
+                }
+                dv = mk(dvx, dvy, dvz); dw = mk(dwx, dwy, dwz);
+            }
             if (pass == 1 && own_os) {
-                // frictions of this lane's object-vs-static contacts; the rows of the next one are prefetched
+                // frictions of this lane's further object-vs-static contacts; the rows of the next one are prefetched
                 float dvx = dv.x, dvy = dv.y, dvz = dv.z, dwx = dw.x, dwy = dw.y, dwz = dw.z;
                 unsigned rem = own_os;
                 int c = __ffs(rem) - 1;
@@ -955,7 +1040,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                         na0 = LDB4(3 * c + 1, 0); na1 = LDB4(3 * c + 1, 4); na2 = LDB4(3 * c + 1, 8);
                         nc0 = LDB4(3 * c + 2, 0); nc1 = LDB4(3 * c + 2, 4); nc2 = LDB4(3 * c + 2, 8);
                     }
-                    if (!(hi > 0.0f)) continue;          // bounds [-0, 0]: lambda stays 0, nothing moves
+                    if (!(hi > 0.0f) && a2.w == 0.0f && c2.w == 0.0f) continue;   // bounds [-0, 0] and lambda already 0: nothing moves
                     OS_ROW_STEP(a0, a1, a2, -hi, hi, 3 * cc + 1);
                     OS_ROW_STEP(c0, c1, c2, -hi, hi, 3 * cc + 2);
                 }
@@ -977,7 +1062,6 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     const bool own = mineA || mineB;
                     const bool rob = robot && l < NB;
                     const float ln = LD(L_BASE + (3 * c) * 12 + 11), mu = LD(L_MU + c);
-                    if (pass == 1 && !(mu * ln > 0.0f)) continue;   // bounds [-0, 0]: lambda stays 0, nothing moves
                     const float hi = pass == 0 ? 1e10f : mu * ln, lo = pass == 0 ? 0.0f : -hi;
                     const int orb0 = robot ? L_ROB + (rslot * 3) * 22 + lj : lj;    // harmless address when no robot part
                     for (int r = r0; r < r1; r++) {
@@ -1034,6 +1118,16 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     if (mineB) { dv = dv + dir * (-dl * inv_mass); dw = dw + mang * dl; }
                 }
             }
+        }
+    }
+    // impulses of the register-resident contact rows go back to their LDS slots (contact forces / touch sensors below)
+#pragma unroll
+    for (int i = 0; i < KOS; i++) {
+        const int c = (os_cs >> (8 * i)) & 255;
+        if (c != 255) {
+            LD(L_BASE + (3 * c) * 12 + 11) = os_ln[i];
+            LD(L_BASE + (3 * c + 1) * 12 + 11) = os_l1[i];
+            LD(L_BASE + (3 * c + 2) * 12 + 11) = os_l2[i];
         }
     }
     // ---- integrate: lanes 0..10 joints, lanes 11..13 objects

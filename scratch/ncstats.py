@@ -8,13 +8,13 @@ N = 4096
 env = BatchedREALRobotEnv(N, objects=3, width=128, height=128, want_mask=False)
 ids = np.arange(N)
 cache = {}
-for t in range(260):
+for t in range(300):
     key = t // 20
     if key not in cache: cache[key] = synthetic_actions(ids, key * 20, hold_prob=0.05) * 0.5
     env.step(cache[key])
-    if t in (160, 200, 259):
+    if t in (160, 180, 200, 220, 240, 259, 280, 299):
         ncs, nrob, nact = [], [], []
-        for i in range(0, N, 37):
+        for i in range(0, N, 17):
             c = env.contacts(i)
             ncs.append(len(c)); nrob.append(int(((c[:, 0] >= 0) & (c[:, 0] < 16)).sum()) if len(c) else 0)
             nact.append(int((c[:, 10] > 0).sum()) if len(c) else 0)
