@@ -624,6 +624,10 @@ template <int ROR>
 __device__ __forceinline__ float dpp_ror(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + ROR, 0xf, 0xf, false));
 }
+// value of lane J of each 16-lane row, in every lane of that row (gfx90a+ DPP row_newbcast)
+template <int J> __device__ __forceinline__ float row_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float group_sum(float v) {
     v += dpp_ror<8>(v);
     v += dpp_ror<4>(v);
@@ -715,7 +719,7 @@ __device__ float build_row(const BodyParams &B, const SimParams &P, const DevPtr
 // b0,b1,b2 = the row's base part (dir.xyz ang.x | ang.yz mang.xy | mang.z rhs dinv lambda), bounds [lo, hi].
 #define OS_ROW_STEP(b0, b1, b2, lo, hi, rowidx)                                                                   \
     do {                                                                                                          \
-        const float jv_ = (b0).x * dvx + (b0).y * dvy + (b0).z * dvz + (b0).w * dwx + (b1).x * dwy + (b1).y * dwz;    \
+        const float jv_ = (b0).x * dv.x + (b0).y * dv.y + (b0).z * dv.z + (b0).w * dw.x + (b1).x * dw.y + (b1).y * dw.z;    \
         const float lam_ = (b2).w;                                                                                \
         const float dl0_ = (b2).y - jv_ * (b2).z;                                                                 \
         const float s0_ = lam_ + dl0_;                                                                            \
@@ -723,25 +727,25 @@ __device__ float build_row(const BodyParams &B, const SimParams &P, const DevPtr
         const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - lam_;                                                     \
         LD(L_BASE + (rowidx) * 12 + 11) = sum_;                                                                   \
         const float sm_ = dl_ * inv_mass;                                                                         \
-        dvx += (b0).x * sm_; dvy += (b0).y * sm_; dvz += (b0).z * sm_;                                            \
-        dwx += (b1).z * dl_; dwy += (b1).w * dl_; dwz += (b2).x * dl_;                                            \
+        dv.x += (b0).x * sm_; dv.y += (b0).y * sm_; dv.z += (b0).z * sm_;                                            \
+        dw.x += (b1).z * dl_; dw.y += (b1).w * dl_; dw.z += (b2).x * dl_;                                            \
     } while (0)
 
 // Same step for a row held in registers (b0, b1, b2 as above but lambda in `lam`).  An all-zero row with lam = 0 is a
 // no-op (dl = 0), which is how absent rows are represented -- no predicates, no scalar mask registers.
 #define REG_ROW_STEP(b0, b1, b2, lam, lo, hi)                                                                     \
     do {                                                                                                          \
-        const float jv_ = (b0).x * dvx + (b0).y * dvy + (b0).z * dvz + (b0).w * dwx + (b1).x * dwy + (b1).y * dwz;    \
+        const float jv_ = (b0).x * dv.x + (b0).y * dv.y + (b0).z * dv.z + (b0).w * dw.x + (b1).x * dw.y + (b1).y * dw.z;    \
         const float dl0_ = (b2).y - jv_ * (b2).z;                                                                 \
         const float s0_ = (lam) + dl0_;                                                                           \
         const float sum_ = fminf(fmaxf(s0_, (lo)), (hi));                                                         \
         const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - (lam);                                                    \
         (lam) = sum_;                                                                                             \
         const float sm_ = dl_ * inv_mass;                                                                         \
-        dvx += (b0).x * sm_; dvy += (b0).y * sm_; dvz += (b0).z * sm_;                                            \
-        dwx += (b1).z * dl_; dwy += (b1).w * dl_; dwz += (b2).x * dl_;                                            \
+        dv.x += (b0).x * sm_; dv.y += (b0).y * sm_; dv.z += (b0).z * sm_;                                            \
+        dw.x += (b1).z * dl_; dw.y += (b1).w * dl_; dw.z += (b2).x * dl_;                                            \
     } while (0)
-#define KLIM 4           // joint-limit rows kept in registers (usually two: the finger lower limits)
+#define KLIM 2           // joint-limit rows kept in registers (usually two: the finger lower limits)
 #define KOS 4            // object-vs-static contacts per object kept in registers (a resting object has <= 4)
 
 __device__ __forceinline__ float4 sel4(bool has, float4 v) {
@@ -949,28 +953,52 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         }
         own_os = rem;                                    // contacts left for the LDS loops
     }
+    // motors: every lane evaluates the step of "its" row from its own dq; row J's impulse change is lane J's value,
+    // broadcast to the 16 lanes of the env with one DPP row_newbcast (branch-free clamp, same values as if/else)
+#define MOTOR_STEP(J)                                                                     \
+        {                                                                                 \
+            const float dl0_ = m_rhs - dq * m_dinv;                                       \
+            const float s0_ = m_lam + dl0_;                                               \
+            const float sum_ = fminf(fmaxf(s0_, -max_imp), max_imp);                      \
+            const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - m_lam;                        \
+            m_lam = (l == (J)) ? sum_ : m_lam;                                            \
+            dq += minv_l[J] * row_bcast<J>(dl_);                                          \
+        }
+#define SWEEP_MOTORS                                                                                  \
+        MOTOR_STEP(0) MOTOR_STEP(1) MOTOR_STEP(2) MOTOR_STEP(3) MOTOR_STEP(4) MOTOR_STEP(5)           \
+        MOTOR_STEP(6) MOTOR_STEP(7) MOTOR_STEP(8) MOTOR_STEP(9) MOTOR_STEP(10)
+#define LIMIT_STEP(k)   /* joint limit held in registers; absent rows are all-zero: dl = 0 */        \
+        {                                                                                             \
+            const float dqj_ = group_sum(l == lim_j[k] ? dq : 0.0f);                                  \
+            const float dl0_ = lim_rhs[k] - lim_sg[k] * dqj_ * lim_dinv[k];                           \
+            const float s0_ = lim_lam[k] + dl0_;                                                      \
+            const float sum_ = fminf(fmaxf(s0_, 0.0f), 100.0f);                                       \
+            const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - lim_lam[k];                               \
+            lim_lam[k] = sum_;                                                                        \
+            dq += lim_col[k] * (lim_sg[k] * dl_);                                                     \
+        }
+#define OSN_STEP(i) REG_ROW_STEP(os_n0[i], os_n1[i], os_n2[i], os_ln[i], 0.0f, 1e10f);
+#define OSF_STEP(i)                                                                                   \
+        {                                                                                             \
+            const float hi_ = os_mu[i] * os_ln[i];                                                    \
+            REG_ROW_STEP(os_a0[i], os_a1[i], os_a2[i], os_l1[i], -hi_, hi_);                          \
+            REG_ROW_STEP(os_b0[i], os_b1[i], os_b2[i], os_l2[i], -hi_, hi_);                          \
+        }
+    static_assert(KLIM == 2 && KOS == 4, "the sweeps below are written out for KLIM = 2, KOS = 4");
+    // When no env of this wave has a row outside the registers (no robot or object-object contact, no further limit
+    // or contact rows), an iteration is one straight-line block: the robot chain (motors, limits) and the object chain
+    // (normals, frictions) are independent and the scheduler overlaps them.
+    const bool simple = __ballot(!(nc == n_os && own_os == 0 && limmask == 0)) == 0ull;
     for (int it = 0; it < P.iters; it++) {
-#pragma unroll
-        for (int j = 0; j < NB; j++) {          // motors
-            float dl = m_rhs - dq * m_dinv;
-            float sum = m_lam + dl;
-            if (sum < -max_imp) { dl = -max_imp - m_lam; sum = -max_imp; }
-            else if (sum > max_imp) { dl = max_imp - m_lam; sum = max_imp; }
-            const bool is_j = l == j;
-            m_lam = is_j ? sum : m_lam;
-            const float dlj = group_sum(is_j ? dl : 0.0f);
-            dq += minv_l[j] * dlj;
+        if (simple) {
+            SWEEP_MOTORS
+            LIMIT_STEP(0) LIMIT_STEP(1)
+            OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3)
+            OSF_STEP(0) OSF_STEP(1) OSF_STEP(2) OSF_STEP(3)
+            continue;
         }
-#pragma unroll
-        for (int k = 0; k < KLIM; k++) {        // joint limits held in registers
-            const float dqj = group_sum(l == lim_j[k] ? dq : 0.0f);
-            float dl = lim_rhs[k] - lim_sg[k] * dqj * lim_dinv[k];
-            float sum = lim_lam[k] + dl;
-            if (sum < 0) { dl = -lim_lam[k]; sum = 0; }
-            else if (sum > 100.0f) { dl = 100.0f - lim_lam[k]; sum = 100.0f; }
-            lim_lam[k] = sum;
-            dq += lim_col[k] * (lim_sg[k] * dl);           // absent rows are all-zero: dl = 0
-        }
+        SWEEP_MOTORS
+        LIMIT_STEP(0) LIMIT_STEP(1)
 #pragma unroll 1
         for (unsigned rem = limmask; rem; rem &= rem - 1) {   // further joint limits (existing rows only)
             const int js = __ffs(rem) - 1;
@@ -988,14 +1016,8 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         }
         // ---- object-vs-static contacts, normals (rows 3c): every object lane walks its own contacts in contact order
         //      (divergent loop; rows of different objects are independent, so this equals the sequential sweep)
-        {
-            float dvx = dv.x, dvy = dv.y, dvz = dv.z, dwx = dw.x, dwy = dw.y, dwz = dw.z;
-#pragma unroll
-            for (int i = 0; i < KOS; i++) REG_ROW_STEP(os_n0[i], os_n1[i], os_n2[i], os_ln[i], 0.0f, 1e10f);
-            dv = mk(dvx, dvy, dvz); dw = mk(dwx, dwy, dwz);
-        }
+        OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3)
         if (own_os) {
-            float dvx = dv.x, dvy = dv.y, dvz = dv.z, dwx = dw.x, dwy = dw.y, dwz = dw.z;
             unsigned rem = own_os;
             int c = __ffs(rem) - 1;
             float4 n0 = LDB4(3 * c, 0), n1 = LDB4(3 * c, 4), n2 = LDB4(3 * c, 8);
@@ -1006,24 +1028,13 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                 if (rem) { c = __ffs(rem) - 1; n0 = LDB4(3 * c, 0); n1 = LDB4(3 * c, 4); n2 = LDB4(3 * c, 8); }
                 OS_ROW_STEP(b0, b1, b2, 0.0f, 1e10f, 3 * cc);
             }
-            dv = mk(dvx, dvy, dvz); dw = mk(dwx, dwy, dwz);
         }
         // ---- object-vs-static contacts, frictions (rows 3c+1, 3c+2) are swept after ALL normals (Bullet's order),
         //      i.e. after the generic normals below; see the friction pass.
         for (int pass = 0; pass < 2; pass++) {  // all normals, then all frictions
-            if (pass == 1) {
-                float dvx = dv.x, dvy = dv.y, dvz = dv.z, dwx = dw.x, dwy = dw.y, dwz = dw.z;
-#pragma unroll
-                for (int i = 0; i < KOS; i++) {
-                    const float hi = os_mu[i] * os_ln[i];
-                    REG_ROW_STEP(os_a0[i], os_a1[i], os_a2[i], os_l1[i], -hi, hi);
-                    REG_ROW_STEP(os_b0[i], os_b1[i], os_b2[i], os_l2[i], -hi, hi);
-                }
-                dv = mk(dvx, dvy, dvz); dw = mk(dwx, dwy, dwz);
-            }
+            if (pass == 1) { OSF_STEP(0) OSF_STEP(1) OSF_STEP(2) OSF_STEP(3) }
             if (pass == 1 && own_os) {
                 // frictions of this lane's further object-vs-static contacts; the rows of the next one are prefetched
-                float dvx = dv.x, dvy = dv.y, dvz = dv.z, dwx = dw.x, dwy = dw.y, dwz = dw.z;
                 unsigned rem = own_os;
                 int c = __ffs(rem) - 1;
                 float nln = LD(L_BASE + (3 * c) * 12 + 11), nmu = LD(L_MU + c);
@@ -1044,7 +1055,6 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     OS_ROW_STEP(a0, a1, a2, -hi, hi, 3 * cc + 1);
                     OS_ROW_STEP(c0, c1, c2, -hi, hi, 3 * cc + 2);
                 }
-                dv = mk(dvx, dvy, dvz); dw = mk(dwx, dwy, dwz);
             }
             for (int c = n_os; c < nc; c++) {
                 const int meta = *(const int *)&LD(L_META + c);
