@@ -69,6 +69,8 @@ struct ShapeData {    // global memory, read uniformly
     float sphere[MAXSHAPES][4];
     float fric[MAXSHAPES], rest[MAXSHAPES];
     int pair_a[MAXPAIRS], pair_b[MAXPAIRS];
+    int pair_meta[MAXPAIRS][4];      // {bodyA, bodyB, link of shape a, 0}: body = -1 static, 0..15 robot body, 16+i object i
+    float pair_mat[MAXPAIRS][2];     // {friction, restitution} products of the two shapes
 };
 
 struct RenderModel {
@@ -131,6 +133,8 @@ struct DevPtrs {
     const unsigned long long *static_vis;   // [H*W] visibility keys of the never-moving instances (or nullptr)
     unsigned long long *static_vis_out;
     unsigned char *static_rgb; float *static_depth; int *static_mask;   // [H*W] shaded static layer (shared by all envs)
+    unsigned *collide_work;  // [N*npairs] (env | pair << 24) items that passed the bounding-sphere test
+    unsigned *collide_count; // [1]
     uint2 *frag_list;       // [N*ntiles][TILE_PIX] pixels won by moving triangles: {depth bits, pixel-in-tile << 18 | triangle}
     unsigned *frag_count;   // [N*ntiles]
 };
@@ -417,145 +421,162 @@ __global__ void __launch_bounds__(64) k_prep(BodyParams B, SimParams P, DevPtrs 
 // ---------------------------------------------------------------------------------------------- k_collide
 struct Xf { m3 R; v3 p; };
 
+// World transform of the owner of shape s.  All loads are unconditional and from always-valid addresses (the values are
+// selected afterwards): with loads under the owner-type branches the compiler merges the branches into a select of base
+// pointers whose value is undefined on the static path and may still issue the load -- a fault at a garbage address.
 __device__ __forceinline__ Xf load_xf(const ShapeData *S, int s, const float *state, const float *scratch, int N, int env) {
     Xf X;
-    int ot = S->otype[s], oi = S->oidx[s];
-    if (ot == 0) {
-        m3 I = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
-        X.R = I; X.p = mk(0, 0, 0);
-    } else if (ot == 1) {
-        for (int k = 0; k < 9; k++) X.R.m[k] = SCR(S_BR + 9 * oi + k);
-        X.p = mk(SCR(S_BP + 3 * oi), SCR(S_BP + 3 * oi + 1), SCR(S_BP + 3 * oi + 2));
-    } else {
-        for (int k = 0; k < 9; k++) X.R.m[k] = SCR(S_OR + 9 * oi + k);
-        X.p = mk(STT(ST_OPOS + 3 * oi), STT(ST_OPOS + 3 * oi + 1), STT(ST_OPOS + 3 * oi + 2));
-    }
+    const int ot = S->otype[s];
+    const int oi = ot == 0 ? 0 : S->oidx[s];
+    const int rslot = (ot == 1 ? S_BR : S_OR) + 9 * oi;
+    float r[9];
+    r[0] = SCR(rslot); r[1] = SCR(rslot + 1); r[2] = SCR(rslot + 2); r[3] = SCR(rslot + 3); r[4] = SCR(rslot + 4);
+    r[5] = SCR(rslot + 5); r[6] = SCR(rslot + 6); r[7] = SCR(rslot + 7); r[8] = SCR(rslot + 8);
+    const int ob = ot == 2 ? oi : 0, bb = ot == 1 ? oi : 0;
+    const float pbx = SCR(S_BP + 3 * bb), pby = SCR(S_BP + 3 * bb + 1), pbz = SCR(S_BP + 3 * bb + 2);
+    const float pox = STT(ST_OPOS + 3 * ob), poy = STT(ST_OPOS + 3 * ob + 1), poz = STT(ST_OPOS + 3 * ob + 2);
+    const bool st = ot == 0, body = ot == 1;
+    X.R.m[0] = st ? 1.0f : r[0]; X.R.m[1] = st ? 0.0f : r[1]; X.R.m[2] = st ? 0.0f : r[2];
+    X.R.m[3] = st ? 0.0f : r[3]; X.R.m[4] = st ? 1.0f : r[4]; X.R.m[5] = st ? 0.0f : r[5];
+    X.R.m[6] = st ? 0.0f : r[6]; X.R.m[7] = st ? 0.0f : r[7]; X.R.m[8] = st ? 1.0f : r[8];
+    X.p = mk(st ? 0.0f : (body ? pbx : pox), st ? 0.0f : (body ? pby : poy), st ? 0.0f : (body ? pbz : poz));
     return X;
 }
 
-struct Cand { float x, y, z, s; int code; };   // code: plane index | (direction << 8)
-// Candidates live in LDS, laid out [candidate][lane] so a wave's accesses are conflict free. The arrays are
-// file-scope __shared__ objects addressed directly (ds_read/ds_write): generic (flat) pointers into LDS or
-// private memory must not be used in this library -- see DESIGN.md "address spaces".
-#define COLLIDE_THREADS 32
-__shared__ float4 g_cand_xs[2 * VMAXC * COLLIDE_THREADS];
-__shared__ int g_cand_code[2 * VMAXC * COLLIDE_THREADS];
-struct CandStore {
-    __device__ __forceinline__ void put(int i, const Cand &c) {
-        g_cand_xs[i * COLLIDE_THREADS + threadIdx.x] = make_float4(c.x, c.y, c.z, c.s);
-        g_cand_code[i * COLLIDE_THREADS + threadIdx.x] = c.code;
-    }
-    __device__ __forceinline__ Cand get(int i) const {
-        float4 v = g_cand_xs[i * COLLIDE_THREADS + threadIdx.x];
-        Cand c = {v.x, v.y, v.z, v.w, g_cand_code[i * COLLIDE_THREADS + threadIdx.x]};
-        return c;
-    }
-};
-
-__device__ int verts_in_planes(const ShapeData *S, int sa, const Xf &Xa, int sb, const Xf &Xb, int dirflag, float margin,
-                               CandStore &out, int n) {
-    int nv = S->nv[sa], nf = S->nf[sb];
-    for (int v = 0; v < nv; v++) {
-        v3 xw = mulv(Xa.R, mk(S->verts[sa][v][0], S->verts[sa][v][1], S->verts[sa][v][2])) + Xa.p;
-        v3 xl = tmulv(Xb.R, xw - Xb.p);
-        float best = -1e30f;
-        int bf = 0;
-        for (int f = 0; f < nf; f++) {
-            float s = S->planes[sb][f][0] * xl.x + S->planes[sb][f][1] * xl.y + S->planes[sb][f][2] * xl.z - S->planes[sb][f][3];
-            if (s > best) { best = s; bf = f; }
-        }
-        if (best < margin) {
-            v3 nw = mulv(Xb.R, mk(S->planes[sb][bf][0], S->planes[sb][bf][1], S->planes[sb][bf][2]));
-            Cand c;
-            c.x = xw.x - 0.5f * best * nw.x; c.y = xw.y - 0.5f * best * nw.y; c.z = xw.z - 0.5f * best * nw.z;
-            c.s = best;
-            c.code = bf | (dirflag << 8);
-            out.put(n++, c);
-        }
-    }
-    return n;
-}
-
-__global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtrs D, int nblk) {
+// ---- collision: broad phase (one thread per env x pair) + narrow phase (one wavefront per surviving env x pair) --------
+// The narrow phase of a pair is ~2 x 32 vertices against ~32 planes plus a manifold reduction: as a per-thread loop it is
+// a chain of ~20k dependent instructions and, with only three or four close pairs per env, the kernel is as slow as that
+// chain.  Here the broad phase only runs the bounding-sphere test and appends the surviving (env, pair) items to a work
+// list; the narrow phase gives every item a whole wavefront: lanes 0..31 test the vertices of shape a against the planes
+// of shape b (direction 0), lanes 32..63 the vertices of b against the planes of a (direction 1).  Candidate order
+// (direction 0 by vertex index, then direction 1) equals lane order, so "first best wins" selections of the oracle's
+// reduce4() become wave reductions with lowest-lane tie-breaks -- results are identical to the serial formulation.
+#define COLLIDE_THREADS 64
+__global__ void __launch_bounds__(COLLIDE_THREADS) k_collide_broad(SimParams P, DevPtrs D, int nblk) {
     const int N = P.N;
-    int pair = blockIdx.x / nblk;
-    int env = (blockIdx.x - pair * nblk) * COLLIDE_THREADS + threadIdx.x;
+    const int pair = blockIdx.x / nblk;
+    const int env = (blockIdx.x - pair * nblk) * COLLIDE_THREADS + threadIdx.x;
     if (env >= N) return;
     const float *state = D.state;
     float *scratch = D.scratch;
     if (D.errflags[env]) return;
+    if (P.ablate & 2048) return;
     const ShapeData *S = D.shapes;
-    int sa = S->pair_a[pair], sb = S->pair_b[pair];
-    Xf Xa = load_xf(S, sa, state, scratch, N, env), Xb = load_xf(S, sb, state, scratch, N, env);
-    v3 ca = mulv(Xa.R, mk(S->sphere[sa][0], S->sphere[sa][1], S->sphere[sa][2])) + Xa.p;
-    v3 cb = mulv(Xb.R, mk(S->sphere[sb][0], S->sphere[sb][1], S->sphere[sb][2])) + Xb.p;
-    v3 d = ca - cb;
-    float rr = S->sphere[sa][3] + S->sphere[sb][3] + P.margin;
-    int *pcount = (int *)&SCR(S_PCOUNT + pair);
-    if (dot(d, d) > rr * rr) { *pcount = 0; return; }
-    CandStore cand;
-    int n = 0;
-    n = verts_in_planes(S, sa, Xa, sb, Xb, 0, P.margin, cand, n);
-    n = verts_in_planes(S, sb, Xb, sa, Xa, 1, P.margin, cand, n);
-    int sel[4], k = 0;
-    if (n <= 4) { for (int i = 0; i < n; i++) sel[i] = i; k = n; }
-    else {
-        // manifold reduction, same rule as the oracle's reduce4(): deepest first, then maximal spread, preferring
-        // the candidates within TIER_TOL of the deepest penetration at every pick
-        int k0 = 0;
-        float sbest = cand.get(0).s;
-        for (int i = 1; i < n; i++) { float si = cand.get(i).s; if (si < sbest) { sbest = si; k0 = i; } }
-        const float lim = sbest + 0.001f;
-        Cand c0_ = cand.get(k0);
-        v3 x0 = mk(c0_.x, c0_.y, c0_.z);
-        int k1 = -1, k2 = -1, k3 = -1;
-        for (int tier = 0; tier < 2 && k1 < 0; tier++) {
-            float best = -1;
-            for (int i = 0; i < n; i++) {
-                Cand ci_ = cand.get(i);
-                if (i == k0 || (tier == 0 && !(ci_.s < lim))) continue;
-                v3 dd = mk(ci_.x, ci_.y, ci_.z) - x0;
-                float v = dot(dd, dd);
-                if (v > best) { best = v; k1 = i; }
+    const int sa = S->pair_a[pair], sb = S->pair_b[pair];
+    if (P.ablate & 4096) { *(int *)&SCR(S_PCOUNT + pair) = sa + sb; return; }
+    const Xf Xa = load_xf(S, sa, state, scratch, N, env), Xb = load_xf(S, sb, state, scratch, N, env);
+    if (P.ablate & 8192) { *(int *)&SCR(S_PCOUNT + pair) = (int)(Xa.p.x + Xb.p.y + Xa.R.m[3] + Xb.R.m[8]); return; }
+    const v3 ca = mulv(Xa.R, mk(S->sphere[sa][0], S->sphere[sa][1], S->sphere[sa][2])) + Xa.p;
+    const v3 cb = mulv(Xb.R, mk(S->sphere[sb][0], S->sphere[sb][1], S->sphere[sb][2])) + Xb.p;
+    const v3 d = ca - cb;
+    const float rr = S->sphere[sa][3] + S->sphere[sb][3] + P.margin;
+    *(int *)&SCR(S_PCOUNT + pair) = 0;
+    if (dot(d, d) > rr * rr) return;
+    if (P.ablate & 256) return;
+    D.collide_work[atomicAdd(D.collide_count, 1u)] = (unsigned)env | ((unsigned)pair << 24);
+}
+
+// wave-wide "first lane holding the maximum of v among lanes with ok" (returns -1 when no lane is ok or none exceeds floor)
+__device__ __forceinline__ int wave_argmax_first(float v, bool ok, float floor_) {
+    float m = ok ? v : -3.0e38f;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (!(m > floor_)) return -1;
+    const unsigned long long b = __ballot(ok && v == m);
+    return b ? __ffsll((long long)b) - 1 : -1;
+}
+__device__ __forceinline__ float lane_f(float v, int src) { return __shfl(v, src); }
+
+__global__ void __launch_bounds__(COLLIDE_THREADS) k_collide_narrow(SimParams P, DevPtrs D) {
+    const int N = P.N;
+    const float *state = D.state;
+    float *scratch = D.scratch;
+    const ShapeData *S = D.shapes;
+    __shared__ float4 planes[2][FMAXC];
+    const int lane = threadIdx.x;
+    const unsigned nitems = *D.collide_count;
+    for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const unsigned w = D.collide_work[item];
+        const int env = (int)(w & 0xffffffu), pair = (int)(w >> 24);
+        const int sa = S->pair_a[pair], sb = S->pair_b[pair];
+        const Xf Xa = load_xf(S, sa, state, scratch, N, env), Xb = load_xf(S, sb, state, scratch, N, env);
+        const int dirflag = lane >> 5, v = lane & 31;
+        // "mine" = the shape whose vertex this lane tests, "other" = the shape whose planes it is tested against
+        const int sm = dirflag ? sb : sa, so = dirflag ? sa : sb;
+        __syncthreads();        // previous item's plane reads are done
+        if (lane < FMAXC) planes[0][lane] = make_float4(S->planes[sb][lane][0], S->planes[sb][lane][1], S->planes[sb][lane][2], S->planes[sb][lane][3]);
+        else planes[1][lane - FMAXC] = make_float4(S->planes[sa][lane - FMAXC][0], S->planes[sa][lane - FMAXC][1], S->planes[sa][lane - FMAXC][2], S->planes[sa][lane - FMAXC][3]);
+        __syncthreads();
+        Xf Xm, Xo;
+#pragma unroll
+        for (int kk = 0; kk < 9; kk++) { Xm.R.m[kk] = dirflag ? Xb.R.m[kk] : Xa.R.m[kk]; Xo.R.m[kk] = dirflag ? Xa.R.m[kk] : Xb.R.m[kk]; }
+        Xm.p = mk(dirflag ? Xb.p.x : Xa.p.x, dirflag ? Xb.p.y : Xa.p.y, dirflag ? Xb.p.z : Xa.p.z);
+        Xo.p = mk(dirflag ? Xa.p.x : Xb.p.x, dirflag ? Xa.p.y : Xb.p.y, dirflag ? Xa.p.z : Xb.p.z);
+        const int nv = S->nv[sm], nf = S->nf[so];
+        bool hit = false;
+        float cx = 0, cy = 0, cz = 0, cs = 0;
+        int bf = 0;
+        if (v < nv) {
+            const v3 xw = mulv(Xm.R, mk(S->verts[sm][v][0], S->verts[sm][v][1], S->verts[sm][v][2])) + Xm.p;
+            const v3 xl = tmulv(Xo.R, xw - Xo.p);
+            float best = -1e30f;
+            for (int f = 0; f < nf; f++) {
+                const float4 pl = planes[dirflag][f];
+                const float sd = pl.x * xl.x + pl.y * xl.y + pl.z * xl.z - pl.w;
+                if (sd > best) { best = sd; bf = f; }
+            }
+            if (best < P.margin) {
+                const float4 pl = planes[dirflag][bf];
+                const v3 nw = mulv(Xo.R, mk(pl.x, pl.y, pl.z));
+                cx = xw.x - 0.5f * best * nw.x; cy = xw.y - 0.5f * best * nw.y; cz = xw.z - 0.5f * best * nw.z;
+                cs = best;
+                hit = true;
             }
         }
-        Cand c1_ = cand.get(k1);
-        v3 e = mk(c1_.x, c1_.y, c1_.z) - x0;
-        v3 cr2 = mk(0, 0, 0);
-        for (int tier = 0; tier < 2 && k2 < 0; tier++) {
-            float best = -1;
-            for (int i = 0; i < n; i++) {
-                Cand ci_ = cand.get(i);
-                if (i == k0 || i == k1 || (tier == 0 && !(ci_.s < lim))) continue;
-                v3 cr = cross(mk(ci_.x, ci_.y, ci_.z) - x0, e);
-                float v = dot(cr, cr);
-                if (v > best) { best = v; k2 = i; cr2 = cr; }
-            }
+        const unsigned long long hmask = __ballot(hit);
+        const int n = __popcll(hmask);
+        // manifold reduction, same rule as the oracle's reduce4(): deepest first, then maximal spread, preferring the
+        // candidates within TIER_TOL (1 mm) of the deepest penetration at every pick; ties go to the first candidate
+        int sel0 = -1, sel1 = -1, sel2 = -1, sel3 = -1, k = 0;
+        if (n <= 4) {
+            unsigned long long r = hmask;
+            if (r) { sel0 = __ffsll((long long)r) - 1; r &= r - 1; k = 1; }
+            if (r) { sel1 = __ffsll((long long)r) - 1; r &= r - 1; k = 2; }
+            if (r) { sel2 = __ffsll((long long)r) - 1; r &= r - 1; k = 3; }
+            if (r) { sel3 = __ffsll((long long)r) - 1; k = 4; }
+        } else {
+            sel0 = wave_argmax_first(-cs, hit, -3.0e38f);         // smallest s, first one
+            const float sbest = lane_f(cs, sel0);
+            const float lim = sbest + 0.001f;
+            const v3 x0 = mk(lane_f(cx, sel0), lane_f(cy, sel0), lane_f(cz, sel0));
+            const v3 dd = mk(cx, cy, cz) - x0;
+            const float v1 = dot(dd, dd);
+            const bool t0 = cs < lim;
+            sel1 = wave_argmax_first(v1, hit && lane != sel0 && t0, -1.0f);
+            if (sel1 < 0) sel1 = wave_argmax_first(v1, hit && lane != sel0, -1.0f);
+            const v3 e = mk(lane_f(cx, sel1), lane_f(cy, sel1), lane_f(cz, sel1)) - x0;
+            const v3 cr = cross(dd, e);
+            const float v2 = dot(cr, cr);
+            sel2 = wave_argmax_first(v2, hit && lane != sel0 && lane != sel1 && t0, -1.0f);
+            if (sel2 < 0) sel2 = wave_argmax_first(v2, hit && lane != sel0 && lane != sel1, -1.0f);
+            const v3 cr2 = mk(lane_f(cr.x, sel2), lane_f(cr.y, sel2), lane_f(cr.z, sel2));
+            const float v3_ = -dot(cr, cr2);
+            const bool o3 = hit && lane != sel0 && lane != sel1 && lane != sel2;
+            sel3 = wave_argmax_first(v3_, o3 && t0, 0.0f);
+            if (sel3 < 0) sel3 = wave_argmax_first(v3_, o3, 0.0f);
+            k = sel3 >= 0 ? 4 : 3;
         }
-        for (int tier = 0; tier < 2 && k3 < 0; tier++) {
-            float best = 0;
-            for (int i = 0; i < n; i++) {
-                Cand ci_ = cand.get(i);
-                if (i == k0 || i == k1 || i == k2 || (tier == 0 && !(ci_.s < lim))) continue;
-                v3 cr = cross(mk(ci_.x, ci_.y, ci_.z) - x0, e);
-                float v = -dot(cr, cr2);
-                if (v > best) { best = v; k3 = i; }
-            }
+        if (lane == 0) *(int *)&SCR(S_PCOUNT + pair) = k;
+        const int slot = lane == sel0 ? 0 : (lane == sel1 ? 1 : (lane == sel2 ? 2 : (lane == sel3 ? 3 : -1)));
+        if (hit && slot >= 0) {
+            const float4 pl = planes[dirflag][bf];
+            v3 nw = mulv(Xo.R, mk(pl.x, pl.y, pl.z));
+            if (dirflag) nw = nw * -1.0f;
+            const int base = S_PDATA + (pair * 4 + slot) * 7;
+            SCR(base) = cx; SCR(base + 1) = cy; SCR(base + 2) = cz;
+            SCR(base + 3) = nw.x; SCR(base + 4) = nw.y; SCR(base + 5) = nw.z;
+            SCR(base + 6) = cs;
         }
-        sel[0] = k0; sel[1] = k1; sel[2] = k2; k = 3;
-        if (k3 >= 0) { sel[3] = k3; k = 4; }
-    }
-    *pcount = k;
-    for (int i = 0; i < k; i++) {
-        Cand c = cand.get(sel[i]);
-        int dirflag = c.code >> 8, bf = c.code & 255;
-        v3 nw;
-        if (dirflag == 0) nw = mulv(Xb.R, mk(S->planes[sb][bf][0], S->planes[sb][bf][1], S->planes[sb][bf][2]));
-        else nw = mulv(Xa.R, mk(S->planes[sa][bf][0], S->planes[sa][bf][1], S->planes[sa][bf][2])) * -1.0f;
-        int base = S_PDATA + (pair * 4 + i) * 7;
-        SCR(base) = c.x; SCR(base + 1) = c.y; SCR(base + 2) = c.z;
-        SCR(base + 3) = nw.x; SCR(base + 4) = nw.y; SCR(base + 5) = nw.z;
-        SCR(base + 6) = c.s;
     }
 }
 
@@ -748,6 +769,21 @@ __device__ float build_row(const BodyParams &B, const SimParams &P, const DevPtr
 #define KLIM 2           // joint-limit rows kept in registers (usually two: the finger lower limits)
 #define KOS 4            // object-vs-static contacts per object kept in registers (a resting object has <= 4)
 
+#ifdef RR_RASTER_STATS
+// development build only: cycle stamps of the solver phases (wave 0 lane 0 of every block), see scratch/sprof.py
+__device__ unsigned long long g_sprof[16];
+#define SPROF(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_sprof[i], now_ - sp_t0); sp_t0 = now_; } while (0)
+#define SPROF_INIT unsigned long long sp_t0 = __builtin_readcyclecounter();
+extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sprof), sizeof(g_sprof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sprof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define SPROF(i)
+#define SPROF_INIT
+#endif
+
 __device__ __forceinline__ float4 sel4(bool has, float4 v) {
     return make_float4(has ? v.x : 0.0f, has ? v.y : 0.0f, has ? v.z : 0.0f, has ? v.w : 0.0f);
 }
@@ -763,8 +799,10 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     const float dt = P.dt;
     const int lj = l < NB ? l : 0;               // joint owned by this lane (lanes >= 11 alias joint 0, masked)
     const int lo_ = (l >= NB && l < NB + NOBJ) ? l - NB : -1;   // object owned by this lane
+    SPROF_INIT
     // ---- stage Minv in LDS
     for (int i = l; i < NB * NB; i += 16) LD(L_MINV + i) = SCR(S_MINV + i);
+    SPROF(0);
     // ---- gather contacts in pair order, build rows (all lanes of the group run the control flow redundantly)
     // The 92 per-pair candidate counts are fetched in one go: lane l loads the counts of pairs l, l+16, ... and the
     // non-empty pairs are collected into per-group bit masks with wave ballots (no chain of dependent global loads).
@@ -776,54 +814,83 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         const unsigned long long bal = __ballot(cntl > 0);
         pmask[k] = (unsigned)(bal >> (16 * grp)) & 0xffffu;
     }
+    SPROF(7);
     int nc = 0, nrob = 0, nbs = 0;
-#pragma unroll
+    static_assert(MAXPAIRS / 16 == 6, "pair-mask select chain below");
+#pragma unroll 1        // one copy of the (large) row-building body: the kernel must stay inside the instruction cache
     for (int k = 0; k < MAXPAIRS / 16; k++)
-    for (unsigned rem = pmask[k]; rem && nc < MAXC; rem &= rem - 1) {
+    for (unsigned rem = k == 0 ? pmask[0] : (k == 1 ? pmask[1] : (k == 2 ? pmask[2] : (k == 3 ? pmask[3] : (k == 4 ? pmask[4] : pmask[5]))));
+         rem && nc < MAXC; rem &= rem - 1) {
         const int pair = 16 * k + __ffs(rem) - 1;
+        // Two round trips per non-empty pair: (1) its count and metadata, (2) all of its candidate points and, for an
+        // object-vs-static pair, the object's pose / inertia / velocity -- nothing is fetched inside the contact loop.
         const int cnt = *(const int *)&SCR(S_PCOUNT + pair);
-        int sa = S->pair_a[pair], sb = S->pair_b[pair];
-        int bodyA = S->otype[sa] == 0 ? -1 : (S->otype[sa] == 1 ? S->oidx[sa] : 16 + S->oidx[sa]);
-        int bodyB = S->otype[sb] == 0 ? -1 : (S->otype[sb] == 1 ? S->oidx[sb] : 16 + S->oidx[sb]);
-        float mu = S->fric[sa] * S->fric[sb], rest = S->rest[sa] * S->rest[sb];
+        const int4 pm = *(const int4 *)S->pair_meta[pair];
+        const float2 pmat = *(const float2 *)S->pair_mat[pair];
+        const int bodyA = pm.x, bodyB = pm.y, linkA = pm.z;
+        const float mu = pmat.x, rest = pmat.y;
         const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
         const bool objobj = bodyA >= 16 && bodyB >= 16;
+        float cd[4][7];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int kk = 0; kk < 7; kk++) cd[i][kk] = i < cnt ? SCR(S_PDATA + (pair * 4 + i) * 7 + kk) : 0.0f;
+        const bool ospair = bodyA >= 16 && bodyB < 0;
+        const int ob = ospair ? bodyA - 16 : 0;
+        v3 op = mk(0, 0, 0), vs = mk(0, 0, 0), ws = mk(0, 0, 0);
+        m3 Iinv;
+        float oimass = 0.0f;
+        if (ospair) {
+            op = mk(STT(ST_OPOS + 3 * ob), STT(ST_OPOS + 3 * ob + 1), STT(ST_OPOS + 3 * ob + 2));
+#pragma unroll
+            for (int kk = 0; kk < 9; kk++) Iinv.m[kk] = SCR(S_OIINV + 9 * ob + kk);
+            vs = mk(SCR(S_OVS + 3 * ob), SCR(S_OVS + 3 * ob + 1), SCR(S_OVS + 3 * ob + 2));
+            ws = mk(SCR(S_OWS + 3 * ob), SCR(S_OWS + 3 * ob + 1), SCR(S_OWS + 3 * ob + 2));
+            oimass = 1.0f / B.obj_mass[ob];
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 9; kk++) Iinv.m[kk] = 0.0f;
+        }
+        SPROF(8);
+        // every value fetched above is waited for here, once: with no load in flight the contact loop below needs no
+        // vmcnt waits, which on gfx9 would also wait for the acknowledgement of the contact-record stores it issues
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            asm volatile("" : "+v"(cd[i][0]), "+v"(cd[i][1]), "+v"(cd[i][2]), "+v"(cd[i][3]), "+v"(cd[i][4]), "+v"(cd[i][5]), "+v"(cd[i][6]));
+        asm volatile("" : "+v"(op.x), "+v"(op.y), "+v"(op.z), "+v"(vs.x), "+v"(vs.y), "+v"(vs.z), "+v"(ws.x), "+v"(ws.y), "+v"(ws.z), "+v"(oimass));
+        asm volatile("" : "+v"(Iinv.m[0]), "+v"(Iinv.m[1]), "+v"(Iinv.m[2]), "+v"(Iinv.m[3]), "+v"(Iinv.m[4]), "+v"(Iinv.m[5]), "+v"(Iinv.m[6]), "+v"(Iinv.m[7]), "+v"(Iinv.m[8]));
+        SPROF(9);
         for (int i = 0; i < cnt && nc < MAXC; i++, nc++) {
-            int base = S_PDATA + (pair * 4 + i) * 7;
-            v3 x = mk(SCR(base), SCR(base + 1), SCR(base + 2));
-            v3 n = mk(SCR(base + 3), SCR(base + 4), SCR(base + 5));
-            float dist = SCR(base + 6);
+            float c7[7];
+#pragma unroll
+            for (int kk = 0; kk < 7; kk++) c7[kk] = i == 0 ? cd[0][kk] : (i == 1 ? cd[1][kk] : (i == 2 ? cd[2][kk] : cd[3][kk]));
+            const v3 x = mk(c7[0], c7[1], c7[2]), n = mk(c7[3], c7[4], c7[5]);
+            const float dist = c7[6];
             int rslot = 15, bslot = 15;
             bool fast = nc < LC;
             if (robot) { if (nrob < LR && fast) rslot = nrob; else fast = false; nrob++; }
             if (objobj) { if (nbs < LB && fast) bslot = nbs; else fast = false; nbs++; }
             if (!fast) { rslot = 15; bslot = 15; }
             // "fast" is recoverable from the meta word: c < LC and (no robot side or rslot != 15) and (no B object or bslot != 15)
-            int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((S->link[sa] & 255) << 16) | (rslot << 24) | (bslot << 28);
+            int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | (rslot << 24) | (bslot << 28);
             if (l == 0) {
                 *(int *)&LD(L_META + nc) = meta;
                 if (nc < LC) LD(L_MU + nc) = mu;
-                float *ct = &SCR(S_CT + nc * 12);
-                const size_t Ns = (size_t)N;
-                ct[0] = (float)bodyA; ct[Ns] = (float)bodyB; ct[2 * Ns] = (float)S->link[sa];
-                ct[3 * Ns] = x.x; ct[4 * Ns] = x.y; ct[5 * Ns] = x.z; ct[6 * Ns] = n.x; ct[7 * Ns] = n.y; ct[8 * Ns] = n.z;
-                ct[9 * Ns] = dist; ct[10 * Ns] = 0; ct[11 * Ns] = mu;
+            }
+            if (l < 12) {   // contact record (rr_get_contacts, touch sensors): field l is stored by lane l, one instruction
+                const float fld = l == 0 ? (float)bodyA : l == 1 ? (float)bodyB : l == 2 ? (float)linkA : l == 3 ? x.x : l == 4 ? x.y :
+                                  l == 5 ? x.z : l == 6 ? n.x : l == 7 ? n.y : l == 8 ? n.z : l == 9 ? dist : l == 10 ? 0.0f : mu;
+                SCR(S_CT + nc * 12 + l) = fld;
             }
             if (fast && bodyA >= 16 && bodyB < 0) {
                 // object-vs-static contact: the three rows (n, t1, t2) are built by lanes 0, 1, 2 in parallel
-                const int ob = bodyA - 16;
                 v3 t1, t2;
                 plane_space(n, t1, t2);
                 const v3 dir = l == 0 ? n : (l == 1 ? t1 : t2);
-                const v3 op = mk(STT(ST_OPOS + 3 * ob), STT(ST_OPOS + 3 * ob + 1), STT(ST_OPOS + 3 * ob + 2));
                 const v3 ang = cross(x - op, dir);
-                m3 Iinv;
-#pragma unroll
-                for (int kk = 0; kk < 9; kk++) Iinv.m[kk] = SCR(S_OIINV + 9 * ob + kk);
                 const v3 mang = mulv(Iinv, ang);
-                const v3 vs = mk(SCR(S_OVS + 3 * ob), SCR(S_OVS + 3 * ob + 1), SCR(S_OVS + 3 * ob + 2));
-                const v3 ws = mk(SCR(S_OWS + 3 * ob), SCR(S_OWS + 3 * ob + 1), SCR(S_OWS + 3 * ob + 2));
-                const float diag = dot(dir, dir) * (1.0f / B.obj_mass[ob]) + dot(ang, mang);
+                const float diag = dot(dir, dir) * oimass + dot(ang, mang);
                 const float rel = dot(dir, vs) + dot(ang, ws);
                 const float dinv = diag > 0 ? 1.0f / diag : 0.0f;
                 float rr = 0;
@@ -864,7 +931,9 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             }
             if (!fast) ROW_FENCE();
         }
+        SPROF(10);
     }
+    SPROF(1);
     if (l == 0) *(int *)&SCR(S_NCT) = nc;
     // ---- motor + limit rows: lane j < 11 builds the rows of joint j
     const float q_l = STT(ST_Q + lj), qds_l = SCR(S_QDS + lj);
@@ -888,6 +957,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             LD(L_LIM + 2 * (2 * l + side) + 1) = 0.0f;
         }
     }
+    SPROF(2);
     // compact list of the limit rows that exist (usually the two finger lower limits), in row order
     unsigned limmask = 0;
     for (int js = 0; js < 2 * NB; js++) if (LD(L_LIM + 2 * js) > -1e29f) limmask |= 1u << js;
@@ -984,6 +1054,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             REG_ROW_STEP(os_a0[i], os_a1[i], os_a2[i], os_l1[i], -hi_, hi_);                          \
             REG_ROW_STEP(os_b0[i], os_b1[i], os_b2[i], os_l2[i], -hi_, hi_);                          \
         }
+    SPROF(3);
     static_assert(KLIM == 2 && KOS == 4, "the sweeps below are written out for KLIM = 2, KOS = 4");
     // When no env of this wave has a row outside the registers (no robot or object-object contact, no further limit
     // or contact rows), an iteration is one straight-line block: the robot chain (motors, limits) and the object chain
@@ -1130,6 +1201,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             }
         }
     }
+    SPROF(4);
     // impulses of the register-resident contact rows go back to their LDS slots (contact forces / touch sensors below)
 #pragma unroll
     for (int i = 0; i < KOS; i++) {
@@ -1188,6 +1260,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         for (int k = 0; k < 3; k++) op[k] = STT(ST_OPOS + 3 * i + k);
         op[3] = r0 * inv; op[4] = r1 * inv; op[5] = r2 * inv; op[6] = r3 * inv;
     }
+    SPROF(5);
     if (!finite) atomicOr(&D.errflags[env], 1u);
     // ---- touch sensors (robot.py:152-163) + contact forces: lane 0
     if (l == 0) {
@@ -1209,6 +1282,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         for (int k = 0; k < 4; k++) D.touch[(size_t)env * 4 + k] = touch[k];
         D.timestep[env] += 1;
     }
+    SPROF(6);
 }
 
 // obs pack without stepping (after reset / set_state)
@@ -2101,6 +2175,7 @@ struct rr_env {
     hipStream_t aux;         // side stream: the HBM-bound static-layer copy runs beside the VALU-bound physics / visibility kernels
     hipEvent_t ev_fork, ev_join;
     bool copy_in_flight;
+    int narrow_blocks;       // persistent wavefronts of the narrow phase
     float t_ms[RR_NUM_KERNELS];
     int t_n[RR_NUM_KERNELS];
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -2290,6 +2365,13 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     for (int r = 0; r < n_robot; r++) for (int s = 0; s < 2; s++) { S.pair_a[np] = n_static + r; S.pair_b[np++] = s; }
     for (int r = 0; r < n_robot; r++) for (int i = 0; i < P.nobj; i++) { S.pair_a[np] = n_static + r; S.pair_b[np++] = s_obj0 + i; }
     P.npairs = np;
+    for (int k = 0; k < np; k++) {
+        const int sa = S.pair_a[k], sb = S.pair_b[k];
+        S.pair_meta[k][0] = S.otype[sa] == 0 ? -1 : (S.otype[sa] == 1 ? S.oidx[sa] : 16 + S.oidx[sa]);
+        S.pair_meta[k][1] = S.otype[sb] == 0 ? -1 : (S.otype[sb] == 1 ? S.oidx[sb] : 16 + S.oidx[sb]);
+        S.pair_meta[k][2] = S.link[sa]; S.pair_meta[k][3] = 0;
+        S.pair_mat[k][0] = S.fric[sa] * S.fric[sb]; S.pair_mat[k][1] = S.rest[sa] * S.rest[sb];
+    }
 
     // render model
     RenderModel &RM = e->RM;
@@ -2325,6 +2407,12 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     ALLOC(D.scratch, (size_t)S_TOTAL * N);
     ALLOC(D.timestep, (size_t)N);
     ALLOC(D.errflags, (size_t)N);
+    ALLOC(D.collide_work, (size_t)N * MAXPAIRS);
+    ALLOC(D.collide_count, 1);
+    {
+        hipDeviceProp_t prop;
+        e->narrow_blocks = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess ? prop.multiProcessorCount : 256) * 8;
+    }
     ALLOC(D.cmd, (size_t)N * 9);
     ALLOC(D.joints, (size_t)N * 9);
     ALLOC(D.touch, (size_t)N * 4);
@@ -2501,6 +2589,14 @@ static int do_render(rr_env *e, bool use_flags) {
     return RR_OK;
 }
 
+static void launch_collide(rr_env *e) {
+    const int N = e->P.N, nblk = (N + COLLIDE_THREADS - 1) / COLLIDE_THREADS;
+    hipMemsetAsync(e->D.collide_count, 0, 4, e->stream);
+    hipLaunchKernelGGL(k_collide_broad, dim3(nblk * e->P.npairs), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D, nblk);
+    if (getenv("RR_DEBUG_SYNC")) { hipError_t e__ = hipStreamSynchronize(e->stream); unsigned cnt = 0; hipMemcpy(&cnt, e->D.collide_count, 4, hipMemcpyDeviceToHost); fprintf(stderr, "[rr] broad done: %s, items %u, narrow blocks %d\n", hipGetErrorString(e__), cnt, e->narrow_blocks); }
+    if (!(e->P.ablate & 512)) hipLaunchKernelGGL(k_collide_narrow, dim3(e->narrow_blocks), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D);
+}
+
 int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t render_mode, const uint8_t *render_flags_host) {
     if (!e) return fail(RR_EINVAL, "null env");
     if (render_mode < 0 || render_mode > 2 || (render_mode == 2 && !render_flags_host)) return fail(RR_EINVAL, "rr_step: bad render_mode");
@@ -2511,7 +2607,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     if (render_mode == 2) HIPCHK(hipMemcpyAsync(e->D.render_flags, render_flags_host, N, hipMemcpyHostToDevice, e->stream));
     if (render_mode) fork_static_copy(e, render_mode == 2);
     TIMED(0, hipLaunchKernelGGL(k_prep, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, e->D));
-    TIMED(1, hipLaunchKernelGGL(k_collide, dim3(((N + COLLIDE_THREADS - 1) / COLLIDE_THREADS) * e->P.npairs), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D, (N + COLLIDE_THREADS - 1) / COLLIDE_THREADS));
+    TIMED(1, launch_collide(e));
     TIMED(2, hipLaunchKernelGGL(k_solve, dim3((N + SGRP - 1) / SGRP), dim3(SGRP * 16), 0, e->stream, e->B, e->P, e->D));
     HIPCHK(hipGetLastError());
     if (render_mode) return do_render(e, render_mode == 2);

@@ -1,0 +1,27 @@
+"""Solver phase cycle stamps on the bench workload (development; needs `make -C real_robots_amd/csrc stats`)."""
+import os, sys, ctypes
+sys.path.insert(0, '/root/repo')
+os.environ['RR_LIB'] = os.path.join(os.path.dirname(__file__), '..', 'real_robots_amd', 'csrc', 'librealrobot_hip_stats.so')
+import numpy as np, torch
+from real_robots_amd import _native as nat
+from real_robots_amd.batched import BatchedREALRobotEnv
+from real_robots_amd.distributed import synthetic_actions
+N = 4096
+env = BatchedREALRobotEnv(N, objects=3, width=128, height=128)
+lib = nat.load_library()
+ids = list(range(N))
+for t in range(160):
+    env.step(synthetic_actions(ids, (t // 20) * 20) * 0.5, render=False)
+out = (ctypes.c_ulonglong * 16)()
+torch.cuda.synchronize()
+lib.rr_debug_solver_prof(out, 1)
+K = 20
+for t in range(K):
+    env.step(synthetic_actions(ids, 160) * 0.5, render=False)
+torch.cuda.synchronize()
+lib.rr_debug_solver_prof(out, 0)
+v = np.array(list(out), dtype=np.float64) / (K * N / 4)
+names = ['stage Minv', 'gather: loop overhead/tail', 'motor+limit rows', 'limmask + register rows', 'PGS iterations', 'integrate', 'touch/forces', 'gather: pair counts', 'gather: pair meta (sum)', 'gather: pin loads (sum)', 'gather: contact loops (sum)']
+tot = v[:11].sum()
+for n, x in zip(names, v): print(f'{n:28s} {x:10.0f} ticks  {100 * x / tot:5.1f} %')
+print('total', tot, 'ticks (s_memtime: 100 MHz constant clock on gfx9)')
