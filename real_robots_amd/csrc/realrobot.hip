@@ -133,8 +133,6 @@ struct DevPtrs {
     const unsigned long long *static_vis;   // [H*W] visibility keys of the never-moving instances (or nullptr)
     unsigned long long *static_vis_out;
     unsigned char *static_rgb; float *static_depth; int *static_mask;   // [H*W] shaded static layer (shared by all envs)
-    unsigned *collide_work;  // [N*npairs] (env | pair << 24) items that passed the bounding-sphere test
-    unsigned *collide_count; // [1]
     uint2 *frag_list;       // [N*ntiles][TILE_PIX] pixels won by moving triangles: {depth bits, pixel-in-tile << 18 | triangle}
     unsigned *frag_count;   // [N*ntiles]
 };
@@ -443,38 +441,18 @@ __device__ __forceinline__ Xf load_xf(const ShapeData *S, int s, const float *st
     return X;
 }
 
-// ---- collision: broad phase (one thread per env x pair) + narrow phase (one wavefront per surviving env x pair) --------
+// ---- collision: one wavefront per env ------------------------------------------------------------------------------
 // The narrow phase of a pair is ~2 x 32 vertices against ~32 planes plus a manifold reduction: as a per-thread loop it is
-// a chain of ~20k dependent instructions and, with only three or four close pairs per env, the kernel is as slow as that
-// chain.  Here the broad phase only runs the bounding-sphere test and appends the surviving (env, pair) items to a work
-// list; the narrow phase gives every item a whole wavefront: lanes 0..31 test the vertices of shape a against the planes
-// of shape b (direction 0), lanes 32..63 the vertices of b against the planes of a (direction 1).  Candidate order
-// (direction 0 by vertex index, then direction 1) equals lane order, so "first best wins" selections of the oracle's
-// reduce4() become wave reductions with lowest-lane tie-breaks -- results are identical to the serial formulation.
+// a chain of ~20k dependent instructions and, with only three or four close pairs per env, a kernel built that way is
+// as slow as that chain.  Here a wavefront owns an env:
+//   1. lanes 0..ns-1 load the transform of "their" shape and its world bounding-sphere centre into LDS (one round trip);
+//   2. the pairs are sphere-tested 64 at a time, survivors are collected with ballots;
+//   3. every surviving pair is handled by the whole wave: lanes 0..31 test the vertices of shape a against the planes
+//      of shape b (direction 0), lanes 32..63 the vertices of b against the planes of a (direction 1).
+// Candidate order (direction 0 by vertex index, then direction 1) equals lane order, so the "first best wins"
+// selections of the oracle's reduce4() become wave reductions with lowest-lane tie-breaks -- results are identical
+// to the serial formulation.  No atomics, no work list: results do not depend on scheduling.
 #define COLLIDE_THREADS 64
-__global__ void __launch_bounds__(COLLIDE_THREADS) k_collide_broad(SimParams P, DevPtrs D, int nblk) {
-    const int N = P.N;
-    const int pair = blockIdx.x / nblk;
-    const int env = (blockIdx.x - pair * nblk) * COLLIDE_THREADS + threadIdx.x;
-    if (env >= N) return;
-    const float *state = D.state;
-    float *scratch = D.scratch;
-    if (D.errflags[env]) return;
-    if (P.ablate & 2048) return;
-    const ShapeData *S = D.shapes;
-    const int sa = S->pair_a[pair], sb = S->pair_b[pair];
-    if (P.ablate & 4096) { *(int *)&SCR(S_PCOUNT + pair) = sa + sb; return; }
-    const Xf Xa = load_xf(S, sa, state, scratch, N, env), Xb = load_xf(S, sb, state, scratch, N, env);
-    if (P.ablate & 8192) { *(int *)&SCR(S_PCOUNT + pair) = (int)(Xa.p.x + Xb.p.y + Xa.R.m[3] + Xb.R.m[8]); return; }
-    const v3 ca = mulv(Xa.R, mk(S->sphere[sa][0], S->sphere[sa][1], S->sphere[sa][2])) + Xa.p;
-    const v3 cb = mulv(Xb.R, mk(S->sphere[sb][0], S->sphere[sb][1], S->sphere[sb][2])) + Xb.p;
-    const v3 d = ca - cb;
-    const float rr = S->sphere[sa][3] + S->sphere[sb][3] + P.margin;
-    *(int *)&SCR(S_PCOUNT + pair) = 0;
-    if (dot(d, d) > rr * rr) return;
-    if (P.ablate & 256) return;
-    D.collide_work[atomicAdd(D.collide_count, 1u)] = (unsigned)env | ((unsigned)pair << 24);
-}
 
 // wave-wide "first lane holding the maximum of v among lanes with ok" (returns -1 when no lane is ok or none exceeds floor)
 __device__ __forceinline__ int wave_argmax_first(float v, bool ok, float floor_) {
@@ -487,95 +465,143 @@ __device__ __forceinline__ int wave_argmax_first(float v, bool ok, float floor_)
 }
 __device__ __forceinline__ float lane_f(float v, int src) { return __shfl(v, src); }
 
-__global__ void __launch_bounds__(COLLIDE_THREADS) k_collide_narrow(SimParams P, DevPtrs D) {
+__global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtrs D, int ns) {
     const int N = P.N;
+    const int env = blockIdx.x;
     const float *state = D.state;
     float *scratch = D.scratch;
+    if (D.errflags[env]) return;
     const ShapeData *S = D.shapes;
+    __shared__ float xf[MAXSHAPES][12];        // R (row-major 9), p (3) of every shape's owner
+    __shared__ float4 sph[MAXSHAPES];          // world bounding sphere
     __shared__ float4 planes[2][FMAXC];
     const int lane = threadIdx.x;
-    const unsigned nitems = *D.collide_count;
-    for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const unsigned w = D.collide_work[item];
-        const int env = (int)(w & 0xffffffu), pair = (int)(w >> 24);
-        const int sa = S->pair_a[pair], sb = S->pair_b[pair];
-        const Xf Xa = load_xf(S, sa, state, scratch, N, env), Xb = load_xf(S, sb, state, scratch, N, env);
-        const int dirflag = lane >> 5, v = lane & 31;
-        // "mine" = the shape whose vertex this lane tests, "other" = the shape whose planes it is tested against
-        const int sm = dirflag ? sb : sa, so = dirflag ? sa : sb;
-        __syncthreads();        // previous item's plane reads are done
-        if (lane < FMAXC) planes[0][lane] = make_float4(S->planes[sb][lane][0], S->planes[sb][lane][1], S->planes[sb][lane][2], S->planes[sb][lane][3]);
-        else planes[1][lane - FMAXC] = make_float4(S->planes[sa][lane - FMAXC][0], S->planes[sa][lane - FMAXC][1], S->planes[sa][lane - FMAXC][2], S->planes[sa][lane - FMAXC][3]);
-        __syncthreads();
-        Xf Xm, Xo;
+    if (lane < ns) {
+        const Xf X = load_xf(S, lane, state, scratch, N, env);
 #pragma unroll
-        for (int kk = 0; kk < 9; kk++) { Xm.R.m[kk] = dirflag ? Xb.R.m[kk] : Xa.R.m[kk]; Xo.R.m[kk] = dirflag ? Xa.R.m[kk] : Xb.R.m[kk]; }
-        Xm.p = mk(dirflag ? Xb.p.x : Xa.p.x, dirflag ? Xb.p.y : Xa.p.y, dirflag ? Xb.p.z : Xa.p.z);
-        Xo.p = mk(dirflag ? Xa.p.x : Xb.p.x, dirflag ? Xa.p.y : Xb.p.y, dirflag ? Xa.p.z : Xb.p.z);
-        const int nv = S->nv[sm], nf = S->nf[so];
-        bool hit = false;
-        float cx = 0, cy = 0, cz = 0, cs = 0;
-        int bf = 0;
-        if (v < nv) {
-            const v3 xw = mulv(Xm.R, mk(S->verts[sm][v][0], S->verts[sm][v][1], S->verts[sm][v][2])) + Xm.p;
-            const v3 xl = tmulv(Xo.R, xw - Xo.p);
-            float best = -1e30f;
-            for (int f = 0; f < nf; f++) {
-                const float4 pl = planes[dirflag][f];
-                const float sd = pl.x * xl.x + pl.y * xl.y + pl.z * xl.z - pl.w;
-                if (sd > best) { best = sd; bf = f; }
+        for (int k = 0; k < 9; k++) xf[lane][k] = X.R.m[k];
+        xf[lane][9] = X.p.x; xf[lane][10] = X.p.y; xf[lane][11] = X.p.z;
+        const v3 c = mulv(X.R, mk(S->sphere[lane][0], S->sphere[lane][1], S->sphere[lane][2])) + X.p;
+        sph[lane] = make_float4(c.x, c.y, c.z, S->sphere[lane][3]);
+    }
+    __syncthreads();
+    for (int p0 = 0; p0 < P.npairs; p0 += 64) {
+        const int pr = p0 + lane;
+        bool close = false;
+        if (pr < P.npairs) {
+            const float4 a = sph[S->pair_a[pr]], b = sph[S->pair_b[pr]];
+            const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, rr = a.w + b.w + P.margin;
+            close = !(dx * dx + dy * dy + dz * dz > rr * rr);
+            *(int *)&SCR(S_PCOUNT + pr) = 0;
+        }
+        const int dirflag = lane >> 5, v = lane & 31;
+        unsigned long long todo = __ballot(close);
+        // plane (lane & 31) of the "other" shape of this lane's direction; the planes of the next pair are fetched while
+        // the current one is processed
+        float4 nextpl = make_float4(0, 0, 0, 0);
+        if (todo) {
+            const int pn = p0 + __ffsll((long long)todo) - 1;
+            nextpl = *(const float4 *)S->planes[dirflag ? S->pair_a[pn] : S->pair_b[pn]][v];
+        }
+        for (; todo; todo &= todo - 1) {
+            const int pair = p0 + __ffsll((long long)todo) - 1;
+            const int sa = S->pair_a[pair], sb = S->pair_b[pair];
+            // "mine" = the shape whose vertex this lane tests, "other" = the shape whose planes it is tested against
+            const int sm = dirflag ? sb : sa, so = dirflag ? sa : sb;
+            __syncthreads();        // previous item's plane reads are done
+            planes[dirflag][v] = nextpl;
+            __syncthreads();
+            {
+                const unsigned long long rest = todo & (todo - 1);
+                if (rest) {
+                    const int pn = p0 + __ffsll((long long)rest) - 1;
+                    nextpl = *(const float4 *)S->planes[dirflag ? S->pair_a[pn] : S->pair_b[pn]][v];
+                }
             }
-            if (best < P.margin) {
+            Xf Xm, Xo;
+#pragma unroll
+            for (int kk = 0; kk < 9; kk++) { Xm.R.m[kk] = xf[sm][kk]; Xo.R.m[kk] = xf[so][kk]; }
+            Xm.p = mk(xf[sm][9], xf[sm][10], xf[sm][11]);
+            Xo.p = mk(xf[so][9], xf[so][10], xf[so][11]);
+            const int nv = S->nv[sm], nf = S->nf[so];
+            {   // exact cull: when the bounding sphere of "mine" lies beyond one plane of "other" by more than the margin, no
+                // vertex of "mine" can be a candidate; with that true for both directions the pair has no contact
+                const float4 cm = sph[sm];
+                const v3 cl = tmulv(Xo.R, mk(cm.x, cm.y, cm.z) - Xo.p);
+                bool sep = false;
+                if (v < nf) {
+                    const float4 pl = planes[dirflag][v];
+                    sep = pl.x * cl.x + pl.y * cl.y + pl.z * cl.z - pl.w > cm.w + P.margin;
+                }
+                const unsigned long long sb_ = __ballot(sep);
+                if ((sb_ & 0xffffffffull) && (sb_ >> 32)) continue;        // S_PCOUNT is already 0
+            }
+            bool hit = false;
+            float cx = 0, cy = 0, cz = 0, cs = 0;
+            int bf = 0;
+            if (v < nv) {
+                const v3 xw = mulv(Xm.R, mk(S->verts[sm][v][0], S->verts[sm][v][1], S->verts[sm][v][2])) + Xm.p;
+                const v3 xl = tmulv(Xo.R, xw - Xo.p);
+                float best = -1e30f;
+                // all FMAXC slots: padded planes are (0, 0, 0, 1e9), i.e. sd = -1e9, and never win against a real plane
+#pragma unroll 8
+                for (int f = 0; f < FMAXC; f++) {
+                    const float4 pl = planes[dirflag][f];
+                    const float sd = pl.x * xl.x + pl.y * xl.y + pl.z * xl.z - pl.w;
+                    if (sd > best) { best = sd; bf = f; }
+                }
+                if (best < P.margin) {
+                    const float4 pl = planes[dirflag][bf];
+                    const v3 nw = mulv(Xo.R, mk(pl.x, pl.y, pl.z));
+                    cx = xw.x - 0.5f * best * nw.x; cy = xw.y - 0.5f * best * nw.y; cz = xw.z - 0.5f * best * nw.z;
+                    cs = best;
+                    hit = true;
+                }
+            }
+            const unsigned long long hmask = __ballot(hit);
+            const int n = __popcll(hmask);
+            // manifold reduction, same rule as the oracle's reduce4(): deepest first, then maximal spread, preferring the
+            // candidates within TIER_TOL (1 mm) of the deepest penetration at every pick; ties go to the first candidate
+            int sel0 = -1, sel1 = -1, sel2 = -1, sel3 = -1, k = 0;
+            if (n <= 4) {
+                unsigned long long r = hmask;
+                if (r) { sel0 = __ffsll((long long)r) - 1; r &= r - 1; k = 1; }
+                if (r) { sel1 = __ffsll((long long)r) - 1; r &= r - 1; k = 2; }
+                if (r) { sel2 = __ffsll((long long)r) - 1; r &= r - 1; k = 3; }
+                if (r) { sel3 = __ffsll((long long)r) - 1; k = 4; }
+            } else {
+                sel0 = wave_argmax_first(-cs, hit, -3.0e38f);         // smallest s, first one
+                const float sbest = lane_f(cs, sel0);
+                const float lim = sbest + 0.001f;
+                const v3 x0 = mk(lane_f(cx, sel0), lane_f(cy, sel0), lane_f(cz, sel0));
+                const v3 dd = mk(cx, cy, cz) - x0;
+                const float v1 = dot(dd, dd);
+                const bool t0 = cs < lim;
+                sel1 = wave_argmax_first(v1, hit && lane != sel0 && t0, -1.0f);
+                if (sel1 < 0) sel1 = wave_argmax_first(v1, hit && lane != sel0, -1.0f);
+                const v3 e = mk(lane_f(cx, sel1), lane_f(cy, sel1), lane_f(cz, sel1)) - x0;
+                const v3 cr = cross(dd, e);
+                const float v2 = dot(cr, cr);
+                sel2 = wave_argmax_first(v2, hit && lane != sel0 && lane != sel1 && t0, -1.0f);
+                if (sel2 < 0) sel2 = wave_argmax_first(v2, hit && lane != sel0 && lane != sel1, -1.0f);
+                const v3 cr2 = mk(lane_f(cr.x, sel2), lane_f(cr.y, sel2), lane_f(cr.z, sel2));
+                const float v3_ = -dot(cr, cr2);
+                const bool o3 = hit && lane != sel0 && lane != sel1 && lane != sel2;
+                sel3 = wave_argmax_first(v3_, o3 && t0, 0.0f);
+                if (sel3 < 0) sel3 = wave_argmax_first(v3_, o3, 0.0f);
+                k = sel3 >= 0 ? 4 : 3;
+            }
+            if (lane == 0) *(int *)&SCR(S_PCOUNT + pair) = k;
+            const int slot = lane == sel0 ? 0 : (lane == sel1 ? 1 : (lane == sel2 ? 2 : (lane == sel3 ? 3 : -1)));
+            if (hit && slot >= 0) {
                 const float4 pl = planes[dirflag][bf];
-                const v3 nw = mulv(Xo.R, mk(pl.x, pl.y, pl.z));
-                cx = xw.x - 0.5f * best * nw.x; cy = xw.y - 0.5f * best * nw.y; cz = xw.z - 0.5f * best * nw.z;
-                cs = best;
-                hit = true;
+                v3 nw = mulv(Xo.R, mk(pl.x, pl.y, pl.z));
+                if (dirflag) nw = nw * -1.0f;
+                const int base = S_PDATA + (pair * 4 + slot) * 7;
+                SCR(base) = cx; SCR(base + 1) = cy; SCR(base + 2) = cz;
+                SCR(base + 3) = nw.x; SCR(base + 4) = nw.y; SCR(base + 5) = nw.z;
+                SCR(base + 6) = cs;
             }
-        }
-        const unsigned long long hmask = __ballot(hit);
-        const int n = __popcll(hmask);
-        // manifold reduction, same rule as the oracle's reduce4(): deepest first, then maximal spread, preferring the
-        // candidates within TIER_TOL (1 mm) of the deepest penetration at every pick; ties go to the first candidate
-        int sel0 = -1, sel1 = -1, sel2 = -1, sel3 = -1, k = 0;
-        if (n <= 4) {
-            unsigned long long r = hmask;
-            if (r) { sel0 = __ffsll((long long)r) - 1; r &= r - 1; k = 1; }
-            if (r) { sel1 = __ffsll((long long)r) - 1; r &= r - 1; k = 2; }
-            if (r) { sel2 = __ffsll((long long)r) - 1; r &= r - 1; k = 3; }
-            if (r) { sel3 = __ffsll((long long)r) - 1; k = 4; }
-        } else {
-            sel0 = wave_argmax_first(-cs, hit, -3.0e38f);         // smallest s, first one
-            const float sbest = lane_f(cs, sel0);
-            const float lim = sbest + 0.001f;
-            const v3 x0 = mk(lane_f(cx, sel0), lane_f(cy, sel0), lane_f(cz, sel0));
-            const v3 dd = mk(cx, cy, cz) - x0;
-            const float v1 = dot(dd, dd);
-            const bool t0 = cs < lim;
-            sel1 = wave_argmax_first(v1, hit && lane != sel0 && t0, -1.0f);
-            if (sel1 < 0) sel1 = wave_argmax_first(v1, hit && lane != sel0, -1.0f);
-            const v3 e = mk(lane_f(cx, sel1), lane_f(cy, sel1), lane_f(cz, sel1)) - x0;
-            const v3 cr = cross(dd, e);
-            const float v2 = dot(cr, cr);
-            sel2 = wave_argmax_first(v2, hit && lane != sel0 && lane != sel1 && t0, -1.0f);
-            if (sel2 < 0) sel2 = wave_argmax_first(v2, hit && lane != sel0 && lane != sel1, -1.0f);
-            const v3 cr2 = mk(lane_f(cr.x, sel2), lane_f(cr.y, sel2), lane_f(cr.z, sel2));
-            const float v3_ = -dot(cr, cr2);
-            const bool o3 = hit && lane != sel0 && lane != sel1 && lane != sel2;
-            sel3 = wave_argmax_first(v3_, o3 && t0, 0.0f);
-            if (sel3 < 0) sel3 = wave_argmax_first(v3_, o3, 0.0f);
-            k = sel3 >= 0 ? 4 : 3;
-        }
-        if (lane == 0) *(int *)&SCR(S_PCOUNT + pair) = k;
-        const int slot = lane == sel0 ? 0 : (lane == sel1 ? 1 : (lane == sel2 ? 2 : (lane == sel3 ? 3 : -1)));
-        if (hit && slot >= 0) {
-            const float4 pl = planes[dirflag][bf];
-            v3 nw = mulv(Xo.R, mk(pl.x, pl.y, pl.z));
-            if (dirflag) nw = nw * -1.0f;
-            const int base = S_PDATA + (pair * 4 + slot) * 7;
-            SCR(base) = cx; SCR(base + 1) = cy; SCR(base + 2) = cz;
-            SCR(base + 3) = nw.x; SCR(base + 4) = nw.y; SCR(base + 5) = nw.z;
-            SCR(base + 6) = cs;
         }
     }
 }
@@ -2175,7 +2201,7 @@ struct rr_env {
     hipStream_t aux;         // side stream: the HBM-bound static-layer copy runs beside the VALU-bound physics / visibility kernels
     hipEvent_t ev_fork, ev_join;
     bool copy_in_flight;
-    int narrow_blocks;       // persistent wavefronts of the narrow phase
+    int n_shapes;
     float t_ms[RR_NUM_KERNELS];
     int t_n[RR_NUM_KERNELS];
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -2365,6 +2391,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     for (int r = 0; r < n_robot; r++) for (int s = 0; s < 2; s++) { S.pair_a[np] = n_static + r; S.pair_b[np++] = s; }
     for (int r = 0; r < n_robot; r++) for (int i = 0; i < P.nobj; i++) { S.pair_a[np] = n_static + r; S.pair_b[np++] = s_obj0 + i; }
     P.npairs = np;
+    e->n_shapes = ns;
     for (int k = 0; k < np; k++) {
         const int sa = S.pair_a[k], sb = S.pair_b[k];
         S.pair_meta[k][0] = S.otype[sa] == 0 ? -1 : (S.otype[sa] == 1 ? S.oidx[sa] : 16 + S.oidx[sa]);
@@ -2407,12 +2434,6 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     ALLOC(D.scratch, (size_t)S_TOTAL * N);
     ALLOC(D.timestep, (size_t)N);
     ALLOC(D.errflags, (size_t)N);
-    ALLOC(D.collide_work, (size_t)N * MAXPAIRS);
-    ALLOC(D.collide_count, 1);
-    {
-        hipDeviceProp_t prop;
-        e->narrow_blocks = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess ? prop.multiProcessorCount : 256) * 8;
-    }
     ALLOC(D.cmd, (size_t)N * 9);
     ALLOC(D.joints, (size_t)N * 9);
     ALLOC(D.touch, (size_t)N * 4);
@@ -2590,11 +2611,7 @@ static int do_render(rr_env *e, bool use_flags) {
 }
 
 static void launch_collide(rr_env *e) {
-    const int N = e->P.N, nblk = (N + COLLIDE_THREADS - 1) / COLLIDE_THREADS;
-    hipMemsetAsync(e->D.collide_count, 0, 4, e->stream);
-    hipLaunchKernelGGL(k_collide_broad, dim3(nblk * e->P.npairs), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D, nblk);
-    if (getenv("RR_DEBUG_SYNC")) { hipError_t e__ = hipStreamSynchronize(e->stream); unsigned cnt = 0; hipMemcpy(&cnt, e->D.collide_count, 4, hipMemcpyDeviceToHost); fprintf(stderr, "[rr] broad done: %s, items %u, narrow blocks %d\n", hipGetErrorString(e__), cnt, e->narrow_blocks); }
-    if (!(e->P.ablate & 512)) hipLaunchKernelGGL(k_collide_narrow, dim3(e->narrow_blocks), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D);
+    hipLaunchKernelGGL(k_collide, dim3(e->P.N), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D, e->n_shapes);
 }
 
 int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t render_mode, const uint8_t *render_flags_host) {
