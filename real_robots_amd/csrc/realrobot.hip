@@ -1879,12 +1879,9 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     const int npix = rows * W;
     const int tid = threadIdx.x;
     const bool layered = (pass == 0) && (D.static_vis != nullptr);
-    if (layered) {
-        const unsigned long long *sv = D.static_vis + (size_t)row0 * W;
-        for (int i = tid; i < npix; i += RASTER_THREADS) vis[i] = sv[i];
-    } else {
-        for (int i = tid; i < npix; i += RASTER_THREADS) vis[i] = ~0ull;
-    }
+    // The tile starts empty (an LDS-only fill); the static layer's keys are compared at compaction time and only for the
+    // few pixels a moving triangle reached (min is associative) -- no 128 KB read of the static keys per env.
+    for (int i = tid; i < npix; i += RASTER_THREADS) vis[i] = ~0ull;
     if (tid == 0) { nlist = 0; wcount = 0; wnext = 0; }
     stage_instances(RM, D, env, tid, RASTER_THREADS, mvp, nullptr);
     __syncthreads();
@@ -2060,12 +2057,12 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         for (int i = tid; i < npix; i += RASTER_THREADS) sv[i] = vis[i];
     }
     // ---- compaction: pixels owned by a triangle rasterised in this pass go to the fragment list of this (env, tile)
-    const unsigned first_dyn = layered ? (unsigned)RM.first_dynamic_tri : 0u;
     uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
+    const unsigned long long *sv = layered ? D.static_vis + (size_t)row0 * W : nullptr;
     for (int i = tid; i < npix; i += RASTER_THREADS) {
         const unsigned long long key = vis[i];
         const unsigned tri = (unsigned)(key & 0xffffffffu);
-        if (key != ~0ull && tri >= first_dyn) {
+        if (key != ~0ull && (!sv || key < sv[i])) {
             const unsigned slot = atomicAdd(&nlist, 1u);
             lst[slot] = make_uint2((unsigned)(key >> 32), ((unsigned)i << 18) | tri);
         }
