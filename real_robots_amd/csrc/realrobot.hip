@@ -1856,8 +1856,12 @@ extern "C" int rr_debug_raster_stats(unsigned long long *out16, int reset) {
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rstats), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
+// phase ablations of k_raster for the time breakdown in DESIGN.md (RR_ABLATE bits: 1 no rasterisation after projection,
+// 2 no wave-cooperative path, 8 no triangles at all); compiled out of the shipped library
+#define ABL(bit) (P.ablate & (bit))
 #else
 #define RSTAT(i, v)
+#define ABL(bit) false
 #endif
 
 // Visibility pass of one (env, tile).  pass 0 = per-env frame: starts from the static layer's keys when D.static_vis !=
@@ -1893,7 +1897,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     // Window queue: one thread per 64-triangle cluster ("window"; never spans two instances) runs the frustum test of the
     // cluster's bounding sphere and appends survivors to an LDS list; the waves then pull windows from that list with an
     // LDS counter, so culled windows cost nothing in the wave loops and waves that drew cheap windows take more of them.
-    const int t_stop = (P.ablate & 8) ? 0 : t_end;
+    const int t_stop = ABL(8) ? 0 : t_end;
     const int lane = tid & 63, lx = lane & 7, ly = lane >> 3;
     const int nwin = (t_stop - t_begin + 63) >> 6;
     for (int wi = tid; wi < nwin; wi += RASTER_THREADS) {
@@ -1955,7 +1959,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
                 area = (x1 - x0 + 1) * (y1 - y0 + 1);
             }
         }
-        if (P.ablate & 1) continue;
+        if (ABL(1)) continue;
         const bool big = live && area > P.small_area;
 #ifdef RR_RASTER_STATS
         {
@@ -1972,31 +1976,12 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
 #endif
         if (live && !big) {   // small: the owning lane walks its <= small_area sample points
             int px = x0, py = y0;
-            if (P.ablate & 0xe0) {      // EXPERIMENT (timing only)
-                for (int i = 0; i < area; i++) {
-#pragma clang fp contract(off)
-                    const float fx = (float)px, fy = (float)py;
-                    const float b0 = ((s.sx[1] - fx) * (s.sy[2] - fy) - (s.sx[2] - fx) * (s.sy[1] - fy)) * ia;
-                    const float b1 = ((s.sx[2] - fx) * (s.sy[0] - fy) - (s.sx[0] - fx) * (s.sy[2] - fy)) * ia;
-                    const float b2 = 1.0f - b0 - b1;
-                    const float z = b0 * s.sz[0] + b1 * s.sz[1] + b2 * s.sz[2];
-                    const float d = 0.5f * z + 0.5f;
-                    if ((b0 >= 0 && b1 >= 0 && b2 >= 0) && (d >= 0.0f && d <= 1.0f)) {
-                        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
-                        const int r_ = H - 1 - py - row0;
-                        if (P.ablate & 32) { if (key == 12345ull) vis[0] = key; }
-                        else if (P.ablate & 64) { if (key < vis[r_ * W + px]) vis[r_ * W + px] = key; }
-                        else atomicMin(&vis[r_ * W + ((px + 2 * r_) & (W - 1))], key);
-                    }
-                    if (++px > x1) { px = x0; py++; }
-                }
-            } else
             for (int i = 0; i < area; i++) {
                 raster_pixel_hoisted(s, ia, t, px, py, H, W, row0, vis);
                 if (++px > x1) { px = x0; py++; }
             }
         }
-        unsigned long long todo = (P.ablate & 2) ? 0ull : __ballot(big);
+        unsigned long long todo = ABL(2) ? 0ull : __ballot(big);
         while (todo) {        // wave-cooperative: all 64 lanes rasterise the triangle of lane `src`
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
@@ -2013,7 +1998,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
             const int bx0 = __builtin_amdgcn_readlane(x0, src), by0 = __builtin_amdgcn_readlane(y0, src);
             const int bw = __builtin_amdgcn_readlane(x1, src) - bx0 + 1, bh = __builtin_amdgcn_readlane(y1, src) - by0 + 1;
             const int nbx = (bw + 7) >> 3, nby = (bh + 7) >> 3, nblk = nbx * nby;
-            if (nblk <= 4 || (P.ablate & 16)) {
+            if (nblk <= 4) {
                 for (int by = 0; by < bh; by += 8)
                     for (int bx = 0; bx < bw; bx += 8) {
                         const int ox = bx + lx, oy = by + ly;
