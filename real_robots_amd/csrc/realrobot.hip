@@ -2559,8 +2559,10 @@ static int g_skip = getenv("RR_SKIP") ? atoi(getenv("RR_SKIP")) : 0;
     } while (0)
 
 // The static-layer copy only depends on work already enqueued on the main stream (the previous frame's consumers and the
-// render flags), not on this step's physics: it is forked to the side stream at the start of the step and joined before
-// k_shade.  In timing mode every kernel runs alone on the main stream.
+// render flags): it is forked to the side stream next to k_raster -- the copy is HBM-write bound, the visibility pass is
+// VALU bound with one 16-wave workgroup per CU, so the two share the CUs well (beside the latency-bound physics kernels
+// the copy only slowed those down) -- and joined before k_shade.  In timing mode every kernel runs alone on the main
+// stream.
 static void fork_static_copy(rr_env *e, bool use_flags) {
     e->copy_in_flight = false;
     if (!e->aux || e->timing || ((g_skip >> 5) & 1)) return;
@@ -2578,6 +2580,7 @@ static int do_render(rr_env *e, bool use_flags) {
     DevPtrs D = e->D;
     if (!use_flags) D.render_flags = nullptr;
     TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((e->P.N + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, D));
+    fork_static_copy(e, use_flags);
     TIMED(4, hipLaunchKernelGGL(k_raster, dim3(e->P.N, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, D, e->n_inst_used, 0));
     const ImageOut io = env_images(e);
     if (e->copy_in_flight) {
@@ -2604,7 +2607,6 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     if (!joint_cmd) HIPCHK(hipMemsetAsync(e->D.cmd, 0, (size_t)N * 36, e->stream));      // env.py:333-334
     else if (joint_cmd != e->D.cmd) HIPCHK(hipMemcpyAsync(e->D.cmd, joint_cmd, (size_t)N * 36, cmd_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
     if (render_mode == 2) HIPCHK(hipMemcpyAsync(e->D.render_flags, render_flags_host, N, hipMemcpyHostToDevice, e->stream));
-    if (render_mode) fork_static_copy(e, render_mode == 2);
     TIMED(0, hipLaunchKernelGGL(k_prep, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, e->D));
     TIMED(1, launch_collide(e));
     TIMED(2, hipLaunchKernelGGL(k_solve, dim3((N + SGRP - 1) / SGRP), dim3(SGRP * 16), 0, e->stream, e->B, e->P, e->D));
@@ -2616,7 +2618,6 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
 int rr_render(rr_env *e) {
     if (!e) return fail(RR_EINVAL, "null env");
     HIPCHK(hipSetDevice(e->cfg.device));
-    fork_static_copy(e, false);
     return do_render(e, false);
 }
 
