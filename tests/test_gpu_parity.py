@@ -292,3 +292,44 @@ def test_device_side_nonfinite_command_is_flagged_and_skipped():
     j = torch.as_tensor(env.device_buffer(nat.F_JOINTS), device='cuda')
     assert j.shape == (N, 9) and torch.isfinite(j).all()
     env.close()
+
+
+def test_piled_objects_overflow_rows_match_oracle():
+    """Three objects dropped into each other next to the gripper: object-object pairs (more than the 8 LDS slots of the
+    solver's B-side parts), object-table contacts and robot-object contacts at once -- exercises the generic and the
+    overflow (global-memory) row paths. fp32 oracle, short horizon (stacking is chaotic): joints < 2e-3 rad, object
+    positions < 5e-3 m; the contact lists must agree exactly in size and bodies at the first step."""
+    N = 3
+    env = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    o = Oracle(3, 64, 64, f32=True)
+    poses = [np.array([-0.10, 0.00, 0.33, 0, 0, 0, 1], np.float32),
+             np.array([-0.08, 0.02, 0.36, 0, 0, 0, 1], np.float32),
+             np.array([-0.12, -0.01, 0.40, 0.7071068, 0, 0, 0.7071068], np.float32)]
+    for k, p in enumerate(poses):
+        o.set_object_pose(k, p.astype(np.float64))
+        for i in range(N):
+            env.set_object_pose(i, k, p)
+    from real_robots_amd.kinematics import inverse_kinematics, quat_from_euler
+    q = inverse_kinematics(np.zeros(11), [-0.1, 0.0, 0.50], quat_from_euler(0, 3.14, -1.57))
+    cmd = np.concatenate([q[:7], [0.3, 0.0]]).astype(np.float32)
+    max_objobj = max_nc = 0
+    for t in range(60):
+        env.step(np.tile(cmd, (N, 1)))
+        o.step(cmd.astype(np.float64))
+        c = env.contacts(0)
+        oc = o.contacts()
+        if t == 0:
+            assert len(c) == len(oc)
+            assert (c[:, :3] == oc[:, :3]).all()
+        if len(c):
+            max_nc = max(max_nc, len(c))
+            max_objobj = max(max_objobj, int(((c[:, 0] >= 16) & (c[:, 1] >= 16)).sum()))
+        if t in (0, 9, 29):
+            st = env.state[0]
+            assert np.abs(st[:11] - o.state[:11]).max() < 2e-3, t
+            assert np.abs(_objs(st)[:, :3] - _objs(o.state)[:, :3]).max() < 5e-3, t
+    assert max_objobj > 8 and max_nc > 16, (max_objobj, max_nc)      # the overflow slots were really used
+    st = env.state
+    assert np.abs(st - st[0]).max() == 0.0
+    assert (env.host(nat.F_ERRFLAGS) == 0).all()
+    env.close()
