@@ -128,6 +128,8 @@ struct DevPtrs {
     const float4 *tri_rec;  // AoS [NT][8]: one 128-byte shading record per triangle {pos[9], nrm[9], uv[6], inst, pad}
     const int *tri_inst;    // [NT]
     const float4 *cluster_sphere; // [NT/64] bounding sphere (instance frame) of each 64-triangle raster cluster
+    const float *cluster_verts;   // [NT/64][3][64] the cluster's distinct vertex positions (x row, y row, z row)
+    const int *tri_vidx;          // [NT] cluster-local vertex indices of the triangle's corners, v0 | v1 << 8 | v2 << 16
     const unsigned *tex;    // RGBX texels
     const ShapeData *shapes;
     const unsigned long long *static_vis;   // [H*W] visibility keys of the never-moving instances (or nullptr)
@@ -1691,6 +1693,22 @@ __device__ __forceinline__ bool project_tri(const float *mvp, const float *tp /*
     return true;
 }
 
+// One vertex of project_tri (identical arithmetic); a vertex nearer than the near plane yields sx = NaN.
+__device__ __forceinline__ void project_vertex(const float *mvp, float vx, float vy, float vz, int W, int H, float &sx, float &sy, float &sz) {
+#pragma clang fp contract(off)
+    const float cx = mvp[0] * vx + mvp[1] * vy + mvp[2] * vz + mvp[3];
+    const float cy = mvp[4] * vx + mvp[5] * vy + mvp[6] * vz + mvp[7];
+    const float cz = mvp[8] * vx + mvp[9] * vy + mvp[10] * vz + mvp[11];
+    const float cw = mvp[12] * vx + mvp[13] * vy + mvp[14] * vz + mvp[15];
+    const float iw = 1.0f / cw;
+    sx = (cw < 0.1f) ? __int_as_float(0x7fc00000) : (cx * iw + 1.0f) * (0.5f * (float)W);
+    sy = (cy * iw + 1.0f) * (0.5f * (float)H);
+    sz = cz * iw;
+}
+__device__ __forceinline__ float lane_gather(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+
 __device__ __forceinline__ bool bary(const STri &s, float px, float py, float *b) {
 #pragma clang fp contract(off)
     float x0 = s.sx[0], y0 = s.sy[0], x1 = s.sx[1], y1 = s.sy[1], x2 = s.sx[2], y2 = s.sy[2];
@@ -1932,14 +1950,21 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         STri s;
         int x0 = 0, y0 = 0, x1 = -1, y1 = -1, area = 0;
         float ia = 0.0f;
-        if (live) {
-            float tp[9];
+        {
+            // The window is one cluster: lane l projects the cluster's vertex l (<= 64 distinct positions for its 64
+            // triangles, so a vertex is transformed once instead of once per incident corner); every triangle lane then
+            // gathers its three corners from the owning lanes (ds_bpermute).  Same arithmetic as project_tri.
+            const float *cv = D.cluster_verts + (size_t)(tb >> 6) * 192;
+            float psx, psy, psz;
+            project_vertex(mvp[inst], cv[lane], cv[64 + lane], cv[128 + lane], W, H, psx, psy, psz);
+            const int vi = D.tri_vidx[t];
 #pragma unroll
-            for (int k = 0; k < 9; k++) tp[k] = D.tri_pos[(size_t)k * NT + t];
-            // all nine loads are issued back to back and waited for once (otherwise the compiler sinks the loads of
-            // vertices 1 and 2 below project_tri's near-plane early-outs: three dependent round trips per window)
-            asm volatile("" : "+v"(tp[0]), "+v"(tp[1]), "+v"(tp[2]), "+v"(tp[3]), "+v"(tp[4]), "+v"(tp[5]), "+v"(tp[6]), "+v"(tp[7]), "+v"(tp[8]));
-            live = project_tri(mvp[inst], tp, W, H, s);
+            for (int k = 0; k < 3; k++) {
+                const int src = (vi >> (8 * k)) & 63;
+                s.sx[k] = lane_gather(psx, src); s.sy[k] = lane_gather(psy, src); s.sz[k] = lane_gather(psz, src);
+                s.w[k] = 1.0f;
+            }
+            live = live && !(s.sx[0] != s.sx[0] || s.sx[1] != s.sx[1] || s.sx[2] != s.sx[2]);
         }
         if (live) {
             float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
@@ -2460,6 +2485,19 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
             const float *cs;
             if (nt % 64 != 0 || nt / 64 > MAXWIN || nt >= (1 << 18)) { rr_destroy(e); return fail(RR_EMODEL, "rr_create: triangle count must be a multiple of the cluster size 64 and below 65536"); }
             NEED(cs = b.f32("cluster_sphere", (size_t)(nt / 64) * 4));
+            {
+                const float *cvb; const int32_t *tv;
+                NEED(cvb = b.f32("cluster_verts", (size_t)nt * 3)); NEED(tv = b.i32("tri_vidx", nt));
+                std::vector<float> cvs((size_t)nt * 3);          // [cluster][64][3] -> [cluster][3][64]
+                for (int c = 0; c < nt / 64; c++)
+                    for (int v = 0; v < 64; v++)
+                        for (int k = 0; k < 3; k++) cvs[((size_t)c * 3 + k) * 64 + v] = cvb[((size_t)c * 64 + v) * 3 + k];
+                float *dcv; int *dtv;
+                ALLOC(dcv, (size_t)nt * 3); ALLOC(dtv, (size_t)nt);
+                hipMemcpy(dcv, cvs.data(), (size_t)nt * 12, hipMemcpyHostToDevice);
+                hipMemcpy(dtv, tv, (size_t)nt * 4, hipMemcpyHostToDevice);
+                D.cluster_verts = dcv; D.tri_vidx = dtv;
+            }
             float4 *dcs;
             ALLOC(dcs, (size_t)nt / 64);
             hipMemcpy(dcs, cs, (size_t)(nt / 64) * 16, hipMemcpyHostToDevice);

@@ -321,6 +321,88 @@ class Blob:
         return off
 
 
+def build_meshlets(P32, max_t=CLUSTER, max_v=CLUSTER):
+    """Greedy meshlets over the float32 corner positions P32[T,3,3]: groups of <= max_t triangles that reference <=
+    max_v distinct vertex positions (welded by exact float32 equality), grown from a seed over shared vertices, adding
+    the triangle that brings the fewest new vertices (ties: closest to the running centroid).  Under-filled meshlets are
+    merged with their nearest neighbour when the limits allow.  Returns a list of triangle-index lists."""
+    T = len(P32)
+    keys = {}
+    idx = np.zeros((T, 3), np.int64)
+    for t in range(T):
+        for k in range(3):
+            idx[t, k] = keys.setdefault(P32[t, k].tobytes(), len(keys))
+    cent = P32.astype(np.float64).mean(1)
+    v2t = {}
+    for t in range(T):
+        for v in idx[t]:
+            v2t.setdefault(int(v), []).append(t)
+    used = np.zeros(T, bool)
+    order = np.lexsort((cent[:, 0], cent[:, 1], cent[:, 2]))       # deterministic seed sweep (z, then y, then x)
+    out, ptr = [], 0
+    while True:
+        while ptr < T and used[order[ptr]]:
+            ptr += 1
+        if ptr >= T:
+            break
+        seed = int(order[ptr])
+        cur = [seed]
+        used[seed] = True
+        verts = set(int(v) for v in idx[seed])
+        frontier = set()
+
+        def push(t):
+            for v in idx[t]:
+                for u in v2t[int(v)]:
+                    if not used[u]:
+                        frontier.add(u)
+        push(seed)
+        c0 = cent[seed].copy()
+        while len(cur) < max_t and frontier:
+            best, bestscore = None, None
+            for u in sorted(frontier):
+                newv = sum(1 for v in idx[u] if int(v) not in verts)
+                if len(verts) + newv > max_v:
+                    continue
+                sc = (newv, float(np.sum((cent[u] - c0) ** 2)), u)
+                if bestscore is None or sc < bestscore:
+                    best, bestscore = u, sc
+            if best is None:
+                break
+            frontier.discard(best)
+            cur.append(best)
+            used[best] = True
+            verts.update(int(v) for v in idx[best])
+            push(best)
+            c0 = cent[cur].mean(0)
+        out.append(cur)
+    changed = True
+    while changed:                                             # merge under-filled meshlets
+        changed = False
+        out.sort(key=lambda m: (len(m), m[0]))
+        for i in range(len(out)):
+            if len(out[i]) >= max_t // 2:
+                continue
+            ci = cent[out[i]].mean(0)
+            vi = set(idx[out[i]].ravel().tolist())
+            best, bd = None, None
+            for j in range(len(out)):
+                if j == i or len(out[i]) + len(out[j]) > max_t:
+                    continue
+                if len(vi | set(idx[out[j]].ravel().tolist())) > max_v:
+                    continue
+                d = (float(np.sum((cent[out[j]].mean(0) - ci) ** 2)), j)
+                if bd is None or d < bd:
+                    best, bd = j, d
+            if best is not None:
+                out[best] = out[best] + out[i]
+                del out[i]
+                changed = True
+                break
+    out.sort(key=lambda m: min(m))
+    return out
+
+
 def main(out_path):
     meshes = os.path.join(REF, 'meshes')
     urdf = os.path.join(REF, 'urdf')
@@ -543,6 +625,7 @@ def main(out_path):
 
     inst = []
     tri_pos, tri_nrm, tri_uv = [], [], []
+    cl_verts, tri_vidx = [], []
 
     def add_instance(name, owner_type, owner_idx, uid, L, R, p):
         tp, tn, tu, _ = get_mesh(L.mesh)
@@ -555,17 +638,42 @@ def main(out_path):
         tid = get_tex(texpath)
         # colour: textured meshes show the texel unmodified; untextured use the MTL Kd (skin: 0.8)
         col = (1.0, 1.0, 1.0) if tid >= 0 else kd
-        # pad every instance to a multiple of CLUSTER triangles with degenerate (zero-area) triangles so that a
-        # 64-triangle window of the rasteriser never spans two instances (wave-uniform cluster culling)
-        pad = (-len(P)) % CLUSTER
-        if pad:
-            P = np.concatenate([P, np.repeat(P[:1, :1, :], 3, axis=1).repeat(pad, axis=0)])
-            Nn = np.concatenate([Nn, np.repeat(Nn[:1], pad, axis=0)])
-            tu = np.concatenate([tu, np.repeat(tu[:1], pad, axis=0)])
+        # Raster clusters ("meshlets"): the triangles of the instance are regrouped into clusters of <= CLUSTER
+        # triangles over <= CLUSTER distinct vertices; every cluster is padded to exactly CLUSTER triangles with
+        # degenerate (zero-area) ones, so a 64-triangle window of the rasteriser is one cluster of one instance: the
+        # wave culls it with one sphere test and projects each of its vertices once (one lane per vertex).
+        P32 = P.astype(np.float32)
+        groups = build_meshlets(P32)
+        Pn, Nnn, tun, cverts, vidx = [], [], [], [], []
+        for g in groups:
+            keys, loc = {}, np.zeros((CLUSTER, 3), np.int32)
+            cv = np.zeros((CLUSTER, 3), np.float32)
+            for r, t in enumerate(g):
+                for k in range(3):
+                    key = P32[t, k].tobytes()
+                    if key not in keys:
+                        keys[key] = len(keys)
+                        cv[keys[key]] = P32[t, k]
+                    loc[r, k] = keys[key]
+            assert len(keys) <= CLUSTER and len(g) <= CLUSTER
+            cv[len(keys):] = cv[0]
+            padn = CLUSTER - len(g)
+            Pg = np.concatenate([P[g], np.repeat(P[g[0]][None, :1, :], 3, axis=1).repeat(padn, axis=0)]) if padn else P[g]
+            if padn:
+                first_local = loc[0, 0]
+                loc[len(g):] = first_local
+            Pn.append(Pg)
+            Nnn.append(np.concatenate([Nn[g], np.repeat(Nn[g[0]][None], padn, axis=0)]) if padn else Nn[g])
+            tun.append(np.concatenate([tu[g], np.repeat(tu[g[0]][None], padn, axis=0)]) if padn else tu[g])
+            cverts.append(cv)
+            vidx.append(loc)
+        P, Nn, tu = np.concatenate(Pn), np.concatenate(Nnn), np.concatenate(tun)
         start = sum(len(x) for x in tri_pos)
         tri_pos.append(P)
         tri_nrm.append(Nn)
         tri_uv.append(tu)
+        cl_verts.append(np.stack(cverts))
+        tri_vidx.append(np.concatenate(vidx))
         inst.append(dict(name=name, otype=owner_type, oidx=owner_idx, uid=uid, tex=tid, col=col,
                          start=start, count=len(P)))
 
@@ -581,6 +689,12 @@ def main(out_path):
     tri_pos = np.concatenate(tri_pos)
     tri_nrm = np.concatenate(tri_nrm)
     tri_uv = np.concatenate(tri_uv)
+    cl_verts = np.concatenate(cl_verts)                      # [ncl, CLUSTER, 3] float32, instance frame
+    tri_vidx = np.concatenate(tri_vidx)                      # [NT, 3] cluster-local vertex indices
+    # consistency: the cluster vertices reproduce the float32 corner positions bit for bit
+    chk = cl_verts[np.arange(len(tri_vidx)) // CLUSTER][np.arange(len(tri_vidx))[:, None], tri_vidx]
+    assert np.array_equal(chk, tri_pos.astype(np.float32)), 'cluster vertices do not reproduce tri_pos'
+    tri_vpack = (tri_vidx[:, 0] | (tri_vidx[:, 1] << 8) | (tri_vidx[:, 2] << 16)).astype(np.int32)
     NI = len(inst)
     in_owner = np.zeros((NI, 4), np.int32)   # otype, oidx, uid, tex
     in_range = np.zeros((NI, 2), np.int32)
@@ -600,6 +714,8 @@ def main(out_path):
     for i, I in enumerate(inst):
         P = tri_pos[I['start']:I['start'] + I['count']]
         Nn = tri_nrm[I['start']:I['start'] + I['count']]
+        real = ~(np.all(P[:, 0] == P[:, 1], axis=1) & np.all(P[:, 0] == P[:, 2], axis=1))     # drop the padding triangles
+        P, Nn = P[real], Nn[real]
         gn = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
         agree = float(((gn * Nn.mean(1)).sum(1) > 0).mean())
         vol = float(np.einsum('ij,ij->i', P[:, 0], np.cross(P[:, 1], P[:, 2])).sum() / 6)
@@ -689,6 +805,8 @@ def main(out_path):
     B.add('tri_uv', tri_uv, F)
     B.add('tri_inst', tri_inst, I32)
     B.add('cluster_sphere', cl_sphere, F)
+    B.add('cluster_verts', cl_verts, F)
+    B.add('tri_vidx', tri_vpack, I32)
     B.add('tex_info', tex_info, I32)
     B.add('tex_data', tex_data, U8)
     B.add('act_min', min_j, F)
