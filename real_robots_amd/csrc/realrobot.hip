@@ -1370,32 +1370,45 @@ __global__ void k_state_io(SimParams P, DevPtrs D, float *aos /*[N][61]*/, int t
 }
 
 // ---------------------------------------------------------------------------------------------- render setup
+// Instance transforms for the rasteriser, one thread per (env, instance): a robot-link thread composes the joint
+// transforms of its body's ancestors only (same operations, in the same order, as fk_all() for that chain), an object
+// thread converts the object's quaternion; the 12 floats of an instance are stored as three 16-byte words, so a wave
+// writes a contiguous span.  (One thread per env needed 264 stores with a 1.5 KB stride between lanes.)
 __global__ void __launch_bounds__(64) k_render_setup(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D) {
     const RenderModel &RM = *RMp;
     const int N = P.N;
-    int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= N) return;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = gid >> 5, i = gid & (MAXINST - 1);
+    static_assert(MAXINST == 32, "thread -> (env, instance) mapping");
+    if (env >= N || i >= RM.ni) return;
     const float *state = D.state;
-    float q[NB];
+    m3 R = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+    v3 p = mk(0, 0, 0);
+    const int ot = RM.in_otype[i], oi = RM.in_oidx[i];
+    if (ot == 1) {
+        unsigned anc = 0;
 #pragma unroll
-    for (int i = 0; i < NB; i++) q[i] = STT(ST_Q + i);
-    m3 bR[NB]; v3 bp[NB], bax[NB];
-    fk_all(B, q, bR, bp, bax);
-    for (int i = 0; i < RM.ni; i++) {
-        m3 R = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
-        v3 p = mk(0, 0, 0);
-        int ot = RM.in_otype[i], oi = RM.in_oidx[i];
-        if (ot == 1) {
+        for (int b = 0; b < NB; b++) if (oi == b) anc = ANC[b];
+        p = mk(B.robot_pos[0], B.robot_pos[1], B.robot_pos[2]);
 #pragma unroll
-            for (int b = 0; b < NB; b++) if (b == oi) { R = bR[b]; p = bp[b]; }
-        } else if (ot == 2) {
-            R = quat_to_m3(STT(ST_OQUAT + 4 * oi), STT(ST_OQUAT + 4 * oi + 1), STT(ST_OQUAT + 4 * oi + 2), STT(ST_OQUAT + 4 * oi + 3));
-            p = mk(STT(ST_OPOS + 3 * oi), STT(ST_OPOS + 3 * oi + 1), STT(ST_OPOS + 3 * oi + 2));
+        for (int b = 0; b < NB; b++) {
+            if (!((anc >> b) & 1u)) continue;
+            m3 jr;
+#pragma unroll
+            for (int k = 0; k < 9; k++) jr.m[k] = B.jrot[b][k];
+            const m3 Rj = mul(R, jr);
+            const v3 ax = mk(B.axis[b][0], B.axis[b][1], B.axis[b][2]);
+            p = p + mulv(R, mk(B.jpos[b][0], B.jpos[b][1], B.jpos[b][2]));
+            R = mul(Rj, axis_angle(ax, STT(ST_Q + b)));
         }
-        float *o = D.inst_xf + ((size_t)env * MAXINST + i) * 12;
-        for (int k = 0; k < 9; k++) o[k] = R.m[k];
-        o[9] = p.x; o[10] = p.y; o[11] = p.z;
+    } else if (ot == 2) {
+        R = quat_to_m3(STT(ST_OQUAT + 4 * oi), STT(ST_OQUAT + 4 * oi + 1), STT(ST_OQUAT + 4 * oi + 2), STT(ST_OQUAT + 4 * oi + 3));
+        p = mk(STT(ST_OPOS + 3 * oi), STT(ST_OPOS + 3 * oi + 1), STT(ST_OPOS + 3 * oi + 2));
     }
+    float4 *o = (float4 *)(D.inst_xf + ((size_t)env * MAXINST + i) * 12);
+    o[0] = make_float4(R.m[0], R.m[1], R.m[2], R.m[3]);
+    o[1] = make_float4(R.m[4], R.m[5], R.m[6], R.m[7]);
+    o[2] = make_float4(R.m[8], p.x, p.y, p.z);
 }
 
 // link poses (COM frame) for rr_link_poses
@@ -2296,7 +2309,7 @@ static int build_static_layer(rr_env *e) {
         ImageOut so;
         so.rgb = e->D.static_rgb; so.depth = e->D.static_depth; so.mask = e->D.static_mask; so.env_stride = 0;
         e->D.static_vis = nullptr;
-        hipLaunchKernelGGL(k_render_setup, dim3((e->P.N + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D);
+        hipLaunchKernelGGL(k_render_setup, dim3((e->P.N * MAXINST + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D);
         hipLaunchKernelGGL(k_raster, dim3(1, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1);
         hipLaunchKernelGGL(k_shade, dim3(1, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, e->D, so, 0);
     }
@@ -2617,7 +2630,7 @@ static void fork_static_copy(rr_env *e, bool use_flags) {
 static int do_render(rr_env *e, bool use_flags) {
     DevPtrs D = e->D;
     if (!use_flags) D.render_flags = nullptr;
-    TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((e->P.N + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, D));
+    TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((e->P.N * MAXINST + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, D));
     fork_static_copy(e, use_flags);
     TIMED(4, hipLaunchKernelGGL(k_raster, dim3(e->P.N, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, D, e->n_inst_used, 0));
     const ImageOut io = env_images(e);
