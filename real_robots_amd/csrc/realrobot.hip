@@ -1702,7 +1702,7 @@ __device__ __forceinline__ bool project_tri(const float *mvp, const float *tp /*
         s.sx[k] = (cx * iw + 1.0f) * (0.5f * (float)W);
         s.sy[k] = (cy * iw + 1.0f) * (0.5f * (float)H);
         s.sz[k] = cz * iw;
-        s.w[k] = cw;
+        s.w[k] = iw;             // reciprocal clip w (deferred shading)
     }
     return true;
 }
@@ -1819,14 +1819,15 @@ __device__ __forceinline__ void shade_pixel(const ShadeCtx &c, int t, int px, in
     project_tri(c.mvp + inst * 16, tp, W, H, s);
     float b[3] = {0, 0, 0};
     bary(s, (float)px, (float)(H - 1 - row), b);
-    float c0 = b[0] / s.w[0], c1 = b[1] / s.w[1], c2 = b[2] / s.w[2];
+    // perspective-correct weights b_k / w_k: s.w holds 1 / w_k (the reciprocal the projection computed anyway)
+    float c0 = b[0] * s.w[0], c1 = b[1] * s.w[1], c2 = b[2] * s.w[2];
     float cs = 1.0f / (c0 + c1 + c2);
     c0 *= cs; c1 *= cs; c2 *= cs;
     float n0 = c0 * nn[0] + c1 * nn[3] + c2 * nn[6], n1 = c0 * nn[1] + c1 * nn[4] + c2 * nn[7], n2 = c0 * nn[2] + c1 * nn[5] + c2 * nn[8];
     const float *xf = c.sinst + inst * 16;
     float w0 = xf[0] * n0 + xf[1] * n1 + xf[2] * n2, w1 = xf[3] * n0 + xf[4] * n1 + xf[5] * n2, w2 = xf[6] * n0 + xf[7] * n1 + xf[8] * n2;
     float nlen = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
-    if (nlen > 0) { w0 /= nlen; w1 /= nlen; w2 /= nlen; }
+    if (nlen > 0) { const float inl = 1.0f / nlen; w0 *= inl; w1 *= inl; w2 *= inl; }
     float ndl = w0 * L0 + w1 * L1 + w2 * L2;
     float diff = fmaxf(ndl, 0.0f);
     float r0 = w0 * (2 * ndl) - L0, r1 = w1 * (2 * ndl) - L1, r2 = w2 * (2 * ndl) - L2;
