@@ -444,6 +444,21 @@ __device__ __forceinline__ Xf load_xf(const ShapeData *S, int s, const float *st
     return X;
 }
 
+#ifdef RR_RASTER_STATS
+// development build only: cycle stamps of kernel phases (lane 0 of every block), see scratch/sprof.py
+__device__ unsigned long long g_sprof[16];
+#define SPROF(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_sprof[i], now_ - sp_t0); sp_t0 = now_; } while (0)
+#define SPROF_INIT unsigned long long sp_t0 = __builtin_readcyclecounter();
+extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sprof), sizeof(g_sprof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sprof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define SPROF(i)
+#define SPROF_INIT
+#endif
+
 // ---- collision: one wavefront per env ------------------------------------------------------------------------------
 // The narrow phase of a pair is ~2 x 32 vertices against ~32 planes plus a manifold reduction: as a per-thread loop it is
 // a chain of ~20k dependent instructions and, with only three or four close pairs per env, a kernel built that way is
@@ -798,21 +813,6 @@ __device__ float build_row(const BodyParams &B, const SimParams &P, const DevPtr
 #define KLIM 2           // joint-limit rows kept in registers (usually two: the finger lower limits)
 #define KOS 4            // object-vs-static contacts per object kept in registers (a resting object has <= 4)
 
-#ifdef RR_RASTER_STATS
-// development build only: cycle stamps of the solver phases (wave 0 lane 0 of every block), see scratch/sprof.py
-__device__ unsigned long long g_sprof[16];
-#define SPROF(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_sprof[i], now_ - sp_t0); sp_t0 = now_; } while (0)
-#define SPROF_INIT unsigned long long sp_t0 = __builtin_readcyclecounter();
-extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
-    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sprof), sizeof(g_sprof)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sprof), z, sizeof(z)) != hipSuccess) return -1; }
-    return 0;
-}
-#else
-#define SPROF(i)
-#define SPROF_INIT
-#endif
-
 __device__ __forceinline__ float4 sel4(bool has, float4 v) {
     return make_float4(has ? v.x : 0.0f, has ? v.y : 0.0f, has ? v.z : 0.0f, has ? v.w : 0.0f);
 }
@@ -843,7 +843,6 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         const unsigned long long bal = __ballot(cntl > 0);
         pmask[k] = (unsigned)(bal >> (16 * grp)) & 0xffffu;
     }
-    SPROF(7);
     int nc = 0, nrob = 0, nbs = 0;
     static_assert(MAXPAIRS / 16 == 6, "pair-mask select chain below");
 #pragma unroll 1        // one copy of the (large) row-building body: the kernel must stay inside the instruction cache
@@ -881,7 +880,6 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
 #pragma unroll
             for (int kk = 0; kk < 9; kk++) Iinv.m[kk] = 0.0f;
         }
-        SPROF(8);
         // every value fetched above is waited for here, once: with no load in flight the contact loop below needs no
         // vmcnt waits, which on gfx9 would also wait for the acknowledgement of the contact-record stores it issues
 #pragma unroll
@@ -889,7 +887,6 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             asm volatile("" : "+v"(cd[i][0]), "+v"(cd[i][1]), "+v"(cd[i][2]), "+v"(cd[i][3]), "+v"(cd[i][4]), "+v"(cd[i][5]), "+v"(cd[i][6]));
         asm volatile("" : "+v"(op.x), "+v"(op.y), "+v"(op.z), "+v"(vs.x), "+v"(vs.y), "+v"(vs.z), "+v"(ws.x), "+v"(ws.y), "+v"(ws.z), "+v"(oimass));
         asm volatile("" : "+v"(Iinv.m[0]), "+v"(Iinv.m[1]), "+v"(Iinv.m[2]), "+v"(Iinv.m[3]), "+v"(Iinv.m[4]), "+v"(Iinv.m[5]), "+v"(Iinv.m[6]), "+v"(Iinv.m[7]), "+v"(Iinv.m[8]));
-        SPROF(9);
         for (int i = 0; i < cnt && nc < MAXC; i++, nc++) {
             float c7[7];
 #pragma unroll
@@ -960,7 +957,6 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             }
             if (!fast) ROW_FENCE();
         }
-        SPROF(10);
     }
     SPROF(1);
     if (l == 0) *(int *)&SCR(S_NCT) = nc;

@@ -21,7 +21,7 @@ for t in range(K):
 torch.cuda.synchronize()
 lib.rr_debug_solver_prof(out, 0)
 v = np.array(list(out), dtype=np.float64) / (K * N / 4)
-names = ['stage Minv', 'gather: loop overhead/tail', 'motor+limit rows', 'limmask + register rows', 'PGS iterations', 'integrate', 'touch/forces', 'gather: pair counts', 'gather: pair meta (sum)', 'gather: pin loads (sum)', 'gather: contact loops (sum)']
-tot = v[:11].sum()
+names = ['stage Minv', 'gather contacts + build rows', 'motor+limit rows', 'limmask + register rows', 'PGS iterations', 'integrate', 'touch/forces']
+tot = v[:7].sum()
 for n, x in zip(names, v): print(f'{n:28s} {x:10.0f} ticks  {100 * x / tot:5.1f} %')
-print('total', tot, 'ticks (s_memtime: 100 MHz constant clock on gfx9)')
+print('total', tot, 'ticks (shader clock cycles)')
