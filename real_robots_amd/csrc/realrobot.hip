@@ -471,17 +471,39 @@ extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
 // selections of the oracle's reduce4() become wave reductions with lowest-lane tie-breaks -- results are identical
 // to the serial formulation.  No atomics, no work list: results do not depend on scheduling.
 #define COLLIDE_THREADS 64
+#ifdef RR_RASTER_STATS
+#define CABL(bit) (P.ablate & (bit))      // development build: phase ablations (256 stage only, 512 no pairs, 1024 cull only)
+#else
+#define CABL(bit) false
+#endif
 
-// wave-wide "first lane holding the maximum of v among lanes with ok" (returns -1 when no lane is ok or none exceeds floor)
+// wave-wide "first lane holding the maximum of v among lanes with ok" (returns -1 when no lane is ok or none exceeds
+// floor).  The maximum is reduced with DPP row rotations inside each 16-lane row and four v_readlane across the rows
+// (an LDS-crossbar butterfly of six dependent ds_bpermute costs ten times as much on a chain this short).
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_max(float m) {
+    m = fmaxf(m, dpp_mov<0x128>(m));     // row_ror:8
+    m = fmaxf(m, dpp_mov<0x124>(m));     // row_ror:4
+    m = fmaxf(m, dpp_mov<0x122>(m));     // row_ror:2
+    m = fmaxf(m, dpp_mov<0x121>(m));     // row_ror:1  -> every lane holds its row's maximum
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
 __device__ __forceinline__ int wave_argmax_first(float v, bool ok, float floor_) {
-    float m = ok ? v : -3.0e38f;
-#pragma unroll
-    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float m = wave_max(ok ? v : -3.0e38f);
     if (!(m > floor_)) return -1;
     const unsigned long long b = __ballot(ok && v == m);
     return b ? __ffsll((long long)b) - 1 : -1;
 }
-__device__ __forceinline__ float lane_f(float v, int src) { return __shfl(v, src); }
+// value of lane src (wave-uniform) in every lane
+__device__ __forceinline__ float lane_f(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
 
 __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtrs D, int ns) {
     const int N = P.N;
@@ -493,8 +515,12 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
     __shared__ float xf[MAXSHAPES][12];        // R (row-major 9), p (3) of every shape's owner
     __shared__ float4 sph[MAXSHAPES];          // world bounding sphere
     __shared__ float4 planes[2][FMAXC];
+    __shared__ int pair_ab[MAXPAIRS];          // shape a | shape b << 8 of every pair   } staged once: no global load of
+    __shared__ int shape_n[MAXSHAPES];         // vertex count | plane count << 8        } metadata inside the pair loop
     const int lane = threadIdx.x;
+    for (int pr = lane; pr < P.npairs; pr += COLLIDE_THREADS) pair_ab[pr] = S->pair_a[pr] | (S->pair_b[pr] << 8);
     if (lane < ns) {
+        shape_n[lane] = S->nv[lane] | (S->nf[lane] << 8);
         const Xf X = load_xf(S, lane, state, scratch, N, env);
 #pragma unroll
         for (int k = 0; k < 9; k++) xf[lane][k] = X.R.m[k];
@@ -503,37 +529,44 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
         sph[lane] = make_float4(c.x, c.y, c.z, S->sphere[lane][3]);
     }
     __syncthreads();
+    if (CABL(256)) return;
     for (int p0 = 0; p0 < P.npairs; p0 += 64) {
         const int pr = p0 + lane;
         bool close = false;
         if (pr < P.npairs) {
-            const float4 a = sph[S->pair_a[pr]], b = sph[S->pair_b[pr]];
+            const float4 a = sph[pair_ab[pr] & 255], b = sph[pair_ab[pr] >> 8];
             const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, rr = a.w + b.w + P.margin;
             close = !(dx * dx + dy * dy + dz * dz > rr * rr);
             *(int *)&SCR(S_PCOUNT + pr) = 0;
         }
         const int dirflag = lane >> 5, v = lane & 31;
-        unsigned long long todo = __ballot(close);
+        unsigned long long todo = CABL(512) ? 0ull : __ballot(close);
         // plane (lane & 31) of the "other" shape of this lane's direction; the planes of the next pair are fetched while
         // the current one is processed
         float4 nextpl = make_float4(0, 0, 0, 0);
+        float nvx = 0, nvy = 0, nvz = 0;       // vertex v of "mine", fetched one pair ahead as well
         if (todo) {
             const int pn = p0 + __ffsll((long long)todo) - 1;
-            nextpl = *(const float4 *)S->planes[dirflag ? S->pair_a[pn] : S->pair_b[pn]][v];
+            const int pa = pair_ab[pn] & 255, pb = pair_ab[pn] >> 8;
+            nextpl = *(const float4 *)S->planes[dirflag ? pa : pb][v];
+            const float *vp = S->verts[dirflag ? pb : pa][v];
+            nvx = vp[0]; nvy = vp[1]; nvz = vp[2];
         }
         for (; todo; todo &= todo - 1) {
             const int pair = p0 + __ffsll((long long)todo) - 1;
-            const int sa = S->pair_a[pair], sb = S->pair_b[pair];
+            const int sa = pair_ab[pair] & 255, sb = pair_ab[pair] >> 8;
             // "mine" = the shape whose vertex this lane tests, "other" = the shape whose planes it is tested against
             const int sm = dirflag ? sb : sa, so = dirflag ? sa : sb;
-            __syncthreads();        // previous item's plane reads are done
-            planes[dirflag][v] = nextpl;
-            __syncthreads();
+            const float4 mypl = nextpl;     // plane v of "other"
+            const float mvx = nvx, mvy = nvy, mvz = nvz;
             {
                 const unsigned long long rest = todo & (todo - 1);
                 if (rest) {
                     const int pn = p0 + __ffsll((long long)rest) - 1;
-                    nextpl = *(const float4 *)S->planes[dirflag ? S->pair_a[pn] : S->pair_b[pn]][v];
+                    const int pa = pair_ab[pn] & 255, pb = pair_ab[pn] >> 8;
+                    nextpl = *(const float4 *)S->planes[dirflag ? pa : pb][v];
+                    const float *vp = S->verts[dirflag ? pb : pa][v];
+                    nvx = vp[0]; nvy = vp[1]; nvz = vp[2];
                 }
             }
             Xf Xm, Xo;
@@ -541,24 +574,25 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
             for (int kk = 0; kk < 9; kk++) { Xm.R.m[kk] = xf[sm][kk]; Xo.R.m[kk] = xf[so][kk]; }
             Xm.p = mk(xf[sm][9], xf[sm][10], xf[sm][11]);
             Xo.p = mk(xf[so][9], xf[so][10], xf[so][11]);
-            const int nv = S->nv[sm], nf = S->nf[so];
+            const int nv = shape_n[sm] & 255, nf = shape_n[so] >> 8;
             {   // exact cull: when the bounding sphere of "mine" lies beyond one plane of "other" by more than the margin, no
-                // vertex of "mine" can be a candidate; with that true for both directions the pair has no contact
+                // vertex of "mine" can be a candidate; with that true for both directions the pair has no contact.
+                // Evaluated on the plane each lane already holds in a register, before anything is staged in LDS.
                 const float4 cm = sph[sm];
                 const v3 cl = tmulv(Xo.R, mk(cm.x, cm.y, cm.z) - Xo.p);
-                bool sep = false;
-                if (v < nf) {
-                    const float4 pl = planes[dirflag][v];
-                    sep = pl.x * cl.x + pl.y * cl.y + pl.z * cl.z - pl.w > cm.w + P.margin;
-                }
+                const bool sep = v < nf && mypl.x * cl.x + mypl.y * cl.y + mypl.z * cl.z - mypl.w > cm.w + P.margin;
                 const unsigned long long sb_ = __ballot(sep);
                 if ((sb_ & 0xffffffffull) && (sb_ >> 32)) continue;        // S_PCOUNT is already 0
             }
+            if (CABL(1024)) continue;
+            __syncthreads();        // previous item's plane reads are done
+            planes[dirflag][v] = mypl;
+            __syncthreads();
             bool hit = false;
             float cx = 0, cy = 0, cz = 0, cs = 0;
             int bf = 0;
             if (v < nv) {
-                const v3 xw = mulv(Xm.R, mk(S->verts[sm][v][0], S->verts[sm][v][1], S->verts[sm][v][2])) + Xm.p;
+                const v3 xw = mulv(Xm.R, mk(mvx, mvy, mvz)) + Xm.p;
                 const v3 xl = tmulv(Xo.R, xw - Xo.p);
                 float best = -1e30f;
                 // all FMAXC slots: padded planes are (0, 0, 0, 1e9), i.e. sd = -1e9, and never win against a real plane
@@ -577,6 +611,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 }
             }
             const unsigned long long hmask = __ballot(hit);
+            if (CABL(2048)) { if (hmask == 0x123456789ull) *(int *)&SCR(S_PCOUNT + pair) = 1; continue; }
             const int n = __popcll(hmask);
             // manifold reduction, same rule as the oracle's reduce4(): deepest first, then maximal spread, preferring the
             // candidates within TIER_TOL (1 mm) of the deepest penetration at every pick; ties go to the first candidate
