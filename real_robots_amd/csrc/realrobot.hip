@@ -739,13 +739,17 @@ __device__ __forceinline__ float group_sum(float v) {
 // ancestors-or-self of body b as a bit mask over joints (kinematic tree PARENT)
 __device__ constexpr unsigned ANC[NB] = {0x001, 0x003, 0x007, 0x00f, 0x01f, 0x03f, 0x07f, 0x0ff, 0x1ff, 0x27f, 0x67f};
 
+// Per-object data a contact row needs (pose, world inverse inertia, unconstrained velocities), fetched once per pair.
+struct ObjData { v3 op, vs, ws; m3 Iinv; float imass; };
+
 // Builds row k (0 normal, 1, 2 tangents) of contact c along `dir`; returns the relative velocity A - B along dir.
-// Executed by all 16 lanes of the env's group; `l` is the lane index within the group.
-__device__ float build_row(const BodyParams &B, const SimParams &P, const DevPtrs &D, int env, int grp, int l, int c, int k,
-                           bool fast, int rslot, int bslot, int bodyA, int bodyB, v3 x, v3 dir) {
+// Executed by all 16 lanes of the env's group; `l` is the lane index within the group.  Nothing is read from global
+// memory here: the lane's joint frame (pk, ak), its unconstrained velocity qds and the objects' data are passed in.
+__device__ float build_row(const SimParams &P, const DevPtrs &D, int env, int grp, int l, int c, int k,
+                           bool fast, int rslot, int bslot, int bodyA, int bodyB, v3 x, v3 dir,
+                           v3 pk, v3 ak, float qds, const ObjData &oA, const ObjData &oB) {
     const int N = P.N;
     float *scratch = D.scratch;
-    const float *state = D.state;
     const int row = 3 * c + k;
     float diag = 0, rel = 0;
 #pragma unroll
@@ -757,48 +761,36 @@ __device__ float build_row(const BodyParams &B, const SimParams &P, const DevPtr
             // lane l < 11: Jacobian entry of joint l (zero unless joint l is an ancestor-or-self of the body)
             float ja = 0;
             const int lj = l < NB ? l : 0;
-            if (l < NB && ((ANC[body] >> l) & 1u)) {
-                v3 pk = mk(SCR(S_BP + 3 * lj), SCR(S_BP + 3 * lj + 1), SCR(S_BP + 3 * lj + 2));
-                v3 ak = mk(SCR(S_BAX + 3 * lj), SCR(S_BAX + 3 * lj + 1), SCR(S_BAX + 3 * lj + 2));
-                ja = sg * dot(dir, cross(ak, x - pk));
-            }
+            if (l < NB && ((ANC[body] >> l) & 1u)) ja = sg * dot(dir, cross(ak, x - pk));
             float mja = 0;
-#pragma unroll
-            for (int j = 0; j < NB; j++) {
-                float jj = __shfl(ja, j, 16);
-                mja += LD(L_MINV + lj * NB + j) * jj;
-            }
+#define MJA_STEP(J) mja += LD(L_MINV + lj * NB + (J)) * row_bcast<J>(ja);
+            MJA_STEP(0) MJA_STEP(1) MJA_STEP(2) MJA_STEP(3) MJA_STEP(4) MJA_STEP(5) MJA_STEP(6) MJA_STEP(7) MJA_STEP(8) MJA_STEP(9) MJA_STEP(10)
+#undef MJA_STEP
             if (l < NB) {
                 if (fast) { LD(L_ROB + (rslot * 3 + k) * 22 + l) = ja; LD(L_ROB + (rslot * 3 + k) * 22 + 11 + l) = mja; }
                 else { ROWS(row, l, ja); ROWS(row, 11 + l, mja); }
             } else mja = 0;
             diag += group_sum(ja * mja);
-            rel += group_sum(l < NB ? ja * SCR(S_QDS + lj) : 0.0f);
+            rel += group_sum(l < NB ? ja * qds : 0.0f);
         } else {
-            int ob = body - 16;
-            v3 op = mk(STT(ST_OPOS + 3 * ob), STT(ST_OPOS + 3 * ob + 1), STT(ST_OPOS + 3 * ob + 2));
+            const ObjData &o = side == 0 ? oA : oB;
             v3 lin = dir * sg;
-            v3 ang = cross(x - op, lin);
-            m3 Iinv;
-#pragma unroll
-            for (int kk = 0; kk < 9; kk++) Iinv.m[kk] = SCR(S_OIINV + 9 * ob + kk);
-            v3 mang = mulv(Iinv, ang);
+            v3 ang = cross(x - o.op, lin);
+            v3 mang = mulv(o.Iinv, ang);
             if (l == 0) {
                 if (fast) {
                     // the base part holds the angular data of the contact's (first) object; the Bside part exists
                     // only for object-object contacts
-                    const int o = (side == 0 || bodyA < 16) ? L_BASE + row * 12 + 3 : L_BS + (bslot * 3 + k) * 6;
-                    LD(o) = ang.x; LD(o + 1) = ang.y; LD(o + 2) = ang.z; LD(o + 3) = mang.x; LD(o + 4) = mang.y; LD(o + 5) = mang.z;
+                    const int oo = (side == 0 || bodyA < 16) ? L_BASE + row * 12 + 3 : L_BS + (bslot * 3 + k) * 6;
+                    LD(oo) = ang.x; LD(oo + 1) = ang.y; LD(oo + 2) = ang.z; LD(oo + 3) = mang.x; LD(oo + 4) = mang.y; LD(oo + 5) = mang.z;
                 } else {
-                    int o = side == 0 ? 25 : 31;
-                    ROWS(row, o, ang.x); ROWS(row, o + 1, ang.y); ROWS(row, o + 2, ang.z);
-                    ROWS(row, o + 3, mang.x); ROWS(row, o + 4, mang.y); ROWS(row, o + 5, mang.z);
+                    int oo = side == 0 ? 25 : 31;
+                    ROWS(row, oo, ang.x); ROWS(row, oo + 1, ang.y); ROWS(row, oo + 2, ang.z);
+                    ROWS(row, oo + 3, mang.x); ROWS(row, oo + 4, mang.y); ROWS(row, oo + 5, mang.z);
                 }
             }
-            v3 vs = mk(SCR(S_OVS + 3 * ob), SCR(S_OVS + 3 * ob + 1), SCR(S_OVS + 3 * ob + 2));
-            v3 ws = mk(SCR(S_OWS + 3 * ob), SCR(S_OWS + 3 * ob + 1), SCR(S_OWS + 3 * ob + 2));
-            diag += dot(lin, lin) * (1.0f / B.obj_mass[ob]) + dot(ang, mang);
-            rel += dot(lin, vs) + dot(ang, ws);
+            diag += dot(lin, lin) * o.imass + dot(ang, mang);
+            rel += dot(lin, o.vs) + dot(ang, o.ws);
         }
     }
     float dinv = diag > 0 ? 1.0f / diag : 0.0f;
@@ -864,8 +856,11 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     const int lj = l < NB ? l : 0;               // joint owned by this lane (lanes >= 11 alias joint 0, masked)
     const int lo_ = (l >= NB && l < NB + NOBJ) ? l - NB : -1;   // object owned by this lane
     SPROF_INIT
-    // ---- stage Minv in LDS
+    // ---- stage Minv in LDS; the lane's joint frame and unconstrained velocity go to registers (same round trip)
     for (int i = l; i < NB * NB; i += 16) LD(L_MINV + i) = SCR(S_MINV + i);
+    const v3 pk_l = mk(SCR(S_BP + 3 * lj), SCR(S_BP + 3 * lj + 1), SCR(S_BP + 3 * lj + 2));
+    const v3 ak_l = mk(SCR(S_BAX + 3 * lj), SCR(S_BAX + 3 * lj + 1), SCR(S_BAX + 3 * lj + 2));
+    const float q_l = STT(ST_Q + lj), qds_l = SCR(S_QDS + lj);
     SPROF(0);
     // ---- gather contacts in pair order, build rows (all lanes of the group run the control flow redundantly)
     // The 92 per-pair candidate counts are fetched in one go: lane l loads the counts of pairs l, l+16, ... and the
@@ -900,28 +895,29 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
 #pragma unroll
             for (int kk = 0; kk < 7; kk++) cd[i][kk] = i < cnt ? SCR(S_PDATA + (pair * 4 + i) * 7 + kk) : 0.0f;
         const bool ospair = bodyA >= 16 && bodyB < 0;
-        const int ob = ospair ? bodyA - 16 : 0;
-        v3 op = mk(0, 0, 0), vs = mk(0, 0, 0), ws = mk(0, 0, 0);
-        m3 Iinv;
-        float oimass = 0.0f;
-        if (ospair) {
-            op = mk(STT(ST_OPOS + 3 * ob), STT(ST_OPOS + 3 * ob + 1), STT(ST_OPOS + 3 * ob + 2));
+        ObjData oA, oB;
 #pragma unroll
-            for (int kk = 0; kk < 9; kk++) Iinv.m[kk] = SCR(S_OIINV + 9 * ob + kk);
-            vs = mk(SCR(S_OVS + 3 * ob), SCR(S_OVS + 3 * ob + 1), SCR(S_OVS + 3 * ob + 2));
-            ws = mk(SCR(S_OWS + 3 * ob), SCR(S_OWS + 3 * ob + 1), SCR(S_OWS + 3 * ob + 2));
-            oimass = 1.0f / B.obj_mass[ob];
-        } else {
+        for (int side = 0; side < 2; side++) {
+            ObjData &o = side == 0 ? oA : oB;
+            const int body = side == 0 ? bodyA : bodyB;
+            const bool isobj = body >= 16;
+            const int ob = isobj ? body - 16 : 0;        // always-valid addresses; the values are only used for objects
+            o.op = mk(STT(ST_OPOS + 3 * ob), STT(ST_OPOS + 3 * ob + 1), STT(ST_OPOS + 3 * ob + 2));
 #pragma unroll
-            for (int kk = 0; kk < 9; kk++) Iinv.m[kk] = 0.0f;
+            for (int kk = 0; kk < 9; kk++) o.Iinv.m[kk] = SCR(S_OIINV + 9 * ob + kk);
+            o.vs = mk(SCR(S_OVS + 3 * ob), SCR(S_OVS + 3 * ob + 1), SCR(S_OVS + 3 * ob + 2));
+            o.ws = mk(SCR(S_OWS + 3 * ob), SCR(S_OWS + 3 * ob + 1), SCR(S_OWS + 3 * ob + 2));
+            o.imass = 1.0f / (ob == 0 ? B.obj_mass[0] : (ob == 1 ? B.obj_mass[1] : B.obj_mass[2]));
         }
         // every value fetched above is waited for here, once: with no load in flight the contact loop below needs no
         // vmcnt waits, which on gfx9 would also wait for the acknowledgement of the contact-record stores it issues
 #pragma unroll
         for (int i = 0; i < 4; i++)
             asm volatile("" : "+v"(cd[i][0]), "+v"(cd[i][1]), "+v"(cd[i][2]), "+v"(cd[i][3]), "+v"(cd[i][4]), "+v"(cd[i][5]), "+v"(cd[i][6]));
-        asm volatile("" : "+v"(op.x), "+v"(op.y), "+v"(op.z), "+v"(vs.x), "+v"(vs.y), "+v"(vs.z), "+v"(ws.x), "+v"(ws.y), "+v"(ws.z), "+v"(oimass));
-        asm volatile("" : "+v"(Iinv.m[0]), "+v"(Iinv.m[1]), "+v"(Iinv.m[2]), "+v"(Iinv.m[3]), "+v"(Iinv.m[4]), "+v"(Iinv.m[5]), "+v"(Iinv.m[6]), "+v"(Iinv.m[7]), "+v"(Iinv.m[8]));
+        asm volatile("" : "+v"(oA.op.x), "+v"(oA.op.y), "+v"(oA.op.z), "+v"(oA.vs.x), "+v"(oA.vs.y), "+v"(oA.vs.z), "+v"(oA.ws.x), "+v"(oA.ws.y), "+v"(oA.ws.z));
+        asm volatile("" : "+v"(oA.Iinv.m[0]), "+v"(oA.Iinv.m[1]), "+v"(oA.Iinv.m[2]), "+v"(oA.Iinv.m[3]), "+v"(oA.Iinv.m[4]), "+v"(oA.Iinv.m[5]), "+v"(oA.Iinv.m[6]), "+v"(oA.Iinv.m[7]), "+v"(oA.Iinv.m[8]));
+        asm volatile("" : "+v"(oB.op.x), "+v"(oB.op.y), "+v"(oB.op.z), "+v"(oB.vs.x), "+v"(oB.vs.y), "+v"(oB.vs.z), "+v"(oB.ws.x), "+v"(oB.ws.y), "+v"(oB.ws.z));
+        asm volatile("" : "+v"(oB.Iinv.m[0]), "+v"(oB.Iinv.m[1]), "+v"(oB.Iinv.m[2]), "+v"(oB.Iinv.m[3]), "+v"(oB.Iinv.m[4]), "+v"(oB.Iinv.m[5]), "+v"(oB.Iinv.m[6]), "+v"(oB.Iinv.m[7]), "+v"(oB.Iinv.m[8]));
         for (int i = 0; i < cnt && nc < MAXC; i++, nc++) {
             float c7[7];
 #pragma unroll
@@ -949,10 +945,10 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                 v3 t1, t2;
                 plane_space(n, t1, t2);
                 const v3 dir = l == 0 ? n : (l == 1 ? t1 : t2);
-                const v3 ang = cross(x - op, dir);
-                const v3 mang = mulv(Iinv, ang);
-                const float diag = dot(dir, dir) * oimass + dot(ang, mang);
-                const float rel = dot(dir, vs) + dot(ang, ws);
+                const v3 ang = cross(x - oA.op, dir);
+                const v3 mang = mulv(oA.Iinv, ang);
+                const float diag = dot(dir, dir) * oA.imass + dot(ang, mang);
+                const float rel = dot(dir, oA.vs) + dot(ang, oA.ws);
                 const float dinv = diag > 0 ? 1.0f / diag : 0.0f;
                 float rr = 0;
                 if (fabsf(rel) >= P.rest_thresh) { rr = rest * -rel; if (rr < 0) rr = 0; }
@@ -969,7 +965,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                 continue;
             }
             // normal row
-            float rel = build_row(B, P, D, env, grp, l, nc, 0, fast, rslot, bslot, bodyA, bodyB, x, n);
+            float rel = build_row(P, D, env, grp, l, nc, 0, fast, rslot, bslot, bodyA, bodyB, x, n, pk_l, ak_l, qds_l, oA, oB);
             float r = 0;
             if (fabsf(rel) >= P.rest_thresh) { r = rest * -rel; if (r < 0) r = 0; }
             float verr = r - rel, perr = 0;
@@ -977,8 +973,8 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             else perr = -dist * P.erp / dt;
             v3 t1, t2;
             plane_space(n, t1, t2);
-            float rel1 = build_row(B, P, D, env, grp, l, nc, 1, fast, rslot, bslot, bodyA, bodyB, x, t1);
-            float rel2 = build_row(B, P, D, env, grp, l, nc, 2, fast, rslot, bslot, bodyA, bodyB, x, t2);
+            float rel1 = build_row(P, D, env, grp, l, nc, 1, fast, rslot, bslot, bodyA, bodyB, x, t1, pk_l, ak_l, qds_l, oA, oB);
+            float rel2 = build_row(P, D, env, grp, l, nc, 2, fast, rslot, bslot, bodyA, bodyB, x, t2, pk_l, ak_l, qds_l, oA, oB);
             if (l == 0) {
                 if (fast) {
                     LD(L_BASE + (3 * nc) * 12 + 9) = (perr + verr) * LD(L_BASE + (3 * nc) * 12 + 10);
@@ -996,7 +992,6 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     SPROF(1);
     if (l == 0) *(int *)&SCR(S_NCT) = nc;
     // ---- motor + limit rows: lane j < 11 builds the rows of joint j
-    const float q_l = STT(ST_Q + lj), qds_l = SCR(S_QDS + lj);
     if (l < NB) {
         float dinv = 1.0f / LD(L_MINV + l * NB + l);
         float vt = P.kp * (STT(ST_TGT + l) - q_l) / dt + qds_l + P.kd * (0.0f - qds_l);
@@ -1196,38 +1191,45 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                 const int r0 = pass == 0 ? 3 * c : 3 * c + 1, r1 = pass == 0 ? 3 * c + 1 : 3 * c + 3;
                 const bool mineA = (lo_ >= 0) && (bodyA == 16 + lo_), mineB = (lo_ >= 0) && (bodyB == 16 + lo_);
                 if (fast) {
-                    // LDS-resident contact: predicated, branch-light row steps.
-                    // sgn: +1 when this lane owns object A, -1 when it owns object B, 0 otherwise
-                    // (selects, not multiplications by 0/1: unused slots of a part may hold non-finite garbage)
-                    const float sgn = mineA ? 1.0f : (mineB ? -1.0f : 0.0f);
+                    // LDS-resident contact: branch-free row steps (selects only: unused slots of a part may hold
+                    // non-finite garbage, so nothing is multiplied by 0/1 masks); the second friction row is
+                    // fetched while the first one is swept.
+                    // sgn: +1 when this lane owns object A, -1 when it owns object B
+                    const float sgn = mineA ? 1.0f : -1.0f;
                     const bool own = mineA || mineB;
                     const bool rob = robot && l < NB;
+                    const bool useB = objobj && mineB;     // second object of an object-object contact: Bside part
                     const float ln = LD(L_BASE + (3 * c) * 12 + 11), mu = LD(L_MU + c);
                     const float hi = pass == 0 ? 1e10f : mu * ln, lo = pass == 0 ? 0.0f : -hi;
-                    const int orb0 = robot ? L_ROB + (rslot * 3) * 22 + lj : lj;    // harmless address when no robot part
+                    const int orb0 = (robot ? L_ROB + (rslot * 3) * 22 + lj : lj) + (r0 - 3 * c) * 22;   // harmless address when no robot part
+                    const int obs0 = L_BS + ((objobj ? bslot : 0) * 3 + (r0 - 3 * c)) * 6;               // likewise for the Bside part
+                    float4 n0 = LDB4(r0, 0), n1 = LDB4(r0, 4), n2 = LDB4(r0, 8);
+                    float njal = LD(orb0), nmjal = LD(orb0 + 11);
+                    float nb0 = LD(obs0), nb1 = LD(obs0 + 1), nb2 = LD(obs0 + 2), nb3 = LD(obs0 + 3), nb4 = LD(obs0 + 4), nb5 = LD(obs0 + 5);
                     for (int r = r0; r < r1; r++) {
-                        const int kk = r - 3 * c;
-                        const float4 b0 = *(const float4 *)&LD(L_BASE + r * 12);        // dir.xyz, ang.x
-                        const float4 b1 = *(const float4 *)&LD(L_BASE + r * 12 + 4);    // ang.yz, mang.xy
-                        const float4 b2 = *(const float4 *)&LD(L_BASE + r * 12 + 8);    // mang.z, rhs, dinv, lambda
-                        const float jal = LD(orb0 + kk * 22), mjal = LD(orb0 + kk * 22 + 11);
-                        v3 dir = mk(b0.x, b0.y, b0.z), ang = mk(b0.w, b1.x, b1.y), mang = mk(b1.z, b1.w, b2.x);
-                        if (objobj && mineB) {   // second object of an object-object contact: Bside part
-                            const int obs_ = L_BS + (bslot * 3 + kk) * 6;
-                            ang = mk(LD(obs_), LD(obs_ + 1), LD(obs_ + 2)); mang = mk(LD(obs_ + 3), LD(obs_ + 4), LD(obs_ + 5));
+                        const float4 b0 = n0, b1 = n1, b2 = n2;          // dir.xyz ang.x | ang.yz mang.xy | mang.z rhs dinv lambda
+                        const float jal = njal, mjal = nmjal;
+                        const float q0 = nb0, q1 = nb1, q2 = nb2, q3 = nb3, q4 = nb4, q5 = nb5;
+                        if (r + 1 < r1) {
+                            n0 = LDB4(r + 1, 0); n1 = LDB4(r + 1, 4); n2 = LDB4(r + 1, 8);
+                            njal = LD(orb0 + 22); nmjal = LD(orb0 + 33);
+                            nb0 = LD(obs0 + 6); nb1 = LD(obs0 + 7); nb2 = LD(obs0 + 8); nb3 = LD(obs0 + 9); nb4 = LD(obs0 + 10); nb5 = LD(obs0 + 11);
                         }
-                        float part = 0.0f;
-                        if (rob) part = jal * dq;
-                        if (own) part = sgn * dot(dir, dv) + dot(ang, dw);
+                        const v3 dir = mk(b0.x, b0.y, b0.z);
+                        const v3 ang = mk(useB ? q0 : b0.w, useB ? q1 : b1.x, useB ? q2 : b1.y);
+                        const v3 mang = mk(useB ? q3 : b1.z, useB ? q4 : b1.w, useB ? q5 : b2.x);
+                        const float part = own ? sgn * dot(dir, dv) + dot(ang, dw) : (rob ? jal * dq : 0.0f);
                         const float jv = group_sum(part);
                         const float lam = b2.w;
-                        float dl = b2.y - jv * b2.z;
-                        float sum = lam + dl;
-                        if (sum < lo) { dl = lo - lam; sum = lo; }
-                        else if (sum > hi) { dl = hi - lam; sum = hi; }
-                        if (l == 0) LD(L_BASE + r * 12 + 11) = sum;
-                        if (rob) dq += mjal * dl;
-                        if (own) { dv = dv + dir * (sgn * dl * inv_mass); dw = dw + mang * dl; }
+                        const float dl0 = b2.y - jv * b2.z;
+                        const float s0 = lam + dl0;
+                        const float sum = fminf(fmaxf(s0, lo), hi);
+                        const float dl = (sum == s0) ? dl0 : sum - lam;
+                        LD(L_BASE + r * 12 + 11) = sum;                   // every lane writes the same value
+                        dq += rob ? mjal * dl : 0.0f;
+                        const float so = own ? dl : 0.0f, sm = sgn * so * inv_mass;
+                        dv = dv + dir * sm;
+                        dw = dw + mk(own ? mang.x * dl : 0.0f, own ? mang.y * dl : 0.0f, own ? mang.z * dl : 0.0f);
                     }
                     continue;
                 }
