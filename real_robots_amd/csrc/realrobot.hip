@@ -2691,9 +2691,12 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     HIPCHK(hipSetDevice(e->cfg.device));
     const int N = e->P.N;
     if (!joint_cmd) HIPCHK(hipMemsetAsync(e->D.cmd, 0, (size_t)N * 36, e->stream));      // env.py:333-334
-    else if (joint_cmd != e->D.cmd) HIPCHK(hipMemcpyAsync(e->D.cmd, joint_cmd, (size_t)N * 36, cmd_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    else if (!cmd_on_device) HIPCHK(hipMemcpyAsync(e->D.cmd, joint_cmd, (size_t)N * 36, hipMemcpyHostToDevice, e->stream));
+    // a device-resident command buffer is read in place by k_prep (stream order protects it like a copy would)
+    DevPtrs Dp = e->D;
+    if (joint_cmd && cmd_on_device) Dp.cmd = const_cast<float *>(joint_cmd);
     if (render_mode == 2) HIPCHK(hipMemcpyAsync(e->D.render_flags, render_flags_host, N, hipMemcpyHostToDevice, e->stream));
-    TIMED(0, hipLaunchKernelGGL(k_prep, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, e->D));
+    TIMED(0, hipLaunchKernelGGL(k_prep, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp));
     TIMED(1, launch_collide(e));
     TIMED(2, hipLaunchKernelGGL(k_solve, dim3((N + SGRP - 1) / SGRP), dim3(SGRP * 16), 0, e->stream, e->B, e->P, e->D));
     HIPCHK(hipGetLastError());
