@@ -1714,6 +1714,10 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 #define RASTER_THREADS 1024
 #define TILE_PIX 16384
 #define MAXWIN 1024      // 64-triangle windows per model (rr_create checks nt)
+#ifndef INLINE_PIX
+#define INLINE_PIX 2     // sample points of a small triangle walked by its own lane; the rest is redistributed over the wave
+#endif
+#define SEG_CAP 1024     // slots of the per-wave redistribution list (bytes of LDS)
 #define SMALL_AREA 32    // bbox area (pixels) up to which the owning lane rasterises a triangle itself (measured optimum 16..64)
 
 struct STri { float sx[3], sy[3], sz[3], w[3]; };
@@ -1754,6 +1758,19 @@ __device__ __forceinline__ void project_vertex(const float *mvp, float vx, float
 }
 __device__ __forceinline__ float lane_gather(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ int lane_gather_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+// exclusive prefix sum over the 64 lanes of a wave (DPP row_shr scan inside each 16-lane row + the row totals)
+template <int SHR> __device__ __forceinline__ int dpp_shr0(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + SHR, 0xf, 0xf, true); }
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
+    int x = v;
+    x += dpp_shr0<1>(x); x += dpp_shr0<2>(x); x += dpp_shr0<4>(x); x += dpp_shr0<8>(x);
+    const int t0 = __builtin_amdgcn_readlane(x, 15), t1 = __builtin_amdgcn_readlane(x, 31), t2 = __builtin_amdgcn_readlane(x, 47),
+              t3 = __builtin_amdgcn_readlane(x, 63);
+    const int row = lane >> 4;
+    const int off = row == 0 ? 0 : (row == 1 ? t0 : (row == 2 ? t0 + t1 : t0 + t1 + t2));
+    total = t0 + t1 + t2 + t3;
+    return x + off - v;
 }
 
 __device__ __forceinline__ bool bary(const STri &s, float px, float py, float *b) {
@@ -1916,7 +1933,7 @@ __device__ __forceinline__ void stage_instances(const RenderModel &RM, const Dev
 #ifdef RR_RASTER_STATS
 // Development-only work counters (librealrobot_hip_stats.so, `make stats`; never part of the shipped library).
 __device__ unsigned long long g_rstats[16];
-#define RSTAT(i, v) atomicAdd(&g_rstats[i], (unsigned long long)(v))
+#define RSTAT(i, v) do { if (P.ablate & 0x8000) atomicAdd(&g_rstats[i], (unsigned long long)(v)); } while (0)   /* RR_ABLATE=32768 */
 extern "C" int rr_debug_raster_stats(unsigned long long *out16, int reset) {
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rstats), sizeof(g_rstats)) != hipSuccess) return -1;
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rstats), z, sizeof(z)) != hipSuccess) return -1; }
@@ -1941,6 +1958,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     __shared__ float mvp[MAXINST][16];
     __shared__ unsigned nlist, wcount, wnext;
     __shared__ unsigned short wlist[MAXWIN];
+    __shared__ unsigned char seg[RASTER_THREADS / 64][SEG_CAP];
     const int env = blockIdx.x, tile = blockIdx.y;
     if (pass == 0 && D.render_flags && !D.render_flags[env]) return;
     const int W = RM.W, H = RM.H;
@@ -2047,11 +2065,50 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
             if (big) RSTAT(8, area);
         }
 #endif
-        if (live && !big) {   // small: the owning lane walks its <= small_area sample points
+        // Small triangles.  Most cover one or two sample points, a few up to small_area: a per-lane walk of the whole
+        // bounding box makes the wave wait for its largest triangle (~20 % lane utilisation).  So every lane walks only
+        // the first INLINE_PIX points of its box; the remaining points of all lanes are dealt out evenly: a wave prefix
+        // sum gives every point a slot, the owners write their lane id into the slots (an LDS byte per point) and
+        // then each lane takes slots lane, lane+64, ...: it fetches the owner's triangle with ds_bpermute and tests
+        // its point.  Same per-point arithmetic, and ds_min is order independent.
+        {
+            const bool small = live && !big;
+            const int bw = x1 - x0 + 1;
+            const int ninl = small ? min(area, INLINE_PIX) : 0;
             int px = x0, py = y0;
-            for (int i = 0; i < area; i++) {
+            for (int i = 0; i < ninl; i++) {
                 raster_pixel_hoisted(s, ia, t, px, py, H, W, row0, vis);
                 if (++px > x1) { px = x0; py++; }
+            }
+            const int rem = small ? area - ninl : 0;
+            int total;
+            const int pre = wave_excl_scan(rem, lane, total);
+            if (total > 0) {
+                if (total <= SEG_CAP) {
+                    unsigned char *sg = seg[tid >> 6];
+                    for (int j = 0; j < rem; j++) sg[pre + j] = (unsigned char)lane;
+                    for (int w0 = 0; w0 < total; w0 += 64) {     // wave-uniform trip count: ds_bpermute needs the owner lanes active
+                        const int w = w0 + lane;
+                        const bool valid = w < total;
+                        const int src = valid ? sg[w] : 0;
+                        STri bs;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            bs.sx[k] = lane_gather(s.sx[k], src); bs.sy[k] = lane_gather(s.sy[k], src); bs.sz[k] = lane_gather(s.sz[k], src);
+                            bs.w[k] = 1.0f;
+                        }
+                        const float bia = lane_gather(ia, src);
+                        const int sx0 = lane_gather_i(x0, src), sy0 = lane_gather_i(y0, src), sbw = lane_gather_i(bw, src);
+                        const int idx = INLINE_PIX + w - lane_gather_i(pre, src);
+                        const int ry = (int)(((float)idx + 0.5f) / (float)sbw);      // exact for these small integers
+                        if (valid) raster_pixel_hoisted(bs, bia, tb + src, sx0 + idx - ry * sbw, sy0 + ry, H, W, row0, vis);
+                    }
+                } else {      // more left-over points than slots (never seen at <= 320x240): owners finish their own boxes
+                    for (int i = ninl; i < ninl + rem; i++) {
+                        raster_pixel_hoisted(s, ia, t, px, py, H, W, row0, vis);
+                        if (++px > x1) { px = x0; py++; }
+                    }
+                }
             }
         }
         unsigned long long todo = ABL(2) ? 0ull : __ballot(big);

@@ -1,5 +1,6 @@
 """Raster work counters on the bench workload (development; needs `make -C real_robots_amd/csrc stats`)."""
 import os, sys, ctypes
+os.environ['RR_ABLATE'] = '32768'      # enables the work counters of the development build
 sys.path.insert(0, '/root/repo')
 os.environ['RR_LIB'] = os.path.join(os.path.dirname(__file__), '..', 'real_robots_amd', 'csrc', 'librealrobot_hip_stats.so')
 import numpy as np, torch
