@@ -1718,7 +1718,7 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 #define INLINE_PIX 2     // sample points of a small triangle walked by its own lane; the rest is redistributed over the wave
 #endif
 #define SEG_CAP 1024     // slots of the per-wave redistribution list (bytes of LDS)
-#define SMALL_AREA 32    // bbox area (pixels) up to which the owning lane rasterises a triangle itself (measured optimum 16..64)
+#define SMALL_AREA 64    // bbox area (sample points) up to which a triangle takes the per-lane + redistribution path (A/B: 16 0.60, 32 0.54, 64 0.53, 128 0.54 ms)
 
 struct STri { float sx[3], sy[3], sz[3], w[3]; };
 
