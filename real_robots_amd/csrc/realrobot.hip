@@ -447,7 +447,7 @@ __device__ __forceinline__ Xf load_xf(const ShapeData *S, int s, const float *st
 #ifdef RR_RASTER_STATS
 // development build only: cycle stamps of kernel phases (lane 0 of every block), see scratch/sprof.py
 __device__ unsigned long long g_sprof[16];
-#define SPROF(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_sprof[i], now_ - sp_t0); sp_t0 = now_; } while (0)
+#define SPROF(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && (!(P.ablate & 0x4000) || (int)blockIdx.x == (P.ablate >> 16))) atomicAdd(&g_sprof[i], now_ - sp_t0); sp_t0 = now_; } while (0)   /* RR_ABLATE = block << 16 | 0x4000: one block only */
 #define SPROF_INIT unsigned long long sp_t0 = __builtin_readcyclecounter();
 extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sprof), sizeof(g_sprof)) != hipSuccess) return -1;
@@ -873,7 +873,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         const unsigned long long bal = __ballot(cntl > 0);
         pmask[k] = (unsigned)(bal >> (16 * grp)) & 0xffffu;
     }
-    int nc = 0, nrob = 0, nbs = 0;
+    int nc = 0, gidx = 0;      // gidx: index among the generic (not object-vs-static) contacts, which all follow the object-vs-static ones
     static_assert(MAXPAIRS / 16 == 6, "pair-mask select chain below");
 #pragma unroll 1        // one copy of the (large) row-building body: the kernel must stay inside the instruction cache
     for (int k = 0; k < MAXPAIRS / 16; k++)
@@ -926,8 +926,11 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             const float dist = c7[6];
             int rslot = 15, bslot = 15;
             bool fast = nc < LC;
-            if (robot) { if (nrob < LR && fast) rslot = nrob; else fast = false; nrob++; }
-            if (objobj) { if (nbs < LB && fast) bslot = nbs; else fast = false; nbs++; }
+            // the robot / Bside part of generic contact j lives in slot j of its LDS section: sweep code finds it without
+            // reading the meta word (object-object pairs precede the robot pairs, so they get the low Bside slots)
+            if (robot) { if (gidx < LR && fast) rslot = gidx; else fast = false; }
+            if (objobj) { if (gidx < LB && fast) bslot = gidx; else fast = false; }
+            if (robot || objobj) gidx++;
             if (!fast) { rslot = 15; bslot = 15; }
             // "fast" is recoverable from the meta word: c < LC and (no robot side or rslot != 15) and (no B object or bslot != 15)
             int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | (rslot << 24) | (bslot << 28);
@@ -1110,6 +1113,123 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             REG_ROW_STEP(os_b0[i], os_b1[i], os_b2[i], os_l2[i], -hi_, hi_);                          \
         }
     SPROF(3);
+    // Generic contacts (robot involved, or two objects) in LDS: their per-lane roles are loop invariant, so they are
+    // decoded once into bit masks (bit j = generic contact j = contact n_os + j); its robot / Bside part is in slot j.
+    unsigned g_robot = 0, g_objobj = 0, g_ownA = 0, g_ownB = 0;
+    bool g_allfast = nc - n_os <= 32;
+    for (int c = n_os; c < nc && c - n_os < 32; c++) {
+        const int meta = *(const int *)&LD(L_META + c);
+        const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta);
+        const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
+        const bool objobj = bodyA >= 16 && bodyB >= 16;
+        const bool fast = (c < LC) && (!robot || meta_rslot(meta) != 15) && (!objobj || meta_bslot(meta) != 15);
+        g_allfast = g_allfast && fast;
+        const unsigned bit = 1u << (c - n_os);
+        if (robot) g_robot |= bit;
+        if (objobj) g_objobj |= bit;
+        if (lo_ >= 0 && bodyA == 16 + lo_) g_ownA |= bit;
+        if (lo_ >= 0 && bodyB == 16 + lo_) g_ownB |= bit;
+    }
+    const int G = nc - n_os;
+    struct GenRow { float4 b0, b1, b2; float jal, mjal, q0, q1, q2, q3, q4, q5, ln, mu; };
+    // loads of generic row step idx of pass p (p = 0: normal rows, p = 1: the two friction rows of every contact)
+#define GEN_LOAD(row_, p_, idx_)                                                                                   \
+    do {                                                                                                           \
+        const int j_ = (p_) == 0 ? (idx_) : (idx_) >> 1, k_ = (p_) == 0 ? 0 : 1 + ((idx_) & 1);                   \
+        const int c_ = n_os + j_, r_ = 3 * c_ + k_;                                                                \
+        const bool rb_ = (g_robot >> j_) & 1u, oo_ = (g_objobj >> j_) & 1u;                                        \
+        const int orb_ = rb_ ? L_ROB + (j_ * 3 + k_) * 22 + lj : lj;                                               \
+        const int obs_ = L_BS + ((oo_ ? j_ : 0) * 3 + k_) * 6;                                                     \
+        (row_).b0 = LDB4(r_, 0); (row_).b1 = LDB4(r_, 4); (row_).b2 = LDB4(r_, 8);                                 \
+        (row_).jal = LD(orb_); (row_).mjal = LD(orb_ + 11);                                                        \
+        (row_).q0 = LD(obs_); (row_).q1 = LD(obs_ + 1); (row_).q2 = LD(obs_ + 2);                                  \
+        (row_).q3 = LD(obs_ + 3); (row_).q4 = LD(obs_ + 4); (row_).q5 = LD(obs_ + 5);                              \
+        (row_).ln = LD(L_BASE + (3 * c_) * 12 + 11); (row_).mu = LD(L_MU + c_);                                    \
+    } while (0)
+#define GEN_STEP(row_, p_, idx_)                                                                                   \
+    do {                                                                                                           \
+        const int j_ = (p_) == 0 ? (idx_) : (idx_) >> 1, k_ = (p_) == 0 ? 0 : 1 + ((idx_) & 1);                   \
+        const int r_ = 3 * (n_os + j_) + k_;                                                                       \
+        const bool mineA_ = (g_ownA >> j_) & 1u, mineB_ = (g_ownB >> j_) & 1u;                                     \
+        const bool own_ = mineA_ || mineB_, rob_ = ((g_robot >> j_) & 1u) && l < NB;                               \
+        const bool useB_ = ((g_objobj >> j_) & 1u) && mineB_;                                                      \
+        const float sgn_ = mineA_ ? 1.0f : -1.0f;                                                                  \
+        const float hi_ = (p_) == 0 ? 1e10f : (row_).mu * (row_).ln, lo_b = (p_) == 0 ? 0.0f : -hi_;              \
+        const v3 dir_ = mk((row_).b0.x, (row_).b0.y, (row_).b0.z);                                                 \
+        const v3 ang_ = mk(useB_ ? (row_).q0 : (row_).b0.w, useB_ ? (row_).q1 : (row_).b1.x, useB_ ? (row_).q2 : (row_).b1.y); \
+        const v3 mang_ = mk(useB_ ? (row_).q3 : (row_).b1.z, useB_ ? (row_).q4 : (row_).b1.w, useB_ ? (row_).q5 : (row_).b2.x); \
+        const float part_ = own_ ? sgn_ * dot(dir_, dv) + dot(ang_, dw) : (rob_ ? (row_).jal * dq : 0.0f);         \
+        const float jv_ = group_sum(part_);                                                                        \
+        const float lam_ = (row_).b2.w;                                                                            \
+        const float dl0_ = (row_).b2.y - jv_ * (row_).b2.z;                                                        \
+        const float s0_ = lam_ + dl0_;                                                                             \
+        const float sum_ = fminf(fmaxf(s0_, lo_b), hi_);                                                           \
+        const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - lam_;                                                      \
+        LD(L_BASE + r_ * 12 + 11) = sum_;                                                                          \
+        dq += rob_ ? (row_).mjal * dl_ : 0.0f;                                                                     \
+        const float so_ = own_ ? dl_ : 0.0f, sm_ = sgn_ * so_ * inv_mass;                                          \
+        dv = dv + dir_ * sm_;                                                                                      \
+        dw = dw + mk(own_ ? mang_.x * dl_ : 0.0f, own_ ? mang_.y * dl_ : 0.0f, own_ ? mang_.z * dl_ : 0.0f);       \
+    } while (0)
+#define GEN_SWEEP(p_)                                                                                              \
+    do {                                                                                                           \
+        const int R_ = (p_) == 0 ? G : 2 * G;                                                                      \
+        if (R_ > 0) {                                                                                              \
+            GenRow cur_, nxt_;                                                                                     \
+            GEN_LOAD(cur_, p_, 0);                                                                                 \
+            nxt_ = cur_;                                                                                           \
+            for (int idx = 0; idx < R_; idx++) {                                                                   \
+                if (idx + 1 < R_) GEN_LOAD(nxt_, p_, idx + 1);                                                     \
+                GEN_STEP(cur_, p_, idx);                                                                           \
+                cur_ = nxt_;                                                                                       \
+            }                                                                                                      \
+        }                                                                                                          \
+    } while (0)
+    // Up to NGU generic contacts: fully written-out sweep.  Contact index, row offsets and slots are compile-time
+    // constants, so a row step is ~45 instructions (immediate-offset LDS reads, bit tests on the role masks) instead of
+    // ~120 with run-time addressing -- with one wave per SIMD a row costs (instructions x ~8 cycles).  The normal impulse
+    // and the friction coefficient of each contact stay in registers between the two passes.
+#define NGU 12
+    const bool g_unrolled = g_allfast && G <= NGU;
+    const int gbase = grp * L_TOTAL + L_BASE + n_os * 36, rbase = grp * L_TOTAL + L_ROB + lj, bbase = grp * L_TOTAL + L_BS;
+    float gln[NGU], gmu[NGU];
+#pragma unroll
+    for (int j = 0; j < NGU; j++) { gln[j] = 0.0f; gmu[j] = (g_unrolled && j < G) ? LD(L_MU + n_os + j) : 0.0f; }
+#define GROW(J, K, LOB, HIB)                                                                                       \
+    {                                                                                                              \
+        const int ro_ = gbase + ((J) * 3 + (K)) * 12, rr_ = rbase + ((J) * 3 + (K)) * 22;                         \
+        const float4 b0_ = *(const float4 *)&g_slds[ro_], b1_ = *(const float4 *)&g_slds[ro_ + 4], b2_ = *(const float4 *)&g_slds[ro_ + 8]; \
+        const float jal_ = g_slds[rr_], mjal_ = g_slds[rr_ + 11];                                                  \
+        const bool mineA_ = (g_ownA >> (J)) & 1u, mineB_ = (g_ownB >> (J)) & 1u;                                   \
+        const bool own_ = mineA_ || mineB_, rob_ = ((g_robot >> (J)) & 1u) && l < NB;                              \
+        float a0_ = b0_.w, a1_ = b1_.x, a2_ = b1_.y, m0_ = b1_.z, m1_ = b1_.w, m2_ = b2_.x;                        \
+        if ((J) < LB) {                                                                                            \
+            const bool useB_ = ((g_objobj >> (J)) & 1u) && mineB_;                                                 \
+            const int bo_ = bbase + ((J) * 3 + (K)) * 6;                                                           \
+            a0_ = useB_ ? g_slds[bo_] : a0_; a1_ = useB_ ? g_slds[bo_ + 1] : a1_; a2_ = useB_ ? g_slds[bo_ + 2] : a2_;       \
+            m0_ = useB_ ? g_slds[bo_ + 3] : m0_; m1_ = useB_ ? g_slds[bo_ + 4] : m1_; m2_ = useB_ ? g_slds[bo_ + 5] : m2_;   \
+        }                                                                                                          \
+        const float sgn_ = mineA_ ? 1.0f : -1.0f;                                                                  \
+        const float part_ = own_ ? sgn_ * (b0_.x * dv.x + b0_.y * dv.y + b0_.z * dv.z) + (a0_ * dw.x + a1_ * dw.y + a2_ * dw.z) \
+                                 : (rob_ ? jal_ * dq : 0.0f);                                                      \
+        const float jv_ = group_sum(part_);                                                                        \
+        const float lam_ = b2_.w;                                                                                  \
+        const float dl0_ = b2_.y - jv_ * b2_.z;                                                                    \
+        const float s0_ = lam_ + dl0_;                                                                             \
+        const float sum_ = fminf(fmaxf(s0_, (LOB)), (HIB));                                                        \
+        const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - lam_;                                                      \
+        g_slds[ro_ + 11] = sum_;                                                                                   \
+        if ((K) == 0) gln[J] = sum_;                                                                               \
+        dq += rob_ ? mjal_ * dl_ : 0.0f;                                                                           \
+        const float so_ = own_ ? dl_ : 0.0f, sm_ = sgn_ * so_ * inv_mass;                                          \
+        dv.x += b0_.x * sm_; dv.y += b0_.y * sm_; dv.z += b0_.z * sm_;                                             \
+        dw.x += own_ ? m0_ * dl_ : 0.0f; dw.y += own_ ? m1_ * dl_ : 0.0f; dw.z += own_ ? m2_ * dl_ : 0.0f;         \
+    }
+#define GNORMAL(J) if ((J) < G) GROW(J, 0, 0.0f, 1e10f)
+#define GFRICT(J) if ((J) < G) { const float hi_ = gmu[J] * gln[J]; GROW(J, 1, -hi_, hi_) GROW(J, 2, -hi_, hi_) }
+#define GEN_UNROLLED_N GNORMAL(0) GNORMAL(1) GNORMAL(2) GNORMAL(3) GNORMAL(4) GNORMAL(5) GNORMAL(6) GNORMAL(7) GNORMAL(8) GNORMAL(9) GNORMAL(10) GNORMAL(11)
+#define GEN_UNROLLED_F GFRICT(0) GFRICT(1) GFRICT(2) GFRICT(3) GFRICT(4) GFRICT(5) GFRICT(6) GFRICT(7) GFRICT(8) GFRICT(9) GFRICT(10) GFRICT(11)
+    static_assert(NGU == 12, "GEN_UNROLLED_* are written out for 12 contacts");
     static_assert(KLIM == 2 && KOS == 4, "the sweeps below are written out for KLIM = 2, KOS = 4");
     // When no env of this wave has a row outside the registers (no robot or object-object contact, no further limit
     // or contact rows), an iteration is one straight-line block: the robot chain (motors, limits) and the object chain
@@ -1182,6 +1302,11 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     OS_ROW_STEP(c0, c1, c2, -hi, hi, 3 * cc + 2);
                 }
             }
+            if (g_unrolled) {      // wave-divergent only between the four envs of the wave
+                if (pass == 0) { GEN_UNROLLED_N } else { GEN_UNROLLED_F }
+            } else if (g_allfast) {
+                if (pass == 0) GEN_SWEEP(0); else GEN_SWEEP(1);
+            } else
             for (int c = n_os; c < nc; c++) {
                 const int meta = *(const int *)&LD(L_META + c);
                 const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta), rslot = meta_rslot(meta), bslot = meta_bslot(meta);
