@@ -235,16 +235,26 @@ __device__ void fk_all(const BodyParams &bp_, const float *q, m3 *bR, v3 *bp, v3
 }
 
 // ---------------------------------------------------------------------------------------------- k_prep
-__global__ void __launch_bounds__(64) k_prep(BodyParams B, SimParams P, DevPtrs D) {
+// The preparation of a step runs as two kernels: PHASE 1 = action
+// protocol, forward kinematics, object terms -- all the collision kernel needs -- and PHASE 2 = joint-space dynamics
+// (mass matrix, bias forces, Cholesky, M^-1, unconstrained velocities), which only the solver needs and which therefore
+// runs on the side stream next to k_collide (both kernels are latency bound with few wavefronts in flight; when the
+// kernels are timed one by one the two halves run back to back and are reported together as "k_prep").
+template <int PHASE>
+__device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &P, const DevPtrs &D) {
     const int N = P.N;
     int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= N) return;
     float *state = D.state, *scratch = D.scratch;
-    if (D.errflags[env] & 1u) return;   // frozen env
-    D.errflags[env] &= ~2u;
+    if (PHASE == 2) { if (D.errflags[env]) return; }    // frozen, or command rejected by phase 1
+    else {
+        if (D.errflags[env] & 1u) return;   // frozen env
+        D.errflags[env] &= ~2u;
+    }
     float q[NB], qd[NB];
 #pragma unroll
     for (int i = 0; i < NB; i++) { q[i] = STT(ST_Q + i); qd[i] = STT(ST_QD + i); }
+    if (PHASE != 2) {
     // ---- action protocol
     float a[9], cur[9];
 #pragma unroll
@@ -277,6 +287,7 @@ __global__ void __launch_bounds__(64) k_prep(BodyParams B, SimParams P, DevPtrs 
     tgt[7] = a[7]; tgt[9] = a[7]; tgt[8] = -a[8]; tgt[10] = -a[8];                        // robot.py:195-201
 #pragma unroll
     for (int i = 0; i < NB; i++) STT(ST_TGT + i) = tgt[i];
+    }
 
     // ---- kinematics
     m3 bR[NB]; v3 bp[NB], bax[NB], bcom[NB]; m3 bI[NB];
@@ -285,11 +296,14 @@ __global__ void __launch_bounds__(64) k_prep(BodyParams B, SimParams P, DevPtrs 
     for (int b = 0; b < NB; b++) {
         bcom[b] = bp[b] + mulv(bR[b], mk(B.com[b][0], B.com[b][1], B.com[b][2]));
         bI[b] = inertia_world(bR[b], B.inertia[b]);
+        if (PHASE != 2) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) SCR(S_BR + 9 * b + k) = bR[b].m[k];
-        SCR(S_BP + 3 * b) = bp[b].x; SCR(S_BP + 3 * b + 1) = bp[b].y; SCR(S_BP + 3 * b + 2) = bp[b].z;
-        SCR(S_BAX + 3 * b) = bax[b].x; SCR(S_BAX + 3 * b + 1) = bax[b].y; SCR(S_BAX + 3 * b + 2) = bax[b].z;
+            for (int k = 0; k < 9; k++) SCR(S_BR + 9 * b + k) = bR[b].m[k];
+            SCR(S_BP + 3 * b) = bp[b].x; SCR(S_BP + 3 * b + 1) = bp[b].y; SCR(S_BP + 3 * b + 2) = bp[b].z;
+            SCR(S_BAX + 3 * b) = bax[b].x; SCR(S_BAX + 3 * b + 1) = bax[b].y; SCR(S_BAX + 3 * b + 2) = bax[b].z;
+        }
     }
+    if (PHASE != 1) {
     // ---- composite rigid body mass matrix
     float cm[NB]; v3 cc[NB]; m3 cI[NB];
 #pragma unroll
@@ -400,6 +414,8 @@ __global__ void __launch_bounds__(64) k_prep(BodyParams B, SimParams P, DevPtrs 
     }
 #pragma unroll
     for (int i = 0; i < NB; i++) SCR(S_QDS + i) = qd[i] + P.dt * qdd[i];
+    }
+    if (PHASE == 2) return;
     // ---- objects: rotation, inverse inertia, unconstrained velocities
     for (int i = 0; i < P.nobj; i++) {
         m3 R = quat_to_m3(STT(ST_OQUAT + 4 * i), STT(ST_OQUAT + 4 * i + 1), STT(ST_OQUAT + 4 * i + 2), STT(ST_OQUAT + 4 * i + 3));
@@ -418,6 +434,8 @@ __global__ void __launch_bounds__(64) k_prep(BodyParams B, SimParams P, DevPtrs 
         SCR(S_OWS + 3 * i) = ws.x; SCR(S_OWS + 3 * i + 1) = ws.y; SCR(S_OWS + 3 * i + 2) = ws.z;
     }
 }
+__global__ void __launch_bounds__(64) k_prep_a(BodyParams B, SimParams P, DevPtrs D) { prep_body<1>(B, P, D); }
+__global__ void __launch_bounds__(64) k_prep_b(BodyParams B, SimParams P, DevPtrs D) { prep_body<2>(B, P, D); }
 
 // ---------------------------------------------------------------------------------------------- k_collide
 struct Xf { m3 R; v3 p; };
@@ -2436,7 +2454,7 @@ struct rr_env {
     bool timing;
     hipEvent_t ev[2 * RR_NUM_KERNELS];
     hipStream_t aux;         // side stream: the HBM-bound static-layer copy runs beside the VALU-bound physics / visibility kernels
-    hipEvent_t ev_fork, ev_join;
+    hipEvent_t ev_fork, ev_join, ev_dyn;
     bool copy_in_flight;
     int n_shapes;
     float t_ms[RR_NUM_KERNELS];
@@ -2507,6 +2525,7 @@ int rr_destroy(rr_env *e) {
     if (e->aux) { hipStreamSynchronize(e->aux); hipStreamDestroy(e->aux); }
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
+    if (e->ev_dyn) hipEventDestroy(e->ev_dyn);
     delete e;
     return RR_OK;
 }
@@ -2737,7 +2756,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     for (int i = 0; i < 2 * RR_NUM_KERNELS; i++) hipEventCreate(&e->ev[i]);
     if (!getenv("RR_NO_AUX_STREAM")) {
         if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
+            hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_dyn, hipEventDisableTiming) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
     }
     e->field_ptr[RR_F_JOINTS] = D.joints; e->field_bytes[RR_F_JOINTS] = (size_t)N * 9 * 4;
     e->field_ptr[RR_F_TOUCH] = D.touch; e->field_bytes[RR_F_TOUCH] = (size_t)N * 4 * 4;
@@ -2863,6 +2882,11 @@ static int do_render(rr_env *e, bool use_flags) {
     return RR_OK;
 }
 
+static void launch_prep_serial(rr_env *e, const DevPtrs &Dp) {
+    hipLaunchKernelGGL(k_prep_a, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp);
+    hipLaunchKernelGGL(k_prep_b, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp);
+}
+
 static void launch_collide(rr_env *e) {
     hipLaunchKernelGGL(k_collide, dim3(e->P.N), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D, e->n_shapes);
 }
@@ -2878,8 +2902,20 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     DevPtrs Dp = e->D;
     if (joint_cmd && cmd_on_device) Dp.cmd = const_cast<float *>(joint_cmd);
     if (render_mode == 2) HIPCHK(hipMemcpyAsync(e->D.render_flags, render_flags_host, N, hipMemcpyHostToDevice, e->stream));
-    TIMED(0, hipLaunchKernelGGL(k_prep, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp));
+    bool dyn_forked = false;
+    if (e->aux && !e->timing && !g_skip) {
+        // phase 1 on the main stream, phase 2 (dynamics, needed by k_solve only) on the side stream beside k_collide
+        hipLaunchKernelGGL(k_prep_a, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp);
+        hipEventRecord(e->ev_fork, e->stream);
+        hipStreamWaitEvent(e->aux, e->ev_fork, 0);
+        hipLaunchKernelGGL(k_prep_b, env_grid(e), dim3(e->epb), 0, e->aux, e->B, e->P, Dp);
+        hipEventRecord(e->ev_dyn, e->aux);
+        dyn_forked = true;
+    } else {
+        TIMED(0, launch_prep_serial(e, Dp));
+    }
     TIMED(1, launch_collide(e));
+    if (dyn_forked) hipStreamWaitEvent(e->stream, e->ev_dyn, 0);
     TIMED(2, hipLaunchKernelGGL(k_solve, dim3((N + SGRP - 1) / SGRP), dim3(SGRP * 16), 0, e->stream, e->B, e->P, e->D));
     HIPCHK(hipGetLastError());
     if (render_mode) return do_render(e, render_mode == 2);
