@@ -2095,14 +2095,14 @@ extern "C" int rr_debug_raster_stats(unsigned long long *out16, int reset) {
 // shelf, robot base link_0; one launch at creation, result shared by all envs).  Output: the list of pixels won by a
 // rasterised triangle {depth bits, pixel-in-tile << 18 | triangle}, shaded by k_shade; everything else in the image is the
 // static layer, copied by k_static_copy.
-__global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int pass) {
+__global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int pass, int env0) {
     const RenderModel &RM = *RMp;
     __shared__ unsigned long long vis[TILE_PIX];
     __shared__ float mvp[MAXINST][16];
     __shared__ unsigned nlist, wcount, wnext;
     __shared__ unsigned short wlist[MAXWIN];
     __shared__ unsigned char seg[RASTER_THREADS / 64][SEG_CAP];
-    const int env = blockIdx.x, tile = blockIdx.y;
+    const int env = blockIdx.x + env0, tile = blockIdx.y;
     if (pass == 0 && D.render_flags && !D.render_flags[env]) return;
     const int W = RM.W, H = RM.H;
     const int row0 = tile * RM.tile_h;
@@ -2365,11 +2365,11 @@ __global__ void k_background(const RenderModel *RMp, DevPtrs D) {
 // chunk lies beyond the list exit at once): the longest list no longer sets the tail of the launch.
 #define SHADE_THREADS 256
 #define SHADE_SPLIT 8
-__global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags) {
+__global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags, int env0) {
     const RenderModel &RM = *RMp;
     __shared__ float mvp[MAXINST][16];
     __shared__ float sinst[MAXINST][16];
-    const int env = blockIdx.x, tile = blockIdx.y;
+    const int env = blockIdx.x + env0, tile = blockIdx.y;
     if (use_flags && D.render_flags && !D.render_flags[env]) return;
     const unsigned n = D.frag_count[(size_t)env * RM.ntiles + tile];
     if (blockIdx.z * SHADE_THREADS >= n) return;
@@ -2455,7 +2455,6 @@ struct rr_env {
     hipEvent_t ev[2 * RR_NUM_KERNELS];
     hipStream_t aux;         // side stream: the HBM-bound static-layer copy runs beside the VALU-bound physics / visibility kernels
     hipEvent_t ev_fork, ev_join, ev_dyn;
-    bool copy_in_flight;
     int n_shapes;
     float t_ms[RR_NUM_KERNELS];
     int t_n[RR_NUM_KERNELS];
@@ -2546,8 +2545,8 @@ static int build_static_layer(rr_env *e) {
         so.rgb = e->D.static_rgb; so.depth = e->D.static_depth; so.mask = e->D.static_mask; so.env_stride = 0;
         e->D.static_vis = nullptr;
         hipLaunchKernelGGL(k_render_setup, dim3((e->P.N * MAXINST + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D);
-        hipLaunchKernelGGL(k_raster, dim3(1, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1);
-        hipLaunchKernelGGL(k_shade, dim3(1, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, e->D, so, 0);
+        hipLaunchKernelGGL(k_raster, dim3(1, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1, 0);
+        hipLaunchKernelGGL(k_shade, dim3(1, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, e->D, so, 0, 0);
     }
     if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(RR_EDEVICE, "static layer pass failed");
     e->D.static_vis = e->D.static_vis_out;
@@ -2845,39 +2844,29 @@ static int g_skip = getenv("RR_SKIP") ? atoi(getenv("RR_SKIP")) : 0;
         }                                                                   \
     } while (0)
 
-// The static-layer copy only depends on work already enqueued on the main stream (the previous frame's consumers and the
-// render flags): it is forked to the side stream next to k_raster -- the copy is HBM-write bound, the visibility pass is
-// VALU bound with one 16-wave workgroup per CU, so the two share the CUs well (beside the latency-bound physics kernels
-// the copy only slowed those down) -- and joined before k_shade.  In timing mode every kernel runs alone on the main
-// stream.
-static void fork_static_copy(rr_env *e, bool use_flags) {
-    e->copy_in_flight = false;
-    if (!e->aux || e->timing || ((g_skip >> 5) & 1)) return;
-    DevPtrs D = e->D;
-    if (!use_flags) D.render_flags = nullptr;
-    const int copy_blocks = std::min(16, (e->RM.W * e->RM.H / 4 + COPY_THREADS - 1) / COPY_THREADS);
-    hipEventRecord(e->ev_fork, e->stream);
-    hipStreamWaitEvent(e->aux, e->ev_fork, 0);
-    hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, e->P.N), dim3(COPY_THREADS), 0, e->aux, e->RM_dev, D, env_images(e), 1);
-    hipEventRecord(e->ev_join, e->aux);
-    e->copy_in_flight = true;
-}
-
 static int do_render(rr_env *e, bool use_flags) {
     DevPtrs D = e->D;
     if (!use_flags) D.render_flags = nullptr;
-    TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((e->P.N * MAXINST + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, D));
-    fork_static_copy(e, use_flags);
-    TIMED(4, hipLaunchKernelGGL(k_raster, dim3(e->P.N, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, D, e->n_inst_used, 0));
+    const int N = e->P.N;
+    TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, D));
     const ImageOut io = env_images(e);
-    if (e->copy_in_flight) {
-        hipStreamWaitEvent(e->stream, e->ev_join, 0);
-        e->copy_in_flight = false;
-    } else {
-        const int copy_blocks = std::min(16, (e->RM.W * e->RM.H / 4 + COPY_THREADS - 1) / COPY_THREADS);
-        TIMED(5, hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, e->P.N), dim3(COPY_THREADS), 0, e->stream, e->RM_dev, D, io, 1));
+    const int copy_blocks = std::min(16, (e->RM.W * e->RM.H / 4 + COPY_THREADS - 1) / COPY_THREADS);
+    const bool forked = e->aux && !e->timing && !g_skip;
+    if (forked) {
+        // The static-layer copy only depends on work already enqueued on the main stream (the previous frame's consumers,
+        // the render flags): it runs on the side stream beside k_raster -- the copy is HBM-write bound, the visibility
+        // pass VALU bound with one LDS-filling workgroup per CU -- and is joined before k_shade.  (Also tried: pipelining
+        // k_shade of one env chunk against k_raster of the next on the two streams; 2 chunks +7 %, 8 chunks +50 % step
+        // time -- both passes want the VALU and the chunked launches add tails -- so the stage stays three full launches.)
+        hipEventRecord(e->ev_fork, e->stream);
+        hipStreamWaitEvent(e->aux, e->ev_fork, 0);
+        hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, N), dim3(COPY_THREADS), 0, e->aux, e->RM_dev, D, io, 1);
+        hipEventRecord(e->ev_join, e->aux);
     }
-    TIMED(6, hipLaunchKernelGGL(k_shade, dim3(e->P.N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, D, io, 1));
+    TIMED(4, hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, D, e->n_inst_used, 0, 0));
+    if (forked) hipStreamWaitEvent(e->stream, e->ev_join, 0);
+    else TIMED(5, hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, N), dim3(COPY_THREADS), 0, e->stream, e->RM_dev, D, io, 1));
+    TIMED(6, hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, D, io, 1, 0));
     HIPCHK(hipGetLastError());
     return RR_OK;
 }
