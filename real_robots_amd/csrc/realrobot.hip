@@ -1855,12 +1855,16 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 // ---------------------------------------------------------------------------------------------- rasteriser
 // One workgroup per (env, tile). Tile = full-width strip of tile_h rows (<= 16384 pixels -> 128 KiB of LDS keys).
 #define RASTER_THREADS 1024
+#ifndef TILE_PIX
 #define TILE_PIX 16384
+#endif
 #define MAXWIN 1024      // 64-triangle windows per model (rr_create checks nt)
 #ifndef INLINE_PIX
 #define INLINE_PIX 2     // sample points of a small triangle walked by its own lane; the rest is redistributed over the wave
 #endif
+#ifndef SEG_CAP
 #define SEG_CAP 1024     // slots of the per-wave redistribution list (bytes of LDS)
+#endif
 #define SMALL_AREA 64    // bbox area (sample points) up to which a triangle takes the per-lane + redistribution path (A/B: 16 0.60, 32 0.54, 64 0.53, 128 0.54 ms)
 
 struct STri { float sx[3], sy[3], sz[3], w[3]; };
@@ -2127,6 +2131,13 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     const int t_stop = ABL(8) ? 0 : t_end;
     const int lane = tid & 63, lx = lane & 7, ly = lane >> 3;
     const int nwin = (t_stop - t_begin + 63) >> 6;
+    // tile bounds as two more planes of the cull (multi-tile images): NDC y of the tile's first and last sample rows
+    const float ndc_a = 2.0f * ty0 / (float)H - 1.0f, ndc_b = 2.0f * ty1 / (float)H - 1.0f;
+    const float nrm_a = sqrtf((RM.VP[4] - ndc_a * RM.VP[12]) * (RM.VP[4] - ndc_a * RM.VP[12]) + (RM.VP[5] - ndc_a * RM.VP[13]) * (RM.VP[5] - ndc_a * RM.VP[13]) +
+                              (RM.VP[6] - ndc_a * RM.VP[14]) * (RM.VP[6] - ndc_a * RM.VP[14]));
+    const float nrm_b = sqrtf((RM.VP[4] - ndc_b * RM.VP[12]) * (RM.VP[4] - ndc_b * RM.VP[12]) + (RM.VP[5] - ndc_b * RM.VP[13]) * (RM.VP[5] - ndc_b * RM.VP[13]) +
+                              (RM.VP[6] - ndc_b * RM.VP[14]) * (RM.VP[6] - ndc_b * RM.VP[14]));
+    const bool tiled = RM.ntiles > 1;
     for (int wi = tid; wi < nwin; wi += RASTER_THREADS) {
         const int tb = t_begin + (wi << 6);
         const int inst = D.tri_inst[tb];
@@ -2136,7 +2147,8 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         const float cw = m[12] * cs.x + m[13] * cs.y + m[14] * cs.z + m[15];
         const float r = cs.w * 1.001f + 1e-4f;      // conservative
         const bool out = (cw + cx) < -r * RM.plane_norm[0] || (cw - cx) < -r * RM.plane_norm[1] || (cw + cy) < -r * RM.plane_norm[2] ||
-                         (cw - cy) < -r * RM.plane_norm[3] || (cw - 0.1f) < -r * RM.plane_norm[4];
+                         (cw - cy) < -r * RM.plane_norm[3] || (cw - 0.1f) < -r * RM.plane_norm[4] ||
+                         (tiled && ((ndc_a * cw - cy) > r * nrm_a * 1.001f + 1e-4f * cw || (cy - ndc_b * cw) > r * nrm_b * 1.001f + 1e-4f * cw));
         RSTAT(0, 1);                                // windows
         if (!out && inst < n_inst_used) wlist[atomicAdd(&wcount, 1u)] = (unsigned short)wi;
     }
