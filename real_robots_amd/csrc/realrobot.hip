@@ -720,13 +720,14 @@ static_assert(L_TOTAL * 16 * 4 <= 163840, "16 solver slabs must fit the 160 KiB 
 static_assert(L_BASE % 4 == 0 && L_TOTAL % 4 == 0, "base parts must be 16-byte aligned");
 __shared__ __attribute__((aligned(16))) float g_slds[L_TOTAL * SGRP];
 #define LD(slot) g_slds[grp * L_TOTAL + (slot)]
-// Overflow rows in global memory are shared between the 16 lanes of a group (lane 0 writes rhs/dinv/lambda, every
-// lane reads them): the accesses bypass the per-CU vector L1 (agent-scope relaxed atomics -> sc1) and stores are
-// drained with a wavefront fence before other lanes read them.
+// Overflow rows in global memory: the immutable part (Jacobians, directions, rhs, dinv) is written during the row build
+// and made visible to the other lanes of the group with ONE agent-scope fence before the sweeps; the mutable part
+// (lambda) is owned by lane 0, which alone reads and writes it and broadcasts the impulse change with a DPP row
+// broadcast -- plain cached loads and stores, no atomics or fences inside the sweeps.
 #define ROW_ADDR(r, f) (&SCR(S_ROWS + (r) * ROWF + (f)))
-#define ROWL(r, f) __hip_atomic_load(ROW_ADDR(r, f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define ROWS(r, f, v) __hip_atomic_store(ROW_ADDR(r, f), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define ROW_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#define ROWL(r, f) (*ROW_ADDR(r, f))
+#define ROWS(r, f, v) (*ROW_ADDR(r, f) = (v))
+#define ROW_FENCE()
 
 // meta word: bodyA (8) | bodyB (8) | linkA (8) | robot slot (4, 15 = none/global) | Bside slot (4, 15 = none/global)
 __device__ __forceinline__ int meta_bodyA(int m) { return (signed char)(m & 255); }
@@ -891,7 +892,8 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         const unsigned long long bal = __ballot(cntl > 0);
         pmask[k] = (unsigned)(bal >> (16 * grp)) & 0xffffu;
     }
-    int nc = 0, gidx = 0;      // gidx: index among the generic (not object-vs-static) contacts, which all follow the object-vs-static ones
+    int nc = 0, gidx = 0, n_oo = 0;   // gidx: index among the generic (not object-vs-static) contacts, which all follow the
+                                      // object-vs-static ones; n_oo: object-object contacts (their pairs precede the robot pairs)
     static_assert(MAXPAIRS / 16 == 6, "pair-mask select chain below");
 #pragma unroll 1        // one copy of the (large) row-building body: the kernel must stay inside the instruction cache
     for (int k = 0; k < MAXPAIRS / 16; k++)
@@ -944,10 +946,10 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             const float dist = c7[6];
             int rslot = 15, bslot = 15;
             bool fast = nc < LC;
-            // the robot / Bside part of generic contact j lives in slot j of its LDS section: sweep code finds it without
-            // reading the meta word (object-object pairs precede the robot pairs, so they get the low Bside slots)
-            if (robot) { if (gidx < LR && fast) rslot = gidx; else fast = false; }
-            if (objobj) { if (gidx < LB && fast) bslot = gidx; else fast = false; }
+            // the Bside part of generic contact j lives in slot j, its robot part in slot j - n_oo of the LDS sections
+            // (object-object pairs precede the robot pairs): sweep code finds them without reading the meta word
+            if (robot) { if (gidx - n_oo < LR && fast) rslot = gidx - n_oo; else fast = false; }
+            if (objobj) { if (gidx < LB && fast) bslot = gidx; else fast = false; n_oo = gidx + 1; }
             if (robot || objobj) gidx++;
             if (!fast) { rslot = 15; bslot = 15; }
             // "fast" is recoverable from the meta word: c < LC and (no robot side or rslot != 15) and (no B object or bslot != 15)
@@ -1149,73 +1151,20 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         if (lo_ >= 0 && bodyB == 16 + lo_) g_ownB |= bit;
     }
     const int G = nc - n_os;
-    struct GenRow { float4 b0, b1, b2; float jal, mjal, q0, q1, q2, q3, q4, q5, ln, mu; };
-    // loads of generic row step idx of pass p (p = 0: normal rows, p = 1: the two friction rows of every contact)
-#define GEN_LOAD(row_, p_, idx_)                                                                                   \
-    do {                                                                                                           \
-        const int j_ = (p_) == 0 ? (idx_) : (idx_) >> 1, k_ = (p_) == 0 ? 0 : 1 + ((idx_) & 1);                   \
-        const int c_ = n_os + j_, r_ = 3 * c_ + k_;                                                                \
-        const bool rb_ = (g_robot >> j_) & 1u, oo_ = (g_objobj >> j_) & 1u;                                        \
-        const int orb_ = rb_ ? L_ROB + (j_ * 3 + k_) * 22 + lj : lj;                                               \
-        const int obs_ = L_BS + ((oo_ ? j_ : 0) * 3 + k_) * 6;                                                     \
-        (row_).b0 = LDB4(r_, 0); (row_).b1 = LDB4(r_, 4); (row_).b2 = LDB4(r_, 8);                                 \
-        (row_).jal = LD(orb_); (row_).mjal = LD(orb_ + 11);                                                        \
-        (row_).q0 = LD(obs_); (row_).q1 = LD(obs_ + 1); (row_).q2 = LD(obs_ + 2);                                  \
-        (row_).q3 = LD(obs_ + 3); (row_).q4 = LD(obs_ + 4); (row_).q5 = LD(obs_ + 5);                              \
-        (row_).ln = LD(L_BASE + (3 * c_) * 12 + 11); (row_).mu = LD(L_MU + c_);                                    \
-    } while (0)
-#define GEN_STEP(row_, p_, idx_)                                                                                   \
-    do {                                                                                                           \
-        const int j_ = (p_) == 0 ? (idx_) : (idx_) >> 1, k_ = (p_) == 0 ? 0 : 1 + ((idx_) & 1);                   \
-        const int r_ = 3 * (n_os + j_) + k_;                                                                       \
-        const bool mineA_ = (g_ownA >> j_) & 1u, mineB_ = (g_ownB >> j_) & 1u;                                     \
-        const bool own_ = mineA_ || mineB_, rob_ = ((g_robot >> j_) & 1u) && l < NB;                               \
-        const bool useB_ = ((g_objobj >> j_) & 1u) && mineB_;                                                      \
-        const float sgn_ = mineA_ ? 1.0f : -1.0f;                                                                  \
-        const float hi_ = (p_) == 0 ? 1e10f : (row_).mu * (row_).ln, lo_b = (p_) == 0 ? 0.0f : -hi_;              \
-        const v3 dir_ = mk((row_).b0.x, (row_).b0.y, (row_).b0.z);                                                 \
-        const v3 ang_ = mk(useB_ ? (row_).q0 : (row_).b0.w, useB_ ? (row_).q1 : (row_).b1.x, useB_ ? (row_).q2 : (row_).b1.y); \
-        const v3 mang_ = mk(useB_ ? (row_).q3 : (row_).b1.z, useB_ ? (row_).q4 : (row_).b1.w, useB_ ? (row_).q5 : (row_).b2.x); \
-        const float part_ = own_ ? sgn_ * dot(dir_, dv) + dot(ang_, dw) : (rob_ ? (row_).jal * dq : 0.0f);         \
-        const float jv_ = group_sum(part_);                                                                        \
-        const float lam_ = (row_).b2.w;                                                                            \
-        const float dl0_ = (row_).b2.y - jv_ * (row_).b2.z;                                                        \
-        const float s0_ = lam_ + dl0_;                                                                             \
-        const float sum_ = fminf(fmaxf(s0_, lo_b), hi_);                                                           \
-        const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - lam_;                                                      \
-        LD(L_BASE + r_ * 12 + 11) = sum_;                                                                          \
-        dq += rob_ ? (row_).mjal * dl_ : 0.0f;                                                                     \
-        const float so_ = own_ ? dl_ : 0.0f, sm_ = sgn_ * so_ * inv_mass;                                          \
-        dv = dv + dir_ * sm_;                                                                                      \
-        dw = dw + mk(own_ ? mang_.x * dl_ : 0.0f, own_ ? mang_.y * dl_ : 0.0f, own_ ? mang_.z * dl_ : 0.0f);       \
-    } while (0)
-#define GEN_SWEEP(p_)                                                                                              \
-    do {                                                                                                           \
-        const int R_ = (p_) == 0 ? G : 2 * G;                                                                      \
-        if (R_ > 0) {                                                                                              \
-            GenRow cur_, nxt_;                                                                                     \
-            GEN_LOAD(cur_, p_, 0);                                                                                 \
-            nxt_ = cur_;                                                                                           \
-            for (int idx = 0; idx < R_; idx++) {                                                                   \
-                if (idx + 1 < R_) GEN_LOAD(nxt_, p_, idx + 1);                                                     \
-                GEN_STEP(cur_, p_, idx);                                                                           \
-                cur_ = nxt_;                                                                                       \
-            }                                                                                                      \
-        }                                                                                                          \
-    } while (0)
     // Up to NGU generic contacts: fully written-out sweep.  Contact index, row offsets and slots are compile-time
     // constants, so a row step is ~45 instructions (immediate-offset LDS reads, bit tests on the role masks) instead of
     // ~120 with run-time addressing -- with one wave per SIMD a row costs (instructions x ~8 cycles).  The normal impulse
     // and the friction coefficient of each contact stay in registers between the two passes.
 #define NGU 12
     const bool g_unrolled = g_allfast && G <= NGU;
-    const int gbase = grp * L_TOTAL + L_BASE + n_os * 36, rbase = grp * L_TOTAL + L_ROB + lj, bbase = grp * L_TOTAL + L_BS;
+    const int gbase = grp * L_TOTAL + L_BASE + n_os * 36, rbase = grp * L_TOTAL + L_ROB + lj - n_oo * 66, bbase = grp * L_TOTAL + L_BS;
     float gln[NGU], gmu[NGU];
 #pragma unroll
     for (int j = 0; j < NGU; j++) { gln[j] = 0.0f; gmu[j] = (g_unrolled && j < G) ? LD(L_MU + n_os + j) : 0.0f; }
 #define GROW(J, K, LOB, HIB)                                                                                       \
     {                                                                                                              \
-        const int ro_ = gbase + ((J) * 3 + (K)) * 12, rr_ = rbase + ((J) * 3 + (K)) * 22;                         \
+        const int ro_ = gbase + ((J) * 3 + (K)) * 12;                                                              \
+        const int rr_ = ((g_robot >> (J)) & 1u) ? rbase + ((J) * 3 + (K)) * 22 : grp * L_TOTAL + lj;   /* harmless address when no robot part */ \
         const float4 b0_ = *(const float4 *)&g_slds[ro_], b1_ = *(const float4 *)&g_slds[ro_ + 4], b2_ = *(const float4 *)&g_slds[ro_ + 8]; \
         const float jal_ = g_slds[rr_], mjal_ = g_slds[rr_ + 11];                                                  \
         const bool mineA_ = (g_ownA >> (J)) & 1u, mineB_ = (g_ownB >> (J)) & 1u;                                   \
@@ -1248,12 +1197,16 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
 #define GEN_UNROLLED_N GNORMAL(0) GNORMAL(1) GNORMAL(2) GNORMAL(3) GNORMAL(4) GNORMAL(5) GNORMAL(6) GNORMAL(7) GNORMAL(8) GNORMAL(9) GNORMAL(10) GNORMAL(11)
 #define GEN_UNROLLED_F GFRICT(0) GFRICT(1) GFRICT(2) GFRICT(3) GFRICT(4) GFRICT(5) GFRICT(6) GFRICT(7) GFRICT(8) GFRICT(9) GFRICT(10) GFRICT(11)
     static_assert(NGU == 12, "GEN_UNROLLED_* are written out for 12 contacts");
+    if (__ballot(!g_allfast)) __threadfence();       // rows built in global memory become visible to the group's other lanes
     static_assert(KLIM == 2 && KOS == 4, "the sweeps below are written out for KLIM = 2, KOS = 4");
     // When no env of this wave has a row outside the registers (no robot or object-object contact, no further limit
     // or contact rows), an iteration is one straight-line block: the robot chain (motors, limits) and the object chain
     // (normals, frictions) are independent and the scheduler overlaps them.
     const bool simple = __ballot(!(nc == n_os && own_os == 0 && limmask == 0)) == 0ull;
     for (int it = 0; it < P.iters; it++) {
+        // compiler barrier: the row data in LDS / global memory is loop invariant, but hoisting hundreds of such loads out
+        // of the sweep loop exhausts the register file (everything that should live in registers is held explicitly)
+        asm volatile("" ::: "memory");
         if (simple) {
             SWEEP_MOTORS
             LIMIT_STEP(0) LIMIT_STEP(1)
@@ -1322,8 +1275,6 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             }
             if (g_unrolled) {      // wave-divergent only between the four envs of the wave
                 if (pass == 0) { GEN_UNROLLED_N } else { GEN_UNROLLED_F }
-            } else if (g_allfast) {
-                if (pass == 0) GEN_SWEEP(0); else GEN_SWEEP(1);
             } else
             for (int c = n_os; c < nc; c++) {
                 const int meta = *(const int *)&LD(L_META + c);
@@ -1376,9 +1327,10 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     }
                     continue;
                 }
-                // overflow contact: rows in global memory (same arithmetic)
-                const float ln = ROWL(3 * c, 39);
+                // overflow contact: rows in global memory (same arithmetic; lane 0 owns rhs / dinv / lambda)
                 const float mu = SCR(S_CT + c * 12 + 11);
+                float ln = 0.0f;
+                if (l == 0) ln = ROWL(3 * c, 39);
                 for (int r = r0; r < r1; r++) {
                     float lo = 0, hi = 1e10f;
                     if (pass == 1) { hi = mu * ln; lo = -hi; }
@@ -1386,19 +1338,22 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     v3 ang = mk(0, 0, 0), mang = mk(0, 0, 0);
                     float mja = 0;
                     const v3 dir = mk(ROWL(r, 22), ROWL(r, 23), ROWL(r, 24));
-                    const float rhs = ROWL(r, 37), dinv = ROWL(r, 38), lam = ROWL(r, 39);
                     if (robot && l < NB) { part = ROWL(r, l) * dq; mja = ROWL(r, 11 + l); }
                     if (mineA) { ang = mk(ROWL(r, 25), ROWL(r, 26), ROWL(r, 27)); mang = mk(ROWL(r, 28), ROWL(r, 29), ROWL(r, 30)); }
                     if (mineB) { ang = mk(ROWL(r, 31), ROWL(r, 32), ROWL(r, 33)); mang = mk(ROWL(r, 34), ROWL(r, 35), ROWL(r, 36)); }
                     if (mineA) part = dot(dir, dv) + dot(ang, dw);
                     if (mineB) part = -dot(dir, dv) + dot(ang, dw);
                     const float jv = group_sum(part);
-                    float dl = rhs - jv * dinv;
-                    float sum = lam + dl;
-                    if (sum < lo) { dl = lo - lam; sum = lo; }
-                    else if (sum > hi) { dl = hi - lam; sum = hi; }
-                    if (l == 0) ROWS(r, 39, sum);
-                    ROW_FENCE();
+                    float dl = 0.0f;
+                    if (l == 0) {
+                        const float rhs = ROWL(r, 37), dinv = ROWL(r, 38), lam = ROWL(r, 39);
+                        dl = rhs - jv * dinv;
+                        float sum = lam + dl;
+                        if (sum < lo) { dl = lo - lam; sum = lo; }
+                        else if (sum > hi) { dl = hi - lam; sum = hi; }
+                        ROWS(r, 39, sum);
+                    }
+                    dl = row_bcast<0>(dl);
                     dq += mja * dl;
                     if (mineA) { dv = dv + dir * (dl * inv_mass); dw = dw + mang * dl; }
                     if (mineB) { dv = dv + dir * (-dl * inv_mass); dw = dw + mang * dl; }
