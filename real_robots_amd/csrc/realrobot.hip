@@ -2327,11 +2327,12 @@ __global__ void k_background(const RenderModel *RMp, DevPtrs D) {
     }
 }
 
-// Deferred shading of the fragment lists, one lane per listed pixel.  Fragment counts vary from 0 to the whole tile
-// between envs, so every (env, tile) list is dealt out in 256-entry chunks to SHADE_SPLIT workgroups (blocks whose first
-// chunk lies beyond the list exit at once): the longest list no longer sets the tail of the launch.
-#define SHADE_THREADS 256
-#define SHADE_SPLIT 8
+// Deferred shading of the fragment lists, one lane per listed pixel.  Every (env, tile) list is dealt out in
+// SHADE_THREADS-entry chunks to SHADE_SPLIT workgroups (blocks whose first chunk lies beyond the list exit at once).
+// A/B (k_shade, ms): 64x16 0.175, 128x8 0.145, 256x8 0.131, 256x2 0.122, 512x2 0.119, 1024x1 0.120 -- the per-block
+// staging of the instance constants outweighs the tail of long lists.
+#define SHADE_THREADS 512
+#define SHADE_SPLIT 2
 __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags, int env0) {
     const RenderModel &RM = *RMp;
     __shared__ float mvp[MAXINST][16];
