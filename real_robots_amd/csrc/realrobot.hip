@@ -121,7 +121,7 @@ struct DevPtrs {
     float *joints;     // [N][9]
     float *touch;      // [N][4]
     float *objpose;    // [N][nobj][7]
-    float *inst_xf;    // [N][MAXINST][12]  (R row-major 9, p 3)
+    float *inst_xf;    // [N][MAXINST][32]  per-instance render constants: mvp (16), then R (9), colour (3), tex_off, tex_w, tex_h, uid
     unsigned char *render_flags; // [N]
     unsigned char *rgb; float *depth; int *mask;
     const float *tri_pos;   // SoA [9][NT]
@@ -1537,10 +1537,33 @@ __global__ void __launch_bounds__(64) k_render_setup(BodyParams B, SimParams P, 
         R = quat_to_m3(STT(ST_OQUAT + 4 * oi), STT(ST_OQUAT + 4 * oi + 1), STT(ST_OQUAT + 4 * oi + 2), STT(ST_OQUAT + 4 * oi + 3));
         p = mk(STT(ST_OPOS + 3 * oi), STT(ST_OPOS + 3 * oi + 1), STT(ST_OPOS + 3 * oi + 2));
     }
-    float4 *o = (float4 *)(D.inst_xf + ((size_t)env * MAXINST + i) * 12);
-    o[0] = make_float4(R.m[0], R.m[1], R.m[2], R.m[3]);
-    o[1] = make_float4(R.m[4], R.m[5], R.m[6], R.m[7]);
-    o[2] = make_float4(R.m[8], p.x, p.y, p.z);
+    // mvp = VP * [R p; 0 1] (same summation order as the oracle's 4x4 product, no FMA contraction), then the shading
+    // constants: the raster and shading workgroups just copy these 128 bytes per instance into LDS
+    float mvp[16];
+    {
+#pragma clang fp contract(off)
+        const float xf[12] = {R.m[0], R.m[1], R.m[2], R.m[3], R.m[4], R.m[5], R.m[6], R.m[7], R.m[8], p.x, p.y, p.z};
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int r = e >> 2, c = e & 3;
+            float a = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) a += RM.VP[4 * r + k] * (c < 3 ? xf[3 * k + c] : xf[9 + k]);
+            a += RM.VP[4 * r + 3] * (c == 3 ? 1.0f : 0.0f);
+            mvp[e] = a;
+        }
+    }
+    const int tidx = RM.in_tex[i];
+    float4 *o = (float4 *)(D.inst_xf + ((size_t)env * MAXINST + i) * 32);
+    o[0] = make_float4(mvp[0], mvp[1], mvp[2], mvp[3]);
+    o[1] = make_float4(mvp[4], mvp[5], mvp[6], mvp[7]);
+    o[2] = make_float4(mvp[8], mvp[9], mvp[10], mvp[11]);
+    o[3] = make_float4(mvp[12], mvp[13], mvp[14], mvp[15]);
+    o[4] = make_float4(R.m[0], R.m[1], R.m[2], R.m[3]);
+    o[5] = make_float4(R.m[4], R.m[5], R.m[6], R.m[7]);
+    o[6] = make_float4(R.m[8], RM.in_color[i][0], RM.in_color[i][1], RM.in_color[i][2]);
+    o[7] = make_float4(__int_as_float(tidx >= 0 ? RM.tex_off[tidx] : 0), __int_as_float(tidx >= 0 ? RM.tex_w[tidx] : 0),
+                       __int_as_float(tidx >= 0 ? RM.tex_h[tidx] : 0), __int_as_float(RM.in_uid[i]));
 }
 
 // link poses (COM frame) for rr_link_poses
@@ -2003,32 +2026,15 @@ __device__ __forceinline__ void shade_pixel(const ShadeCtx &c, int t, int px, in
     mask = __float_as_int(xf[15]);
 }
 
-// Stages the per-instance constants of one env in LDS: mvp = VP * [R p; 0 1] (same summation order as the oracle's 4x4
-// product, no FMA contraction) and, when sinst != nullptr, the shading constants. Caller synchronises.
+// Stages the per-instance constants of one env (computed by k_render_setup) in LDS: mvp and, when sinst != nullptr, the
+// shading constants. A plain copy, 16 bytes per thread. Caller synchronises.
 __device__ __forceinline__ void stage_instances(const RenderModel &RM, const DevPtrs &D, int env, int tid, int nthreads,
                                                 float (*mvp)[16], float (*sinst)[16]) {
-    for (int i = tid; i < RM.ni * 16; i += nthreads) {
-        const int inst = i >> 4, e = i & 15, r = e >> 2, c = e & 3;
-        const float *xf = D.inst_xf + ((size_t)env * MAXINST + inst) * 12;
-        {
-#pragma clang fp contract(off)
-            float a = 0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) a += RM.VP[4 * r + k] * (c < 3 ? xf[3 * k + c] : xf[9 + k]);
-            a += RM.VP[4 * r + 3] * (c == 3 ? 1.0f : 0.0f);
-            mvp[inst][e] = a;
-        }
-        if (sinst) {
-            const int tidx = RM.in_tex[inst];
-            float sv;
-            if (e < 9) sv = xf[e];
-            else if (e < 12) sv = RM.in_color[inst][e - 9];
-            else if (e == 12) sv = __int_as_float(tidx >= 0 ? RM.tex_off[tidx] : 0);
-            else if (e == 13) sv = __int_as_float(tidx >= 0 ? RM.tex_w[tidx] : 0);
-            else if (e == 14) sv = __int_as_float(tidx >= 0 ? RM.tex_h[tidx] : 0);
-            else sv = __int_as_float(RM.in_uid[inst]);
-            sinst[inst][e] = sv;
-        }
+    const float4 *src = (const float4 *)(D.inst_xf + (size_t)env * MAXINST * 32);
+    for (int i = tid; i < RM.ni * 8; i += nthreads) {
+        const int inst = i >> 3, q = i & 7;
+        if (q < 4) *(float4 *)&mvp[inst][4 * q] = src[i];
+        else if (sinst) *(float4 *)&sinst[inst][4 * (q - 4)] = src[i];
     }
 }
 
@@ -2057,7 +2063,7 @@ extern "C" int rr_debug_raster_stats(unsigned long long *out16, int reset) {
 __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int pass, int env0) {
     const RenderModel &RM = *RMp;
     __shared__ unsigned long long vis[TILE_PIX];
-    __shared__ float mvp[MAXINST][16];
+    __shared__ __attribute__((aligned(16))) float mvp[MAXINST][16];
     __shared__ unsigned nlist, wcount, wnext;
     __shared__ unsigned short wlist[MAXWIN];
     __shared__ unsigned char seg[RASTER_THREADS / 64][SEG_CAP];
@@ -2335,8 +2341,8 @@ __global__ void k_background(const RenderModel *RMp, DevPtrs D) {
 #define SHADE_SPLIT 2
 __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags, int env0) {
     const RenderModel &RM = *RMp;
-    __shared__ float mvp[MAXINST][16];
-    __shared__ float sinst[MAXINST][16];
+    __shared__ __attribute__((aligned(16))) float mvp[MAXINST][16];
+    __shared__ __attribute__((aligned(16))) float sinst[MAXINST][16];
     const int env = blockIdx.x + env0, tile = blockIdx.y;
     if (use_flags && D.render_flags && !D.render_flags[env]) return;
     const unsigned n = D.frag_count[(size_t)env * RM.ntiles + tile];
@@ -2661,7 +2667,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     ALLOC(D.joints, (size_t)N * 9);
     ALLOC(D.touch, (size_t)N * 4);
     ALLOC(D.objpose, (size_t)N * P.nobj * 7);
-    ALLOC(D.inst_xf, (size_t)N * MAXINST * 12);
+    ALLOC(D.inst_xf, (size_t)N * MAXINST * 32);
     ALLOC(D.render_flags, (size_t)N);
     const size_t npx = (size_t)N * RM.W * RM.H;
     ALLOC(D.rgb, npx * 3);
