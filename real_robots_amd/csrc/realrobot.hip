@@ -2308,10 +2308,10 @@ struct ImageOut { unsigned char *rgb; float *depth; int *mask; size_t env_stride
 // Copies the static layer (or the background when there is none) into the images of every rendered env: 4 pixels per
 // thread (W % 4 == 0 enforced at create).  Pure streaming: reads hit L2, writes are the obs bytes of SURVEY 8(d).
 #define COPY_THREADS 256
-__global__ void __launch_bounds__(COPY_THREADS) k_static_copy(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags) {
-    const int env = blockIdx.y;
-    if (use_flags && D.render_flags && !D.render_flags[env]) return;
+__global__ void __launch_bounds__(COPY_THREADS) k_static_copy(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags, int N) {
     const int ngroups = (RMp->W * RMp->H) >> 2;
+    for (int env = blockIdx.y; env < N; env += gridDim.y) {
+    if (use_flags && D.render_flags && !D.render_flags[env]) continue;
     const size_t base = (size_t)env * out.env_stride;
     for (int g = blockIdx.x * COPY_THREADS + threadIdx.x; g < ngroups; g += gridDim.x * COPY_THREADS) {
         const unsigned *srgb = (const unsigned *)(D.static_rgb) + (size_t)3 * g;
@@ -2321,6 +2321,7 @@ __global__ void __launch_bounds__(COPY_THREADS) k_static_copy(const RenderModel 
         rgbp[0] = r0; rgbp[1] = r1; rgbp[2] = r2;
         *(float4 *)(out.depth + base + (size_t)4 * g) = dv;
         if (out.mask) *(int4 *)(out.mask + base + (size_t)4 * g) = *(const int4 *)(D.static_mask + (size_t)4 * g);
+    }
     }
 }
 
@@ -2834,12 +2835,16 @@ static int do_render(rr_env *e, bool use_flags) {
         // time -- both passes want the VALU and the chunked launches add tails -- so the stage stays three full launches.)
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
-        hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, N), dim3(COPY_THREADS), 0, e->aux, e->RM_dev, D, io, 1);
+        // throttled: 16 x 16 persistent workgroups (about one per CU) that walk all envs -- the copy has the whole
+        // visibility pass to finish in, and at full width it slowed that pass down (A/B step time: all envs at once 0.946,
+        // 64 slots 0.927, 16 slots 0.908, 4 slots 0.912, 2 slots 0.99 ms)
+        static const int copy_envs = getenv("RR_COPY_ENVS") ? std::max(1, atoi(getenv("RR_COPY_ENVS"))) : 16;
+        hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, std::min(N, copy_envs)), dim3(COPY_THREADS), 0, e->aux, e->RM_dev, D, io, 1, N);
         hipEventRecord(e->ev_join, e->aux);
     }
     TIMED(4, hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, D, e->n_inst_used, 0, 0));
     if (forked) hipStreamWaitEvent(e->stream, e->ev_join, 0);
-    else TIMED(5, hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, N), dim3(COPY_THREADS), 0, e->stream, e->RM_dev, D, io, 1));
+    else TIMED(5, hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, N), dim3(COPY_THREADS), 0, e->stream, e->RM_dev, D, io, 1, N));
     TIMED(6, hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, D, io, 1, 0));
     HIPCHK(hipGetLastError());
     return RR_OK;
