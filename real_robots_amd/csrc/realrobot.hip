@@ -1840,9 +1840,6 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 #ifndef INLINE_PIX
 #define INLINE_PIX 2     // sample points of a small triangle walked by its own lane; the rest is redistributed over the wave
 #endif
-#ifndef SEG_CAP
-#define SEG_CAP 1024     // slots of the per-wave redistribution list (bytes of LDS)
-#endif
 #define SMALL_AREA 64    // bbox area (sample points) up to which a triangle takes the per-lane + redistribution path (A/B: 16 0.60, 32 0.54, 64 0.53, 128 0.54 ms)
 
 struct STri { float sx[3], sy[3], sz[3], w[3]; };
@@ -2066,7 +2063,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     __shared__ __attribute__((aligned(16))) float mvp[MAXINST][16];
     __shared__ unsigned nlist, wcount, wnext;
     __shared__ unsigned short wlist[MAXWIN];
-    __shared__ unsigned char seg[RASTER_THREADS / 64][SEG_CAP];
+    __shared__ int wends[RASTER_THREADS / 64][64];      // per wave: running ends of the lanes' left-over points
     const int env = blockIdx.x + env0, tile = blockIdx.y;
     if (pass == 0 && D.render_flags && !D.render_flags[env]) return;
     const int W = RM.W, H = RM.H;
@@ -2184,9 +2181,9 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         // Small triangles.  Most cover one or two sample points, a few up to small_area: a per-lane walk of the whole
         // bounding box makes the wave wait for its largest triangle (~20 % lane utilisation).  So every lane walks only
         // the first INLINE_PIX points of its box; the remaining points of all lanes are dealt out evenly: a wave prefix
-        // sum gives every point a slot, the owners write their lane id into the slots (an LDS byte per point) and
-        // then each lane takes slots lane, lane+64, ...: it fetches the owner's triangle with ds_bpermute and tests
-        // its point.  Same per-point arithmetic, and ds_min is order independent.
+        // sum numbers them, each lane takes points lane, lane+64, ..., finds the owner with a 6-step binary search over
+        // the running ends (64 ints of LDS per wave), fetches the owner's triangle with ds_bpermute and tests its point.
+        // Same per-point arithmetic, and ds_min is order independent.
         {
             const bool small = live && !big;
             const int bw = x1 - x0 + 1;
@@ -2200,30 +2197,26 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
             int total;
             const int pre = wave_excl_scan(rem, lane, total);
             if (total > 0) {
-                if (total <= SEG_CAP) {
-                    unsigned char *sg = seg[tid >> 6];
-                    for (int j = 0; j < rem; j++) sg[pre + j] = (unsigned char)lane;
-                    for (int w0 = 0; w0 < total; w0 += 64) {     // wave-uniform trip count: ds_bpermute needs the owner lanes active
-                        const int w = w0 + lane;
-                        const bool valid = w < total;
-                        const int src = valid ? sg[w] : 0;
-                        STri bs;
+                int *we = wends[tid >> 6];
+                we[lane] = pre + rem;                                // inclusive ends, non-decreasing over the lanes
+                for (int w0 = 0; w0 < total; w0 += 64) {             // wave-uniform trip count: ds_bpermute needs the owner lanes active
+                    const int w = w0 + lane;
+                    const bool valid = w < total;
+                    int src = 0;                                     // owner = number of lanes whose points end at or before w
 #pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                            bs.sx[k] = lane_gather(s.sx[k], src); bs.sy[k] = lane_gather(s.sy[k], src); bs.sz[k] = lane_gather(s.sz[k], src);
-                            bs.w[k] = 1.0f;
-                        }
-                        const float bia = lane_gather(ia, src);
-                        const int sx0 = lane_gather_i(x0, src), sy0 = lane_gather_i(y0, src), sbw = lane_gather_i(bw, src);
-                        const int idx = INLINE_PIX + w - lane_gather_i(pre, src);
-                        const int ry = (int)(((float)idx + 0.5f) / (float)sbw);      // exact for these small integers
-                        if (valid) raster_pixel_hoisted(bs, bia, tb + src, sx0 + idx - ry * sbw, sy0 + ry, H, W, row0, vis);
+                    for (int step = 32; step; step >>= 1) if (we[src + step - 1] <= w) src += step;
+                    src = valid ? src : 0;
+                    STri bs;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        bs.sx[k] = lane_gather(s.sx[k], src); bs.sy[k] = lane_gather(s.sy[k], src); bs.sz[k] = lane_gather(s.sz[k], src);
+                        bs.w[k] = 1.0f;
                     }
-                } else {      // more left-over points than slots (never seen at <= 320x240): owners finish their own boxes
-                    for (int i = ninl; i < ninl + rem; i++) {
-                        raster_pixel_hoisted(s, ia, t, px, py, H, W, row0, vis);
-                        if (++px > x1) { px = x0; py++; }
-                    }
+                    const float bia = lane_gather(ia, src);
+                    const int sx0 = lane_gather_i(x0, src), sy0 = lane_gather_i(y0, src), sbw = lane_gather_i(bw, src);
+                    const int idx = INLINE_PIX + w - lane_gather_i(pre, src);
+                    const int ry = (int)(((float)idx + 0.5f) / (float)sbw);      // exact for these small integers
+                    if (valid) raster_pixel_hoisted(bs, bia, tb + src, sx0 + idx - ry * sbw, sy0 + ry, H, W, row0, vis);
                 }
             }
         }
