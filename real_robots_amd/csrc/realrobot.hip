@@ -523,6 +523,9 @@ __device__ __forceinline__ float lane_f(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
+// the workgroup is a single wavefront: LDS traffic is ordered per wave, so a compiler-level fence replaces s_barrier
+#define CSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+static_assert(COLLIDE_THREADS == 64, "k_collide synchronises with wave-level fences");
 __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtrs D, int ns) {
     const int N = P.N;
     const int env = blockIdx.x;
@@ -546,7 +549,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
         const v3 c = mulv(X.R, mk(S->sphere[lane][0], S->sphere[lane][1], S->sphere[lane][2])) + X.p;
         sph[lane] = make_float4(c.x, c.y, c.z, S->sphere[lane][3]);
     }
-    __syncthreads();
+    CSYNC();
     if (CABL(256)) return;
     for (int p0 = 0; p0 < P.npairs; p0 += 64) {
         const int pr = p0 + lane;
@@ -603,9 +606,9 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 if ((sb_ & 0xffffffffull) && (sb_ >> 32)) continue;        // S_PCOUNT is already 0
             }
             if (CABL(1024)) continue;
-            __syncthreads();        // previous item's plane reads are done
+            CSYNC();        // previous item's plane reads are done
             planes[dirflag][v] = mypl;
-            __syncthreads();
+            CSYNC();
             bool hit = false;
             float cx = 0, cy = 0, cz = 0, cs = 0;
             int bf = 0;
