@@ -2119,6 +2119,9 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     // of the projected triangle, 64 sample points per step in 8x8 blocks) so that one large triangle does not make 63
     // lanes wait.
     const unsigned nw = wcount;
+#ifdef RR_RASTER_STATS
+    const unsigned long long t_loop0_ = __builtin_readcyclecounter();
+#endif
     for (;;) {
         unsigned k = 0;
         if (lane == 0) k = atomicAdd(&wnext, 1u);
@@ -2278,7 +2281,15 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
             }
         }
     }
+#ifdef RR_RASTER_STATS
+    const unsigned long long t_exit_ = __builtin_readcyclecounter();
+#endif
     __syncthreads();
+#ifdef RR_RASTER_STATS
+    if (lane == 0 && (P.ablate & 0x2000)) {   // RR_ABLATE=8192: only these two (idle at the barrier / busy in the loop)
+        atomicAdd(&g_rstats[14], (unsigned long long)(__builtin_readcyclecounter() - t_exit_)); atomicAdd(&g_rstats[15], (unsigned long long)(t_exit_ - t_loop0_));
+    }
+#endif
     if (pass == 1) {   // publish the static layer's keys
         unsigned long long *sv = D.static_vis_out + (size_t)row0 * W;
         for (int i = tid; i < npix; i += RASTER_THREADS) sv[i] = vis[i];

@@ -1,6 +1,6 @@
 """Raster work counters on the bench workload (development; needs `make -C real_robots_amd/csrc stats`)."""
 import os, sys, ctypes
-os.environ['RR_ABLATE'] = '32768'      # enables the work counters of the development build
+os.environ['RR_ABLATE'] = os.environ.get('RR_ABLATE', '32768')      # enables the work counters of the development build
 sys.path.insert(0, '/root/repo')
 os.environ['RR_LIB'] = os.path.join(os.path.dirname(__file__), '..', 'real_robots_amd', 'csrc', 'librealrobot_hip_stats.so')
 import numpy as np, torch
@@ -19,5 +19,5 @@ env.step(synthetic_actions(ids, 160) * 0.5, render=True); env.sync() if hasattr(
 torch.cuda.synchronize()
 lib.rr_debug_raster_stats(out, 0)
 v = np.array(list(out), dtype=np.float64) / N
-names = ['windows', 'windows after cluster cull', 'live tris', 'big tris', 'sum small area', 'sum window-max small area', 'windows with live', 'windows with small', 'sum big area', 'hier blocks rasterised', 'hier tris', 'hier blocks total', 'pixlist', 'blocks']
+names = ['windows', 'windows after cluster cull', 'live tris', 'big tris', 'sum small area', 'sum window-max small area', 'windows with live', 'windows with small', 'sum big area', 'hier blocks rasterised', 'hier tris', 'hier blocks total', 'pixlist', 'blocks', 'wave cycles idle at loop-end barrier (sum over 16 waves)', 'wave cycles in the window loop (sum over 16 waves)']
 for n, x in zip(names, v): print(f'{n:32s} {x:10.1f} per env')
