@@ -1,16 +1,21 @@
 // realrobot.hip -- batched REALRobot env.step() for MI355X (gfx950): HIP kernels + C ABI (include/realrobot.h).
 //
 // One process per GPU; N independent envs per device.  State lives in HBM as SoA [field][env] fp32 so that a
-// wavefront whose lanes are consecutive envs reads/writes 256-byte contiguous lines.  The step is five kernels:
-//   k_prep          1 thread / env : action protocol (env.py:314-321, 257-264; robot.py:188-201), forward kinematics,
-//                                    joint-space mass matrix (composite rigid bodies) + bias (RNEA), Cholesky inverse,
-//                                    unconstrained velocities
-//   k_collide       1 thread / (env, shape pair): bounding-sphere cull, vertex-vs-plane convex tests, <=4 points
-//   k_solve         1 thread / env : row assembly (motors, joint limits, contact normal + 2 friction), PGS,
-//                                    semi-implicit Euler, touch sensors, observation pack (robot.py:152-163,203-211)
-//   k_render_setup  1 thread / env : FK at the new state -> per-instance model matrices
-//   k_raster        1 workgroup / (env, tile): triangle-parallel visibility buffer in LDS (64-bit atomic min of
-//                                    depth|triangle id), cooperative path for large triangles, deferred shading
+// wavefront whose lanes are consecutive envs reads/writes 256-byte contiguous lines.  A step is these kernels
+// (main stream unless noted; DESIGN.md 5 has the work-item maps and what bounds each of them):
+//   k_prep_a        1 thread / env : action protocol (env.py:314-321, 257-264; robot.py:188-201), forward kinematics,
+//                                    object terms (rotation, world inverse inertia, unconstrained velocities)
+//   k_prep_b        1 thread / env : joint-space mass matrix (composite rigid bodies), bias (RNEA), Cholesky, M^-1,
+//                                    unconstrained joint velocities -- side stream, beside k_collide
+//   k_collide       1 wavefront / env: bounding spheres -> pair list -> lane-per-vertex convex tests -> <=4 points/pair
+//   k_solve         16 lanes / env : row assembly (motors, joint limits, contact normal + 2 friction), PGS with the
+//                                    common rows in registers, semi-implicit Euler, touch sensors, observation pack
+//                                    (robot.py:152-163,203-211)
+//   k_render_setup  1 thread / (env, instance): FK of the ancestor chain -> model-view-projection + shading constants
+//   k_raster        1 workgroup / (env, tile): visibility only -- 64-bit atomic-min buffer (depth | triangle id) in LDS,
+//                                    meshlet clusters, fragment list out
+//   k_static_copy   static layer -> every env's image (side stream, beside k_raster)
+//   k_shade         deferred shading of the fragment lists
 // The arithmetic restates what the reference delegates to pybullet.stepSimulation / getCameraImage
 // (env.py:340, 536-567); the algorithm and its constants are specified in DESIGN.md and checked against
 // oracle/rr_oracle.c by tests/ (never linked here).
