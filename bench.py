@@ -206,7 +206,10 @@ def main():
                 "unit": "GB/s", "frac": round(kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(algo[dom] * n_local),
                 "whole_step_achieved_GBs": round(ALGO_BYTES_PER_ENV_STEP * n_local * args.steps / elapsed / 1e9, 2),
-                "kernels": kernels}
+                "kernels": kernels,
+                "timing_note": "per-kernel durations: HIP events on the library's stream, every kernel alone on the stream "
+                               "(no side-stream overlap), %d steps of the same workload right after the timed region; "
+                               "rocprofv3 --stats of the overlapped run is under profiles/" % nprof}
 
     if rank == 0:
         out = {
