@@ -755,6 +755,11 @@ __device__ __forceinline__ float dpp_ror(float v) {
 template <int J> __device__ __forceinline__ float row_bcast(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xf, 0xf, false));
 }
+// value of an arbitrary lane of the wavefront (ds_bpermute; the source lane must be active)
+__device__ __forceinline__ float lane_gather(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ int lane_gather_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 __device__ __forceinline__ float group_sum(float v) {
     v += dpp_ror<8>(v);
     v += dpp_ror<4>(v);
@@ -888,6 +893,18 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     const v3 pk_l = mk(SCR(S_BP + 3 * lj), SCR(S_BP + 3 * lj + 1), SCR(S_BP + 3 * lj + 2));
     const v3 ak_l = mk(SCR(S_BAX + 3 * lj), SCR(S_BAX + 3 * lj + 1), SCR(S_BAX + 3 * lj + 2));
     const float q_l = STT(ST_Q + lj), qds_l = SCR(S_QDS + lj);
+    // lanes 11..13 also fetch "their" object's pose / inverse inertia / unconstrained velocities here; the row builder
+    // pulls the data of a pair's objects from those lanes with ds_bpermute instead of a round trip to memory per pair
+    ObjData myobj;
+    {
+        const int ob = (l >= NB && l < NB + NOBJ && l - NB < P.nobj) ? l - NB : 0;
+        myobj.op = mk(STT(ST_OPOS + 3 * ob), STT(ST_OPOS + 3 * ob + 1), STT(ST_OPOS + 3 * ob + 2));
+#pragma unroll
+        for (int kk = 0; kk < 9; kk++) myobj.Iinv.m[kk] = SCR(S_OIINV + 9 * ob + kk);
+        myobj.vs = mk(SCR(S_OVS + 3 * ob), SCR(S_OVS + 3 * ob + 1), SCR(S_OVS + 3 * ob + 2));
+        myobj.ws = mk(SCR(S_OWS + 3 * ob), SCR(S_OWS + 3 * ob + 1), SCR(S_OWS + 3 * ob + 2));
+        myobj.imass = 1.0f / (ob == 0 ? B.obj_mass[0] : (ob == 1 ? B.obj_mass[1] : B.obj_mass[2]));
+    }
     SPROF(0);
     // ---- gather contacts in pair order, build rows (all lanes of the group run the control flow redundantly)
     // The 92 per-pair candidate counts are fetched in one go: lane l loads the counts of pairs l, l+16, ... and the
@@ -908,44 +925,39 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     for (unsigned rem = k == 0 ? pmask[0] : (k == 1 ? pmask[1] : (k == 2 ? pmask[2] : (k == 3 ? pmask[3] : (k == 4 ? pmask[4] : pmask[5]))));
          rem && nc < MAXC; rem &= rem - 1) {
         const int pair = 16 * k + __ffs(rem) - 1;
-        // Two round trips per non-empty pair: (1) its count and metadata, (2) all of its candidate points and, for an
-        // object-vs-static pair, the object's pose / inertia / velocity -- nothing is fetched inside the contact loop.
+        // One round trip per non-empty pair: its count, metadata and (unconditionally) all four candidate slots; the
+        // objects' data comes from the object lanes.  Nothing is fetched inside the contact loop.
         const int cnt = *(const int *)&SCR(S_PCOUNT + pair);
         const int4 pm = *(const int4 *)S->pair_meta[pair];
         const float2 pmat = *(const float2 *)S->pair_mat[pair];
-        const int bodyA = pm.x, bodyB = pm.y, linkA = pm.z;
-        const float mu = pmat.x, rest = pmat.y;
-        const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
-        const bool objobj = bodyA >= 16 && bodyB >= 16;
         float cd[4][7];
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int kk = 0; kk < 7; kk++) cd[i][kk] = i < cnt ? SCR(S_PDATA + (pair * 4 + i) * 7 + kk) : 0.0f;
+            for (int kk = 0; kk < 7; kk++) cd[i][kk] = SCR(S_PDATA + (pair * 4 + i) * 7 + kk);
+        const int bodyA = pm.x, bodyB = pm.y, linkA = pm.z;
+        const float mu = pmat.x, rest = pmat.y;
+        const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
+        const bool objobj = bodyA >= 16 && bodyB >= 16;
         const bool ospair = bodyA >= 16 && bodyB < 0;
         ObjData oA, oB;
 #pragma unroll
         for (int side = 0; side < 2; side++) {
             ObjData &o = side == 0 ? oA : oB;
             const int body = side == 0 ? bodyA : bodyB;
-            const bool isobj = body >= 16;
-            const int ob = isobj ? body - 16 : 0;        // always-valid addresses; the values are only used for objects
-            o.op = mk(STT(ST_OPOS + 3 * ob), STT(ST_OPOS + 3 * ob + 1), STT(ST_OPOS + 3 * ob + 2));
+            const int src = (threadIdx.x & ~15) + NB + (body >= 16 ? body - 16 : 0);     // the object's lane in this group
+            o.op = mk(lane_gather(myobj.op.x, src), lane_gather(myobj.op.y, src), lane_gather(myobj.op.z, src));
 #pragma unroll
-            for (int kk = 0; kk < 9; kk++) o.Iinv.m[kk] = SCR(S_OIINV + 9 * ob + kk);
-            o.vs = mk(SCR(S_OVS + 3 * ob), SCR(S_OVS + 3 * ob + 1), SCR(S_OVS + 3 * ob + 2));
-            o.ws = mk(SCR(S_OWS + 3 * ob), SCR(S_OWS + 3 * ob + 1), SCR(S_OWS + 3 * ob + 2));
-            o.imass = 1.0f / (ob == 0 ? B.obj_mass[0] : (ob == 1 ? B.obj_mass[1] : B.obj_mass[2]));
+            for (int kk = 0; kk < 9; kk++) o.Iinv.m[kk] = lane_gather(myobj.Iinv.m[kk], src);
+            o.vs = mk(lane_gather(myobj.vs.x, src), lane_gather(myobj.vs.y, src), lane_gather(myobj.vs.z, src));
+            o.ws = mk(lane_gather(myobj.ws.x, src), lane_gather(myobj.ws.y, src), lane_gather(myobj.ws.z, src));
+            o.imass = lane_gather(myobj.imass, src);
         }
         // every value fetched above is waited for here, once: with no load in flight the contact loop below needs no
         // vmcnt waits, which on gfx9 would also wait for the acknowledgement of the contact-record stores it issues
 #pragma unroll
         for (int i = 0; i < 4; i++)
             asm volatile("" : "+v"(cd[i][0]), "+v"(cd[i][1]), "+v"(cd[i][2]), "+v"(cd[i][3]), "+v"(cd[i][4]), "+v"(cd[i][5]), "+v"(cd[i][6]));
-        asm volatile("" : "+v"(oA.op.x), "+v"(oA.op.y), "+v"(oA.op.z), "+v"(oA.vs.x), "+v"(oA.vs.y), "+v"(oA.vs.z), "+v"(oA.ws.x), "+v"(oA.ws.y), "+v"(oA.ws.z));
-        asm volatile("" : "+v"(oA.Iinv.m[0]), "+v"(oA.Iinv.m[1]), "+v"(oA.Iinv.m[2]), "+v"(oA.Iinv.m[3]), "+v"(oA.Iinv.m[4]), "+v"(oA.Iinv.m[5]), "+v"(oA.Iinv.m[6]), "+v"(oA.Iinv.m[7]), "+v"(oA.Iinv.m[8]));
-        asm volatile("" : "+v"(oB.op.x), "+v"(oB.op.y), "+v"(oB.op.z), "+v"(oB.vs.x), "+v"(oB.vs.y), "+v"(oB.vs.z), "+v"(oB.ws.x), "+v"(oB.ws.y), "+v"(oB.ws.z));
-        asm volatile("" : "+v"(oB.Iinv.m[0]), "+v"(oB.Iinv.m[1]), "+v"(oB.Iinv.m[2]), "+v"(oB.Iinv.m[3]), "+v"(oB.Iinv.m[4]), "+v"(oB.Iinv.m[5]), "+v"(oB.Iinv.m[6]), "+v"(oB.Iinv.m[7]), "+v"(oB.Iinv.m[8]));
         for (int i = 0; i < cnt && nc < MAXC; i++, nc++) {
             float c7[7];
 #pragma unroll
@@ -1886,10 +1898,6 @@ __device__ __forceinline__ void project_vertex(const float *mvp, float vx, float
     sy = (cy * iw + 1.0f) * (0.5f * (float)H);
     sz = cz * iw;
 }
-__device__ __forceinline__ float lane_gather(float v, int src_lane) {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
-}
-__device__ __forceinline__ int lane_gather_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 // exclusive prefix sum over the 64 lanes of a wave (DPP row_shr scan inside each 16-lane row + the row totals)
 template <int SHR> __device__ __forceinline__ int dpp_shr0(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + SHR, 0xf, 0xf, true); }
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
