@@ -1174,13 +1174,14 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     // Up to NGU generic contacts: fully written-out sweep.  Contact index, row offsets and slots are compile-time
     // constants, so a row step is ~45 instructions (immediate-offset LDS reads, bit tests on the role masks) instead of
     // ~120 with run-time addressing -- with one wave per SIMD a row costs (instructions x ~8 cycles).  The normal impulse
-    // and the friction coefficient of each contact stay in registers between the two passes.
+    // of each contact stays in a register between the two passes.
 #define NGU 12
     const bool g_unrolled = g_allfast && G <= NGU;
     const int gbase = grp * L_TOTAL + L_BASE + n_os * 36, rbase = grp * L_TOTAL + L_ROB + lj - n_oo * 66, bbase = grp * L_TOTAL + L_BS;
-    float gln[NGU], gmu[NGU];
+    float gln[NGU];
 #pragma unroll
-    for (int j = 0; j < NGU; j++) { gln[j] = 0.0f; gmu[j] = (g_unrolled && j < G) ? LD(L_MU + n_os + j) : 0.0f; }
+    for (int j = 0; j < NGU; j++) gln[j] = 0.0f;
+    const int mubase = grp * L_TOTAL + L_MU + n_os;
 #define GROW(J, K, LOB, HIB)                                                                                       \
     {                                                                                                              \
         const int ro_ = gbase + ((J) * 3 + (K)) * 12;                                                              \
@@ -1213,7 +1214,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         dw.x += own_ ? m0_ * dl_ : 0.0f; dw.y += own_ ? m1_ * dl_ : 0.0f; dw.z += own_ ? m2_ * dl_ : 0.0f;         \
     }
 #define GNORMAL(J) if ((J) < G) GROW(J, 0, 0.0f, 1e10f)
-#define GFRICT(J) if ((J) < G) { const float hi_ = gmu[J] * gln[J]; GROW(J, 1, -hi_, hi_) GROW(J, 2, -hi_, hi_) }
+#define GFRICT(J) if ((J) < G) { const float hi_ = g_slds[mubase + (J)] * gln[J]; GROW(J, 1, -hi_, hi_) GROW(J, 2, -hi_, hi_) }
 #define GEN_UNROLLED_N GNORMAL(0) GNORMAL(1) GNORMAL(2) GNORMAL(3) GNORMAL(4) GNORMAL(5) GNORMAL(6) GNORMAL(7) GNORMAL(8) GNORMAL(9) GNORMAL(10) GNORMAL(11)
 #define GEN_UNROLLED_F GFRICT(0) GFRICT(1) GFRICT(2) GFRICT(3) GFRICT(4) GFRICT(5) GFRICT(6) GFRICT(7) GFRICT(8) GFRICT(9) GFRICT(10) GFRICT(11)
     static_assert(NGU == 12, "GEN_UNROLLED_* are written out for 12 contacts");
