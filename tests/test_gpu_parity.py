@@ -85,7 +85,7 @@ def test_robot_object_contact_parity_and_touch_sensors():
     env.close()
 
 
-@pytest.mark.parametrize("W,H", [(128, 128), (320, 240)])
+@pytest.mark.parametrize("W,H", [(128, 128), (320, 240), (256, 256), (64, 48)])
 def test_raster_parity(W, H):
     N = 4
     env = BatchedREALRobotEnv(N, objects=3, width=W, height=H)
