@@ -357,3 +357,25 @@ def test_soak_full_range_commands_stay_finite_and_reproducible():
     assert robot > 0                                   # the generic solver rows were exercised
     ef2, st2, rgb2, dep2, _ = run()
     assert (st == st2).all() and (rgb == rgb2).all() and (dep == dep2).all()
+
+
+def test_raster_parity_many_poses_near_camera():
+    """24 envs with wide joint commands (links pass close to the camera: near-plane drops, screen-filling slivers, the
+    hierarchical block path), three frames each: mask identical, RGB within 1 grey level, depth within 1e-5 (the oracle's
+    forward kinematics is float64, the device's float32: for geometry a few centimetres from the near plane the GL depth
+    is steep in 1/w, measured worst case 1.5e-6)."""
+    N, W, H = 24, 128, 128
+    env = BatchedREALRobotEnv(N, objects=3, width=W, height=H)
+    o = Oracle(3, W, H)
+    for t in range(180):
+        act = synthetic_actions(range(N), t, seed=11) * 0.8
+        env.step(act, render=(t % 60 == 59))
+        if t % 60 == 59:
+            st, rgb, dep, msk = env.state, env.host(nat.F_RGB), env.host(nat.F_DEPTH), env.host(nat.F_MASK)
+            for i in range(N):
+                o.state = st[i].astype(np.float64)
+                r, d, m = o.render()
+                assert (m == msk[i]).all(), (t, i)
+                assert np.abs(r.astype(int) - rgb[i].astype(int)).max() <= 1, (t, i)
+                assert np.abs(d - dep[i]).max() < 1e-5, (t, i)
+    env.close()
