@@ -2309,12 +2309,13 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         for (int i = tid; i < npix; i += RASTER_THREADS) sv[i] = vis[i];
     }
     // ---- compaction: pixels owned by a triangle rasterised in this pass go to the fragment list of this (env, tile)
+    // (the comparison with the static layer's key is left to k_shade: a dependent global read at the tail of this
+    // LDS-limited workgroup is exposed latency, in the high-occupancy shading kernel it is not)
     uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
-    const unsigned long long *sv = layered ? D.static_vis + (size_t)row0 * W : nullptr;
     for (int i = tid; i < npix; i += RASTER_THREADS) {
         const unsigned long long key = vis[i];
         const unsigned tri = (unsigned)(key & 0xffffffffu);
-        if (key != ~0ull && (!sv || key < sv[i])) {
+        if (key != ~0ull) {
             const unsigned slot = atomicAdd(&nlist, 1u);
             lst[slot] = make_uint2((unsigned)(key >> 32), ((unsigned)i << 18) | tri);
         }
@@ -2376,9 +2377,12 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp,
     const uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
     const int row0 = tile * RM.tile_h;
     const size_t base = (size_t)env * out.env_stride + (size_t)row0 * RM.W;
+    const unsigned long long *sv = D.static_vis ? D.static_vis + (size_t)row0 * RM.W : nullptr;   // null while the static layer itself is built
     for (unsigned i = blockIdx.z * SHADE_THREADS + threadIdx.x; i < n; i += gridDim.z * SHADE_THREADS) {
         const uint2 f = lst[i];
         const int pi = (int)(f.y >> 18), t = (int)(f.y & 0x3ffffu);
+        // a moving triangle only shows where it beats the static layer (depth, then triangle id; static ids are lower)
+        if (sv && !((((unsigned long long)f.x << 32) | (unsigned)t) < sv[pi])) continue;
         const int lrow = pi / RM.W, px = pi - lrow * RM.W;
         unsigned char c3[3]; int m;
         shade_pixel(ctx, t, px, row0 + lrow, c3, m);
