@@ -24,6 +24,31 @@ def test_library_exports_every_declared_symbol():
     assert L.rr_abi_version() == nat.RR_ABI_VERSION
 
 
+def test_header_is_plain_c_and_a_c_caller_links(tmp_path):
+    """include/realrobot.h must be consumable from C99 (the boundary has no C++/torch types) and a C program must link
+    against the shared library; the program only calls the two entry points that need no GPU."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    src = tmp_path / 'caller.c'
+    src.write_text(
+        '#include <stdio.h>\n#include "realrobot.h"\n'
+        'int main(void) {\n'
+        '    rr_config cfg = {0};\n    rr_env *env = NULL;\n'
+        '    cfg.abi_version = RR_ABI_VERSION; cfg.num_envs = 0;      /* invalid on purpose */\n'
+        '    int rc = rr_create(&cfg, NULL, 0, NULL, &env);\n'
+        '    printf("%d %d %s\\n", rr_abi_version(), rc, rr_last_error());\n'
+        '    return (rc == RR_EINVAL && env == NULL && sizeof(rr_config) == 80) ? 0 : 1;\n}\n')
+    exe = tmp_path / 'caller'
+    libdir = os.path.dirname(nat.LIB_PATH)
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe),
+                    '-L', libdir, '-l:' + os.path.basename(nat.LIB_PATH), '-Wl,-rpath,' + libdir], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.split()[0] == str(nat.RR_ABI_VERSION)
+
+
 def test_create_rejects_bad_arguments_and_fails_loudly_without_gpu():
     L = nat.load_library()
     blob = nat.model_blob()
