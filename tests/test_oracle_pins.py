@@ -267,3 +267,42 @@ def test_reference_macro_plan_tracking():
             o.step(plan[i])
             if i in tg:
                 assert np.linalg.norm(o.link_pose('base')[:3] - tg[i]) < 0.01, (p1, p2, i)
+
+
+def test_table_top_coverage_and_depth_match_analytic_ray_casting():
+    """Known answer for the camera + rasteriser conventions (SURVEY 8c "raster of a single axis-aligned box"): the top
+    face of the table (an axis-aligned rectangle at z = 0.279403) is ray-cast analytically in float64 with the OpenGL
+    look-at / perspective matrices of env.py:136-141,253-255,518,548-551, the sample-point convention ndc_x = 2 col / W - 1,
+    ndc_y = 2 (H - 1 - row) / H - 1, and GL depth 0.5 z_ndc + 0.5.  Every pixel whose ray meets the rectangle's plane
+    inside the strip -0.15 < x < 0.05 (clear of robot, shelf and the parked cube) must be table (mask 1) exactly when
+    the hit lies inside the rectangle's y range, with the analytic depth to 1e-6."""
+    W = H = 128
+    o = Oracle(1, W, H)
+    o.set_object_pose(0, [0.2, 0.0, 0.45, 0, 0, 0, 1])          # cube parked on the shelf side, outside the strip
+    rgb, depth, mask = o.render()
+    eye, tgt, up = np.array([0.01, 0.0, 1.2]), np.array([0.0, 0.0, 0.08]), np.array([0.0, 0.0, 1.0])
+    f = (tgt - eye) / np.linalg.norm(tgt - eye)
+    s = np.cross(f, up); s /= np.linalg.norm(s)
+    u = np.cross(s, f)
+    V = np.eye(4); V[0, :3], V[1, :3], V[2, :3] = s, u, -f; V[:3, 3] = -V[:3, :3] @ eye
+    n, fa, t = 0.1, 100.0, 1.0 / np.tan(np.radians(80.0) / 2)
+    Pm = np.array([[t / (W / H), 0, 0, 0], [0, t, 0, 0], [0, 0, (n + fa) / (n - fa), 2 * n * fa / (n - fa)], [0, 0, -1, 0]])
+    inv = np.linalg.inv(Pm @ V)
+    z_top, ylo, yhi = 0.279403, -0.505576, 0.495054
+    checked = 0
+    for row in range(H):
+        for col in range(W):
+            nd = np.array([2.0 * col / W - 1.0, 2.0 * (H - 1 - row) / H - 1.0])
+            a = inv @ np.array([nd[0], nd[1], -1.0, 1.0]); b = inv @ np.array([nd[0], nd[1], 1.0, 1.0])
+            a, b = a[:3] / a[3], b[:3] / b[3]
+            lam = (z_top - a[2]) / (b[2] - a[2])
+            hit = a + lam * (b - a)
+            if not (-0.15 < hit[0] < 0.05) or min(abs(hit[1] - ylo), abs(hit[1] - yhi)) < 1e-4:
+                continue
+            inside = ylo < hit[1] < yhi
+            assert (mask[row, col] == 1) == inside, (row, col, hit)
+            if inside:
+                c = Pm @ V @ np.append(hit, 1.0)
+                assert abs(depth[row, col] - (0.5 * c[2] / c[3] + 0.5)) < 1e-6
+                checked += 1
+    assert checked > 1000
