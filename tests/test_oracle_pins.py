@@ -306,3 +306,28 @@ def test_table_top_coverage_and_depth_match_analytic_ray_casting():
                 assert abs(depth[row, col] - (0.5 * c[2] / c[3] + 0.5)) < 1e-6
                 checked += 1
     assert checked > 1000
+
+
+def test_sliding_friction_matches_coulomb_pyramid():
+    """Known answer for the friction rows: a cube at rest on the table is given 0.4 m/s along world +y (a tangent
+    direction of btPlaneSpace1 for an up-pointing normal).  While it slides, the deceleration must be mu g plus Bullet's
+    linear damping v (0.04 + 0.04 |v|) with mu = friction(cube) x friction(table) = 0.5 x 1.0 (cube.urdf / table.urdf
+    <lateral_friction>), and the cube must then stop and stay stopped (friction bounds +-mu lambda_n hold it)."""
+    o = Oracle(1, 32, 32)
+    for _ in range(300):
+        o.step(None)
+    st = o.state.copy()
+    st[22 + 8] = 0.4                                   # object 0: pos3 quat4 lin3 ang3 -> lin.y
+    o.state = st
+    mu, g, dt = 0.5, 9.81, 0.005
+    v_prev, sliding = 0.4, 0
+    for k in range(40):
+        o.step(None)
+        v = o.state[22 + 8]
+        if v > 0.02:
+            a = (v_prev - v) / dt
+            assert abs(a - (mu * g + v_prev * (0.04 + 0.04 * v_prev))) < 5e-3, (k, a)
+            sliding += 1
+        v_prev = v
+    assert sliding >= 12 and abs(o.state[22 + 8]) < 1e-6 and abs(o.state[22 + 7]) < 1e-6     # stopped, no sideways drift
+    assert abs(o.state[22 + 2] - st[22 + 2]) < 1e-4                                            # still resting on the table
