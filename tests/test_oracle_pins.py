@@ -331,3 +331,17 @@ def test_sliding_friction_matches_coulomb_pyramid():
         v_prev = v
     assert sliding >= 12 and abs(o.state[22 + 8]) < 1e-6 and abs(o.state[22 + 7]) < 1e-6     # stopped, no sideways drift
     assert abs(o.state[22 + 2] - st[22 + 2]) < 1e-4                                            # still resting on the table
+
+
+def test_resting_contact_forces_carry_the_weight():
+    """Static equilibrium known answer: for an object at rest on the table the normal forces reported by the contact list
+    (Kuka.get_contacts column `normal force`, robot.py:131-150) sum to m g, with m from the object URDFs (cube 1.5 kg,
+    tomato 3 kg, mustard 2 kg) -- pins the normal rows, ERP handling and the impulse -> force conversion."""
+    o = Oracle(3, 32, 32)
+    for _ in range(400):
+        o.step(None)
+    c = o.contacts()
+    for ob, mass in enumerate((1.5, 3.0, 2.0)):
+        sel = c[:, 0] == 16 + ob
+        assert 3 <= sel.sum() <= 4 and (c[sel, 1] < 0).all()            # a 3-4 point manifold against a static body
+        assert abs(c[sel, 10].sum() - mass * 9.81) < 2e-3 * mass * 9.81, (ob, c[sel, 10].sum())
