@@ -379,3 +379,35 @@ def test_raster_parity_many_poses_near_camera():
                 assert np.abs(r.astype(int) - rgb[i].astype(int)).max() <= 1, (t, i)
                 assert np.abs(d - dep[i]).max() < 1e-5, (t, i)
     env.close()
+
+
+def test_known_answers_hold_on_the_device_path():
+    """The analytic known answers of tests/test_oracle_pins.py evaluated on the HIP path itself (no oracle involved):
+    resting contact forces sum to m g; a cube launched at 0.4 m/s along +y decelerates at mu g + v (0.04 + 0.04 v)
+    with mu = 0.5 and stops; free fall follows semi-implicit Euler."""
+    env = BatchedREALRobotEnv(4, objects=3, width=64, height=64)
+    z0 = env.state[0, 22 + 2]
+    env.step(None)
+    z1 = env.state[0, 22 + 2]
+    assert abs((z0 - z1) - 9.81 * 0.005 ** 2 * (1 - 0.0)) < 2e-6          # first step of free fall: dz = g dt^2 (v0 = 0)
+    for _ in range(400):
+        env.step(None)
+    c = env.contacts(0)
+    for ob, mass in enumerate((1.5, 3.0, 2.0)):
+        sel = c[:, 0] == 16 + ob
+        assert 3 <= sel.sum() <= 4
+        assert abs(c[sel, 10].sum() - mass * 9.81) < 5e-3 * mass * 9.81, (ob, c[sel, 10].sum())
+    st = env.state.copy()
+    st[:, 22 + 8] = 0.4
+    env.state = st
+    v_prev, sliding = 0.4, 0
+    for k in range(40):
+        env.step(None)
+        v = float(env.state[0, 22 + 8])
+        if v > 0.02:
+            a = (v_prev - v) / 0.005
+            assert abs(a - (0.5 * 9.81 + v_prev * (0.04 + 0.04 * v_prev))) < 2e-2, (k, a)
+            sliding += 1
+        v_prev = v
+    assert sliding >= 12 and abs(env.state[0, 22 + 8]) < 1e-5
+    env.close()
