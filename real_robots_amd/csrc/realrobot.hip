@@ -102,8 +102,7 @@ enum {
     S_OVS = S_OIINV + 27,        // 9
     S_OWS = S_OVS + 9,           // 9
     S_PCOUNT = S_OWS + 9,        // MAXPAIRS (int)
-    S_PDATA = S_PCOUNT + MAXPAIRS,           // MAXPAIRS*4*7
-    S_ROWS = S_PDATA + MAXPAIRS * 28,        // 3*MAXC*ROWF
+    S_ROWS = S_PCOUNT + MAXPAIRS,            // 3*MAXC*ROWF
     S_RMETA = S_ROWS + 3 * MAXC * ROWF,      // MAXC (int: bodyA | bodyB<<8 | linkA<<16)
     S_CT = S_RMETA + MAXC,                   // MAXC*12 (contact records for the API)
     S_NCT = S_CT + MAXC * 12,                // 1 (int)
@@ -120,6 +119,9 @@ enum {
 struct DevPtrs {
     float *state;      // [ST_TOTAL][N]
     float *scratch;    // [S_TOTAL][N]
+    float4 *pdata;     // [N][MAXPAIRS][4][2]  contact candidates per env and pair: {x, y, z, nx | ny, nz, depth, -}: written by one
+                       // k_collide workgroup, read by one k_solve group -- contiguous per env (the SoA slab would spread a
+                       // pair's 28 floats over 28 cache lines shared with 31 other envs)
     int *timestep;     // [N]
     unsigned *errflags;// [N]
     float *cmd;        // [N][9]
@@ -676,10 +678,9 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 const float4 pl = planes[dirflag][bf];
                 v3 nw = mulv(Xo.R, mk(pl.x, pl.y, pl.z));
                 if (dirflag) nw = nw * -1.0f;
-                const int base = S_PDATA + (pair * 4 + slot) * 7;
-                SCR(base) = cx; SCR(base + 1) = cy; SCR(base + 2) = cz;
-                SCR(base + 3) = nw.x; SCR(base + 4) = nw.y; SCR(base + 5) = nw.z;
-                SCR(base + 6) = cs;
+                float4 *pd = D.pdata + (((size_t)env * MAXPAIRS + pair) * 4 + slot) * 2;
+                pd[0] = make_float4(cx, cy, cz, nw.x);
+                pd[1] = make_float4(nw.y, nw.z, cs, 0.0f);
             }
         }
     }
@@ -931,10 +932,14 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         const int4 pm = *(const int4 *)S->pair_meta[pair];
         const float2 pmat = *(const float2 *)S->pair_mat[pair];
         float cd[4][7];
+        {
+            const float4 *pd = D.pdata + ((size_t)env * MAXPAIRS + pair) * 8;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int kk = 0; kk < 7; kk++) cd[i][kk] = SCR(S_PDATA + (pair * 4 + i) * 7 + kk);
+            for (int i = 0; i < 4; i++) {
+                const float4 a = pd[2 * i], b = pd[2 * i + 1];
+                cd[i][0] = a.x; cd[i][1] = a.y; cd[i][2] = a.z; cd[i][3] = a.w; cd[i][4] = b.x; cd[i][5] = b.y; cd[i][6] = b.z;
+            }
+        }
         const int bodyA = pm.x, bodyB = pm.y, linkA = pm.z;
         const float mu = pmat.x, rest = pmat.y;
         const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
@@ -2687,6 +2692,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
 #define ALLOC(ptr, count) if ((rc = dev_alloc(e, &(ptr), (count))) != RR_OK) { rr_destroy(e); return rc; }
     ALLOC(D.state, (size_t)ST_TOTAL * N);
     ALLOC(D.scratch, (size_t)S_TOTAL * N);
+    ALLOC(D.pdata, (size_t)N * MAXPAIRS * 8);
     ALLOC(D.timestep, (size_t)N);
     ALLOC(D.errflags, (size_t)N);
     ALLOC(D.cmd, (size_t)N * 9);
