@@ -918,6 +918,8 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         const unsigned long long bal = __ballot(cntl > 0);
         pmask[k] = (unsigned)(bal >> (16 * grp)) & 0xffffu;
     }
+    int n_os = 0;
+    unsigned own_os = 0;
     int nc = 0, gidx = 0, n_oo = 0;   // gidx: index among the generic (not object-vs-static) contacts, which all follow the
                                       // object-vs-static ones; n_oo: object-object contacts (their pairs precede the robot pairs)
     static_assert(MAXPAIRS / 16 == 6, "pair-mask select chain below");
@@ -976,6 +978,10 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             if (robot) { if (gidx - n_oo < LR && fast) rslot = gidx - n_oo; else fast = false; }
             if (objobj) { if (gidx < LB && fast) bslot = gidx; else fast = false; n_oo = gidx + 1; }
             if (robot || objobj) gidx++;
+            else if (gidx == 0 && nc < LC) {       // still inside the leading run of object-vs-static contacts
+                n_os = nc + 1;
+                if (lo_ >= 0 && bodyA == 16 + lo_) own_os |= 1u << nc;
+            }
             if (!fast) { rslot = 15; bslot = 15; }
             // "fast" is recoverable from the meta word: c < LC and (no robot side or rslot != 15) and (no B object or bslot != 15)
             int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | (rslot << 24) | (bslot << 28);
@@ -1063,7 +1069,8 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     SPROF(2);
     // compact list of the limit rows that exist (usually the two finger lower limits), in row order
     unsigned limmask = 0;
-    for (int js = 0; js < 2 * NB; js++) if (LD(L_LIM + 2 * js) > -1e29f) limmask |= 1u << js;
+#pragma unroll
+    for (int js = 0; js < 2 * NB; js++) if (LD(L_LIM + 2 * js) > -1e29f) limmask |= 1u << js;    // 22 independent LDS reads
     // ---- PGS.  Lane state: dq (lanes 0..10) or (dv, dw) of object lane-11 (lanes 11..13)
     float dq = 0;
     v3 dv = mk(0, 0, 0), dw = mk(0, 0, 0);
@@ -1079,14 +1086,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     float m_lam = 0.0f;
     // Leading object-vs-static contacts (the common case: objects resting on the table) get a specialised sweep:
     // ownership of contact c by this lane is one bit of `own_os`, rows are prefetched one step ahead.
-    int n_os = 0;
-    unsigned own_os = 0;
-    for (int c = 0; c < nc && c < LC; c++) {
-        const int meta = *(const int *)&LD(L_META + c);
-        if (!(meta_bodyA(meta) >= 16 && meta_bodyB(meta) < 0)) break;
-        if (lo_ >= 0 && meta_bodyA(meta) == 16 + lo_) own_os |= 1u << c;
-        n_os = c + 1;
-    }
+    // (n_os = number of leading object-vs-static contacts and own_os = this lane's share of them were collected by the gather)
 #define LDB4(r, off) (*(const float4 *)&LD(L_BASE + (r) * 12 + (off)))
     // Each SIMD runs a single wave of this kernel (4 envs), so the sweep is a chain of dependent operations and its LDS
     // round trips are fully exposed.  Rows that are the same in every iteration are therefore lifted into registers
