@@ -844,12 +844,11 @@ __device__ float build_row(const SimParams &P, const DevPtrs &D, int env, int gr
 // b0,b1,b2 = the row's base part (dir.xyz ang.x | ang.yz mang.xy | mang.z rhs dinv lambda), bounds [lo, hi].
 #define OS_ROW_STEP(b0, b1, b2, lo, hi, rowidx)                                                                   \
     do {                                                                                                          \
-        const float jv_ = (b0).x * dv.x + (b0).y * dv.y + (b0).z * dv.z + (b0).w * dw.x + (b1).x * dw.y + (b1).y * dw.z;    \
+        const float jv_ = ((b0).x * dv.x + (b0).y * dv.y + (b0).z * dv.z) + ((b0).w * dw.x + (b1).x * dw.y + (b1).y * dw.z);    \
         const float lam_ = (b2).w;                                                                                \
-        const float dl0_ = (b2).y - jv_ * (b2).z;                                                                 \
-        const float s0_ = lam_ + dl0_;                                                                            \
+        const float s0_ = fmaf(-jv_, (b2).z, lam_ + (b2).y);        /* (lambda + rhs) - dinv * J.v */             \
         const float sum_ = fminf(fmaxf(s0_, (lo)), (hi));                                                         \
-        const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - lam_;                                                     \
+        const float dl_ = sum_ - lam_;                                                                            \
         LD(L_BASE + (rowidx) * 12 + 11) = sum_;                                                                   \
         const float sm_ = dl_ * inv_mass;                                                                         \
         dv.x += (b0).x * sm_; dv.y += (b0).y * sm_; dv.z += (b0).z * sm_;                                            \
@@ -860,11 +859,10 @@ __device__ float build_row(const SimParams &P, const DevPtrs &D, int env, int gr
 // no-op (dl = 0), which is how absent rows are represented -- no predicates, no scalar mask registers.
 #define REG_ROW_STEP(b0, b1, b2, lam, lo, hi)                                                                     \
     do {                                                                                                          \
-        const float jv_ = (b0).x * dv.x + (b0).y * dv.y + (b0).z * dv.z + (b0).w * dw.x + (b1).x * dw.y + (b1).y * dw.z;    \
-        const float dl0_ = (b2).y - jv_ * (b2).z;                                                                 \
-        const float s0_ = (lam) + dl0_;                                                                           \
+        const float jv_ = ((b0).x * dv.x + (b0).y * dv.y + (b0).z * dv.z) + ((b0).w * dw.x + (b1).x * dw.y + (b1).y * dw.z);    \
+        const float s0_ = fmaf(-jv_, (b2).z, (lam) + (b2).y);       /* (lambda + rhs) - dinv * J.v */             \
         const float sum_ = fminf(fmaxf(s0_, (lo)), (hi));                                                         \
-        const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - (lam);                                                    \
+        const float dl_ = sum_ - (lam);                                                                           \
         (lam) = sum_;                                                                                             \
         const float sm_ = dl_ * inv_mass;                                                                         \
         dv.x += (b0).x * sm_; dv.y += (b0).y * sm_; dv.z += (b0).z * sm_;                                            \
@@ -1083,7 +1081,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
 #pragma unroll
     for (int j = 0; j < NB; j++) minv_l[j] = l < NB ? LD(L_MINV + lj * NB + j) : 0.0f;
     const float m_rhs = l < NB ? LD(L_MOT + 3 * lj) : 0.0f, m_dinv = l < NB ? LD(L_MOT + 3 * lj + 1) : 0.0f;
-    float m_lam = 0.0f;
+    float m_lam = 0.0f, m_c = m_rhs;        // m_c = lambda + rhs of this lane's motor row, kept up to date off the critical chain
     // Leading object-vs-static contacts (the common case: objects resting on the table) get a specialised sweep:
     // ownership of contact c by this lane is one bit of `own_os`, rows are prefetched one step ahead.
     // (n_os = number of leading object-vs-static contacts and own_os = this lane's share of them were collected by the gather)
@@ -1130,11 +1128,11 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     // broadcast to the 16 lanes of the env with one DPP row_newbcast (branch-free clamp, same values as if/else)
 #define MOTOR_STEP(J)                                                                     \
         {                                                                                 \
-            const float dl0_ = m_rhs - dq * m_dinv;                                       \
-            const float s0_ = m_lam + dl0_;                                               \
+            const float s0_ = fmaf(-dq, m_dinv, m_c);          /* (lambda + rhs) - dinv * dq */ \
             const float sum_ = fminf(fmaxf(s0_, -max_imp), max_imp);                      \
-            const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - m_lam;                        \
+            const float dl_ = sum_ - m_lam;                                               \
             m_lam = (l == (J)) ? sum_ : m_lam;                                            \
+            m_c = (l == (J)) ? sum_ + m_rhs : m_c;                                        \
             dq += minv_l[J] * row_bcast<J>(dl_);                                          \
         }
 #define SWEEP_MOTORS                                                                                  \
@@ -1143,10 +1141,9 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
 #define LIMIT_STEP(k)   /* joint limit held in registers; absent rows are all-zero: dl = 0 */        \
         {                                                                                             \
             const float dqj_ = group_sum(l == lim_j[k] ? dq : 0.0f);                                  \
-            const float dl0_ = lim_rhs[k] - lim_sg[k] * dqj_ * lim_dinv[k];                           \
-            const float s0_ = lim_lam[k] + dl0_;                                                      \
+            const float s0_ = fmaf(-(lim_sg[k] * dqj_), lim_dinv[k], lim_lam[k] + lim_rhs[k]);         \
             const float sum_ = fminf(fmaxf(s0_, 0.0f), 100.0f);                                       \
-            const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - lim_lam[k];                               \
+            const float dl_ = sum_ - lim_lam[k];                                                      \
             lim_lam[k] = sum_;                                                                        \
             dq += lim_col[k] * (lim_sg[k] * dl_);                                                     \
         }
@@ -1207,10 +1204,9 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                                  : (rob_ ? jal_ * dq : 0.0f);                                                      \
         const float jv_ = group_sum(part_);                                                                        \
         const float lam_ = b2_.w;                                                                                  \
-        const float dl0_ = b2_.y - jv_ * b2_.z;                                                                    \
-        const float s0_ = lam_ + dl0_;                                                                             \
+        const float s0_ = fmaf(-jv_, b2_.z, lam_ + b2_.y);                                                         \
         const float sum_ = fminf(fmaxf(s0_, (LOB)), (HIB));                                                        \
-        const float dl_ = (sum_ == s0_) ? dl0_ : sum_ - lam_;                                                      \
+        const float dl_ = sum_ - lam_;                                                                             \
         g_slds[ro_ + 11] = sum_;                                                                                   \
         if ((K) == 0) gln[J] = sum_;                                                                               \
         dq += rob_ ? mjal_ * dl_ : 0.0f;                                                                           \
@@ -1341,10 +1337,9 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                         const float part = own ? sgn * dot(dir, dv) + dot(ang, dw) : (rob ? jal * dq : 0.0f);
                         const float jv = group_sum(part);
                         const float lam = b2.w;
-                        const float dl0 = b2.y - jv * b2.z;
-                        const float s0 = lam + dl0;
+                        const float s0 = fmaf(-jv, b2.z, lam + b2.y);
                         const float sum = fminf(fmaxf(s0, lo), hi);
-                        const float dl = (sum == s0) ? dl0 : sum - lam;
+                        const float dl = sum - lam;
                         LD(L_BASE + r * 12 + 11) = sum;                   // every lane writes the same value
                         dq += rob ? mjal * dl : 0.0f;
                         const float so = own ? dl : 0.0f, sm = sgn * so * inv_mass;

@@ -361,23 +361,34 @@ def test_soak_full_range_commands_stay_finite_and_reproducible():
 
 def test_raster_parity_many_poses_near_camera():
     """24 envs with wide joint commands (links pass close to the camera: near-plane drops, screen-filling slivers, the
-    hierarchical block path), three frames each: mask identical, RGB within 1 grey level, depth within 1e-5 (the oracle's
-    forward kinematics is float64, the device's float32: for geometry a few centimetres from the near plane the GL depth
-    is steep in 1/w, measured worst case 1.5e-6)."""
+    hierarchical block path), three frames each.  Against the float32 build of the oracle (same algorithm, same
+    precision as the device): mask identical, RGB within 1 grey level, depth within 1e-5 at every pixel.  Against the
+    float64 oracle the same bounds hold except at isolated pixels whose centre lies on a triangle edge to within the
+    float32 rounding of the forward kinematics (a few centimetres from the near plane 1/w amplifies the last bit of an
+    instance matrix to ~1e-4 pixel): at most 2 such pixels per frame and 4 over the 72 frames x 16384 pixels, and the
+    mask must still be identical (measured: 1 pixel)."""
     N, W, H = 24, 128, 128
     env = BatchedREALRobotEnv(N, objects=3, width=W, height=H)
-    o = Oracle(3, W, H)
+    o, o32 = Oracle(3, W, H), Oracle(3, W, H, f32=True)
+    flips = 0
     for t in range(180):
         act = synthetic_actions(range(N), t, seed=11) * 0.8
         env.step(act, render=(t % 60 == 59))
         if t % 60 == 59:
             st, rgb, dep, msk = env.state, env.host(nat.F_RGB), env.host(nat.F_DEPTH), env.host(nat.F_MASK)
             for i in range(N):
-                o.state = st[i].astype(np.float64)
-                r, d, m = o.render()
+                o32.state = st[i].astype(np.float64)
+                r, d, m = o32.render()
                 assert (m == msk[i]).all(), (t, i)
                 assert np.abs(r.astype(int) - rgb[i].astype(int)).max() <= 1, (t, i)
                 assert np.abs(d - dep[i]).max() < 1e-5, (t, i)
+                o.state = st[i].astype(np.float64)
+                r, d, m = o.render()
+                assert (m == msk[i]).all(), (t, i)
+                bad = (np.abs(r.astype(int) - rgb[i].astype(int)).max(-1) > 1) | (np.abs(d - dep[i]) >= 1e-5)
+                assert bad.sum() <= 2, (t, i, int(bad.sum()))
+                flips += int(bad.sum())
+    assert flips <= 4, flips
     env.close()
 
 
