@@ -474,6 +474,14 @@ __device__ __forceinline__ Xf load_xf(const ShapeData *S, int s, const float *st
 __device__ unsigned long long g_sprof[16];
 #define SPROF(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && (!(P.ablate & 0x4000) || (int)blockIdx.x == (P.ablate >> 16))) atomicAdd(&g_sprof[i], now_ - sp_t0); sp_t0 = now_; } while (0)   /* RR_ABLATE = block << 16 | 0x4000: one block only */
 #define SPROF_INIT unsigned long long sp_t0 = __builtin_readcyclecounter();
+// per solver workgroup: {cycles, and per env nc | generic << 8 | overflow rows << 16 | LDS robot rows << 24}
+__device__ unsigned g_sblk[4096 * 5];
+#define SBLK_BEGIN const unsigned long long sb_t0 = __builtin_readcyclecounter();
+#define SBLK_END(ncv, gv, ovf, lean) do { if (blockIdx.x < 4096) { if (l == 0) g_sblk[blockIdx.x * 5 + 1 + grp] = (unsigned)(ncv) | ((unsigned)(gv) << 8) | ((unsigned)(ovf) << 16) | ((unsigned)(lean) << 24); \
+    if (threadIdx.x == 0) g_sblk[blockIdx.x * 5] = (unsigned)(__builtin_readcyclecounter() - sb_t0); } } while (0)
+extern "C" int rr_debug_solver_blocks(unsigned *out, int nblocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sblk), sizeof(unsigned) * 5 * (size_t)nblocks) == hipSuccess ? 0 : -1;
+}
 extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sprof), sizeof(g_sprof)) != hipSuccess) return -1;
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sprof), z, sizeof(z)) != hipSuccess) return -1; }
@@ -482,6 +490,8 @@ extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
 #else
 #define SPROF(i)
 #define SPROF_INIT
+#define SBLK_BEGIN
+#define SBLK_END(ncv, gv, ovf, lean)
 #endif
 
 // ---- collision: one wavefront per env ------------------------------------------------------------------------------
@@ -707,28 +717,32 @@ __device__ __forceinline__ void plane_space(v3 n, v3 &p, v3 &q) {   // btPlaneSp
 //   lanes 0..10  own joint velocity delta dq[lane]; a robot row contributes Ja[lane]*dq[lane] and applies MJa[lane]*dl
 //   lanes 11..13 own the velocity delta (dv, dw) of object lane-11
 //   J.v is a 16-lane butterfly sum (ds_swizzle/dpp via __shfl_xor); clamping is done redundantly by every lane.
-// All rows a sweep touches live in LDS (one slab per env):
+// All rows a sweep touches live in LDS.  Per env a fixed part:
 //   Minv (121), motor rows (11 x {rhs, dinv, lambda}), joint-limit rows (22 x {rhs, lambda}), contact meta (48 ints),
-//   friction coefficient (LC) and per contact row
-//     base  part (12): dir[3], aa[3], maa[3], rhs, dinv, lambda          -- first LC contacts
-//     robot part (22): Ja[11], MJa[11]                                   -- first LR robot-involved contacts
-//     Bside part  (6): ab[3], mab[3]                                     -- first LB object-object contacts
-// Contacts beyond those capacities (rare) keep their rows in the global scratch slab with the ROWF layout
+//   friction coefficients (48)
+// and per contact row, taken from the workgroup's row pool according to the env's contact population (the four envs
+// of a workgroup share 8 912 floats: an env pushing an object with 30 robot contacts borrows what its neighbours with
+// a dozen resting contacts do not need):
+//     base  part (12): dir[3], aa[3], maa[3], rhs, dinv, lambda          -- lc contacts
+//     robot part (22): Ja[11], MJa[11]                                   -- lr robot-involved contacts
+//     Bside part  (6): ab[3], mab[3]                                     -- lb object-object contacts
+// Contacts the pool cannot hold (rare) keep their rows in the global scratch slab with the ROWF layout
 // (0..10 Ja, 11..21 MJa, 22..24 dir, 25..27 aa, 28..30 maa, 31..33 ab, 34..36 mab, 37 rhs, 38 dinv, 39 lambda);
 // arithmetic and row order are the same on both paths.
 #define SGRP 4           // envs per workgroup (64 threads)
-#define LC 32
-#define LR 14
-#define LB 8
-enum {
-    L_MINV = 0, L_MOT = L_MINV + 124, L_LIM = L_MOT + 36, L_META = L_LIM + 44, L_MU = L_META + MAXC,
-    L_BASE = L_MU + LC, L_ROB = L_BASE + LC * 3 * 12, L_BS = L_ROB + LR * 3 * 22, L_TOTAL = L_BS + LB * 3 * 6
-    // every section starts on a multiple of 4 floats so that base parts can be read with ds_read_b128
-};
-static_assert(L_TOTAL * 16 * 4 <= 163840, "16 solver slabs must fit the 160 KiB LDS of a CU");
-static_assert(L_BASE % 4 == 0 && L_TOTAL % 4 == 0, "base parts must be 16-byte aligned");
-__shared__ __attribute__((aligned(16))) float g_slds[L_TOTAL * SGRP];
-#define LD(slot) g_slds[grp * L_TOTAL + (slot)]
+enum { LF_MINV = 0, LF_MOT = LF_MINV + 124, LF_LIM = LF_MOT + 36, LF_META = LF_LIM + 44, LF_MU = LF_META + MAXC, LF_TOTAL = LF_MU + MAXC };
+#define SLDS_FLOATS 10112                      // 40 448 B per workgroup: four workgroups (16 envs) per CU
+#define SPOOL (SLDS_FLOATS - SGRP * LF_TOTAL)  // floats of the row pool
+static_assert(SLDS_FLOATS * 4 * 4 <= 163840, "four solver workgroups must fit the 160 KiB LDS of a CU");
+static_assert(LF_TOTAL % 4 == 0, "row parts must be 16-byte aligned");
+__shared__ __attribute__((aligned(16))) float g_slds[SLDS_FLOATS];
+// LDS offsets (floats) of one env's sections and the number of contacts each row section holds
+struct Slab { int fix, base, rob, bs, lc, lr, lb; };
+#define SLAB_NAMES(sl)                                                                                              \
+    const int L_MINV = (sl).fix + LF_MINV, L_MOT = (sl).fix + LF_MOT, L_LIM = (sl).fix + LF_LIM, L_META = (sl).fix + LF_META, \
+              L_MU = (sl).fix + LF_MU, L_BASE = (sl).base, L_ROB = (sl).rob, L_BS = (sl).bs;                          \
+    (void)L_MINV; (void)L_MOT; (void)L_LIM; (void)L_META; (void)L_MU; (void)L_BASE; (void)L_ROB; (void)L_BS;
+#define LD(slot) g_slds[(slot)]
 // Overflow rows in global memory: the immutable part (Jacobians, directions, rhs, dinv) is written during the row build
 // and made visible to the other lanes of the group with ONE agent-scope fence before the sweeps; the mutable part
 // (lambda) is owned by lane 0, which alone reads and writes it and broadcasts the impulse change with a DPP row
@@ -738,12 +752,12 @@ __shared__ __attribute__((aligned(16))) float g_slds[L_TOTAL * SGRP];
 #define ROWS(r, f, v) (*ROW_ADDR(r, f) = (v))
 #define ROW_FENCE()
 
-// meta word: bodyA (8) | bodyB (8) | linkA (8) | robot slot (4, 15 = none/global) | Bside slot (4, 15 = none/global)
+// meta word: bodyA (8) | bodyB (8) | linkA (8) | rows in LDS (1) | lane of the object of a robot-object contact (4,
+// 15 = none) | that object is body B (1)
 __device__ __forceinline__ int meta_bodyA(int m) { return (signed char)(m & 255); }
 __device__ __forceinline__ int meta_bodyB(int m) { return (signed char)((m >> 8) & 255); }
 __device__ __forceinline__ int meta_link(int m) { return (signed char)((m >> 16) & 255); }
-__device__ __forceinline__ int meta_rslot(int m) { return (m >> 24) & 15; }
-__device__ __forceinline__ int meta_bslot(int m) { return (m >> 28) & 15; }
+__device__ __forceinline__ bool meta_fast(int m) { return (m >> 24) & 1; }
 
 // Sum over the 16 lanes of a group (= one DPP row), result in every lane: four rotate-and-add steps on the VALU
 // (v_add_f32 with row_ror:8/4/2/1), no LDS crossbar traffic. Every lane performs the same commutative pairings, so
@@ -778,10 +792,11 @@ struct ObjData { v3 op, vs, ws; m3 Iinv; float imass; };
 // Builds row k (0 normal, 1, 2 tangents) of contact c along `dir`; returns the relative velocity A - B along dir.
 // Executed by all 16 lanes of the env's group; `l` is the lane index within the group.  Nothing is read from global
 // memory here: the lane's joint frame (pk, ak), its unconstrained velocity qds and the objects' data are passed in.
-__device__ float build_row(const SimParams &P, const DevPtrs &D, int env, int grp, int l, int c, int k,
+__device__ float build_row(const SimParams &P, const DevPtrs &D, int env, const Slab &sl, int l, int c, int k,
                            bool fast, int rslot, int bslot, int bodyA, int bodyB, v3 x, v3 dir,
                            v3 pk, v3 ak, float qds, const ObjData &oA, const ObjData &oB) {
     const int N = P.N;
+    SLAB_NAMES(sl)
     float *scratch = D.scratch;
     const int row = 3 * c + k;
     float diag = 0, rel = 0;
@@ -831,6 +846,7 @@ __device__ float build_row(const SimParams &P, const DevPtrs &D, int env, int gr
         if (fast) {
             const int o = L_BASE + row * 12;
             LD(o) = dir.x; LD(o + 1) = dir.y; LD(o + 2) = dir.z; LD(o + 10) = dinv; LD(o + 11) = 0.0f;
+            if (bodyA < 16 && bodyB < 16) { LD(o + 3) = 0.0f; LD(o + 4) = 0.0f; LD(o + 5) = 0.0f; LD(o + 6) = 0.0f; LD(o + 7) = 0.0f; LD(o + 8) = 0.0f; }
         } else {
             ROWS(row, 22, dir.x); ROWS(row, 23, dir.y); ROWS(row, 24, dir.z); ROWS(row, 38, dinv); ROWS(row, 39, 0.0f);
         }
@@ -878,15 +894,19 @@ __device__ __forceinline__ float4 sel4(bool has, float4 v) {
 __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs D) {
     const int N = P.N;
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
-    const int env = blockIdx.x * SGRP + grp;
-    if (env >= N) return;
+    const int env_raw = blockIdx.x * SGRP + grp;
+    const int env = env_raw < N ? env_raw : N - 1;          // groups without an env stay until the row pool is divided
     float *state = D.state, *scratch = D.scratch;
-    if (D.errflags[env]) return;
+    const bool dead = env_raw >= N || D.errflags[env] != 0;
     const ShapeData *S = D.shapes;
+    Slab sl;
+    sl.fix = grp * LF_TOTAL;
+    const int L_MINV = sl.fix + LF_MINV, L_MOT = sl.fix + LF_MOT, L_LIM = sl.fix + LF_LIM, L_META = sl.fix + LF_META, L_MU = sl.fix + LF_MU;
     const float dt = P.dt;
     const int lj = l < NB ? l : 0;               // joint owned by this lane (lanes >= 11 alias joint 0, masked)
     const int lo_ = (l >= NB && l < NB + NOBJ) ? l - NB : -1;   // object owned by this lane
     SPROF_INIT
+    SBLK_BEGIN
     // ---- stage Minv in LDS; the lane's joint frame and unconstrained velocity go to registers (same round trip)
     for (int i = l; i < NB * NB; i += 16) LD(L_MINV + i) = SCR(S_MINV + i);
     const v3 pk_l = mk(SCR(S_BP + 3 * lj), SCR(S_BP + 3 * lj + 1), SCR(S_BP + 3 * lj + 2));
@@ -909,15 +929,42 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     // The 92 per-pair candidate counts are fetched in one go: lane l loads the counts of pairs l, l+16, ... and the
     // non-empty pairs are collected into per-group bit masks with wave ballots (no chain of dependent global loads).
     unsigned pmask[MAXPAIRS / 16];
+    float need_c = 0, need_r = 0, need_b = 0;    // candidate contacts of this env: all / robot involved / object-object
 #pragma unroll
     for (int k = 0; k < MAXPAIRS / 16; k++) {
         const int pr = 16 * k + l;
-        const int cntl = pr < P.npairs ? *(const int *)&SCR(S_PCOUNT + pr) : 0;
+        const bool in = pr < P.npairs && !dead;
+        const int cntl = in ? *(const int *)&SCR(S_PCOUNT + pr) : 0;
+        const int2 ab = *(const int2 *)S->pair_meta[in ? pr : 0];
         const unsigned long long bal = __ballot(cntl > 0);
         pmask[k] = (unsigned)(bal >> (16 * grp)) & 0xffffu;
+        need_c += (float)cntl;
+        need_r += ((ab.x >= 0 && ab.x < 16) || (ab.y >= 0 && ab.y < 16)) ? (float)cntl : 0.0f;
+        need_b += (ab.x >= 16 && ab.y >= 16) ? (float)cntl : 0.0f;
     }
+    // ---- divide the workgroup's row pool: every env asks for what its candidate contacts need, served in env order
+    {
+        const int want_c = min((int)group_sum(need_c), MAXC), want_r = min((int)group_sum(need_r), MAXC), want_b = min((int)group_sum(need_b), MAXC);
+        int cursor = SGRP * LF_TOTAL, avail = SPOOL;
+        sl.base = sl.rob = sl.bs = cursor; sl.lc = sl.lr = sl.lb = 0;
+#pragma unroll
+        for (int g = 0; g < SGRP; g++) {
+            const int wc = __builtin_amdgcn_readlane(want_c, 16 * g), wr = __builtin_amdgcn_readlane(want_r, 16 * g), wb = __builtin_amdgcn_readlane(want_b, 16 * g);
+            const int ac = min(wc, avail / 36); avail -= ac * 36;
+            const int ar = min(wr, avail / 66); avail -= ar * 66;
+            const int ab_ = min(wb, avail / 18); avail -= ab_ * 18;
+            if (g == grp) { sl.base = cursor; sl.rob = cursor + ac * 36; sl.bs = sl.rob + ar * 66; sl.lc = ac; sl.lr = ar; sl.lb = ab_; }
+            const int used = ac * 36 + ar * 66 + ab_ * 18, pad = (4 - (used & 3)) & 3;      // base parts stay 16-byte aligned
+            cursor += used + pad;
+            avail = max(avail - pad, 0);
+        }
+    }
+    if (dead) return;
+    const int L_BASE = sl.base, L_ROB = sl.rob, L_BS = sl.bs;
     int n_os = 0;
     unsigned own_os = 0;
+    bool any_slow = false;            // some contact of this env keeps its rows in global memory
+    int c_rf = 0;                     // end of the run of robot contacts whose rows are in LDS (they precede any overflow)
     int nc = 0, gidx = 0, n_oo = 0;   // gidx: index among the generic (not object-vs-static) contacts, which all follow the
                                       // object-vs-static ones; n_oo: object-object contacts (their pairs precede the robot pairs)
     static_assert(MAXPAIRS / 16 == 6, "pair-mask select chain below");
@@ -970,22 +1017,24 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             const v3 x = mk(c7[0], c7[1], c7[2]), n = mk(c7[3], c7[4], c7[5]);
             const float dist = c7[6];
             int rslot = 15, bslot = 15;
-            bool fast = nc < LC;
+            bool fast = nc < sl.lc;
             // the Bside part of generic contact j lives in slot j, its robot part in slot j - n_oo of the LDS sections
             // (object-object pairs precede the robot pairs): sweep code finds them without reading the meta word
-            if (robot) { if (gidx - n_oo < LR && fast) rslot = gidx - n_oo; else fast = false; }
-            if (objobj) { if (gidx < LB && fast) bslot = gidx; else fast = false; n_oo = gidx + 1; }
+            if (robot) { if (gidx - n_oo < sl.lr && fast) rslot = gidx - n_oo; else fast = false; }
+            if (objobj) { if (gidx < sl.lb && fast) bslot = gidx; else fast = false; n_oo = gidx + 1; }
             if (robot || objobj) gidx++;
-            else if (gidx == 0 && nc < LC) {       // still inside the leading run of object-vs-static contacts
+            else if (gidx == 0 && nc < sl.lc) {       // still inside the leading run of object-vs-static contacts
                 n_os = nc + 1;
                 if (lo_ >= 0 && bodyA == 16 + lo_) own_os |= 1u << nc;
             }
-            if (!fast) { rslot = 15; bslot = 15; }
-            // "fast" is recoverable from the meta word: c < LC and (no robot side or rslot != 15) and (no B object or bslot != 15)
-            int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | (rslot << 24) | (bslot << 28);
+            const int olane = !robot ? 15 : (bodyA >= 16 ? NB + bodyA - 16 : (bodyB >= 16 ? NB + bodyB - 16 : 15));
+            int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | ((fast ? 1 : 0) << 24) | (olane << 25) |
+                       ((robot && bodyB >= 16 ? 1 : 0) << 29);
+            if (robot && fast) c_rf = nc + 1;
+            any_slow = any_slow || !fast;
             if (l == 0) {
                 *(int *)&LD(L_META + nc) = meta;
-                if (nc < LC) LD(L_MU + nc) = mu;
+                LD(L_MU + nc) = mu;
             }
             if (l < 12) {   // contact record (rr_get_contacts, touch sensors): field l is stored by lane l, one instruction
                 const float fld = l == 0 ? (float)bodyA : l == 1 ? (float)bodyB : l == 2 ? (float)linkA : l == 3 ? x.x : l == 4 ? x.y :
@@ -1017,7 +1066,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                 continue;
             }
             // normal row
-            float rel = build_row(P, D, env, grp, l, nc, 0, fast, rslot, bslot, bodyA, bodyB, x, n, pk_l, ak_l, qds_l, oA, oB);
+            float rel = build_row(P, D, env, sl, l, nc, 0, fast, rslot, bslot, bodyA, bodyB, x, n, pk_l, ak_l, qds_l, oA, oB);
             float r = 0;
             if (fabsf(rel) >= P.rest_thresh) { r = rest * -rel; if (r < 0) r = 0; }
             float verr = r - rel, perr = 0;
@@ -1025,8 +1074,8 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             else perr = -dist * P.erp / dt;
             v3 t1, t2;
             plane_space(n, t1, t2);
-            float rel1 = build_row(P, D, env, grp, l, nc, 1, fast, rslot, bslot, bodyA, bodyB, x, t1, pk_l, ak_l, qds_l, oA, oB);
-            float rel2 = build_row(P, D, env, grp, l, nc, 2, fast, rslot, bslot, bodyA, bodyB, x, t2, pk_l, ak_l, qds_l, oA, oB);
+            float rel1 = build_row(P, D, env, sl, l, nc, 1, fast, rslot, bslot, bodyA, bodyB, x, t1, pk_l, ak_l, qds_l, oA, oB);
+            float rel2 = build_row(P, D, env, sl, l, nc, 2, fast, rslot, bslot, bodyA, bodyB, x, t2, pk_l, ak_l, qds_l, oA, oB);
             if (l == 0) {
                 if (fast) {
                     LD(L_BASE + (3 * nc) * 12 + 9) = (perr + verr) * LD(L_BASE + (3 * nc) * 12 + 10);
@@ -1155,71 +1204,39 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             REG_ROW_STEP(os_b0[i], os_b1[i], os_b2[i], os_l2[i], -hi_, hi_);                          \
         }
     SPROF(3);
-    // Generic contacts (robot involved, or two objects) in LDS: their per-lane roles are loop invariant, so they are
-    // decoded once into bit masks (bit j = generic contact j = contact n_os + j); its robot / Bside part is in slot j.
-    unsigned g_robot = 0, g_objobj = 0, g_ownA = 0, g_ownB = 0;
-    bool g_allfast = nc - n_os <= 32;
-    for (int c = n_os; c < nc && c - n_os < 32; c++) {
-        const int meta = *(const int *)&LD(L_META + c);
-        const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta);
-        const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
-        const bool objobj = bodyA >= 16 && bodyB >= 16;
-        const bool fast = (c < LC) && (!robot || meta_rslot(meta) != 15) && (!objobj || meta_bslot(meta) != 15);
-        g_allfast = g_allfast && fast;
-        const unsigned bit = 1u << (c - n_os);
-        if (robot) g_robot |= bit;
-        if (objobj) g_objobj |= bit;
-        if (lo_ >= 0 && bodyA == 16 + lo_) g_ownA |= bit;
-        if (lo_ >= 0 && bodyB == 16 + lo_) g_ownB |= bit;
-    }
-    const int G = nc - n_os;
-    // Up to NGU generic contacts: fully written-out sweep.  Contact index, row offsets and slots are compile-time
-    // constants, so a row step is ~45 instructions (immediate-offset LDS reads, bit tests on the role masks) instead of
-    // ~120 with run-time addressing -- with one wave per SIMD a row costs (instructions x ~8 cycles).  The normal impulse
-    // of each contact stays in a register between the two passes.
-#define NGU 12
-    const bool g_unrolled = g_allfast && G <= NGU;
-    const int gbase = grp * L_TOTAL + L_BASE + n_os * 36, rbase = grp * L_TOTAL + L_ROB + lj - n_oo * 66, bbase = grp * L_TOTAL + L_BS;
-    float gln[NGU];
-#pragma unroll
-    for (int j = 0; j < NGU; j++) gln[j] = 0.0f;
-    const int mubase = grp * L_TOTAL + L_MU + n_os;
-#define GROW(J, K, LOB, HIB)                                                                                       \
+    // Generic contacts (robot involved, or two objects) follow the object-vs-static ones in contact order: first the
+    // object-object contacts [n_os, c_r0), then the robot contacts [c_r0, nc), of which [c_r0, c_rf) have their rows in LDS.
+    // Row step of a robot contact (robot-static or robot-object) for any number of contacts: rows streamed from LDS.
+    // The contact's object (if any) is owned by lane (meta >> 25) & 15; bit 29 says it is body B (direction negated).
+    // Robot-static rows hold zeros in their object slots, lanes >= 11 have dq == 0 and take MJa = 0.
+    const int c_r0 = n_os + n_oo;
+    if (c_rf < c_r0) c_rf = c_r0;
+    const int base4 = L_BASE >> 2;          // base parts are float4-aligned (the pool cursor advances in multiples of 4 floats)
+#define LEAN_LOAD(B, C, K)   /* fetch row K of robot contact C into register set B */                              \
     {                                                                                                              \
-        const int ro_ = gbase + ((J) * 3 + (K)) * 12;                                                              \
-        const int rr_ = ((g_robot >> (J)) & 1u) ? rbase + ((J) * 3 + (K)) * 22 : grp * L_TOTAL + lj;   /* harmless address when no robot part */ \
-        const float4 b0_ = *(const float4 *)&g_slds[ro_], b1_ = *(const float4 *)&g_slds[ro_ + 4], b2_ = *(const float4 *)&g_slds[ro_ + 8]; \
-        const float jal_ = g_slds[rr_], mjal_ = g_slds[rr_ + 11];                                                  \
-        const bool mineA_ = (g_ownA >> (J)) & 1u, mineB_ = (g_ownB >> (J)) & 1u;                                   \
-        const bool own_ = mineA_ || mineB_, rob_ = ((g_robot >> (J)) & 1u) && l < NB;                              \
-        float a0_ = b0_.w, a1_ = b1_.x, a2_ = b1_.y, m0_ = b1_.z, m1_ = b1_.w, m2_ = b2_.x;                        \
-        if ((J) < LB) {                                                                                            \
-            const bool useB_ = ((g_objobj >> (J)) & 1u) && mineB_;                                                 \
-            const int bo_ = bbase + ((J) * 3 + (K)) * 6;                                                           \
-            a0_ = useB_ ? g_slds[bo_] : a0_; a1_ = useB_ ? g_slds[bo_ + 1] : a1_; a2_ = useB_ ? g_slds[bo_ + 2] : a2_;       \
-            m0_ = useB_ ? g_slds[bo_ + 3] : m0_; m1_ = useB_ ? g_slds[bo_ + 4] : m1_; m2_ = useB_ ? g_slds[bo_ + 5] : m2_;   \
-        }                                                                                                          \
-        const float sgn_ = mineA_ ? 1.0f : -1.0f;                                                                  \
-        const float part_ = own_ ? sgn_ * (b0_.x * dv.x + b0_.y * dv.y + b0_.z * dv.z) + (a0_ * dw.x + a1_ * dw.y + a2_ * dw.z) \
-                                 : (rob_ ? jal_ * dq : 0.0f);                                                      \
-        const float jv_ = group_sum(part_);                                                                        \
-        const float lam_ = b2_.w;                                                                                  \
-        const float s0_ = fmaf(-jv_, b2_.z, lam_ + b2_.y);                                                         \
+        B##row = (base4 + (3 * (C) + (K)) * 3) << 2;                                                               \
+        const int rr_ = L_ROB + (((C) - c_r0) * 3 + (K)) * 22 + lj;                                                \
+        B##p = *(const float4 *)&LD(B##row); B##q = *(const float4 *)&LD(B##row + 4); B##r = *(const float4 *)&LD(B##row + 8); \
+        B##j = LD(rr_); B##m = LD(rr_ + 11); B##m = l < NB ? B##m : 0.0f;                                                     \
+    }
+#define LEAN_STEP(B, LOB, HIB)                                                                                     \
+    {                                                                                                              \
+        const float pobj_ = __int_as_float(__float_as_int(B##p.x * dv.x + B##p.y * dv.y + B##p.z * dv.z) ^ sb_) +  \
+                            (B##p.w * dw.x + B##q.x * dw.y + B##q.y * dw.z);                                       \
+        const float jv_ = group_sum(own_ ? pobj_ : B##j * dq);                                                     \
+        const float lam_ = B##r.w;                                                                                 \
+        const float s0_ = fmaf(-jv_, B##r.z, lam_ + B##r.y);                                                       \
         const float sum_ = fminf(fmaxf(s0_, (LOB)), (HIB));                                                        \
         const float dl_ = sum_ - lam_;                                                                             \
-        g_slds[ro_ + 11] = sum_;                                                                                   \
-        if ((K) == 0) gln[J] = sum_;                                                                               \
-        dq += rob_ ? mjal_ * dl_ : 0.0f;                                                                           \
-        const float so_ = own_ ? dl_ : 0.0f, sm_ = sgn_ * so_ * inv_mass;                                          \
-        dv.x += b0_.x * sm_; dv.y += b0_.y * sm_; dv.z += b0_.z * sm_;                                             \
-        dw.x += own_ ? m0_ * dl_ : 0.0f; dw.y += own_ ? m1_ * dl_ : 0.0f; dw.z += own_ ? m2_ * dl_ : 0.0f;         \
+        LD(B##row + 11) = sum_;                                                                                    \
+        dq = fmaf(B##m, dl_, dq);                                                                                  \
+        const float so_ = own_ ? dl_ : 0.0f;                                                                       \
+        const float sm_ = __int_as_float(__float_as_int(so_ * inv_mass) ^ sb_);                                    \
+        dv.x += B##p.x * sm_; dv.y += B##p.y * sm_; dv.z += B##p.z * sm_;                                          \
+        dw.x += B##q.z * so_; dw.y += B##q.w * so_; dw.z += B##r.x * so_;                                          \
     }
-#define GNORMAL(J) if ((J) < G) GROW(J, 0, 0.0f, 1e10f)
-#define GFRICT(J) if ((J) < G) { const float hi_ = g_slds[mubase + (J)] * gln[J]; GROW(J, 1, -hi_, hi_) GROW(J, 2, -hi_, hi_) }
-#define GEN_UNROLLED_N GNORMAL(0) GNORMAL(1) GNORMAL(2) GNORMAL(3) GNORMAL(4) GNORMAL(5) GNORMAL(6) GNORMAL(7) GNORMAL(8) GNORMAL(9) GNORMAL(10) GNORMAL(11)
-#define GEN_UNROLLED_F GFRICT(0) GFRICT(1) GFRICT(2) GFRICT(3) GFRICT(4) GFRICT(5) GFRICT(6) GFRICT(7) GFRICT(8) GFRICT(9) GFRICT(10) GFRICT(11)
-    static_assert(NGU == 12, "GEN_UNROLLED_* are written out for 12 contacts");
-    if (__ballot(!g_allfast)) __threadfence();       // rows built in global memory become visible to the group's other lanes
+#define LEAN_ROLE(M) const bool own_ = (((M) >> 25) & 15) == l; const int sb_ = ((M) << 2) & 0x80000000;
+    if (__ballot(any_slow)) __threadfence();       // rows built in global memory become visible to the group's other lanes
     static_assert(KLIM == 2 && KOS == 4, "the sweeps below are written out for KLIM = 2, KOS = 4");
     // When no env of this wave has a row outside the registers (no robot or object-object contact, no further limit
     // or contact rows), an iteration is one straight-line block: the robot chain (motors, limits) and the object chain
@@ -1295,15 +1312,51 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     OS_ROW_STEP(c0, c1, c2, -hi, hi, 3 * cc + 2);
                 }
             }
-            if (g_unrolled) {      // wave-divergent only between the four envs of the wave
-                if (pass == 0) { GEN_UNROLLED_N } else { GEN_UNROLLED_F }
-            } else
-            for (int c = n_os; c < nc; c++) {
+            // The four envs of the wave walk the same three segments together (object-object, robot contacts in
+            // LDS, overflow), so that the long one -- the robot contacts -- is not serialised between them.
+#pragma unroll 1
+            for (int seg = 0; seg < 2; seg++) {
+            if (seg == 1 && c_rf > c_r0) {
+                // ---- robot contacts with rows in LDS [c_r0, c_rf): software-pipelined row steps, the next row is
+                //      fetched while the current one is swept (one wave per SIMD: LDS latency is otherwise exposed)
+                // two register sets A / B take turns (no copies): one is swept while the other is being filled
+                float4 Ap, Aq, Ar, Bp, Bq, Br; float Aj, Am, Bj, Bm; int Arow, Brow, mA;
+                LEAN_LOAD(A, c_r0, pass)
+                mA = *(const int *)&LD(L_META + c_r0);
+                if (pass == 0) {
+                    for (int cc = c_r0; cc < c_rf; cc += 2) {
+                        const int c1_ = min(cc + 1, c_rf - 1);
+                        LEAN_LOAD(B, c1_, 0)
+                        const int mB = *(const int *)&LD(L_META + c1_);
+                        { LEAN_ROLE(mA) LEAN_STEP(A, 0.0f, 1e10f) }
+                        if (cc + 1 < c_rf) {
+                            const int c2_ = min(cc + 2, c_rf - 1);
+                            LEAN_LOAD(A, c2_, 0)
+                            mA = *(const int *)&LD(L_META + c2_);
+                            { LEAN_ROLE(mB) LEAN_STEP(B, 0.0f, 1e10f) }
+                        }
+                    }
+                } else {
+                    float nmu_ = LD(L_MU + c_r0), nln_ = LD(L_BASE + (3 * c_r0) * 12 + 11);
+                    for (int cc = c_r0; cc < c_rf; cc++) {
+                        const float hi_ = nmu_ * nln_;
+                        LEAN_ROLE(mA)
+                        LEAN_LOAD(B, cc, 2)
+                        LEAN_STEP(A, -hi_, hi_)
+                        const int cn_ = min(cc + 1, c_rf - 1);
+                        LEAN_LOAD(A, cn_, 1)
+                        mA = *(const int *)&LD(L_META + cn_);
+                        nmu_ = LD(L_MU + cn_); nln_ = LD(L_BASE + (3 * cn_) * 12 + 11);
+                        LEAN_STEP(B, -hi_, hi_)
+                    }
+                }
+            }
+            for (int c = seg == 0 ? n_os : c_rf; c < (seg == 0 ? c_r0 : nc); c++) {
                 const int meta = *(const int *)&LD(L_META + c);
-                const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta), rslot = meta_rslot(meta), bslot = meta_bslot(meta);
+                const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta), bslot = c - n_os, rslot = bslot - n_oo;
                 const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
                 const bool objobj = bodyA >= 16 && bodyB >= 16;
-                const bool fast = (c < LC) && (!robot || rslot != 15) && (!objobj || bslot != 15);
+                const bool fast = meta_fast(meta);
                 const int r0 = pass == 0 ? 3 * c : 3 * c + 1, r1 = pass == 0 ? 3 * c + 1 : 3 * c + 3;
                 const bool mineA = (lo_ >= 0) && (bodyA == 16 + lo_), mineB = (lo_ >= 0) && (bodyB == 16 + lo_);
                 if (fast) {
@@ -1317,7 +1370,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     const bool useB = objobj && mineB;     // second object of an object-object contact: Bside part
                     const float ln = LD(L_BASE + (3 * c) * 12 + 11), mu = LD(L_MU + c);
                     const float hi = pass == 0 ? 1e10f : mu * ln, lo = pass == 0 ? 0.0f : -hi;
-                    const int orb0 = (robot ? L_ROB + (rslot * 3) * 22 + lj : lj) + (r0 - 3 * c) * 22;   // harmless address when no robot part
+                    const int orb0 = (robot ? L_ROB + (rslot * 3) * 22 + lj : L_MINV + lj) + (r0 - 3 * c) * 22;   // harmless address when no robot part
                     const int obs0 = L_BS + ((objobj ? bslot : 0) * 3 + (r0 - 3 * c)) * 6;               // likewise for the Bside part
                     float4 n0 = LDB4(r0, 0), n1 = LDB4(r0, 4), n2 = LDB4(r0, 8);
                     float njal = LD(orb0), nmjal = LD(orb0 + 11);
@@ -1368,10 +1421,9 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     float dl = 0.0f;
                     if (l == 0) {
                         const float rhs = ROWL(r, 37), dinv = ROWL(r, 38), lam = ROWL(r, 39);
-                        dl = rhs - jv * dinv;
-                        float sum = lam + dl;
-                        if (sum < lo) { dl = lo - lam; sum = lo; }
-                        else if (sum > hi) { dl = hi - lam; sum = hi; }
+                        const float s0 = fmaf(-jv, dinv, lam + rhs);
+                        const float sum = fminf(fmaxf(s0, lo), hi);
+                        dl = sum - lam;
                         ROWS(r, 39, sum);
                     }
                     dl = row_bcast<0>(dl);
@@ -1380,9 +1432,11 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     if (mineB) { dv = dv + dir * (-dl * inv_mass); dw = dw + mang * dl; }
                 }
             }
+            }
         }
     }
     SPROF(4);
+    SBLK_END(nc, nc - n_os, nc - c_rf, c_rf - c_r0);
     // impulses of the register-resident contact rows go back to their LDS slots (contact forces / touch sensors below)
 #pragma unroll
     for (int i = 0; i < KOS; i++) {
@@ -1450,7 +1504,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             const int meta = *(const int *)&LD(L_META + c);
             const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta), link = meta_link(meta);
             const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
-            const bool fast = (c < LC) && (!robot || meta_rslot(meta) != 15) && (!(bodyA >= 16 && bodyB >= 16) || meta_bslot(meta) != 15);
+            const bool fast = meta_fast(meta);
             float lam = fast ? LD(L_BASE + (3 * c) * 12 + 11) : ROWL(3 * c, 39);
             float f = lam / dt;
             SCR(S_CT + c * 12 + 10) = f;
