@@ -63,7 +63,7 @@ struct BodyParams {   // passed by value as kernel argument -> scalar loads, uni
 };
 
 struct SimParams {
-    int N, nobj, iters, npairs, ablate, small_area;
+    int N, nobj, iters, npairs, ablate, small_area, par;    // par: step parity (double-buffered per-env contact demand)
     float dt, gravity, erp, margin, kp, kd, max_impulse, lin_damp, ang_damp, rest_thresh;
 };
 
@@ -124,6 +124,8 @@ struct DevPtrs {
                        // pair's 28 floats over 28 cache lines shared with 31 other envs)
     int *timestep;     // [N]
     unsigned *errflags;// [N]
+    unsigned *demand;  // [2][N] candidate contacts of the env: all | robot involved << 8 | object-object << 16, written by k_collide
+    int *solve_order;  // [4 * ceil(N / 4)] env handled by each 16-lane group of k_solve (-1: none), written by k_balance
     float *cmd;        // [N][9]
     float *joints;     // [N][9]
     float *touch;      // [N][4]
@@ -556,7 +558,12 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
     __shared__ int pair_ab[MAXPAIRS];          // shape a | shape b << 8 of every pair   } staged once: no global load of
     __shared__ int shape_n[MAXSHAPES];         // vertex count | plane count << 8        } metadata inside the pair loop
     const int lane = threadIdx.x;
-    for (int pr = lane; pr < P.npairs; pr += COLLIDE_THREADS) pair_ab[pr] = S->pair_a[pr] | (S->pair_b[pr] << 8);
+    for (int pr = lane; pr < P.npairs; pr += COLLIDE_THREADS) {
+        const int ba = S->pair_meta[pr][0], bb = S->pair_meta[pr][1];
+        const int cls = (((ba >= 0 && ba < 16) || (bb >= 0 && bb < 16)) ? 1 : 0) | ((ba >= 16 && bb >= 16) ? 2 : 0);
+        pair_ab[pr] = S->pair_a[pr] | (S->pair_b[pr] << 8) | (cls << 16);      // + robot involved (bit 16), object-object (bit 17)
+    }
+    int d_all = 0, d_rob = 0, d_oo = 0;        // candidate contacts of this env (wave-uniform), for k_balance
     if (lane < ns) {
         shape_n[lane] = S->nv[lane] | (S->nf[lane] << 8);
         const Xf X = load_xf(S, lane, state, scratch, N, env);
@@ -572,7 +579,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
         const int pr = p0 + lane;
         bool close = false;
         if (pr < P.npairs) {
-            const float4 a = sph[pair_ab[pr] & 255], b = sph[pair_ab[pr] >> 8];
+            const float4 a = sph[pair_ab[pr] & 255], b = sph[(pair_ab[pr] >> 8) & 255];
             const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, rr = a.w + b.w + P.margin;
             close = !(dx * dx + dy * dy + dz * dz > rr * rr);
             *(int *)&SCR(S_PCOUNT + pr) = 0;
@@ -585,14 +592,14 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
         float nvx = 0, nvy = 0, nvz = 0;       // vertex v of "mine", fetched one pair ahead as well
         if (todo) {
             const int pn = p0 + __ffsll((long long)todo) - 1;
-            const int pa = pair_ab[pn] & 255, pb = pair_ab[pn] >> 8;
+            const int pa = pair_ab[pn] & 255, pb = (pair_ab[pn] >> 8) & 255;
             nextpl = *(const float4 *)S->planes[dirflag ? pa : pb][v];
             const float *vp = S->verts[dirflag ? pb : pa][v];
             nvx = vp[0]; nvy = vp[1]; nvz = vp[2];
         }
         for (; todo; todo &= todo - 1) {
             const int pair = p0 + __ffsll((long long)todo) - 1;
-            const int sa = pair_ab[pair] & 255, sb = pair_ab[pair] >> 8;
+            const int sa = pair_ab[pair] & 255, sb = (pair_ab[pair] >> 8) & 255;
             // "mine" = the shape whose vertex this lane tests, "other" = the shape whose planes it is tested against
             const int sm = dirflag ? sb : sa, so = dirflag ? sa : sb;
             const float4 mypl = nextpl;     // plane v of "other"
@@ -601,7 +608,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 const unsigned long long rest = todo & (todo - 1);
                 if (rest) {
                     const int pn = p0 + __ffsll((long long)rest) - 1;
-                    const int pa = pair_ab[pn] & 255, pb = pair_ab[pn] >> 8;
+                    const int pa = pair_ab[pn] & 255, pb = (pair_ab[pn] >> 8) & 255;
                     nextpl = *(const float4 *)S->planes[dirflag ? pa : pb][v];
                     const float *vp = S->verts[dirflag ? pb : pa][v];
                     nvx = vp[0]; nvy = vp[1]; nvz = vp[2];
@@ -683,6 +690,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 k = sel3 >= 0 ? 4 : 3;
             }
             if (lane == 0) *(int *)&SCR(S_PCOUNT + pair) = k;
+            d_all += k; d_rob += ((pair_ab[pair] >> 16) & 1) ? k : 0; d_oo += ((pair_ab[pair] >> 17) & 1) ? k : 0;
             const int slot = lane == sel0 ? 0 : (lane == sel1 ? 1 : (lane == sel2 ? 2 : (lane == sel3 ? 3 : -1)));
             if (hit && slot >= 0) {
                 const float4 pl = planes[dirflag][bf];
@@ -694,6 +702,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
             }
         }
     }
+    if (lane == 0) D.demand[(size_t)P.par * N + env] = (unsigned)min(d_all, 255) | ((unsigned)min(d_rob, 255) << 8) | ((unsigned)min(d_oo, 255) << 16);
 }
 
 // ---------------------------------------------------------------------------------------------- k_solve
@@ -743,6 +752,57 @@ struct Slab { int fix, base, rob, bs, lc, lr, lb; };
               L_MU = (sl).fix + LF_MU, L_BASE = (sl).base, L_ROB = (sl).rob, L_BS = (sl).bs;                          \
     (void)L_MINV; (void)L_MOT; (void)L_LIM; (void)L_META; (void)L_MU; (void)L_BASE; (void)L_ROB; (void)L_BS;
 #define LD(slot) g_slds[(slot)]
+// ---- k_balance: which env goes to which 16-lane group of k_solve ------------------------------------------------------
+// The four envs of a solver workgroup share one row pool and one instruction stream, so a workgroup is as slow as its
+// heaviest env and envs that ask for more LDS rows than the pool holds fall back to rows in global memory.  One
+// workgroup of this kernel deals the "heavy" envs (an env that alone needs more than a quarter of the pool: a gripper
+// pushing an object) out over the solver workgroups round-robin and fills up with the light ones.  It uses the contact
+// demand k_collide recorded in the PREVIOUS step (contacts persist from step to step), so it runs on the side stream
+// beside k_collide; the order only decides where rows live and which envs wait for each other -- never a result.
+#define BAL_THREADS 1024
+__global__ void __launch_bounds__(BAL_THREADS) k_balance(SimParams P, DevPtrs D) {
+    __shared__ int s_wave[BAL_THREADS / 64];
+    const int N = P.N, t = threadIdx.x, nblk = (N + SGRP - 1) / SGRP;
+    const unsigned *dem = D.demand + (size_t)(P.par ^ 1) * N;
+    if (N > 64 * BAL_THREADS) {                       // beyond the bit mask below: identity order
+        for (int i = t; i < SGRP * nblk; i += BAL_THREADS) D.solve_order[i] = i < N ? i : -1;
+        return;
+    }
+    // thread t owns envs t, t + 1024, ... (coalesced reads)
+    unsigned long long hm = 0;
+    int nh = 0;
+    for (int j = 0, e = t; e < N; e += BAL_THREADS, j++) {
+        const unsigned d = dem[e];
+        const int need = min((int)(d & 255), MAXC) * 36 + min((int)((d >> 8) & 255), MAXC) * 66 + min((int)((d >> 16) & 255), MAXC) * 18;
+        if (need > SPOOL / SGRP) { hm |= 1ull << j; nh++; }
+    }
+    // exclusive prefix of nh over the workgroup
+    int incl = nh;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if ((t & 63) >= d) incl += o; }
+    if ((t & 63) == 63) s_wave[t >> 6] = incl;
+    if (t < SGRP) D.solve_order[SGRP * nblk - 1 - t] = -1;      // the last workgroup may have fewer than four envs
+    __syncthreads();
+    int hbase = incl - nh, H = 0;
+    for (int w = 0; w < BAL_THREADS / 64; w++) { const int c = s_wave[w]; if (w < (t >> 6)) hbase += c; H += c; }
+    // heavy rank h -> workgroup h % nblk, position h / nblk; the light envs fill the remaining positions in order
+    const int q = H / nblk, r = H % nblk;            // workgroups [0, r) hold q + 1 heavy envs, the others q
+    const int ebase = (N / BAL_THREADS) * t + min(t, N % BAL_THREADS);     // envs owned by the threads before this one
+    int hseen = 0;
+    for (int j = 0, e = t; e < N; e += BAL_THREADS, j++) {
+        int slot;
+        if ((hm >> j) & 1ull) {
+            const int h = hbase + hseen++;
+            slot = (h % nblk) * SGRP + h / nblk;
+        } else {
+            int k = ebase + j - (hbase + hseen);     // rank among the light envs
+            if (k < (SGRP - 1 - q) * r) slot = (k / (SGRP - 1 - q)) * SGRP + q + 1 + k % (SGRP - 1 - q);
+            else { k -= (SGRP - 1 - q) * r; slot = (r + k / (SGRP - q)) * SGRP + q + k % (SGRP - q); }
+        }
+        D.solve_order[slot] = e;
+    }
+}
+
 // Overflow rows in global memory: the immutable part (Jacobians, directions, rhs, dinv) is written during the row build
 // and made visible to the other lanes of the group with ONE agent-scope fence before the sweeps; the mutable part
 // (lambda) is owned by lane 0, which alone reads and writes it and broadcasts the impulse change with a DPP row
@@ -894,10 +954,10 @@ __device__ __forceinline__ float4 sel4(bool has, float4 v) {
 __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs D) {
     const int N = P.N;
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
-    const int env_raw = blockIdx.x * SGRP + grp;
-    const int env = env_raw < N ? env_raw : N - 1;          // groups without an env stay until the row pool is divided
+    const int env_raw = D.solve_order[blockIdx.x * SGRP + grp];       // k_balance: heavy envs are dealt out over the workgroups
+    const int env = (env_raw >= 0 && env_raw < N) ? env_raw : N - 1;  // groups without an env stay until the row pool is divided
     float *state = D.state, *scratch = D.scratch;
-    const bool dead = env_raw >= N || D.errflags[env] != 0;
+    const bool dead = env_raw < 0 || env_raw >= N || D.errflags[env] != 0;
     const ShapeData *S = D.shapes;
     Slab sl;
     sl.fix = grp * LF_TOTAL;
@@ -2744,6 +2804,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     ALLOC(D.pdata, (size_t)N * MAXPAIRS * 8);
     ALLOC(D.timestep, (size_t)N);
     ALLOC(D.errflags, (size_t)N);
+    ALLOC(D.demand, (size_t)2 * N);
+    ALLOC(D.solve_order, (size_t)4 * ((N + 3) / 4));
     ALLOC(D.cmd, (size_t)N * 9);
     ALLOC(D.joints, (size_t)N * 9);
     ALLOC(D.touch, (size_t)N * 4);
@@ -2933,6 +2995,7 @@ static int do_render(rr_env *e, bool use_flags) {
 static void launch_prep_serial(rr_env *e, const DevPtrs &Dp) {
     hipLaunchKernelGGL(k_prep_a, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp);
     hipLaunchKernelGGL(k_prep_b, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp);
+    hipLaunchKernelGGL(k_balance, dim3(1), dim3(BAL_THREADS), 0, e->stream, e->P, e->D);
 }
 
 static void launch_collide(rr_env *e) {
@@ -2949,6 +3012,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     // a device-resident command buffer is read in place by k_prep (stream order protects it like a copy would)
     DevPtrs Dp = e->D;
     if (joint_cmd && cmd_on_device) Dp.cmd = const_cast<float *>(joint_cmd);
+    e->P.par ^= 1;          // k_collide records this step's contact demand in one half, k_balance reads the other
     if (render_mode == 2) HIPCHK(hipMemcpyAsync(e->D.render_flags, render_flags_host, N, hipMemcpyHostToDevice, e->stream));
     bool dyn_forked = false;
     if (e->aux && !e->timing && !g_skip) {
@@ -2957,6 +3021,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
         hipLaunchKernelGGL(k_prep_b, env_grid(e), dim3(e->epb), 0, e->aux, e->B, e->P, Dp);
+        hipLaunchKernelGGL(k_balance, dim3(1), dim3(BAL_THREADS), 0, e->aux, e->P, e->D);
         hipEventRecord(e->ev_dyn, e->aux);
         dyn_forked = true;
     } else {
