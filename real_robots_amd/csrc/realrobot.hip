@@ -741,7 +741,7 @@ __device__ __forceinline__ void plane_space(v3 n, v3 &p, v3 &q) {   // btPlaneSp
 #define SGRP 4           // envs per workgroup (64 threads)
 enum { LF_MINV = 0, LF_MOT = LF_MINV + 124, LF_LIM = LF_MOT + 36, LF_META = LF_LIM + 44, LF_MU = LF_META + MAXC, LF_TOTAL = LF_MU + MAXC };
 #define SLDS_FLOATS 10112                      // 40 448 B per workgroup: four workgroups (16 envs) per CU
-#define SPOOL (SLDS_FLOATS - SGRP * LF_TOTAL)  // floats of the row pool
+#define SPOOL (SLDS_FLOATS - SGRP * LF_TOTAL - 128)  // floats of the row pool (the pipelined sweep fetches one row past the end)
 static_assert(SLDS_FLOATS * 4 * 4 <= 163840, "four solver workgroups must fit the 160 KiB LDS of a CU");
 static_assert(LF_TOTAL % 4 == 0, "row parts must be 16-byte aligned");
 __shared__ __attribute__((aligned(16))) float g_slds[SLDS_FLOATS];
@@ -905,7 +905,10 @@ __device__ float build_row(const SimParams &P, const DevPtrs &D, int env, const 
     if (l == 0) {
         if (fast) {
             const int o = L_BASE + row * 12;
-            LD(o) = dir.x; LD(o + 1) = dir.y; LD(o + 2) = dir.z; LD(o + 10) = dinv; LD(o + 11) = 0.0f;
+            // a robot contact stores the direction as its object sees it (negated when the object is body B): the
+            // pipelined sweep needs no sign logic; object-object rows keep the plain direction for both owners
+            const float ds = (bodyA >= 0 && bodyA < 16 && bodyB >= 16) ? -1.0f : 1.0f;
+            LD(o) = ds * dir.x; LD(o + 1) = ds * dir.y; LD(o + 2) = ds * dir.z; LD(o + 10) = dinv; LD(o + 11) = 0.0f;
             if (bodyA < 16 && bodyB < 16) { LD(o + 3) = 0.0f; LD(o + 4) = 0.0f; LD(o + 5) = 0.0f; LD(o + 6) = 0.0f; LD(o + 7) = 0.0f; LD(o + 8) = 0.0f; }
         } else {
             ROWS(row, 22, dir.x); ROWS(row, 23, dir.y); ROWS(row, 24, dir.z); ROWS(row, 38, dinv); ROWS(row, 39, 0.0f);
@@ -1267,7 +1270,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     // Generic contacts (robot involved, or two objects) follow the object-vs-static ones in contact order: first the
     // object-object contacts [n_os, c_r0), then the robot contacts [c_r0, nc), of which [c_r0, c_rf) have their rows in LDS.
     // Row step of a robot contact (robot-static or robot-object) for any number of contacts: rows streamed from LDS.
-    // The contact's object (if any) is owned by lane (meta >> 25) & 15; bit 29 says it is body B (direction negated).
+    // The contact's object (if any) is owned by lane (meta >> 25) & 15; the row's direction is stored as that object sees it.
     // Robot-static rows hold zeros in their object slots, lanes >= 11 have dq == 0 and take MJa = 0.
     const int c_r0 = n_os + n_oo;
     if (c_rf < c_r0) c_rf = c_r0;
@@ -1281,21 +1284,20 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     }
 #define LEAN_STEP(B, LOB, HIB)                                                                                     \
     {                                                                                                              \
-        const float pobj_ = __int_as_float(__float_as_int(B##p.x * dv.x + B##p.y * dv.y + B##p.z * dv.z) ^ sb_) +  \
-                            (B##p.w * dw.x + B##q.x * dw.y + B##q.y * dw.z);                                       \
+        const float pobj_ = (B##p.x * dv.x + B##p.y * dv.y + B##p.z * dv.z) + (B##p.w * dw.x + B##q.x * dw.y + B##q.y * dw.z); \
         const float jv_ = group_sum(own_ ? pobj_ : B##j * dq);                                                     \
         const float lam_ = B##r.w;                                                                                 \
         const float s0_ = fmaf(-jv_, B##r.z, lam_ + B##r.y);                                                       \
-        const float sum_ = fminf(fmaxf(s0_, (LOB)), (HIB));                                                        \
+        const float sum_ = __builtin_amdgcn_fmed3f(s0_, (LOB), (HIB));     /* = min(max(s0, lo), hi) for lo <= hi */ \
         const float dl_ = sum_ - lam_;                                                                             \
         LD(B##row + 11) = sum_;                                                                                    \
         dq = fmaf(B##m, dl_, dq);                                                                                  \
         const float so_ = own_ ? dl_ : 0.0f;                                                                       \
-        const float sm_ = __int_as_float(__float_as_int(so_ * inv_mass) ^ sb_);                                    \
+        const float sm_ = so_ * inv_mass;                                                                          \
         dv.x += B##p.x * sm_; dv.y += B##p.y * sm_; dv.z += B##p.z * sm_;                                          \
         dw.x += B##q.z * so_; dw.y += B##q.w * so_; dw.z += B##r.x * so_;                                          \
     }
-#define LEAN_ROLE(M) const bool own_ = (((M) >> 25) & 15) == l; const int sb_ = ((M) << 2) & 0x80000000;
+#define LEAN_ROLE(M) const bool own_ = (((M) >> 25) & 15) == l;
     if (__ballot(any_slow)) __threadfence();       // rows built in global memory become visible to the group's other lanes
     static_assert(KLIM == 2 && KOS == 4, "the sweeps below are written out for KLIM = 2, KOS = 4");
     // When no env of this wave has a row outside the registers (no robot or object-object contact, no further limit
@@ -1385,14 +1387,12 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                 mA = *(const int *)&LD(L_META + c_r0);
                 if (pass == 0) {
                     for (int cc = c_r0; cc < c_rf; cc += 2) {
-                        const int c1_ = min(cc + 1, c_rf - 1);
-                        LEAN_LOAD(B, c1_, 0)
-                        const int mB = *(const int *)&LD(L_META + c1_);
+                        LEAN_LOAD(B, cc + 1, 0)                // (one row past the end at most: inside the pool's tail pad)
+                        const int mB = *(const int *)&LD(L_META + cc + 1);
                         { LEAN_ROLE(mA) LEAN_STEP(A, 0.0f, 1e10f) }
                         if (cc + 1 < c_rf) {
-                            const int c2_ = min(cc + 2, c_rf - 1);
-                            LEAN_LOAD(A, c2_, 0)
-                            mA = *(const int *)&LD(L_META + c2_);
+                            LEAN_LOAD(A, cc + 2, 0)
+                            mA = *(const int *)&LD(L_META + cc + 2);
                             { LEAN_ROLE(mB) LEAN_STEP(B, 0.0f, 1e10f) }
                         }
                     }
@@ -1401,12 +1401,12 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     for (int cc = c_r0; cc < c_rf; cc++) {
                         const float hi_ = nmu_ * nln_;
                         LEAN_ROLE(mA)
+                        // the next contact's scalars first: they are multiplied at the top of the next trip
+                        mA = *(const int *)&LD(L_META + cc + 1);
+                        nmu_ = LD(L_MU + cc + 1); nln_ = LD(L_BASE + (3 * (cc + 1)) * 12 + 11);
                         LEAN_LOAD(B, cc, 2)
                         LEAN_STEP(A, -hi_, hi_)
-                        const int cn_ = min(cc + 1, c_rf - 1);
-                        LEAN_LOAD(A, cn_, 1)
-                        mA = *(const int *)&LD(L_META + cn_);
-                        nmu_ = LD(L_MU + cn_); nln_ = LD(L_BASE + (3 * cn_) * 12 + 11);
+                        LEAN_LOAD(A, cc + 1, 1)
                         LEAN_STEP(B, -hi_, hi_)
                     }
                 }
