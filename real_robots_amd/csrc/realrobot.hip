@@ -1282,7 +1282,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         B##p = *(const float4 *)&LD(B##row); B##q = *(const float4 *)&LD(B##row + 4); B##r = *(const float4 *)&LD(B##row + 8); \
         B##j = LD(rr_); B##m = LD(rr_ + 11); B##m = l < NB ? B##m : 0.0f;                                                     \
     }
-#define LEAN_STEP(B, LOB, HIB)                                                                                     \
+#define LEAN_STEP(B, LOB, HIB, OUT)                                                                                   \
     {                                                                                                              \
         const float pobj_ = (B##p.x * dv.x + B##p.y * dv.y + B##p.z * dv.z) + (B##p.w * dw.x + B##q.x * dw.y + B##q.y * dw.z); \
         const float jv_ = group_sum(own_ ? pobj_ : B##j * dq);                                                     \
@@ -1290,7 +1290,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         const float s0_ = fmaf(-jv_, B##r.z, lam_ + B##r.y);                                                       \
         const float sum_ = __builtin_amdgcn_fmed3f(s0_, (LOB), (HIB));     /* = min(max(s0, lo), hi) for lo <= hi */ \
         const float dl_ = sum_ - lam_;                                                                             \
-        LD(B##row + 11) = sum_;                                                                                    \
+        LD(B##row + 11) = sum_; OUT = sum_;                                                                        \
         dq = fmaf(B##m, dl_, dq);                                                                                  \
         const float so_ = own_ ? dl_ : 0.0f;                                                                       \
         const float sm_ = so_ * inv_mass;                                                                          \
@@ -1304,6 +1304,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     // or contact rows), an iteration is one straight-line block: the robot chain (motors, limits) and the object chain
     // (normals, frictions) are independent and the scheduler overlaps them.
     const bool simple = __ballot(!(nc == n_os && own_os == 0 && limmask == 0)) == 0ull;
+    unsigned long long ln_pos = 0, fr_nz = 0;   // robot contacts in LDS: normal impulse > 0 after this sweep / a friction impulse != 0
     for (int it = 0; it < P.iters; it++) {
         // compiler barrier: the row data in LDS / global memory is loop invariant, but hoisting hundreds of such loads out
         // of the sweep loop exhausts the register file (everything that should live in registers is held explicitly)
@@ -1383,31 +1384,57 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                 //      fetched while the current one is swept (one wave per SIMD: LDS latency is otherwise exposed)
                 // two register sets A / B take turns (no copies): one is swept while the other is being filled
                 float4 Ap, Aq, Ar, Bp, Bq, Br; float Aj, Am, Bj, Bm; int Arow, Brow, mA;
-                LEAN_LOAD(A, c_r0, pass)
-                mA = *(const int *)&LD(L_META + c_r0);
                 if (pass == 0) {
+                    // normals of all contacts; the ones that carry an impulse afterwards are noted for the friction pass
+                    unsigned long long pos = 0;
+                    float sA_, sB_;
+                    LEAN_LOAD(A, c_r0, 0)
+                    mA = *(const int *)&LD(L_META + c_r0);
                     for (int cc = c_r0; cc < c_rf; cc += 2) {
                         LEAN_LOAD(B, cc + 1, 0)                // (one row past the end at most: inside the pool's tail pad)
                         const int mB = *(const int *)&LD(L_META + cc + 1);
-                        { LEAN_ROLE(mA) LEAN_STEP(A, 0.0f, 1e10f) }
+                        { LEAN_ROLE(mA) LEAN_STEP(A, 0.0f, 1e10f, sA_) }
+                        pos |= sA_ > 0.0f ? 1ull << (cc - c_r0) : 0ull;
                         if (cc + 1 < c_rf) {
                             LEAN_LOAD(A, cc + 2, 0)
                             mA = *(const int *)&LD(L_META + cc + 2);
-                            { LEAN_ROLE(mB) LEAN_STEP(B, 0.0f, 1e10f) }
+                            { LEAN_ROLE(mB) LEAN_STEP(B, 0.0f, 1e10f, sB_) }
+                            pos |= sB_ > 0.0f ? 2ull << (cc - c_r0) : 0ull;
                         }
                     }
+                    ln_pos = pos;
                 } else {
-                    float nmu_ = LD(L_MU + c_r0), nln_ = LD(L_BASE + (3 * c_r0) * 12 + 11);
-                    for (int cc = c_r0; cc < c_rf; cc++) {
-                        const float hi_ = nmu_ * nln_;
-                        LEAN_ROLE(mA)
-                        // the next contact's scalars first: they are multiplied at the top of the next trip
-                        mA = *(const int *)&LD(L_META + cc + 1);
-                        nmu_ = LD(L_MU + cc + 1); nln_ = LD(L_BASE + (3 * (cc + 1)) * 12 + 11);
-                        LEAN_LOAD(B, cc, 2)
-                        LEAN_STEP(A, -hi_, hi_)
-                        LEAN_LOAD(A, cc + 1, 1)
-                        LEAN_STEP(B, -hi_, hi_)
+                    // frictions: a contact without normal impulse (94 % of the robot contacts of a pushing gripper are
+                    // speculative: inside the margin, not touching) whose friction impulses are zero has the bounds
+                    // [-0, 0] and cannot move anything -- only the others are swept, every env walking its own list
+                    unsigned long long todo = ln_pos | fr_nz;
+                    fr_nz = 0;
+                    if (todo) {
+                        int j = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        int cc = c_r0 + j;
+                        LEAN_LOAD(A, cc, 1)
+                        mA = *(const int *)&LD(L_META + cc);
+                        float nmu_ = LD(L_MU + cc), nln_ = LD(L_BASE + (3 * cc) * 12 + 11);
+                        for (;;) {
+                            const float hi_ = nmu_ * nln_;
+                            LEAN_ROLE(mA)
+                            const bool more = todo != 0;
+                            const int jn = more ? __ffsll((long long)todo) - 1 : j;
+                            todo &= todo - 1;
+                            const int cn = c_r0 + jn;
+                            // the next contact's scalars first: they are multiplied at the top of the next trip
+                            mA = *(const int *)&LD(L_META + cn);
+                            nmu_ = LD(L_MU + cn); nln_ = LD(L_BASE + (3 * cn) * 12 + 11);
+                            float s1_, s2_;
+                            LEAN_LOAD(B, cc, 2)
+                            LEAN_STEP(A, -hi_, hi_, s1_)
+                            LEAN_LOAD(A, cn, 1)
+                            LEAN_STEP(B, -hi_, hi_, s2_)
+                            fr_nz |= (s1_ != 0.0f || s2_ != 0.0f) ? 1ull << j : 0ull;
+                            if (!more) break;
+                            j = jn; cc = cn;
+                        }
                     }
                 }
             }
