@@ -768,34 +768,42 @@ __global__ void __launch_bounds__(BAL_THREADS) k_balance(SimParams P, DevPtrs D)
         for (int i = t; i < SGRP * nblk; i += BAL_THREADS) D.solve_order[i] = i < N ? i : -1;
         return;
     }
-    // thread t owns envs t, t + 1024, ... (coalesced reads)
-    unsigned long long hm = 0;
-    int nh = 0;
+    // thread t owns envs t, t + 1024, ... (coalesced reads).  Two heavy classes, dealt in that order: an env that alone
+    // needs more than ~30 % of the pool, and one that needs more than ~15 % (a typical env with a dozen resting contacts
+    // and a few robot contacts needs 10 %)
+    unsigned long long hm1 = 0, hm2 = 0;
+    int n1 = 0, n2 = 0;
     for (int j = 0, e = t; e < N; e += BAL_THREADS, j++) {
         const unsigned d = dem[e];
         const int need = min((int)(d & 255), MAXC) * 36 + min((int)((d >> 8) & 255), MAXC) * 66 + min((int)((d >> 16) & 255), MAXC) * 18;
-        if (need > SPOOL / SGRP) { hm |= 1ull << j; nh++; }
+        if (need > (SPOOL * 3) / 10) { hm1 |= 1ull << j; n1++; }
+        else if (need > (SPOOL * 3) / 20) { hm2 |= 1ull << j; n2++; }
     }
-    // exclusive prefix of nh over the workgroup
-    int incl = nh;
+    // exclusive prefix of both counts over the workgroup (packed: 16 bits each)
+    int incl = n1 | (n2 << 16);
+    const int mine = incl;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if ((t & 63) >= d) incl += o; }
     if ((t & 63) == 63) s_wave[t >> 6] = incl;
     if (t < SGRP) D.solve_order[SGRP * nblk - 1 - t] = -1;      // the last workgroup may have fewer than four envs
     __syncthreads();
-    int hbase = incl - nh, H = 0;
-    for (int w = 0; w < BAL_THREADS / 64; w++) { const int c = s_wave[w]; if (w < (t >> 6)) hbase += c; H += c; }
+    int base = incl - mine, tot = 0;
+    for (int w = 0; w < BAL_THREADS / 64; w++) { const int c = s_wave[w]; if (w < (t >> 6)) base += c; tot += c; }
+    const int H1 = tot & 0xffff, H = H1 + (tot >> 16);
+    int r1 = base & 0xffff, r2 = H1 + (base >> 16);              // next rank of either class for this thread's envs
     // heavy rank h -> workgroup h % nblk, position h / nblk; the light envs fill the remaining positions in order
     const int q = H / nblk, r = H % nblk;            // workgroups [0, r) hold q + 1 heavy envs, the others q
     const int ebase = (N / BAL_THREADS) * t + min(t, N % BAL_THREADS);     // envs owned by the threads before this one
+    const int hbefore = (base & 0xffff) + (base >> 16);                    // heavy envs (both classes) of those threads
     int hseen = 0;
     for (int j = 0, e = t; e < N; e += BAL_THREADS, j++) {
         int slot;
-        if ((hm >> j) & 1ull) {
-            const int h = hbase + hseen++;
+        if (((hm1 | hm2) >> j) & 1ull) {
+            const int h = ((hm1 >> j) & 1ull) ? r1++ : r2++;
+            hseen++;
             slot = (h % nblk) * SGRP + h / nblk;
         } else {
-            int k = ebase + j - (hbase + hseen);     // rank among the light envs
+            int k = ebase + j - (hbefore + hseen);   // rank among the light envs
             if (k < (SGRP - 1 - q) * r) slot = (k / (SGRP - 1 - q)) * SGRP + q + 1 + k % (SGRP - 1 - q);
             else { k -= (SGRP - 1 - q) * r; slot = (r + k / (SGRP - q)) * SGRP + q + k % (SGRP - q); }
         }
@@ -812,8 +820,7 @@ __global__ void __launch_bounds__(BAL_THREADS) k_balance(SimParams P, DevPtrs D)
 #define ROWS(r, f, v) (*ROW_ADDR(r, f) = (v))
 #define ROW_FENCE()
 
-// meta word: bodyA (8) | bodyB (8) | linkA (8) | rows in LDS (1) | lane of the object of a robot-object contact (4,
-// 15 = none) | that object is body B (1)
+// meta word: bodyA (8) | bodyB (8) | linkA (8) | rows in LDS (1)
 __device__ __forceinline__ int meta_bodyA(int m) { return (signed char)(m & 255); }
 __device__ __forceinline__ int meta_bodyB(int m) { return (signed char)((m >> 8) & 255); }
 __device__ __forceinline__ int meta_link(int m) { return (signed char)((m >> 16) & 255); }
@@ -1027,7 +1034,8 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     int n_os = 0;
     unsigned own_os = 0;
     bool any_slow = false;            // some contact of this env keeps its rows in global memory
-    int c_rf = 0;                     // end of the run of robot contacts whose rows are in LDS (they precede any overflow)
+    int c_lf = 0;                     // end of the run of generic contacts whose rows are in LDS (they precede any overflow)
+    unsigned long long g_rob = 0, g_own = 0, g_ownB = 0;   // generic contact j (bit j): robot involved / this lane owns an object of it / ... as body B of an object-object contact
     int nc = 0, gidx = 0, n_oo = 0;   // gidx: index among the generic (not object-vs-static) contacts, which all follow the
                                       // object-vs-static ones; n_oo: object-object contacts (their pairs precede the robot pairs)
     static_assert(MAXPAIRS / 16 == 6, "pair-mask select chain below");
@@ -1080,20 +1088,25 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             const v3 x = mk(c7[0], c7[1], c7[2]), n = mk(c7[3], c7[4], c7[5]);
             const float dist = c7[6];
             int rslot = 15, bslot = 15;
-            bool fast = nc < sl.lc;
+            bool fast = nc < sl.lc && !any_slow;      // rows in LDS form a prefix of the contact list
             // the Bside part of generic contact j lives in slot j, its robot part in slot j - n_oo of the LDS sections
             // (object-object pairs precede the robot pairs): sweep code finds them without reading the meta word
             if (robot) { if (gidx - n_oo < sl.lr && fast) rslot = gidx - n_oo; else fast = false; }
             if (objobj) { if (gidx < sl.lb && fast) bslot = gidx; else fast = false; n_oo = gidx + 1; }
+            if ((robot || objobj) && fast) {
+                // loop-invariant roles of this lane in generic contact gidx, one bit each (no meta decoding in the sweeps)
+                const unsigned long long bit = 1ull << gidx;
+                if (robot) g_rob |= bit;
+                if (lo_ >= 0 && (bodyA == 16 + lo_ || bodyB == 16 + lo_)) g_own |= bit;
+                if (objobj && lo_ >= 0 && bodyB == 16 + lo_) g_ownB |= bit;
+                c_lf = nc + 1;
+            }
             if (robot || objobj) gidx++;
             else if (gidx == 0 && nc < sl.lc) {       // still inside the leading run of object-vs-static contacts
                 n_os = nc + 1;
                 if (lo_ >= 0 && bodyA == 16 + lo_) own_os |= 1u << nc;
             }
-            const int olane = !robot ? 15 : (bodyA >= 16 ? NB + bodyA - 16 : (bodyB >= 16 ? NB + bodyB - 16 : 15));
-            int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | ((fast ? 1 : 0) << 24) | (olane << 25) |
-                       ((robot && bodyB >= 16 ? 1 : 0) << 29);
-            if (robot && fast) c_rf = nc + 1;
+            int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | ((fast ? 1 : 0) << 24);
             any_slow = any_slow || !fast;
             if (l == 0) {
                 *(int *)&LD(L_META + nc) = meta;
@@ -1268,43 +1281,47 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         }
     SPROF(3);
     // Generic contacts (robot involved, or two objects) follow the object-vs-static ones in contact order: first the
-    // object-object contacts [n_os, c_r0), then the robot contacts [c_r0, nc), of which [c_r0, c_rf) have their rows in LDS.
-    // Row step of a robot contact (robot-static or robot-object) for any number of contacts: rows streamed from LDS.
-    // The contact's object (if any) is owned by lane (meta >> 25) & 15; the row's direction is stored as that object sees it.
-    // Robot-static rows hold zeros in their object slots, lanes >= 11 have dq == 0 and take MJa = 0.
-    const int c_r0 = n_os + n_oo;
-    if (c_rf < c_r0) c_rf = c_r0;
+    // object-object contacts [n_os, c_r0), then the robot contacts [c_r0, nc); [n_os, c_lf) have their rows in LDS.
+    // Row step of a generic contact for any number of contacts: rows streamed from LDS, two register sets taking turns.
+    // Roles come from the bit masks collected by the gather.  A robot row stores its direction as its object sees it
+    // and zeros in the object slots of a robot-static row; lanes >= 11 have dq == 0 and take MJa = 0.  The second owner
+    // of an object-object row (body B) reads its angular part from the Bside slot and negates the direction.
+    if (c_lf < n_os) c_lf = n_os;
     const int base4 = L_BASE >> 2;          // base parts are float4-aligned (the pool cursor advances in multiples of 4 floats)
-#define LEAN_LOAD(B, C, K)   /* fetch row K of robot contact C into register set B */                              \
+#define LEAN_LOAD(B, J, K)   /* fetch row K of generic contact J (= contact n_os + J) into register set B */       \
     {                                                                                                              \
-        B##row = (base4 + (3 * (C) + (K)) * 3) << 2;                                                               \
-        const int rr_ = L_ROB + (((C) - c_r0) * 3 + (K)) * 22 + lj;                                                \
-        B##p = *(const float4 *)&LD(B##row); B##q = *(const float4 *)&LD(B##row + 4); B##r = *(const float4 *)&LD(B##row + 8); \
-        B##j = LD(rr_); B##m = LD(rr_ + 11); B##m = l < NB ? B##m : 0.0f;                                                     \
+        B##row = (base4 + (3 * (n_os + (J)) + (K)) * 3) << 2;                                                      \
+        const int rr_ = L_ROB + (((J) - n_oo) * 3 + (K)) * 22 + lj;      /* (a valid LDS address for any J) */     \
+        const int oa_ = ((g_ownB >> (J)) & 1ull) ? L_BS + ((J) * 3 + (K)) * 6 : B##row + 3;                        \
+        B##p = *(const float4 *)&LD(B##row); B##r = *(const float4 *)&LD(B##row + 8);                              \
+        B##a0 = LD(oa_); B##a1 = LD(oa_ + 1); B##a2 = LD(oa_ + 2); B##m0 = LD(oa_ + 3); B##m1 = LD(oa_ + 4); B##m2 = LD(oa_ + 5); \
+        B##j = LD(rr_); B##m = LD(rr_ + 11);                                                                       \
     }
-#define LEAN_STEP(B, LOB, HIB, OUT)                                                                                   \
+#define LEAN_ROLE(J)                                                                                               \
+    const bool own_ = (g_own >> (J)) & 1ull, rob_ = ((g_rob >> (J)) & 1ull) && l < NB;                             \
+    const float sg_ = ((g_ownB >> (J)) & 1ull) ? -1.0f : 1.0f, sgim_ = sg_ * inv_mass;
+#define LEAN_STEP(B, LOB, HIB, OUT)                                                                                \
     {                                                                                                              \
-        const float pobj_ = (B##p.x * dv.x + B##p.y * dv.y + B##p.z * dv.z) + (B##p.w * dw.x + B##q.x * dw.y + B##q.y * dw.z); \
-        const float jv_ = group_sum(own_ ? pobj_ : B##j * dq);                                                     \
+        const float pobj_ = fmaf(sg_, B##p.x * dv.x + B##p.y * dv.y + B##p.z * dv.z, B##a0 * dw.x + B##a1 * dw.y + B##a2 * dw.z); \
+        const float jv_ = group_sum(own_ ? pobj_ : (rob_ ? B##j * dq : 0.0f));                                     \
         const float lam_ = B##r.w;                                                                                 \
         const float s0_ = fmaf(-jv_, B##r.z, lam_ + B##r.y);                                                       \
         const float sum_ = __builtin_amdgcn_fmed3f(s0_, (LOB), (HIB));     /* = min(max(s0, lo), hi) for lo <= hi */ \
         const float dl_ = sum_ - lam_;                                                                             \
         LD(B##row + 11) = sum_; OUT = sum_;                                                                        \
-        dq = fmaf(B##m, dl_, dq);                                                                                  \
+        dq += rob_ ? B##m * dl_ : 0.0f;                                                                            \
         const float so_ = own_ ? dl_ : 0.0f;                                                                       \
-        const float sm_ = so_ * inv_mass;                                                                          \
+        const float sm_ = so_ * sgim_;                                                                             \
         dv.x += B##p.x * sm_; dv.y += B##p.y * sm_; dv.z += B##p.z * sm_;                                          \
-        dw.x += B##q.z * so_; dw.y += B##q.w * so_; dw.z += B##r.x * so_;                                          \
+        dw.x += B##m0 * so_; dw.y += B##m1 * so_; dw.z += B##m2 * so_;                                             \
     }
-#define LEAN_ROLE(M) const bool own_ = (((M) >> 25) & 15) == l;
     if (__ballot(any_slow)) __threadfence();       // rows built in global memory become visible to the group's other lanes
     static_assert(KLIM == 2 && KOS == 4, "the sweeps below are written out for KLIM = 2, KOS = 4");
     // When no env of this wave has a row outside the registers (no robot or object-object contact, no further limit
     // or contact rows), an iteration is one straight-line block: the robot chain (motors, limits) and the object chain
     // (normals, frictions) are independent and the scheduler overlaps them.
     const bool simple = __ballot(!(nc == n_os && own_os == 0 && limmask == 0)) == 0ull;
-    unsigned long long ln_pos = 0, fr_nz = 0;   // robot contacts in LDS: normal impulse > 0 after this sweep / a friction impulse != 0
+    unsigned long long ln_pos = 0, fr_nz = 0;   // generic contacts in LDS: normal impulse > 0 after this sweep / a friction impulse != 0
     for (int it = 0; it < P.iters; it++) {
         // compiler barrier: the row data in LDS / global memory is loop invariant, but hoisting hundreds of such loads out
         // of the sweep loop exhausts the register file (everything that should live in registers is held explicitly)
@@ -1375,31 +1392,25 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     OS_ROW_STEP(c0, c1, c2, -hi, hi, 3 * cc + 2);
                 }
             }
-            // The four envs of the wave walk the same three segments together (object-object, robot contacts in
-            // LDS, overflow), so that the long one -- the robot contacts -- is not serialised between them.
-#pragma unroll 1
-            for (int seg = 0; seg < 2; seg++) {
-            if (seg == 1 && c_rf > c_r0) {
-                // ---- robot contacts with rows in LDS [c_r0, c_rf): software-pipelined row steps, the next row is
-                //      fetched while the current one is swept (one wave per SIMD: LDS latency is otherwise exposed)
-                // two register sets A / B take turns (no copies): one is swept while the other is being filled
-                float4 Ap, Aq, Ar, Bp, Bq, Br; float Aj, Am, Bj, Bm; int Arow, Brow, mA;
+            // ---- generic contacts with rows in LDS [n_os, c_lf): software-pipelined row steps, the next row is fetched
+            //      while the current one is swept (one wave per SIMD: LDS latency is otherwise exposed).  The four envs
+            //      of the wave run this loop together.
+            if (c_lf > n_os) {
+                const int ng = c_lf - n_os;
+                float4 Ap, Ar, Bp, Br; float Aa0, Aa1, Aa2, Am0, Am1, Am2, Aj, Am, Ba0, Ba1, Ba2, Bm0, Bm1, Bm2, Bj, Bm; int Arow, Brow;
                 if (pass == 0) {
                     // normals of all contacts; the ones that carry an impulse afterwards are noted for the friction pass
                     unsigned long long pos = 0;
                     float sA_, sB_;
-                    LEAN_LOAD(A, c_r0, 0)
-                    mA = *(const int *)&LD(L_META + c_r0);
-                    for (int cc = c_r0; cc < c_rf; cc += 2) {
-                        LEAN_LOAD(B, cc + 1, 0)                // (one row past the end at most: inside the pool's tail pad)
-                        const int mB = *(const int *)&LD(L_META + cc + 1);
-                        { LEAN_ROLE(mA) LEAN_STEP(A, 0.0f, 1e10f, sA_) }
-                        pos |= sA_ > 0.0f ? 1ull << (cc - c_r0) : 0ull;
-                        if (cc + 1 < c_rf) {
-                            LEAN_LOAD(A, cc + 2, 0)
-                            mA = *(const int *)&LD(L_META + cc + 2);
-                            { LEAN_ROLE(mB) LEAN_STEP(B, 0.0f, 1e10f, sB_) }
-                            pos |= sB_ > 0.0f ? 2ull << (cc - c_r0) : 0ull;
+                    LEAN_LOAD(A, 0, 0)
+                    for (int j = 0; j < ng; j += 2) {
+                        LEAN_LOAD(B, j + 1, 0)                 // (one row past the end at most: inside the pool's tail pad)
+                        { LEAN_ROLE(j) LEAN_STEP(A, 0.0f, 1e10f, sA_) }
+                        pos |= sA_ > 0.0f ? 1ull << j : 0ull;
+                        if (j + 1 < ng) {
+                            LEAN_LOAD(A, j + 2, 0)
+                            { LEAN_ROLE(j + 1) LEAN_STEP(B, 0.0f, 1e10f, sB_) }
+                            pos |= sB_ > 0.0f ? 2ull << j : 0ull;
                         }
                     }
                     ln_pos = pos;
@@ -1412,83 +1423,35 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     if (todo) {
                         int j = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
-                        int cc = c_r0 + j;
-                        LEAN_LOAD(A, cc, 1)
-                        mA = *(const int *)&LD(L_META + cc);
-                        float nmu_ = LD(L_MU + cc), nln_ = LD(L_BASE + (3 * cc) * 12 + 11);
+                        LEAN_LOAD(A, j, 1)
+                        float nmu_ = LD(L_MU + n_os + j), nln_ = LD(L_BASE + (3 * (n_os + j)) * 12 + 11);
                         for (;;) {
                             const float hi_ = nmu_ * nln_;
-                            LEAN_ROLE(mA)
+                            LEAN_ROLE(j)
                             const bool more = todo != 0;
                             const int jn = more ? __ffsll((long long)todo) - 1 : j;
                             todo &= todo - 1;
-                            const int cn = c_r0 + jn;
                             // the next contact's scalars first: they are multiplied at the top of the next trip
-                            mA = *(const int *)&LD(L_META + cn);
-                            nmu_ = LD(L_MU + cn); nln_ = LD(L_BASE + (3 * cn) * 12 + 11);
+                            nmu_ = LD(L_MU + n_os + jn); nln_ = LD(L_BASE + (3 * (n_os + jn)) * 12 + 11);
                             float s1_, s2_;
-                            LEAN_LOAD(B, cc, 2)
+                            LEAN_LOAD(B, j, 2)
                             LEAN_STEP(A, -hi_, hi_, s1_)
-                            LEAN_LOAD(A, cn, 1)
+                            LEAN_LOAD(A, jn, 1)
                             LEAN_STEP(B, -hi_, hi_, s2_)
                             fr_nz |= (s1_ != 0.0f || s2_ != 0.0f) ? 1ull << j : 0ull;
                             if (!more) break;
-                            j = jn; cc = cn;
+                            j = jn;
                         }
                     }
                 }
             }
-            for (int c = seg == 0 ? n_os : c_rf; c < (seg == 0 ? c_r0 : nc); c++) {
+            // ---- overflow contacts [c_lf, nc): rows in global memory (same arithmetic; lane 0 owns rhs / dinv / lambda)
+            for (int c = c_lf; c < nc; c++) {
                 const int meta = *(const int *)&LD(L_META + c);
-                const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta), bslot = c - n_os, rslot = bslot - n_oo;
+                const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta);
                 const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
-                const bool objobj = bodyA >= 16 && bodyB >= 16;
-                const bool fast = meta_fast(meta);
                 const int r0 = pass == 0 ? 3 * c : 3 * c + 1, r1 = pass == 0 ? 3 * c + 1 : 3 * c + 3;
                 const bool mineA = (lo_ >= 0) && (bodyA == 16 + lo_), mineB = (lo_ >= 0) && (bodyB == 16 + lo_);
-                if (fast) {
-                    // LDS-resident contact: branch-free row steps (selects only: unused slots of a part may hold
-                    // non-finite garbage, so nothing is multiplied by 0/1 masks); the second friction row is
-                    // fetched while the first one is swept.
-                    // sgn: +1 when this lane owns object A, -1 when it owns object B
-                    const float sgn = mineA ? 1.0f : -1.0f;
-                    const bool own = mineA || mineB;
-                    const bool rob = robot && l < NB;
-                    const bool useB = objobj && mineB;     // second object of an object-object contact: Bside part
-                    const float ln = LD(L_BASE + (3 * c) * 12 + 11), mu = LD(L_MU + c);
-                    const float hi = pass == 0 ? 1e10f : mu * ln, lo = pass == 0 ? 0.0f : -hi;
-                    const int orb0 = (robot ? L_ROB + (rslot * 3) * 22 + lj : L_MINV + lj) + (r0 - 3 * c) * 22;   // harmless address when no robot part
-                    const int obs0 = L_BS + ((objobj ? bslot : 0) * 3 + (r0 - 3 * c)) * 6;               // likewise for the Bside part
-                    float4 n0 = LDB4(r0, 0), n1 = LDB4(r0, 4), n2 = LDB4(r0, 8);
-                    float njal = LD(orb0), nmjal = LD(orb0 + 11);
-                    float nb0 = LD(obs0), nb1 = LD(obs0 + 1), nb2 = LD(obs0 + 2), nb3 = LD(obs0 + 3), nb4 = LD(obs0 + 4), nb5 = LD(obs0 + 5);
-                    for (int r = r0; r < r1; r++) {
-                        const float4 b0 = n0, b1 = n1, b2 = n2;          // dir.xyz ang.x | ang.yz mang.xy | mang.z rhs dinv lambda
-                        const float jal = njal, mjal = nmjal;
-                        const float q0 = nb0, q1 = nb1, q2 = nb2, q3 = nb3, q4 = nb4, q5 = nb5;
-                        if (r + 1 < r1) {
-                            n0 = LDB4(r + 1, 0); n1 = LDB4(r + 1, 4); n2 = LDB4(r + 1, 8);
-                            njal = LD(orb0 + 22); nmjal = LD(orb0 + 33);
-                            nb0 = LD(obs0 + 6); nb1 = LD(obs0 + 7); nb2 = LD(obs0 + 8); nb3 = LD(obs0 + 9); nb4 = LD(obs0 + 10); nb5 = LD(obs0 + 11);
-                        }
-                        const v3 dir = mk(b0.x, b0.y, b0.z);
-                        const v3 ang = mk(useB ? q0 : b0.w, useB ? q1 : b1.x, useB ? q2 : b1.y);
-                        const v3 mang = mk(useB ? q3 : b1.z, useB ? q4 : b1.w, useB ? q5 : b2.x);
-                        const float part = own ? sgn * dot(dir, dv) + dot(ang, dw) : (rob ? jal * dq : 0.0f);
-                        const float jv = group_sum(part);
-                        const float lam = b2.w;
-                        const float s0 = fmaf(-jv, b2.z, lam + b2.y);
-                        const float sum = fminf(fmaxf(s0, lo), hi);
-                        const float dl = sum - lam;
-                        LD(L_BASE + r * 12 + 11) = sum;                   // every lane writes the same value
-                        dq += rob ? mjal * dl : 0.0f;
-                        const float so = own ? dl : 0.0f, sm = sgn * so * inv_mass;
-                        dv = dv + dir * sm;
-                        dw = dw + mk(own ? mang.x * dl : 0.0f, own ? mang.y * dl : 0.0f, own ? mang.z * dl : 0.0f);
-                    }
-                    continue;
-                }
-                // overflow contact: rows in global memory (same arithmetic; lane 0 owns rhs / dinv / lambda)
                 const float mu = SCR(S_CT + c * 12 + 11);
                 float ln = 0.0f;
                 if (l == 0) ln = ROWL(3 * c, 39);
@@ -1519,11 +1482,10 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     if (mineB) { dv = dv + dir * (-dl * inv_mass); dw = dw + mang * dl; }
                 }
             }
-            }
         }
     }
     SPROF(4);
-    SBLK_END(nc, nc - n_os, nc - c_rf, c_rf - c_r0);
+    SBLK_END(nc, nc - n_os, nc - c_lf, c_lf - n_os);
     // impulses of the register-resident contact rows go back to their LDS slots (contact forces / touch sensors below)
 #pragma unroll
     for (int i = 0; i < KOS; i++) {
