@@ -63,7 +63,7 @@ struct BodyParams {   // passed by value as kernel argument -> scalar loads, uni
 };
 
 struct SimParams {
-    int N, nobj, iters, npairs, ablate, small_area, par;    // par: step parity (double-buffered per-env contact demand)
+    int N, nobj, iters, npairs, ablate, small_area, par, pool;   // pool: floats of a solver workgroup's LDS row pool (<= SPOOL)    // par: step parity (double-buffered per-env contact demand)
     float dt, gravity, erp, margin, kp, kd, max_impulse, lin_damp, ang_damp, rest_thresh;
 };
 
@@ -776,8 +776,8 @@ __global__ void __launch_bounds__(BAL_THREADS) k_balance(SimParams P, DevPtrs D)
     for (int j = 0, e = t; e < N; e += BAL_THREADS, j++) {
         const unsigned d = dem[e];
         const int need = min((int)(d & 255), MAXC) * 36 + min((int)((d >> 8) & 255), MAXC) * 66 + min((int)((d >> 16) & 255), MAXC) * 18;
-        if (need > (SPOOL * 3) / 10) { hm1 |= 1ull << j; n1++; }
-        else if (need > (SPOOL * 3) / 20) { hm2 |= 1ull << j; n2++; }
+        if (need > (P.pool * 3) / 10) { hm1 |= 1ull << j; n1++; }
+        else if (need > (P.pool * 3) / 20) { hm2 |= 1ull << j; n2++; }
     }
     // exclusive prefix of both counts over the workgroup (packed: 16 bits each)
     int incl = n1 | (n2 << 16);
@@ -1015,7 +1015,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     // ---- divide the workgroup's row pool: every env asks for what its candidate contacts need, served in env order
     {
         const int want_c = min((int)group_sum(need_c), MAXC), want_r = min((int)group_sum(need_r), MAXC), want_b = min((int)group_sum(need_b), MAXC);
-        int cursor = SGRP * LF_TOTAL, avail = SPOOL;
+        int cursor = SGRP * LF_TOTAL, avail = P.pool;
         sl.base = sl.rob = sl.bs = cursor; sl.lc = sl.lr = sl.lb = 0;
 #pragma unroll
         for (int g = 0; g < SGRP; g++) {
@@ -2726,6 +2726,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     P.margin = cfg->margin > 0 ? cfg->margin : 0.02f; P.kp = 0.1f; P.kd = 1.0f; P.max_impulse = 100000.0f * P.dt;
     P.ablate = getenv("RR_ABLATE") ? atoi(getenv("RR_ABLATE")) : 0;
     P.small_area = getenv("RR_SMALL_AREA") ? atoi(getenv("RR_SMALL_AREA")) : SMALL_AREA;
+    P.pool = getenv("RR_SOLVER_POOL") ? std::max(0, std::min(atoi(getenv("RR_SOLVER_POOL")), (int)SPOOL)) : SPOOL;   // tests shrink it to reach the overflow rows
     P.lin_damp = 0.04f; P.ang_damp = 0.04f; P.rest_thresh = 0.2f;
     e->epb = cfg->envs_per_block > 0 ? cfg->envs_per_block : 64;
     if (e->epb > 64) e->epb = 64;   // physics kernels are compiled with __launch_bounds__(64)

@@ -294,11 +294,16 @@ def test_device_side_nonfinite_command_is_flagged_and_skipped():
     env.close()
 
 
-def test_piled_objects_overflow_rows_match_oracle():
-    """Three objects dropped into each other next to the gripper: object-object pairs (more than the 8 LDS slots of the
-    solver's B-side parts), object-table contacts and robot-object contacts at once -- exercises the generic and the
-    overflow (global-memory) row paths. fp32 oracle, short horizon (stacking is chaotic): joints < 2e-3 rad, object
-    positions < 5e-3 m; the contact lists must agree exactly in size and bodies at the first step."""
+@pytest.mark.parametrize("pool", [None, 700, 0])
+def test_piled_objects_generic_and_overflow_rows_match_oracle(pool, monkeypatch):
+    """Three objects dropped into each other next to the gripper: object-object, object-table and robot-object contacts
+    at once (up to ~30 per env).  With the default LDS row pool every row is swept from LDS by the pipelined loop; with
+    RR_SOLVER_POOL=700 the first env of the workgroup keeps 19 base parts and the others nothing, with 0 every row of
+    every env lives in global memory (the overflow path, object-static rows included).  fp32 oracle, short horizon
+    (stacking is chaotic): joints < 2e-3 rad, object positions < 5e-3 m for every env; the contact lists must agree
+    exactly in size and bodies at the first step."""
+    if pool is not None:
+        monkeypatch.setenv("RR_SOLVER_POOL", str(pool))
     N = 3
     env = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
     o = Oracle(3, 64, 64, f32=True)
@@ -325,12 +330,57 @@ def test_piled_objects_overflow_rows_match_oracle():
             max_nc = max(max_nc, len(c))
             max_objobj = max(max_objobj, int(((c[:, 0] >= 16) & (c[:, 1] >= 16)).sum()))
         if t in (0, 9, 29):
-            st = env.state[0]
-            assert np.abs(st[:11] - o.state[:11]).max() < 2e-3, t
-            assert np.abs(_objs(st)[:, :3] - _objs(o.state)[:, :3]).max() < 5e-3, t
-    assert max_objobj > 8 and max_nc > 16, (max_objobj, max_nc)      # the overflow slots were really used
+            for i in range(N):
+                st = env.state[i]
+                assert np.abs(st[:11] - o.state[:11]).max() < 2e-3, (t, i)
+                assert np.abs(_objs(st)[:, :3] - _objs(o.state)[:, :3]).max() < 5e-3, (t, i)
+    assert max_objobj > 8 and max_nc > 16, (max_objobj, max_nc)
     st = env.state
-    assert np.abs(st - st[0]).max() == 0.0
+    if pool is None:
+        assert np.abs(st - st[0]).max() == 0.0      # identical envs on the same path stay bitwise identical
+    assert (env.host(nat.F_ERRFLAGS) == 0).all()
+    env.close()
+
+
+def test_pushing_gripper_one_step_parity():
+    """Macro actions (the gripper sweeps over the table and pushes the objects: dozens of robot-object and some
+    object-object contacts per env, most of them speculative) on 32 envs.  Every 25 steps the envs with the most
+    contacts are checked one step at a time: the fp32 oracle starts from the device state before the step, takes the
+    same plan row, and must land on the device state after the step (joints and joint velocities < 2e-4, object
+    positions < 1e-4 m, object velocities < 5e-3): this pins the pipelined generic sweep, the skipped friction rows of
+    contacts without normal impulse, the shared LDS row pool and the env-to-workgroup dealing of k_balance."""
+    N = 32
+    env = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    o = Oracle(3, 64, 64, f32=True)
+    rng = np.random.default_rng(5)
+    env.plan_macro(rng.uniform([-0.25, -0.5], [0.05, 0.5], size=(N, 2, 2)))
+    plans = [env.get_plan(i) for i in range(N)]
+    checked = heavy = objobj = 0
+    for t in range(800):
+        check = t >= 150 and t % 25 == 0
+        if check:
+            ncs = np.array([len(env.contacts(i)) for i in range(N)])
+            sel = np.argsort(-ncs)[:3]
+            st0 = env.state
+            cont0 = [env.contacts(i) for i in sel]
+        env.step_plan(render=False)
+        if check:
+            st1 = env.state
+            for i in sel:
+                o.state = st0[i].astype(np.float64)
+                o.step(plans[i][t].astype(np.float64))
+                c = env.contacts(i)
+                rob = int((((c[:, 0] >= 0) & (c[:, 0] < 16)) | ((c[:, 1] >= 0) & (c[:, 1] < 16))).sum()) if len(c) else 0
+                heavy = max(heavy, rob)
+                objobj = max(objobj, int(((c[:, 0] >= 16) & (c[:, 1] >= 16)).sum()) if len(c) else 0)
+                assert len(c) == len(o.contacts()), (t, i)
+                d = np.abs(st1[i] - o.state)
+                assert d[:22].max() < 2e-4, (t, i, d[:22].max())
+                objs = _objs(st1[i]) - _objs(o.state)
+                assert np.abs(objs[:, :3]).max() < 1e-4, (t, i)
+                assert np.abs(objs[:, 7:]).max() < 5e-3, (t, i)
+                checked += 1
+    assert checked > 50 and heavy > 12, (checked, heavy, objobj)    # sweeps with more than a dozen robot contacts were checked
     assert (env.host(nat.F_ERRFLAGS) == 0).all()
     env.close()
 
