@@ -8,9 +8,11 @@
 //   k_prep_b        1 thread / env : joint-space mass matrix (composite rigid bodies), bias (RNEA), Cholesky, M^-1,
 //                                    unconstrained joint velocities -- side stream, beside k_collide
 //   k_collide       1 wavefront / env: bounding spheres -> pair list -> lane-per-vertex convex tests -> <=4 points/pair
+//   k_balance       1 workgroup    : env -> solver group order (envs with many contacts dealt out over the solver
+//                                    workgroups) -- side stream, beside k_collide
 //   k_solve         16 lanes / env : row assembly (motors, joint limits, contact normal + 2 friction), PGS with the
-//                                    common rows in registers, semi-implicit Euler, touch sensors, observation pack
-//                                    (robot.py:152-163,203-211)
+//                                    common rows in registers and the others streamed from a per-workgroup LDS row
+//                                    pool, semi-implicit Euler, touch sensors, observation pack (robot.py:152-163,203-211)
 //   k_render_setup  1 thread / (env, instance): FK of the ancestor chain -> model-view-projection + shading constants
 //   k_raster        1 workgroup / (env, tile): visibility only -- 64-bit atomic-min buffer (depth | triangle id) in LDS,
 //                                    meshlet clusters, fragment list out
@@ -755,7 +757,7 @@ struct Slab { int fix, base, rob, bs, lc, lr, lb; };
 // ---- k_balance: which env goes to which 16-lane group of k_solve ------------------------------------------------------
 // The four envs of a solver workgroup share one row pool and one instruction stream, so a workgroup is as slow as its
 // heaviest env and envs that ask for more LDS rows than the pool holds fall back to rows in global memory.  One
-// workgroup of this kernel deals the "heavy" envs (an env that alone needs more than a quarter of the pool: a gripper
+// workgroup of this kernel deals the "heavy" envs (an env that alone needs a large share of the pool: a gripper
 // pushing an object) out over the solver workgroups round-robin and fills up with the light ones.  It uses the contact
 // demand k_collide recorded in the PREVIOUS step (contacts persist from step to step), so it runs on the side stream
 // beside k_collide; the order only decides where rows live and which envs wait for each other -- never a result.
