@@ -2892,6 +2892,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         e->field_ptr[RR_F_FRAG_COUNT] = e->D.frag_count;
         if ((r = build_static_layer(e)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
     }
+    hipLaunchKernelGGL(k_balance, dim3(1), dim3(BAL_THREADS), 0, e->stream, e->P, e->D);     // identity order until contacts appear
+    HIPCHK(hipGetLastError());
     return RR_OK;
 }
 
