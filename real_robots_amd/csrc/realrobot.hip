@@ -2863,8 +2863,11 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     }
     for (int i = 0; i < 2 * RR_NUM_KERNELS; i++) hipEventCreate(&e->ev[i]);
     if (!getenv("RR_NO_AUX_STREAM")) {
-        if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_dyn, hipEventDisableTiming) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
+        // fork / join events order two streams of the same device: no timing, no system-scope fence (the cache writeback
+        // and invalidation a default event performs when it is recorded costs ~6 us on the stream that records it)
+        const unsigned evf = getenv("RR_EVENT_FLAGS") ? (unsigned)strtoul(getenv("RR_EVENT_FLAGS"), nullptr, 0) : (hipEventDisableTiming | hipEventDisableSystemFence);
+        if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, evf) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_join, evf) != hipSuccess || hipEventCreateWithFlags(&e->ev_dyn, evf) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
     }
     e->field_ptr[RR_F_JOINTS] = D.joints; e->field_bytes[RR_F_JOINTS] = (size_t)N * 9 * 4;
     e->field_ptr[RR_F_TOUCH] = D.touch; e->field_bytes[RR_F_TOUCH] = (size_t)N * 4 * 4;
