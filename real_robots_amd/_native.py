@@ -17,7 +17,7 @@ LINK_NAMES = open(os.path.join(_HERE, 'data', 'realrobot_model_links.txt')).read
 RR_ABI_VERSION = 1
 (F_JOINTS, F_TOUCH, F_OBJ_POSE, F_RGB, F_DEPTH, F_MASK, F_TIMESTEP, F_ERRFLAGS, F_STATE, F_FRAG_COUNT) = range(10)
 NUM_KERNELS = 7
-KERNEL_NAMES = ('k_prep', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster', 'k_static_copy', 'k_shade')
+KERNEL_NAMES = ('k_prep', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster', 'k_restore', 'k_shade')
 
 # every symbol include/realrobot.h declares (tests check the library exports all of them)
 SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_object_pose', 'rr_step', 'rr_render',

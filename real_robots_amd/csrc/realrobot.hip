@@ -16,7 +16,8 @@
 //   k_render_setup  1 thread / (env, instance): FK of the ancestor chain -> model-view-projection + shading constants
 //   k_raster        1 workgroup / (env, tile): visibility only -- 64-bit atomic-min buffer (depth | triangle id) in LDS,
 //                                    meshlet clusters, fragment list out
-//   k_static_copy   static layer -> every env's image (side stream, beside k_raster)
+//   k_restore       the pixels of the previous frame's fragment list back to the static layer (the images persist in
+//                                    HBM; k_static_copy, the full copy, only runs for the first frame)
 //   k_shade         deferred shading of the fragment lists
 // The arithmetic restates what the reference delegates to pybullet.stepSimulation / getCameraImage
 // (env.py:340, 536-567); the algorithm and its constants are specified in DESIGN.md and checked against
@@ -1959,6 +1960,8 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 // ---------------------------------------------------------------------------------------------- rasteriser
 // One workgroup per (env, tile). Tile = full-width strip of tile_h rows (<= 16384 pixels -> 128 KiB of LDS keys).
 #define RASTER_THREADS 1024
+#define VIS_WAS_DYNAMIC (~0ull - 1)   // visibility key of a pixel that was dynamic in the previous frame and is not (yet) now
+#define FRAG_VACATED 0x3ffffu         // triangle field of a fragment-list entry for such a pixel: back to the static layer
 #ifndef TILE_PIX
 #define TILE_PIX 16384
 #endif
@@ -2179,7 +2182,8 @@ extern "C" int rr_debug_raster_stats(unsigned long long *out16, int reset) {
 // shelf, robot base link_0; one launch at creation, result shared by all envs).  Output: the list of pixels won by a
 // rasterised triangle {depth bits, pixel-in-tile << 18 | triangle}, shaded by k_shade; everything else in the image is the
 // static layer, copied by k_static_copy.
-__global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int pass, int env0) {
+struct ImageOut { unsigned char *rgb; float *depth; int *mask; size_t env_stride; /* pixels between envs */ };
+__global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int pass, int env0, int restore) {
     const RenderModel &RM = *RMp;
     __shared__ unsigned long long vis[TILE_PIX];
     __shared__ __attribute__((aligned(16))) float mvp[MAXINST][16];
@@ -2218,6 +2222,17 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     const float nrm_b = sqrtf((RM.VP[4] - ndc_b * RM.VP[12]) * (RM.VP[4] - ndc_b * RM.VP[12]) + (RM.VP[5] - ndc_b * RM.VP[13]) * (RM.VP[5] - ndc_b * RM.VP[13]) +
                               (RM.VP[6] - ndc_b * RM.VP[14]) * (RM.VP[6] - ndc_b * RM.VP[14]));
     const bool tiled = RM.ntiles > 1;
+    // Incremental image update (do_render): the env's image in HBM still holds its previous frame.  The pixels of that
+    // frame's fragment list are marked in the (still empty) visibility buffer with a key above every real one; those that
+    // no triangle reaches this time leave the compaction as "vacated" entries, which k_shade puts back to the static layer.
+    if (restore) {
+        const unsigned n_old = D.frag_count[(size_t)env * RM.ntiles + tile];
+        const uint2 *old_lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
+        for (unsigned i = tid; i < n_old; i += RASTER_THREADS) {
+            const unsigned en = old_lst[i].y;
+            if ((en & 0x3ffffu) != FRAG_VACATED) vis[en >> 18] = VIS_WAS_DYNAMIC;     // (a vacated entry was put back last time)
+        }
+    }
     for (int wi = tid; wi < nwin; wi += RASTER_THREADS) {
         const int tb = t_begin + (wi << 6);
         const int inst = D.tri_inst[tb];
@@ -2419,7 +2434,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
     for (int i = tid; i < npix; i += RASTER_THREADS) {
         const unsigned long long key = vis[i];
-        const unsigned tri = (unsigned)(key & 0xffffffffu);
+        const unsigned tri = key == VIS_WAS_DYNAMIC ? FRAG_VACATED : (unsigned)(key & 0xffffffffu);
         if (key != ~0ull) {
             const unsigned slot = atomicAdd(&nlist, 1u);
             lst[slot] = make_uint2((unsigned)(key >> 32), ((unsigned)i << 18) | tri);
@@ -2430,7 +2445,6 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
 }
 
 // Image targets of k_static_copy / k_shade: the per-env observation buffers (pass 0) or the shared static layer (pass 1).
-struct ImageOut { unsigned char *rgb; float *depth; int *mask; size_t env_stride; /* pixels between envs */ };
 
 // Copies the static layer (or the background when there is none) into the images of every rendered env: 4 pixels per
 // thread (W % 4 == 0 enforced at create).  Pure streaming: reads hit L2, writes are the obs bytes of SURVEY 8(d).
@@ -2453,6 +2467,42 @@ __global__ void __launch_bounds__(COPY_THREADS) k_static_copy(const RenderModel 
 }
 
 // Background fill of the shared static images (before the static layer is shaded, and when there is no static layer).
+// Incremental image update: an env's image in HBM still holds its previous frame, and only the pixels of that frame's
+// fragment list differ from the static layer.  Putting the static values back at exactly those pixels (before k_raster
+// overwrites the list) leaves the same image as a full copy of the static layer -- ~1 000 pixels instead of 16 384 per env.
+#define RESTORE_THREADS 256
+__global__ void __launch_bounds__(RESTORE_THREADS) k_restore(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags) {
+    const RenderModel &RM = *RMp;
+    const int env = blockIdx.x, tile = blockIdx.y;
+    if (use_flags && D.render_flags && !D.render_flags[env]) return;
+    const unsigned n = D.frag_count[(size_t)env * RM.ntiles + tile];          // still the previous frame's count
+    const uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
+    const size_t sbase = (size_t)tile * RM.tile_h * RM.W, base = (size_t)env * out.env_stride + sbase;
+    // four fragments per thread and trip, every load of the trip issued before the first store (the kernel is a chain of
+    // dependent round trips: list entry -> static pixel -> store)
+    for (unsigned i0 = 0; i0 < n; i0 += 4 * RESTORE_THREADS) {
+        unsigned pi[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const unsigned i = i0 + k * RESTORE_THREADS + threadIdx.x; pi[k] = i < n ? lst[i].y >> 18 : 0xffffffffu; }
+        unsigned char r[4][3]; float d[4]; int m[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t so = sbase + (pi[k] != 0xffffffffu ? pi[k] : 0u);
+            r[k][0] = D.static_rgb[so * 3]; r[k][1] = D.static_rgb[so * 3 + 1]; r[k][2] = D.static_rgb[so * 3 + 2];
+            d[k] = D.static_depth[so];
+            m[k] = out.mask ? D.static_mask[so] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (pi[k] == 0xffffffffu) continue;
+            const size_t o = base + pi[k];
+            out.rgb[o * 3] = r[k][0]; out.rgb[o * 3 + 1] = r[k][1]; out.rgb[o * 3 + 2] = r[k][2];
+            out.depth[o] = d[k];
+            if (out.mask) out.mask[o] = m[k];
+        }
+    }
+}
+
 __global__ void k_background(const RenderModel *RMp, DevPtrs D) {
     const int npx = RMp->W * RMp->H;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
@@ -2486,8 +2536,18 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp,
     for (unsigned i = blockIdx.z * SHADE_THREADS + threadIdx.x; i < n; i += gridDim.z * SHADE_THREADS) {
         const uint2 f = lst[i];
         const int pi = (int)(f.y >> 18), t = (int)(f.y & 0x3ffffu);
-        // a moving triangle only shows where it beats the static layer (depth, then triangle id; static ids are lower)
-        if (sv && !((((unsigned long long)f.x << 32) | (unsigned)t) < sv[pi])) continue;
+        // a moving triangle only shows where it beats the static layer (depth, then triangle id; static ids are lower);
+        // where it does not, and where the previous frame's fragment has gone, the pixel goes back to the static layer
+        // (the image persists in HBM from frame to frame, do_render)
+        if (t == (int)FRAG_VACATED || (sv && !((((unsigned long long)f.x << 32) | (unsigned)t) < sv[pi]))) {
+            if (sv) {
+                const size_t so = (size_t)row0 * RM.W + (size_t)pi, o = base + (size_t)pi;
+                out.rgb[o * 3] = D.static_rgb[so * 3]; out.rgb[o * 3 + 1] = D.static_rgb[so * 3 + 1]; out.rgb[o * 3 + 2] = D.static_rgb[so * 3 + 2];
+                out.depth[o] = D.static_depth[so];
+                if (out.mask) out.mask[o] = D.static_mask[so];
+            }
+            continue;
+        }
         const int lrow = pi / RM.W, px = pi - lrow * RM.W;
         unsigned char c3[3]; int m;
         shade_pixel(ctx, t, px, row0 + lrow, c3, m);
@@ -2557,6 +2617,8 @@ struct rr_env {
     float *plan; int *plan_step; float *ik_in; float *ik_out; float *ik_err;   // lazily allocated (macro / cartesian adapters)
     std::vector<void *> allocs;
     bool timing;
+    bool full_copy, sep_restore;   // RR_FULL_COPY / RR_SEPARATE_RESTORE at create: the two earlier image-update schemes (tests, A/B)
+    bool images_valid;       // every env's image holds its previous frame (static layer + the pixels of its fragment list)
     hipEvent_t ev[2 * RR_NUM_KERNELS];
     hipStream_t aux;         // side stream: the HBM-bound static-layer copy runs beside the VALU-bound physics / visibility kernels
     hipEvent_t ev_fork, ev_join, ev_dyn;
@@ -2650,11 +2712,14 @@ static int build_static_layer(rr_env *e) {
         so.rgb = e->D.static_rgb; so.depth = e->D.static_depth; so.mask = e->D.static_mask; so.env_stride = 0;
         e->D.static_vis = nullptr;
         hipLaunchKernelGGL(k_render_setup, dim3((e->P.N * MAXINST + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D);
-        hipLaunchKernelGGL(k_raster, dim3(1, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1, 0);
+        hipLaunchKernelGGL(k_raster, dim3(1, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1, 0, 0);
         hipLaunchKernelGGL(k_shade, dim3(1, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, e->D, so, 0, 0);
     }
-    if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(RR_EDEVICE, "static layer pass failed");
+    // the pass above used env 0's fragment list; from here on the lists describe what differs from the static layer
+    if (hipMemsetAsync(e->D.frag_count, 0, (size_t)e->P.N * e->RM.ntiles * sizeof(unsigned), e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess) return fail(RR_EDEVICE, "static layer pass failed");
     e->D.static_vis = e->D.static_vis_out;
+    e->images_valid = false;         // the next render starts from a full copy of the new static layer
     return RR_OK;
 }
 
@@ -2683,6 +2748,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     memset(&e->B, 0, sizeof e->B); memset(&e->RM, 0, sizeof e->RM); memset(&e->D, 0, sizeof e->D);
     memset(e->ev, 0, sizeof e->ev); memset(e->t_ms, 0, sizeof e->t_ms); memset(e->t_n, 0, sizeof e->t_n);
     e->timing = false;
+    e->full_copy = getenv("RR_FULL_COPY") != nullptr;
+    e->sep_restore = getenv("RR_SEPARATE_RESTORE") != nullptr;
     e->plan = nullptr; e->plan_step = nullptr; e->ik_in = nullptr; e->ik_out = nullptr; e->ik_err = nullptr;
     e->cfg = *cfg;
     e->stream = (hipStream_t)stream;
@@ -2964,26 +3031,28 @@ static int do_render(rr_env *e, bool use_flags) {
     const int N = e->P.N;
     TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, D));
     const ImageOut io = env_images(e);
-    const int copy_blocks = std::min(16, (e->RM.W * e->RM.H / 4 + COPY_THREADS - 1) / COPY_THREADS);
-    const bool forked = e->aux && !e->timing && !g_skip;
-    if (forked) {
-        // The static-layer copy only depends on work already enqueued on the main stream (the previous frame's consumers,
-        // the render flags): it runs on the side stream beside k_raster -- the copy is HBM-write bound, the visibility
-        // pass VALU bound with one LDS-filling workgroup per CU -- and is joined before k_shade.  (Also tried: pipelining
-        // k_shade of one env chunk against k_raster of the next on the two streams; 2 chunks +7 %, 8 chunks +50 % step
-        // time -- both passes want the VALU and the chunked launches add tails -- so the stage stays three full launches.)
-        hipEventRecord(e->ev_fork, e->stream);
-        hipStreamWaitEvent(e->aux, e->ev_fork, 0);
-        // throttled: 16 x 16 persistent workgroups (about one per CU) that walk all envs -- the copy has the whole
-        // visibility pass to finish in, and at full width it slowed that pass down (A/B step time: all envs at once 0.946,
-        // 64 slots 0.927, 16 slots 0.908, 4 slots 0.912, 2 slots 0.99 ms)
-        static const int copy_envs = getenv("RR_COPY_ENVS") ? std::max(1, atoi(getenv("RR_COPY_ENVS"))) : 16;
-        hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, std::min(N, copy_envs)), dim3(COPY_THREADS), 0, e->aux, e->RM_dev, D, io, 1, N);
-        hipEventRecord(e->ev_join, e->aux);
+    // The images persist in HBM from frame to frame: after the first frame (or a new static layer) only the pixels of
+    // the previous frame's fragment lists are put back to the static layer (k_restore) instead of copying the static
+    // layer into every env's image (470 MB per frame at 4096 envs, and a side stream with two fork/join bubbles).
+    // (Earlier design, kept for RR_FULL_COPY=1: the full copy throttled to ~one workgroup per CU on the side stream beside
+    // k_raster; pipelining k_shade of one env chunk against k_raster of the next was tried too, +7 % .. +50 % step time.)
+    const bool full_copy = e->full_copy, sep_restore = e->sep_restore;
+    int restore = 1;
+    if (!e->images_valid || full_copy) {
+        const int copy_blocks = std::min(16, (e->RM.W * e->RM.H / 4 + COPY_THREADS - 1) / COPY_THREADS);
+        DevPtrs Dall = D;
+        if (!e->images_valid) Dall.render_flags = nullptr;      // first frame: every env, flagged or not -- all images become valid
+        TIMED(5, hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, N), dim3(COPY_THREADS), 0, e->stream, e->RM_dev, Dall, io, 1, N));
+        if (!e->images_valid) HIPCHK(hipMemsetAsync(e->D.frag_count, 0, (size_t)N * e->RM.ntiles * sizeof(unsigned), e->stream));
+        e->images_valid = true;
+        restore = 0;
+    } else if (sep_restore) {
+        // (Also measured: these stores at the head / tail of k_raster's workgroups -- the same +30 us as this pass: that
+        // kernel holds one LDS-filling workgroup per CU, and a workgroup retires only when its stores are acknowledged.)
+        TIMED(5, hipLaunchKernelGGL(k_restore, dim3(N, e->RM.ntiles), dim3(RESTORE_THREADS), 0, e->stream, e->RM_dev, D, io, 1));
+        restore = 0;
     }
-    TIMED(4, hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, D, e->n_inst_used, 0, 0));
-    if (forked) hipStreamWaitEvent(e->stream, e->ev_join, 0);
-    else TIMED(5, hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, N), dim3(COPY_THREADS), 0, e->stream, e->RM_dev, D, io, 1, N));
+    TIMED(4, hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, D, e->n_inst_used, 0, 0, restore));
     TIMED(6, hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, D, io, 1, 0));
     HIPCHK(hipGetLastError());
     return RR_OK;

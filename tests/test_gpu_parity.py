@@ -442,6 +442,44 @@ def test_raster_parity_many_poses_near_camera():
     env.close()
 
 
+@pytest.mark.parametrize("mode", ["RR_FULL_COPY", "RR_SEPARATE_RESTORE"])
+def test_incremental_image_update_equals_full_copy(mode, monkeypatch):
+    """The images persist in HBM: a frame only rewrites the pixels of its fragments and puts the pixels the previous frame's
+    fragments vacated back to the static layer.  Over 150 steps with wide commands (links sweeping through the image),
+    per-env render flags that skip frames at random, an object teleported away and an env reset in between, every
+    rendered image must equal bit for bit what the two earlier schemes produce: the full copy of the static layer into
+    every image before each frame, and the separate restore pass."""
+    N, W, H = 12, 128, 128
+    rng = np.random.default_rng(2)
+    flags = [(rng.random(N) < 0.6).astype(np.uint8) for _ in range(150)]
+
+    def run(env_var):
+        if env_var:
+            monkeypatch.setenv(env_var, "1")
+        env = BatchedREALRobotEnv(N, objects=3, width=W, height=H)
+        if env_var:
+            monkeypatch.delenv(env_var)
+        frames = []
+        for t in range(150):
+            act = synthetic_actions(range(N), t, seed=3) * 0.9
+            if t == 70:
+                env.set_object_pose(2, 0, np.array([0.05, 0.3, 0.5, 0, 0, 0, 1], np.float32))
+            if t == 100:
+                m = np.zeros(N, np.uint8); m[5] = 1
+                env.reset(m)
+            env.step(act, render=flags[t])
+            if t % 10 == 9:
+                frames.append((env.host(nat.F_RGB).copy(), env.host(nat.F_DEPTH).copy(), env.host(nat.F_MASK).copy()))
+        env.close()
+        return frames
+
+    a, b = run(None), run(mode)
+    assert len(a) == len(b) == 15
+    for k, ((r0, d0, m0), (r1, d1, m1)) in enumerate(zip(a, b)):
+        assert (r0 == r1).all() and (d0 == d1).all() and (m0 == m1).all(), k
+    assert len({fr[0].tobytes() for fr in a}) == 15           # the frames differ from each other
+
+
 def test_known_answers_hold_on_the_device_path():
     """The analytic known answers of tests/test_oracle_pins.py evaluated on the HIP path itself (no oracle involved):
     resting contact forces sum to m g; a cube launched at 0.4 m/s along +y decelerates at mu g + v (0.04 + 0.04 v)

@@ -5,7 +5,7 @@ import re
 import subprocess
 import sys
 
-HOT = ('k_prep_a', 'k_prep_b', 'k_collide', 'k_balance', 'k_solve', 'k_raster', 'k_shade', 'k_static_copy', 'k_render_setup', 'k_ik',
+HOT = ('k_prep_a', 'k_prep_b', 'k_collide', 'k_balance', 'k_solve', 'k_raster', 'k_shade', 'k_static_copy', 'k_restore', 'k_render_setup', 'k_ik',
        'k_plan_macro')
 
 
