@@ -132,7 +132,7 @@ int rr_step_plan(rr_env *env, int32_t render_mode, const uint8_t *render_flags_h
 /* Per-kernel device timing with HIP events on the library's stream (bench.py roofline leg).
  * After rr_set_timing(env, 1), each rr_step/rr_render records events; rr_get_timing returns accumulated
  * milliseconds and launch counts per kernel since the last call and resets them.
- * kernel ids: 0 prep, 1 collide, 2 solve, 3 render_setup, 4 raster, 5 restore (previous frame's pixels back to the static layer; the full static copy on the first frame), 6 shade. */
+ * kernel ids: 0 prep, 1 collide, 2 solve, 3 render_setup, 4 raster, 5 image set-up outside the two render kernels (the full static copy of the first frame; the separate restore pass with RR_SEPARATE_RESTORE), 6 shade. */
 #define RR_NUM_KERNELS 7
 int rr_set_timing(rr_env *env, int32_t enable);
 int rr_get_timing(rr_env *env, float *ms_out /*[RR_NUM_KERNELS]*/, int32_t *launches_out /*[RR_NUM_KERNELS]*/);

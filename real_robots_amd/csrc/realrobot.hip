@@ -15,10 +15,10 @@
 //                                    pool, semi-implicit Euler, touch sensors, observation pack (robot.py:152-163,203-211)
 //   k_render_setup  1 thread / (env, instance): FK of the ancestor chain -> model-view-projection + shading constants
 //   k_raster        1 workgroup / (env, tile): visibility only -- 64-bit atomic-min buffer (depth | triangle id) in LDS,
-//                                    meshlet clusters, fragment list out
-//   k_restore       the pixels of the previous frame's fragment list back to the static layer (the images persist in
-//                                    HBM; k_static_copy, the full copy, only runs for the first frame)
-//   k_shade         deferred shading of the fragment lists
+//                                    meshlet clusters, fragment list out (winners + pixels vacated since the last frame)
+//   k_shade         deferred shading of the fragment lists; vacated / occluded pixels go back to the static layer
+//                                    (the images persist in HBM: k_static_copy, the full copy, only runs for the first
+//                                    frame; k_restore is the separate-pass variant kept for RR_SEPARATE_RESTORE)
 // The arithmetic restates what the reference delegates to pybullet.stepSimulation / getCameraImage
 // (env.py:340, 536-567); the algorithm and its constants are specified in DESIGN.md and checked against
 // oracle/rr_oracle.c by tests/ (never linked here).
