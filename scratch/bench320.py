@@ -3,7 +3,7 @@ import numpy as np, torch
 from real_robots_amd import _native as nat
 from real_robots_amd.batched import BatchedREALRobotEnv
 from real_robots_amd.distributed import synthetic_actions
-for (N, W, H) in ((1024, 320, 240), (4096, 64, 64), (1024, 128, 128)):
+for (N, W, H) in ((1024, 320, 240), (4096, 320, 240), (4096, 64, 64), (1024, 128, 128)):
     env = BatchedREALRobotEnv(N, objects=3, width=W, height=H, want_mask=False)
     ids = np.arange(N); cache = {}
     def act(t):
