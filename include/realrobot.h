@@ -44,7 +44,7 @@ enum {
     RR_F_TIMESTEP = 6,  /* i32 [N]           env.timestep                 env.py:217,346 */
     RR_F_ERRFLAGS = 7,  /* u32 [N]           bit0: non-finite state detected (env auto-frozen) */
     RR_F_STATE = 8,     /* f32 [N, 61]       q[11] qd[11] 3x(pos3 quat4 lin3 ang3)  (checkpoint / parity) */
-    RR_F_FRAG_COUNT = 9,/* u32 [N, tiles]    diagnostic: pixels won by moving geometry in the last render (k_shade's work list) */
+    RR_F_FRAG_COUNT = 9,/* u32 [N, tiles]    diagnostic: entries of k_shade's work list in the last render (pixels won by moving geometry + pixels vacated since the frame before) */
     RR_F_COUNT = 10
 };
 
