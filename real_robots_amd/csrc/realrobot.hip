@@ -2540,12 +2540,11 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp,
         // where it does not, and where the previous frame's fragment has gone, the pixel goes back to the static layer
         // (the image persists in HBM from frame to frame, do_render)
         if (t == (int)FRAG_VACATED || (sv && !((((unsigned long long)f.x << 32) | (unsigned)t) < sv[pi]))) {
-            if (sv) {
-                const size_t so = (size_t)row0 * RM.W + (size_t)pi, o = base + (size_t)pi;
-                out.rgb[o * 3] = D.static_rgb[so * 3]; out.rgb[o * 3 + 1] = D.static_rgb[so * 3 + 1]; out.rgb[o * 3 + 2] = D.static_rgb[so * 3 + 2];
-                out.depth[o] = D.static_depth[so];
-                if (out.mask) out.mask[o] = D.static_mask[so];
-            }
+            // (vacated entries only exist in env frames; with RR_NO_STATIC_LAYER the static buffers hold the background)
+            const size_t so = (size_t)row0 * RM.W + (size_t)pi, o = base + (size_t)pi;
+            out.rgb[o * 3] = D.static_rgb[so * 3]; out.rgb[o * 3 + 1] = D.static_rgb[so * 3 + 1]; out.rgb[o * 3 + 2] = D.static_rgb[so * 3 + 2];
+            out.depth[o] = D.static_depth[so];
+            if (out.mask) out.mask[o] = D.static_mask[so];
             continue;
         }
         const int lrow = pi / RM.W, px = pi - lrow * RM.W;
