@@ -2198,6 +2198,11 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     const int npix = rows * W;
     const int tid = threadIdx.x;
     const bool layered = (pass == 0) && (D.static_vis != nullptr);
+    // (incremental image update, see below: this thread's entry of the previous frame's list is fetched first -- its
+    // round trip hides behind the LDS fill and the instance staging)
+    const unsigned n_old = restore ? D.frag_count[(size_t)env * RM.ntiles + tile] : 0u;
+    const uint2 *old_lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
+    const unsigned en_first = (unsigned)tid < n_old ? old_lst[tid].y : 0xffffffffu;
     // The tile starts empty (an LDS-only fill); the static layer's keys are compared at compaction time and only for the
     // few pixels a moving triangle reached (min is associative) -- no 128 KB read of the static keys per env.
     for (int i = tid; i < npix; i += RASTER_THREADS) vis[i] = ~0ull;
@@ -2226,9 +2231,8 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     // frame's fragment list are marked in the (still empty) visibility buffer with a key above every real one; those that
     // no triangle reaches this time leave the compaction as "vacated" entries, which k_shade puts back to the static layer.
     if (restore) {
-        const unsigned n_old = D.frag_count[(size_t)env * RM.ntiles + tile];
-        const uint2 *old_lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
-        for (unsigned i = tid; i < n_old; i += RASTER_THREADS) {
+        if (en_first != 0xffffffffu && (en_first & 0x3ffffu) != FRAG_VACATED) vis[en_first >> 18] = VIS_WAS_DYNAMIC;
+        for (unsigned i = tid + RASTER_THREADS; i < n_old; i += RASTER_THREADS) {          // more than 1024 entries: rare
             const unsigned en = old_lst[i].y;
             if ((en & 0x3ffffu) != FRAG_VACATED) vis[en >> 18] = VIS_WAS_DYNAMIC;     // (a vacated entry was put back last time)
         }
