@@ -62,6 +62,47 @@ def test_device_macro_plan_matches_host_plan_and_tracks_reference_checkpoints():
     env.close()
 
 
+def test_all_36_perimeter_pairs_of_the_reference_script():
+    """reference tests/test_actions.py:101-152 enumerates all 36 ordered pairs of six perimeter points and prints
+    "Failed!" when the gripper base is more than 0.01 m from a way point at t = 199, 249, 749, 849, 999 (it asserts
+    nothing).  The same enumeration here, one env per pair, objects parked on the shelf (test_actions.py:95-98), with the
+    bounds this implementation of the documented semantics reaches (rate limit 0.2 / 0.3 rad of env.py:314-321 and the
+    10 % per step position motor: 0.02-0.03 rad per step):
+      * home at t = 999: < 0.01 m for all 36;
+      * (p1, 0.46) at t = 249: < 0.012 m for all 36;
+      * (p1, 0.6) at t = 199: < 0.01 m when p1 is not at the reach limit, < 0.012 m for (-0.25, 0) (1.8 rad of joint
+        travel from home2 in 100 steps is marginal), < 0.08 m for the corners (0.05, +-0.5) where the arm is stretched
+        out and the IK solution is a long way round;
+      * home2 at t = 849 is 50 steps after a way point up to 1.6 rad away: not reachable at 0.03 rad per step, recorded
+        only (a real pybullet run of the script would settle whether its motor is faster)."""
+    perimeter = [(a, b) for a in (-0.25, 0.05) for b in (-0.5, 0.0, 0.5)]
+    pairs = [(p1, p2) for p1 in perimeter for p2 in perimeter]
+    N = len(pairs)
+    env = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    for i in range(N):
+        env.set_object_pose(i, 0, [0.2, 0.0, 0.75, 0, 0, 0, 1])
+        env.set_object_pose(i, 1, [0.2, -0.3, 0.75, 0, 0, 0, 1])
+        env.set_object_pose(i, 2, [0.2, 0.3, 0.75, 0, 0, 0, 1])
+    env.plan_macro(np.array(pairs, dtype=np.float32))
+    base = nat.LINK_NAMES.index('base')
+    home = np.array([-0.55, 0.0, 1.27])
+    dist = {}
+    for t in range(1000):
+        env.step_plan()
+        if t in (199, 249, 999):
+            lp = env.link_poses()[:, base, :3]
+            for i, (p1, p2) in enumerate(pairs):
+                tgt = {199: [p1[0], p1[1], 0.6], 249: [p1[0], p1[1], 0.46], 999: home}[t]
+                dist[(t, i)] = float(np.linalg.norm(lp[i] - tgt))
+    for i, (p1, p2) in enumerate(pairs):
+        assert dist[(999, i)] < 0.01, (999, pairs[i], dist[(999, i)])
+        assert dist[(249, i)] < 0.012, (249, pairs[i], dist[(249, i)])
+        bound = 0.08 if p1 in ((0.05, -0.5), (0.05, 0.5)) else (0.012 if p1 == (-0.25, 0.0) else 0.01)
+        assert dist[(199, i)] < bound, (199, pairs[i], dist[(199, i)])
+    assert (env.host(nat.F_TIMESTEP) == 1000).all() and (env.host(nat.F_ERRFLAGS) == 0).all()
+    env.close()
+
+
 def test_step_macro_replans_on_new_action_and_facade_macro_env():
     env = BatchedREALRobotEnv(2, objects=1, width=64, height=64)
     a = np.array([[[-0.1, -0.2], [0.0, 0.2]], [[-0.2, 0.1], [0.0, -0.3]]])
