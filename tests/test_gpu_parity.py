@@ -446,7 +446,7 @@ def test_raster_parity_many_poses_near_camera():
 def test_incremental_image_update_equals_full_copy(mode, monkeypatch):
     """The images persist in HBM: a frame only rewrites the pixels of its fragments and puts the pixels the previous frame's
     fragments vacated back to the static layer.  Over 150 steps with wide commands (links sweeping through the image),
-    per-env render flags that skip frames at random, an object teleported away and an env reset in between, every
+    per-env render flags that skip frames at random, an object teleported away, an env reset and a camera change in between, every
     rendered image must equal bit for bit what the two earlier schemes produce: the full copy of the static layer into
     every image before each frame, and the separate restore pass."""
     N, W, H = 12, 128, 128
@@ -467,6 +467,10 @@ def test_incremental_image_update_equals_full_copy(mode, monkeypatch):
             if t == 100:
                 m = np.zeros(N, np.uint8); m[5] = 1
                 env.reset(m)
+            if t == 120:                            # a new camera: new static layer, the next frame starts from a full copy
+                from real_robots_amd.kinematics import look_at, perspective
+                env.set_camera(look_at(np.array([0.3, 0.2, 1.1]), np.array([0.0, 0.0, 0.2]), np.array([0.0, 0.0, 1.0])),
+                               perspective(70.0, W / H, 0.1, 100.0))
             env.step(act, render=flags[t])
             if t % 10 == 9:
                 frames.append((env.host(nat.F_RGB).copy(), env.host(nat.F_DEPTH).copy(), env.host(nat.F_MASK).copy()))
