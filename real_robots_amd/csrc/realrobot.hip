@@ -1295,7 +1295,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     {                                                                                                              \
         B##row = (base4 + (3 * (n_os + (J)) + (K)) * 3) << 2;                                                      \
         const int rr_ = L_ROB + (((J) - n_oo) * 3 + (K)) * 22 + lj;      /* (a valid LDS address for any J) */     \
-        const int oa_ = ((g_ownB >> (J)) & 1ull) ? L_BS + ((J) * 3 + (K)) * 6 : B##row + 3;                        \
+        const int oa_ = (B##row + 3) + (-(int)((g_ownB >> (J)) & 1ull) & (L_BS + ((J) * 3 + (K)) * 6 - (B##row + 3)));   /* branch-free select */ \
         B##p = *(const float4 *)&LD(B##row); B##r = *(const float4 *)&LD(B##row + 8);                              \
         B##a0 = LD(oa_); B##a1 = LD(oa_ + 1); B##a2 = LD(oa_ + 2); B##m0 = LD(oa_ + 3); B##m1 = LD(oa_ + 4); B##m2 = LD(oa_ + 5); \
         B##j = LD(rr_); B##m = LD(rr_ + 11);                                                                       \
