@@ -1300,8 +1300,8 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         B##a0 = LD(oa_); B##a1 = LD(oa_ + 1); B##a2 = LD(oa_ + 2); B##m0 = LD(oa_ + 3); B##m1 = LD(oa_ + 4); B##m2 = LD(oa_ + 5); \
         B##j = LD(rr_); B##m = LD(rr_ + 11);                                                                       \
     }
-#define LEAN_ROLE(J)                                                                                               \
-    const bool own_ = (g_own >> (J)) & 1ull, rob_ = ((g_rob >> (J)) & 1ull) && l < NB;                             \
+#define LEAN_ROLE(J)   /* one mask test per lane: a joint lane of a robot contact, or the object lane of an owner */ \
+    const bool act_ = (g_act >> (J)) & 1ull, own_ = act_ && l >= NB, rob_ = act_ && l < NB;                        \
     const float sg_ = ((g_ownB >> (J)) & 1ull) ? -1.0f : 1.0f, sgim_ = sg_ * inv_mass;
 #define LEAN_STEP(B, LOB, HIB, OUT)                                                                                \
     {                                                                                                              \
@@ -1318,6 +1318,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         dv.x += B##p.x * sm_; dv.y += B##p.y * sm_; dv.z += B##p.z * sm_;                                          \
         dw.x += B##m0 * so_; dw.y += B##m1 * so_; dw.z += B##m2 * so_;                                             \
     }
+    const unsigned long long g_act = l < NB ? g_rob : g_own;
     if (__ballot(any_slow)) __threadfence();       // rows built in global memory become visible to the group's other lanes
     static_assert(KLIM == 2 && KOS == 4, "the sweeps below are written out for KLIM = 2, KOS = 4");
     // When no env of this wave has a row outside the registers (no robot or object-object contact, no further limit
