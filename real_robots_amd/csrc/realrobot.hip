@@ -2520,8 +2520,8 @@ __global__ void k_background(const RenderModel *RMp, DevPtrs D) {
 // SHADE_THREADS-entry chunks to SHADE_SPLIT workgroups (blocks whose first chunk lies beyond the list exit at once).
 // A/B (k_shade, ms): 64x16 0.175, 128x8 0.145, 256x8 0.131, 256x2 0.122, 512x2 0.119, 1024x1 0.120 -- the per-block
 // staging of the instance constants outweighs the tail of long lists.
-#define SHADE_THREADS 512
-#define SHADE_SPLIT 2
+#define SHADE_THREADS 256
+#define SHADE_SPLIT 8
 __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags, int env0) {
     const RenderModel &RM = *RMp;
     __shared__ __attribute__((aligned(16))) float mvp[MAXINST][16];
