@@ -102,6 +102,9 @@ int rr_set_camera(rr_env *env, const float *view16, const float *proj16);
 
 /* Device pointer + size of an observation/state buffer (valid until rr_destroy). */
 int rr_get_buffer(rr_env *env, int32_t field, void **dev_ptr, size_t *bytes);
+/* The buffers are owned by the library and READ-ONLY for the caller: observations are rewritten by every step, and the
+ * image buffers (RGB, DEPTH, MASK) persist from frame to frame -- a render only rewrites the pixels that differ from the
+ * previous frame of that env, so a caller that scribbles into them would see its marks survive. */
 /* Synchronising copy of a whole field to host memory. */
 int rr_copy_to_host(rr_env *env, int32_t field, void *dst, size_t bytes);
 /* Overwrites the full simulation state from host memory (f32 [N, 61]); checkpoint restore / parity tests. */
