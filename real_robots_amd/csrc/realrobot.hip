@@ -788,7 +788,8 @@ __global__ void __launch_bounds__(BAL_THREADS) k_balance(SimParams P, DevPtrs D)
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if ((t & 63) >= d) incl += o; }
     if ((t & 63) == 63) s_wave[t >> 6] = incl;
-    if (t < SGRP) D.solve_order[SGRP * nblk - 1 - t] = -1;      // the last workgroup may have fewer than four envs
+    for (int i = t; i < SGRP * nblk; i += BAL_THREADS) D.solve_order[i] = -1;     // N need not be a multiple of four: the
+                                                                                  // positions left over stay empty, wherever they are
     __syncthreads();
     int base = incl - mine, tot = 0;
     for (int w = 0; w < BAL_THREADS / 64; w++) { const int c = s_wave[w]; if (w < (t >> 6)) base += c; tot += c; }
