@@ -471,14 +471,14 @@ def test_raster_parity_many_poses_near_camera():
     env.close()
 
 
-@pytest.mark.parametrize("mode", ["RR_FULL_COPY", "RR_SEPARATE_RESTORE"])
-def test_incremental_image_update_equals_full_copy(mode, monkeypatch):
+@pytest.mark.parametrize("mode,W,H", [("RR_FULL_COPY", 128, 128), ("RR_SEPARATE_RESTORE", 128, 128), ("RR_FULL_COPY", 320, 240)])
+def test_incremental_image_update_equals_full_copy(mode, W, H, monkeypatch):
     """The images persist in HBM: a frame only rewrites the pixels of its fragments and puts the pixels the previous frame's
     fragments vacated back to the static layer.  Over 150 steps with wide commands (links sweeping through the image),
     per-env render flags that skip frames at random, an object teleported away, an env reset and a camera change in between, every
     rendered image must equal bit for bit what the two earlier schemes produce: the full copy of the static layer into
     every image before each frame, and the separate restore pass."""
-    N, W, H = 12, 128, 128
+    N = 12                      # 320x240 is rendered in several tiles: fragment lists and markers per tile
     rng = np.random.default_rng(2)
     flags = [(rng.random(N) < 0.6).astype(np.uint8) for _ in range(150)]
 
