@@ -82,6 +82,10 @@ int rr_reset(rr_env *env, const uint8_t *env_mask_host);
 
 /* Replaces BodyPart.reset_pose via robot.object_bodies[name].reset_pose (env.py:159-162; zeroes velocity). */
 int rr_set_object_pose(rr_env *env, int32_t env_index, int32_t obj, const float *pose7);
+/* The pose (xyz + xyzw quaternion, host) object `obj` of env `env_index` (< 0: every env) returns to on rr_reset and when the
+ * out-of-bounds rule fires (env.py:257-264). Replaces in-place edits of Kuka.object_poses (robot.py:19-24; the reference's
+ * tests/test_actions.py:95-98 parks the objects on the shelf that way). Defaults: the poses of the model blob. */
+int rr_set_object_home(rr_env *env, int32_t env_index, int32_t obj, const float *pose7);
 
 /* Replaces one REALRobotEnv.step_joints() (env.py:326-356) for all N envs:
  *   limitActionByJoint (env.py:314-321), control_objects_limits (env.py:257-264), Kuka.apply_action

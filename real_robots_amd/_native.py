@@ -20,7 +20,7 @@ NUM_KERNELS = 7
 KERNEL_NAMES = ('k_prep', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster', 'k_restore', 'k_shade')
 
 # every symbol include/realrobot.h declares (tests check the library exports all of them)
-SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_object_pose', 'rr_step', 'rr_render',
+SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_object_pose', 'rr_set_object_home', 'rr_step', 'rr_render',
            'rr_get_buffer', 'rr_copy_to_host', 'rr_set_state', 'rr_sync', 'rr_link_poses', 'rr_get_contacts',
            'rr_set_timing', 'rr_get_timing', 'rr_last_error', 'rr_abi_version', 'rr_ik', 'rr_plan_macro', 'rr_get_plan',
            'rr_step_plan', 'rr_set_camera')
@@ -73,6 +73,7 @@ def load_library():
     L.rr_set_stream.argtypes = [vp, vp]
     L.rr_reset.argtypes = [vp, vp]
     L.rr_set_object_pose.argtypes = [vp, i32, i32, vp]
+    L.rr_set_object_home.argtypes = [vp, i32, i32, vp]
     L.rr_step.argtypes = [vp, vp, i32, i32, vp]
     L.rr_render.argtypes = [vp]
     L.rr_get_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]

@@ -116,6 +116,13 @@ class BatchedREALRobotEnv:
         assert p.shape == (7,)
         nat.check(self.L.rr_set_object_pose(self.h, int(env), int(obj), p.ctypes.data))
 
+    def set_object_home(self, env, obj, pose7):
+        """Pose object `obj` of env `env` (None: every env) returns to on reset / when it leaves the table
+        (Kuka.object_poses, robot.py:19-24)."""
+        p = np.ascontiguousarray(pose7, dtype=np.float32)
+        assert p.shape == (7,)
+        nat.check(self.L.rr_set_object_home(self.h, -1 if env is None else int(env), int(obj), p.ctypes.data))
+
     def link_poses(self):
         out = np.empty((self.N, len(nat.LINK_NAMES), 7), np.float32)
         nat.check(self.L.rr_link_poses(self.h, out.ctypes.data))

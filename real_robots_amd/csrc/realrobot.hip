@@ -24,6 +24,7 @@
 // oracle/rr_oracle.c by tests/ (never linked here).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -127,6 +128,7 @@ struct DevPtrs {
                        // pair's 28 floats over 28 cache lines shared with 31 other envs)
     int *timestep;     // [N]
     unsigned *errflags;// [N]
+    float *obj_home;   // [NOBJ*7][N] per-env pose an object is put back to by reset / the out-of-bounds rule (robot.py:19-24, mutable there)
     unsigned *demand;  // [2][N] candidate contacts of the env: all | robot involved << 8 | object-object << 16, written by k_collide
     int *solve_order;  // [4 * ceil(N / 4)] env handled by each 16-lane group of k_solve (-1: none), written by k_balance
     float *cmd;        // [N][9]
@@ -286,8 +288,8 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
     for (int i = 0; i < P.nobj; i++) {                               // env.py:257-264
         float x = STT(ST_OPOS + 3 * i), z = STT(ST_OPOS + 3 * i + 2);
         if (z < B.table_z || (x > 0.11f && z < 0.29f)) {
-            for (int k = 0; k < 3; k++) { STT(ST_OPOS + 3 * i + k) = B.obj_pose0[i][k]; STT(ST_OVEL + 3 * i + k) = 0; STT(ST_OANG + 3 * i + k) = 0; }
-            for (int k = 0; k < 4; k++) STT(ST_OQUAT + 4 * i + k) = B.obj_pose0[i][3 + k];
+            for (int k = 0; k < 3; k++) { STT(ST_OPOS + 3 * i + k) = D.obj_home[(size_t)(7 * i + k) * N + env]; STT(ST_OVEL + 3 * i + k) = 0; STT(ST_OANG + 3 * i + k) = 0; }
+            for (int k = 0; k < 4; k++) STT(ST_OQUAT + 4 * i + k) = D.obj_home[(size_t)(7 * i + 3 + k) * N + env];
         }
     }
 #pragma unroll
@@ -1599,8 +1601,8 @@ __global__ void k_reset(BodyParams B, SimParams P, DevPtrs D, const unsigned cha
     float *state = D.state;
     for (int i = 0; i < ST_TOTAL; i++) STT(i) = 0;
     for (int i = 0; i < NOBJ; i++) {
-        for (int k = 0; k < 3; k++) STT(ST_OPOS + 3 * i + k) = B.obj_pose0[i][k];
-        for (int k = 0; k < 4; k++) STT(ST_OQUAT + 4 * i + k) = B.obj_pose0[i][3 + k];
+        for (int k = 0; k < 3; k++) STT(ST_OPOS + 3 * i + k) = D.obj_home[(size_t)(7 * i + k) * N + env];
+        for (int k = 0; k < 4; k++) STT(ST_OQUAT + 4 * i + k) = D.obj_home[(size_t)(7 * i + 3 + k) * N + env];
     }
     D.timestep[env] = 0;
     D.errflags[env] = 0;
@@ -2868,6 +2870,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     ALLOC(D.pdata, (size_t)N * MAXPAIRS * 8);
     ALLOC(D.timestep, (size_t)N);
     ALLOC(D.errflags, (size_t)N);
+    ALLOC(D.obj_home, (size_t)NOBJ * 7 * N);
     ALLOC(D.demand, (size_t)2 * N);
     ALLOC(D.solve_order, (size_t)4 * ((N + 3) / 4));
     ALLOC(D.cmd, (size_t)N * 9);
@@ -2952,6 +2955,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->field_ptr[RR_F_STATE] = e->state_aos; e->field_bytes[RR_F_STATE] = (size_t)N * NSTATE * 4;
     e->field_bytes[RR_F_FRAG_COUNT] = (size_t)N * RM.ntiles * 4;     // pointer set once the list is allocated
     *out = e;
+    for (int i = 0; i < NOBJ; i++) { const int rh = rr_set_object_home(e, -1, i, e->B.obj_pose0[i]); if (rh != RR_OK) { rr_destroy(e); *out = nullptr; return rh; } }
     int r = rr_reset(e, nullptr);
     if (r != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
     {
@@ -2993,6 +2997,28 @@ int rr_reset(rr_env *e, const uint8_t *mask_host) {
     hipLaunchKernelGGL(k_reset, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->B, e->P, e->D, m);
     hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
     HIPCHK(hipGetLastError());
+    return RR_OK;
+}
+
+// The pose an object returns to on reset and when it leaves the table (robot.py:19-24 `object_poses`, which callers of the
+// reference edit in place, e.g. tests/test_actions.py:95-98). env_index < 0: every env.
+int rr_set_object_home(rr_env *e, int32_t env_index, int32_t obj, const float *pose7) {
+    if (!e || !pose7) return fail(RR_EINVAL, "null argument");
+    if (env_index >= e->P.N || obj < 0 || obj >= NOBJ) return fail(RR_EINVAL, "rr_set_object_home: index out of range");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t N = e->P.N;
+    if (env_index >= 0) {
+        for (int k = 0; k < 7; k++)
+            HIPCHK(hipMemcpyAsync(e->D.obj_home + (size_t)(7 * obj + k) * N + env_index, pose7 + k, 4, hipMemcpyHostToDevice, e->stream));
+    } else {
+        std::vector<float> col(N);
+        for (int k = 0; k < 7; k++) {
+            std::fill(col.begin(), col.end(), pose7[k]);
+            HIPCHK(hipMemcpyAsync(e->D.obj_home + (size_t)(7 * obj + k) * N, col.data(), N * 4, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));   // pose7 is host memory
     return RR_OK;
 }
 

@@ -118,6 +118,19 @@ class REALRobotEnv:
                                            solver_iters=self._solver_iters)
         return self._be
 
+    def _sync_object_homes(self):
+        """Kuka.object_poses is a plain dict that callers of the reference edit in place (tests/test_actions.py:95-98);
+        reset and the out-of-bounds rule use it (robot.py:125-129, 165-185, env.py:257-264).  Edits are pushed to the
+        device before the next reset / step."""
+        from ..kinematics import quat_from_euler
+        cur = {k: tuple(float(x) for x in self.robot.object_poses[k]) for k in self.robot.used_objects[1:]}
+        if cur != getattr(self, '_homes_synced', None):
+            be = self._backend()
+            for i, name in enumerate(self.robot.used_objects[1:]):
+                p = cur[name]
+                be.set_object_home(0, i, np.concatenate([p[:3], quat_from_euler(*p[3:])]))
+            self._homes_synced = cur
+
     def close(self):
         if self._be is not None:
             self._be.close()
@@ -157,6 +170,7 @@ class REALRobotEnv:
 
     # ------------------------------------------------------------------ reset / render
     def reset(self):
+        self._sync_object_homes()
         self._backend().reset()
         self.timestep = 0
         return self.get_observation()
@@ -230,6 +244,7 @@ class REALRobotEnv:
         a = np.asarray(joint_action, dtype=np.float64)
         assert np.isfinite(a).all()                     # robot.py:189
         assert len(a) == self.robot.num_joints          # robot.py:190
+        self._sync_object_homes()
         self._backend().step(a.reshape(1, 9), render=camera_on)
         observation = self.get_observation(camera_on, _rendered=True)
         reward = self.reward_func(observation)

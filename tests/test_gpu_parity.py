@@ -543,3 +543,36 @@ def test_known_answers_hold_on_the_device_path():
         v_prev = v
     assert sliding >= 12 and abs(env.state[0, 22 + 8]) < 1e-5
     env.close()
+
+
+def test_object_home_poses_follow_edits_of_object_poses():
+    """Kuka.object_poses is edited in place by callers of the reference (tests/test_actions.py:95-98 parks the objects on the
+    shelf: x and z + 0.3, then reset_object); reset and the out-of-bounds rule (env.py:257-264) must use the edited poses."""
+    import real_robots_amd as rr
+    env = rr.make('REALRobot2020-R2J3-v0', eye_width=64, eye_height=64)
+    env.reset()
+    for obj in env.robot.used_objects[1:]:
+        env.robot.object_poses[obj][0] += 0.3
+        env.robot.object_poses[obj][2] += 0.3
+        env.robot.reset_object(obj)
+    zero = {'joint_command': np.zeros(9), 'render': False}
+    for _ in range(200):
+        env.step(zero)
+    shelf = {o: env.get_obj_pos(o) for o in env.robot.used_objects[1:]}
+    assert all(p[0] > 0.15 and p[2] > 0.4 for p in shelf.values()), shelf           # resting on the shelf
+    # push the cube off the world: the out-of-bounds rule brings it back to the EDITED pose, not the blob's
+    env.robot.object_bodies['cube'].reset_pose([0.5, 0.0, 0.02], [0, 0, 0, 1])
+    env.step(zero)
+    p = env.get_obj_pos('cube')
+    assert abs(p[0] - 0.2) < 0.01 and abs(p[2] - 0.75) < 0.02, p
+    env.reset()                                                                      # reset uses the edited poses as well
+    p = env.get_obj_pos('tomato')
+    assert abs(p[0] - 0.2) < 1e-3 and abs(p[1] + 0.3) < 1e-3 and abs(p[2] - 0.75) < 1e-3, p
+    env.close()
+    # the batched API: per-env homes
+    b = BatchedREALRobotEnv(4, objects=3, width=64, height=64)
+    b.set_object_home(2, 0, [0.0, 0.2, 0.5, 0, 0, 0, 1])
+    b.reset()
+    pose = b.host(nat.F_OBJ_POSE)
+    assert np.abs(pose[2, 0, :3] - [0.0, 0.2, 0.5]).max() < 1e-6 and np.abs(pose[1, 0, :3] - [-0.1, 0.0, 0.45]).max() < 1e-6
+    b.close()
