@@ -1,0 +1,68 @@
+"""Randomised differential run: random batch size, object count, resolution, row pool, commands (random joints / macro plans),
+render flags, resets and teleports; every 20 steps a few envs are checked one step at a time against the fp32 oracle and
+their images against an oracle render of the same state."""
+import os, sys, time; sys.path.insert(0, '/root/repo')
+import numpy as np
+from real_robots_amd import _native as nat
+from real_robots_amd.batched import BatchedREALRobotEnv
+from real_robots_amd.distributed import synthetic_actions
+from oracle.oracle import Oracle
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+only_case = int(sys.argv[3]) if len(sys.argv) > 3 else -1      # replay one case with details
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+t_start = time.time(); case = 0; worst = dict(j=0.0, o=0.0, rgb=0, dep=0.0); bad = []
+while time.time() - t_start < budget:
+    if only_case >= 0:
+        if case > only_case: break
+        case = only_case
+    rng = np.random.default_rng(seed0 * 1000 + case); case += 1
+    N = int(rng.choice([1, 3, 5, 17, 34, 63, 130])); nobj = int(rng.integers(1, 4))
+    W, H = [(64, 48), (64, 64), (128, 128), (160, 120), (320, 240)][int(rng.integers(0, 5))]
+    pool = rng.choice([None, None, "0", "900", "2500"])
+    if pool: os.environ['RR_SOLVER_POOL'] = str(pool)
+    env = BatchedREALRobotEnv(N, objects=nobj, width=W, height=H)
+    os.environ.pop('RR_SOLVER_POOL', None)
+    o = Oracle(nobj, W, H, f32=True)
+    macro = rng.random() < 0.6
+    if macro:
+        env.plan_macro(rng.uniform([-0.25, -0.5], [0.05, 0.5], size=(N, 2, 2))); plans = [env.get_plan(i) for i in range(N)]
+    scale = rng.choice([0.5, 0.8, 1.0]); T = int(rng.integers(120, 420)); t_off = int(rng.integers(0, 400)) if macro else 0
+    if macro and t_off:
+        for i in range(N): plans[i] = np.roll(plans[i], -t_off, axis=0)
+    for t in range(T):
+        cmd = np.stack([plans[i][(t) % 1000] for i in range(N)]).astype(np.float32) if macro else (synthetic_actions(range(N), t, seed=case) * scale).astype(np.float32)
+        if rng.random() < 0.01:
+            m = (rng.random(N) < 0.3).astype(np.uint8); env.reset(m)
+        if rng.random() < 0.01:
+            env.set_object_pose(int(rng.integers(0, N)), int(rng.integers(0, nobj)), np.array([rng.uniform(-0.2, 0.0), rng.uniform(-0.3, 0.3), rng.uniform(0.3, 0.6), 0, 0, 0, 1], np.float32))
+        flags = (rng.random(N) < 0.5).astype(np.uint8)
+        chk = t % 20 == 19
+        if chk:
+            st0 = env.state; ncs = np.array([len(env.contacts(i)) for i in range(N)]); sel = list(np.argsort(-ncs)[:2]) + [int(rng.integers(0, N))]
+            flags[sel] = 1
+        env.step(cmd, render=flags if N > 1 else bool(flags[0]))
+        if chk:
+            st1 = env.state; rgb, dep, msk = env.host(nat.F_RGB), env.host(nat.F_DEPTH), env.host(nat.F_MASK)
+            for i in set(sel):
+                o.state = st0[i].astype(np.float64); o.step(cmd[i].astype(np.float64))
+                dj = float(np.abs(st1[i][:22] - o.state[:22]).max()); do = float(np.abs((st1[i][22:22 + 13 * nobj] - o.state[22:22 + 13 * nobj]).reshape(nobj, 13)[:, :3]).max())
+                o.state = st1[i].astype(np.float64); r, d, m = o.render()
+                drgb = int(np.abs(r.astype(int) - rgb[i].astype(int)).max()); nbad = int((np.abs(r.astype(int) - rgb[i].astype(int)).max(-1) > 1).sum()); dd = float(np.abs(d - dep[i]).max()); mm = int((m != msk[i]).sum())
+                worst['j'] = max(worst['j'], dj); worst['o'] = max(worst['o'], do); worst['dep'] = max(worst['dep'], dd if nbad == 0 and mm == 0 else 0)
+                if dj > 2e-3 or do > 1e-3 or len(env.contacts(i)) != len(o.contacts()) or mm > 2 or nbad > 4:
+                    bad.append((case, N, nobj, W, H, pool, macro, t, int(i), dj, do, len(env.contacts(i)), len(o.contacts()), mm, nbad, dd))
+                    if only_case >= 0 and dj > 2e-3:
+                        ref = BatchedREALRobotEnv(N, objects=nobj, width=W, height=H); ref.state = st0; ref.step(cmd)
+                        np.set_printoptions(precision=5, suppress=True, linewidth=220)
+                        o.state = st0[i].astype(np.float64); o.step(cmd[i].astype(np.float64))
+                        o64 = Oracle(nobj, W, H); o64.state = st0[i].astype(np.float64); o64.step(cmd[i].astype(np.float64))
+                        print("qd: |pool - f32 oracle| %.3f  |pool - f64 oracle| %.3f  |f32 oracle - f64 oracle| %.3f" % (np.abs(st1[i][11:22] - o.state[11:22]).max(), np.abs(st1[i][11:22] - o64.state[11:22]).max(), np.abs(o.state[11:22] - o64.state[11:22]).max()))
+                        print("t", t, "env", i, "q/qd pool   ", st1[i][:22]); print("            q/qd default", ref.state[i][:22]); print("            q/qd oracle ", o.state[:22])
+                        cp, cr, co = env.contacts(i), ref.contacts(i), o.contacts()
+                        for a_, b_, c_ in zip(cp, cr, co):
+                            print("   A %3d B %3d link %2d dist %+.4f force pool %10.3f default %10.3f oracle %10.3f" % (a_[0], a_[1], a_[2], a_[9], a_[10], b_[10], c_[10]))
+                        ref.close(); sys.exit(0)
+    if (env.host(nat.F_ERRFLAGS) != 0).any() or (env.host(nat.F_TIMESTEP) > T).any(): bad.append((case, 'errflags/timestep'))
+    env.close()
+print("cases", case, "worst joints %.2e object pos %.2e depth %.2e" % (worst['j'], worst['o'], worst['dep']), "violations", len(bad))
+for b in bad[:15]: print("  ", b)
