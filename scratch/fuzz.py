@@ -19,6 +19,7 @@ while time.time() - t_start < budget:
     N = int(rng.choice([1, 3, 5, 17, 34, 63, 130])); nobj = int(rng.integers(1, 4))
     W, H = [(64, 48), (64, 64), (128, 128), (160, 120), (320, 240)][int(rng.integers(0, 5))]
     pool = rng.choice([None, None, "0", "900", "2500"])
+    if os.environ.get("FUZZ_DEFAULT_POOL"): pool = None
     if pool: os.environ['RR_SOLVER_POOL'] = str(pool)
     env = BatchedREALRobotEnv(N, objects=nobj, width=W, height=H)
     os.environ.pop('RR_SOLVER_POOL', None)
@@ -50,7 +51,7 @@ while time.time() - t_start < budget:
                 drgb = int(np.abs(r.astype(int) - rgb[i].astype(int)).max()); nbad = int((np.abs(r.astype(int) - rgb[i].astype(int)).max(-1) > 1).sum()); dd = float(np.abs(d - dep[i]).max()); mm = int((m != msk[i]).sum())
                 worst['j'] = max(worst['j'], dj); worst['o'] = max(worst['o'], do); worst['dep'] = max(worst['dep'], dd if nbad == 0 and mm == 0 else 0)
                 if dj > 2e-3 or do > 1e-3 or len(env.contacts(i)) != len(o.contacts()) or mm > 2 or nbad > 4:
-                    bad.append((case, N, nobj, W, H, pool, macro, t, int(i), dj, do, len(env.contacts(i)), len(o.contacts()), mm, nbad, dd))
+                    bad.append((case, N, nobj, W, H, pool, macro, t, int(i), dj, do, len(env.contacts(i)), len(o.contacts()), mm, nbad, dd, 'maxforce %.0f' % (env.contacts(i)[:, 10].max() if len(env.contacts(i)) else 0)))
                     if only_case >= 0 and dj > 2e-3:
                         ref = BatchedREALRobotEnv(N, objects=nobj, width=W, height=H); ref.state = st0; ref.step(cmd)
                         np.set_printoptions(precision=5, suppress=True, linewidth=220)
@@ -65,4 +66,4 @@ while time.time() - t_start < budget:
     if (env.host(nat.F_ERRFLAGS) != 0).any() or (env.host(nat.F_TIMESTEP) > T).any(): bad.append((case, 'errflags/timestep'))
     env.close()
 print("cases", case, "worst joints %.2e object pos %.2e depth %.2e" % (worst['j'], worst['o'], worst['dep']), "violations", len(bad))
-for b in bad[:15]: print("  ", b)
+for b in bad[:40]: print("  ", b)
