@@ -5,15 +5,22 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): REALRobot2020-R2J3-v0, 4096 envs
-per GPU, 3 objects, 128x128 top-down RGB + depth rendered every step; one "step" = one env.step() of every env in
-the batch.  Weak scaling: every rank owns 4096 envs; no collective on the stepping path.  Joint commands are
-synthetic (README-style resample-and-hold keyed by global env id) and are resident in HBM before the timed region.
-Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel (by measured device time): algorithmic bytes per launch / HIP-event duration vs the
-                8 TB/s HBM peak; measured in a separate pass with the library's per-kernel HIP events
-  cpu_baseline  the CPU oracle (oracle/, the checker -- never the product) timed on this box's host cores on a
-                bounded sample of the same workload
+Headline workload (BASELINE.json configs[2], the configuration the metric is quoted on): REALRobot2020-R2J3-v0, 4096 envs
+per GPU, 3 objects, 128x128 top-down RGB + depth rendered every step; one "step" = one env.step() of every env in the
+batch.  Joint commands: README-style resample-and-hold `action_space.sample()` over the FULL joint limits
+(robot.py:58-67), keyed by global env id, resident in HBM before the timed region.
+Weak scaling by default (every rank owns --envs-per-gpu envs; `--scaling strong` splits a fixed total over the ranks);
+no collective on the stepping path; `--gather lowdim|images` adds the optional policy-side observation all-gather
+(RCCL).  Rank 0 prints ONE JSON line.  Extra objects in that line:
+  roofline      per-kernel HIP-event durations (library stream) and, for the unit that dominates the step, ALGORITHMIC bytes
+                per launch / duration against the 8 TB/s HBM peak (`achieved` is that ratio, not a measured HBM rate; the
+                measured HBM bytes of the same configuration, when a committed PMC profile matches it, are `traffic`).
+                `roofline.valu` prices the dominant kernel against the VALU issue peak, which is what actually bounds it.
+  secondary     (N=1 only) the same library on the other workloads a reader needs to judge the headline: half-range
+                commands (round 1's headline), macro-action pushing (BASELINE config 5 shape), BASELINE config 2
+                (1024 envs, 1 object, no render)
+  cpu_baseline  PyBullet ("reference") when importable on this box, else the CPU oracle ("port"; oracle/ is the checker,
+                never the product), timed on the host cores on a bounded sample of the same workload
 """
 import argparse
 import json
@@ -28,21 +35,23 @@ ENVS_PER_GPU = 4096
 N_OBJECTS = 3
 W = H = 128
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
-# algorithmic bytes per env-step, per kernel (DESIGN.md "Roofline accounting")
-STATE_BYTES = (22 + 39 + 11) * 4 * 2 + 9 * 4 + (9 + 4 + 21) * 4          # state R/W + command + low-dim obs
-ALGO_BYTES = {
-    'k_prep': STATE_BYTES,
-    'k_collide': STATE_BYTES,
-    'k_solve': STATE_BYTES,
-    'k_render_setup': 11 * 4 + 39 * 4 + 22 * 12 * 4,
-    'k_raster': 22 * 12 * 4,             # instance matrices in; + 8 B per listed fragment out (measured, added at run time)
-    'k_restore': 0,                      # only with RR_SEPARATE_RESTORE / RR_FULL_COPY (the earlier image-update schemes)
-    'k_shade': 22 * 12 * 4,              # + (8 B list entry in + 7 B pixel out) per list entry (measured, added at run time)
-}
-RENDER_KERNELS = ('k_restore', 'k_raster', 'k_shade')                      # together they produce the observation image
-ALGO_BYTES_PER_ENV_STEP = STATE_BYTES + W * H * 3 + W * H * 4
+# VALU issue peak in wave64 instructions / s: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4
+RENDER_KERNELS = ('k_image_setup', 'k_raster', 'k_shade')                      # together they produce the observation image
 
 
+def algo_bytes(n_obj, w, h):
+    """Algorithmic bytes per env-step and kernel (DESIGN.md "Roofline accounting")."""
+    state = (22 + 13 * n_obj + 11) * 4 * 2 + 9 * 4 + (9 + 4 + 7 * n_obj) * 4          # state R/W + command + low-dim obs
+    inst = 22 * 12 * 4
+    return {'k_prep': state, 'k_collide': state, 'k_solve': state, 'k_render_setup': 11 * 4 + 13 * n_obj * 4 + inst,
+            'k_raster': inst,           # instance matrices in; + 8 B per listed fragment out (measured, added at run time)
+            'k_image_setup': 0,         # steady state: does not run (first frame / earlier image-update schemes only)
+            'k_shade': inst,            # + (8 B list entry in + 7 B pixel out) per list entry (measured, added at run time)
+            '_state': state, '_image': w * h * 7 + inst}
+
+
+# ---------------------------------------------------------------------------------------------- CPU baseline
 def _cpu_worker(args):
     seconds, seed = args
     import numpy as np
@@ -60,22 +69,127 @@ def _cpu_worker(args):
 
 
 def cpu_baseline(seconds=10.0):
-    """Oracle (kind "port") on the host cores this process may use, one env per process, same per-env workload
-    (step + 128x128 render); time-bounded sample."""
+    """Same per-env workload (full-range commands, step + 128x128 render), one env per process on every host core this
+    process may use; time-bounded sample.  kind "reference" = PyBullet through oracle/pybullet_ref.py when `import
+    pybullet` works on this box; otherwise kind "port" = oracle/rr_oracle.c."""
     import multiprocessing as mp
-    from oracle import oracle as orc
-    orc.build()
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    from oracle import pybullet_ref
+    if pybullet_ref.available():
+        try:
+            return pybullet_ref.cpu_baseline(seconds=seconds, cores=cores, n_objects=N_OBJECTS, width=W, height=H)
+        except Exception as ex:        # a broken install must not take the GPU measurement down with it
+            sys.stderr.write("bench.py: PyBullet baseline failed (%r); falling back to the CPU oracle\n" % (ex,))
+    from oracle import oracle as orc
+    orc.build()
     ctx = mp.get_context('spawn')
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(seconds, i) for i in range(cores)])
     rate = sum(n / t for n, t in res)
     return {"value": round(rate, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d processes x 1 env x %.0f s each (%d env-steps in total), 3 objects, 128x128 RGB+depth render "
-                      "every step (oracle/rr_oracle.c, float64 physics)" % (cores, seconds, sum(n for n, _ in res))}
+            "sample": "%d processes x 1 env x %.0f s each (%d env-steps in total), 3 objects, full-range commands, 128x128 "
+                      "RGB+depth render every step (oracle/rr_oracle.c, float64 physics); PyBullet not importable on this box"
+                      % (cores, seconds, sum(n for n, _ in res))}
+
+
+# ---------------------------------------------------------------------------------------------- GPU legs
+def make_commands(torch, np, ids, n_steps, scale, device):
+    """One [n_local, 9] tensor per 20-step resample epoch, resident in HBM; returns the tensor of every step."""
+    from real_robots_amd.distributed import synthetic_actions
+    epochs, cmd_of_step = {}, []
+    for t in range(n_steps):
+        key = t // 20
+        if key not in epochs:
+            epochs[key] = torch.from_numpy(synthetic_actions(ids, key * 20, hold_prob=0.05) * np.float32(scale)).to(device)
+        cmd_of_step.append(epochs[key])
+    return cmd_of_step
+
+
+def kernel_table(env, nat, n_local, n_obj, w, h, render, step_fn, nprof):
+    """Per-kernel HIP-event durations (every kernel alone on the library's stream) over nprof steps of step_fn."""
+    env.set_timing(1)
+    for t in range(nprof):
+        step_fn(t)
+    timing = env.get_timing()
+    env.set_timing(0)
+    algo = algo_bytes(n_obj, w, h)
+    frags = 0.0
+    if render:
+        frags = float(env.host(nat.F_FRAG_COUNT).sum()) / n_local      # list entries (won + vacated pixels), mean per env
+        algo['k_raster'] += 8 * frags
+        algo['k_shade'] += 15 * frags
+    kernels = {}
+    for k, (ms, n) in timing.items():
+        if n:
+            kernels[k] = {"avg_ms": round(ms / n, 4), "launches": n,
+                          "algorithmic_GBs": round(algo[k] * n_local / (ms / n * 1e-3) / 1e9, 2)}
+    return kernels, algo, frags
+
+
+def load_profile(name, cfg):
+    """A committed PMC-derived profile (profiles/<name>) applies to a run only when it was collected on the same
+    configuration; returns (dict, None) or (None, reason)."""
+    path = os.path.join(ROOT, 'profiles', name)
+    if not os.path.exists(path):
+        return None, "no profiles/%s" % name
+    try:
+        prof = json.load(open(path))
+    except Exception as ex:
+        return None, "unreadable profiles/%s: %r" % (name, ex)
+    pc = prof.get('config')
+    if pc != cfg:
+        return None, "profiles/%s was collected on %s, this run is %s" % (name, json.dumps(pc), json.dumps(cfg))
+    return prof, None
+
+
+def secondary_workloads(torch, np, nat, BatchedREALRobotEnv, device, steps):
+    """Short runs of the other workloads (each its own env handle), N=1 only; env-steps/s with the k_solve / k_raster
+    HIP-event times so that a reader sees where the difference to the headline comes from."""
+    out = []
+    dev = 'cuda:%d' % device
+
+    def timed(env, n_local, step_fn, presettle, steps_, label, n_obj, w, h, render):
+        for t in range(presettle):
+            step_fn(t)
+        env.sync()
+        t0 = time.perf_counter()
+        for t in range(presettle, presettle + steps_):
+            step_fn(t)
+        env.sync()
+        el = time.perf_counter() - t0
+        ok = bool((env.host(nat.F_ERRFLAGS) == 0).all())
+        kern, _, _ = kernel_table(env, nat, n_local, n_obj, w, h, render, lambda t: step_fn(presettle + steps_ + t), 10)
+        out.append({"workload": label, "value": round(n_local * steps_ / el, 1), "unit": "env-steps/s",
+                    "ms_per_step": round(el / steps_ * 1e3, 4), "steps": steps_, "all_envs_finite": ok,
+                    "kernels_ms": {k: v["avg_ms"] for k, v in kern.items()}})
+
+    ids = np.arange(ENVS_PER_GPU)
+    # (1) round 1's headline: commands scaled by 0.5 (arms rarely reach the objects)
+    env = BatchedREALRobotEnv(ENVS_PER_GPU, objects=3, width=W, height=H, device=device, want_mask=False)
+    cmds = make_commands(torch, np, ids, 150 + steps + 10, 0.5, dev)
+    timed(env, ENVS_PER_GPU, lambda t: env.step(device_ptr=cmds[t].data_ptr(), render=True), 150, steps,
+          "config 3 with HALF-range commands (x0.5; round 1's headline workload): 4096 envs, 3 objects, 128x128 render every step",
+          3, W, H, True)
+    env.close()
+    # (2) macro actions (BASELINE config 5 shape): the gripper sweeps over the table and pushes the objects
+    env = BatchedREALRobotEnv(ENVS_PER_GPU, objects=3, width=W, height=H, device=device, want_mask=False)
+    rng = np.random.default_rng(0)
+    env.plan_macro(rng.uniform([-0.25, -0.5], [0.05, 0.5], size=(ENVS_PER_GPU, 2, 2)))      # macro_space, env.py:49-52
+    timed(env, ENVS_PER_GPU, lambda t: env.step_plan(render=True), 300, min(steps * 2, 400),
+          "config 5 shape: 4096 envs, random macro actions planned on the device (k_plan_macro), steps 300.. of the 1000-step plans "
+          "(gripper pushing objects), 3 objects, 128x128 render every step", 3, W, H, True)
+    env.close()
+    # (3) BASELINE config 2: dynamics only
+    n2 = 1024
+    env = BatchedREALRobotEnv(n2, objects=1, width=64, height=64, device=device, want_mask=False)
+    cmds2 = make_commands(torch, np, np.arange(n2), 150 + 4 * steps + 10, 1.0, dev)
+    timed(env, n2, lambda t: env.step(device_ptr=cmds2[t].data_ptr(), render=False), 150, 4 * steps,
+          "config 2: REALRobot2020-R2J1, 1024 envs, 1 object, full-range joint commands, no render (dynamics-only)", 1, 64, 64, False)
+    env.close()
+    return out
 
 
 def main():
@@ -84,14 +198,21 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
+    ap.add_argument('--objects', type=int, default=N_OBJECTS)
     ap.add_argument('--envs-per-block', type=int, default=0)
     ap.add_argument('--solver-iters', type=int, default=50)
+    ap.add_argument('--command-scale', type=float, default=1.0,
+                    help='scale of the synthetic joint commands (1.0 = the full joint limits; recorded in config)')
     ap.add_argument('--presettle', type=int, default=150,
                     help='untimed steps before the warmup so that the timed region runs in steady state '
                          '(objects landed on the table, arms moving, contacts active)')
     ap.add_argument('--no-render', action='store_true', help='dynamics-only variant (not the headline metric)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--gather', action='store_true', help='also all-gather the low-dim observations every step (RCCL)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary workloads (profiling runs)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak: --envs-per-gpu envs on every rank; strong: --envs-per-gpu envs in total, split over the ranks')
+    ap.add_argument('--gather', nargs='?', const='lowdim', default='none', choices=('none', 'lowdim', 'images'),
+                    help='also all-gather observations every step (RCCL): joints/touch/object poses, or those + RGB + depth')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -111,39 +232,53 @@ def main():
     import torch.distributed as dist
     from real_robots_amd import _native as nat
     from real_robots_amd.batched import BatchedREALRobotEnv
-    from real_robots_amd.distributed import shard_range, synthetic_actions
+    from real_robots_amd.distributed import gather_images, gather_observations, shard_range
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
+    dev = 'cuda:%d' % local_rank
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl')          # RCCL on ROCm
 
-    n_local = args.envs_per_gpu
-    total = n_local * world
-    start, stop = shard_range(total, rank, world)
+    if args.scaling == 'strong':
+        total = args.envs_per_gpu
+        start, stop = shard_range(total, rank, world)
+        n_local = stop - start
+    else:
+        n_local = args.envs_per_gpu
+        total = n_local * world
+        start, stop = shard_range(total, rank, world)
     ids = np.arange(start, stop)
-    env = BatchedREALRobotEnv(n_local, objects=N_OBJECTS, width=W, height=H, device=local_rank,
+    n_obj = args.objects
+    env = BatchedREALRobotEnv(n_local, objects=n_obj, width=W, height=H, device=local_rank,
                               envs_per_block=args.envs_per_block, solver_iters=args.solver_iters,
                               want_mask=False)     # R2 observations carry no mask (robot.py:99-112)
     render = not args.no_render
 
-    # synthetic commands, resident in HBM before the timed region: one [n_local, 9] tensor per resample epoch
-    n_total_steps = args.presettle + args.warmup + args.steps
-    epochs = {}
-    cmd_of_step = []
-    for t in range(n_total_steps):
-        key = t // 20
-        if key not in epochs:
-            epochs[key] = torch.from_numpy(synthetic_actions(ids, key * 20, hold_prob=0.05) * 0.5).cuda()
-        cmd_of_step.append(epochs[key])
-    joints_buf = torch.as_tensor(env.device_buffer(nat.F_JOINTS), device='cuda:%d' % local_rank) if args.gather else None
+    n_total_steps = args.presettle + args.warmup + args.steps + 20
+    cmd_of_step = make_commands(torch, np, ids, n_total_steps, args.command_scale, dev)
+    views = None
+    if args.gather != 'none':
+        views = {'joints': torch.as_tensor(env.device_buffer(nat.F_JOINTS), device=dev),
+                 'touch': torch.as_tensor(env.device_buffer(nat.F_TOUCH), device=dev),
+                 'objpose': torch.as_tensor(env.device_buffer(nat.F_OBJ_POSE), device=dev)}
+        if args.gather == 'images':
+            views['rgb'] = torch.as_tensor(env.device_buffer(nat.F_RGB), device=dev)
+            views['depth'] = torch.as_tensor(env.device_buffer(nat.F_DEPTH), device=dev)
+    gathered_bytes = 0
 
     def one_step(t):
+        nonlocal gathered_bytes
         env.step(device_ptr=cmd_of_step[t].data_ptr(), render=render)
-        if args.gather and world > 1:
-            parts = [torch.empty_like(joints_buf) for _ in range(world)]
-            dist.all_gather(parts, joints_buf)
+        if views is not None and world > 1:
+            # the library's stream is torch's current stream here (stream=None -> the default stream), so the collective is
+            # ordered after the step that produced the buffers
+            low = gather_observations({k: views[k] for k in ('joints', 'touch', 'objpose')})
+            gathered_bytes = sum(v.numel() * v.element_size() for v in low.values())
+            if args.gather == 'images':
+                rgb, depth = gather_images(views['rgb'], views['depth'])
+                gathered_bytes += rgb.numel() + depth.numel() * 4
 
     for t in range(args.presettle + args.warmup):
         one_step(t)
@@ -152,7 +287,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for t in range(args.presettle + args.warmup, n_total_steps):
+    for t in range(args.presettle + args.warmup, args.presettle + args.warmup + args.steps):
         one_step(t)
     torch.cuda.synchronize()
     if world > 1:
@@ -165,70 +300,97 @@ def main():
         elapsed = float(tt.item())
     assert (env.host(nat.F_ERRFLAGS) == 0).all(), "an env reported a non-finite state"
 
-    # per-kernel device time (HIP events on the library's stream), separate pass
-    env.set_timing(1)
+    # per-kernel device time (HIP events on the library's stream), separate pass right behind the timed region
     nprof = min(20, args.steps)
-    for t in range(nprof):
-        one_step(args.presettle + args.warmup + t)
-    timing = env.get_timing()
-    env.set_timing(0)
-    algo = dict(ALGO_BYTES)
-    if render:
-        frags = float(env.host(nat.F_FRAG_COUNT).sum()) / n_local      # pixels won by moving geometry, mean per env
-        algo['k_raster'] += 8 * frags
-        algo['k_shade'] += 15 * frags
-        algo['k_restore'] += 22 * frags
-    kernels = {}
-    for k, (ms, n) in timing.items():
-        if n:
-            kernels[k] = {"avg_ms": round(ms / n, 4), "launches": n,
-                          "achieved_GBs": round(algo[k] * n_local / (ms / n * 1e-3) / 1e9, 2)}
+    base_t = args.presettle + args.warmup + args.steps
+    views_saved, views = views, None              # the timing pass measures the kernels, not the gather
+    kernels, algo, frags = kernel_table(env, nat, n_local, n_obj, W, H, render, lambda t: one_step(base_t + t), nprof)
+    views = views_saved
     dom_kernel = max(kernels, key=lambda k: kernels[k]["avg_ms"])
     dom = dom_kernel
     if render:
-        # the image is produced by two kernels (visibility, deferred shading incl. putting vacated pixels back to the static
-        # layer; the image persists in HBM from frame to frame): the stage as a whole is what SURVEY 8(d)'s image bytes belong to
-        rms = sum(kernels[k]["avg_ms"] for k in RENDER_KERNELS if k in kernels)
-        kernels['render_stage'] = {"avg_ms": round(rms, 4), "launches": kernels['k_raster']["launches"], "members": [k for k in RENDER_KERNELS if k in kernels],
-                                   "achieved_GBs": round((W * H * 7 + 22 * 12 * 4) * n_local / (rms * 1e-3) / 1e9, 2),
-                                   "fragments_per_env": round(frags, 1)}
-        algo['render_stage'] = W * H * 7 + 22 * 12 * 4
+        # the image is produced by two kernels (visibility; deferred shading incl. putting vacated pixels back to the
+        # static layer): the stage as a whole is what SURVEY 8(d)'s image bytes belong to
+        members = [k for k in RENDER_KERNELS if k in kernels]
+        rms = sum(kernels[k]["avg_ms"] for k in members)
+        kernels['render_stage'] = {"avg_ms": round(rms, 4), "launches": kernels['k_raster']["launches"], "members": members,
+                                   "algorithmic_GBs": round(algo['_image'] * n_local / (rms * 1e-3) / 1e9, 2),
+                                   "list_entries_per_env": round(frags, 1)}
+        algo['render_stage'] = algo['_image']
         if dom_kernel in RENDER_KERNELS:
-            dom = 'render_stage'      # the image is the unit SURVEY 8(d) prices; its three kernels are reported together
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')      # PMC-derived HBM bytes per launch, if collected
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(dom)
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": dom if dom != 'render_stage' else "+".join(k for k in RENDER_KERNELS if k in kernels), "dominant_single_kernel": dom_kernel,
-                "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, 6), "traffic": traffic,
+            dom = 'render_stage'      # the image is the unit SURVEY 8(d) prices; its kernels are reported together
+    run_cfg = {"envs": n_local, "objects": n_obj, "width": W, "height": H, "render": bool(render),
+               "command_scale": args.command_scale, "solver_iters": args.solver_iters}
+    traffic, traffic_src = None, None
+    prof, why = load_profile('traffic_latest.json', run_cfg)
+    if prof is not None:
+        traffic = prof.get(dom)
+        traffic_src = "profiles/traffic_latest.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this configuration, not of this run" % prof.get('source', '?')
+    else:
+        traffic_src = "null: " + why
+    valu = None
+    sq, why_sq = load_profile('sq_latest.json', run_cfg)
+    if sq is not None and dom_kernel in sq.get('valu_wave_instr_per_launch', {}):
+        wi = float(sq['valu_wave_instr_per_launch'][dom_kernel])
+        dur = kernels[dom_kernel]["avg_ms"] * 1e-3
+        valu = {"kernel": dom_kernel, "wave_instr_per_launch": round(wi), "wave_instr_per_env_step": round(wi / n_local, 1),
+                "achieved": round(wi / dur / 1e9, 2), "peak": round(VALU_PEAK_WAVE_INSTR / 1e9, 1), "unit": "G wave64-instr/s",
+                "frac": round(wi / dur / VALU_PEAK_WAVE_INSTR, 4),
+                "source": "SQ_INSTS_VALU of profiles/sq_latest.json (%s, same configuration) / this run's HIP-event duration; "
+                          "peak = 256 CU x 4 SIMD x 2.4 GHz / 4 cycles" % sq.get('source', '?')}
+    else:
+        valu = {"kernel": dom_kernel, "frac": None, "note": "null: " + (why_sq or "kernel not in the profile")}
+    ach = kernels[dom]["algorithmic_GBs"]
+    roofline = {"bound": "hbm", "kernel": dom if dom != 'render_stage' else "+".join(kernels['render_stage']['members']),
+                "dominant_single_kernel": dom_kernel,
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
+                "achieved_is": "ALGORITHMIC bytes per launch / HIP-event duration (full images, although a frame rewrites only "
+                               "the pixels that changed) -- the contract's accounting, not a measured HBM rate; `traffic` is the measured one",
+                "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(algo[dom] * n_local),
-                "whole_step_achieved_GBs": round(ALGO_BYTES_PER_ENV_STEP * n_local * args.steps / elapsed / 1e9, 2),
+                "whole_step_algorithmic_GBs": round((algo['_state'] + (W * H * 7 if render else 0)) * n_local * args.steps / elapsed / 1e9, 2),
+                "bound_note": "HBM is the contract's ceiling for this byte-moving path, but at 116 KB and ~0.3 M instructions per "
+                              "env-step the dominant kernels are VALU-issue / latency bound (roofline.valu; DESIGN.md 5)",
+                "valu": valu,
                 "kernels": kernels,
-                "image_note": "the images persist in HBM from frame to frame: a frame rewrites the pixels of its fragment list and "
-                              "puts vacated pixels back to the static layer (~6 % of an image), so the measured HBM traffic of "
-                              "the render stage is below the algorithmic bytes of a full image write",
                 "timing_note": "per-kernel durations: HIP events on the library's stream, every kernel alone on the stream "
                                "(no side-stream overlap), %d steps of the same workload right after the timed region; "
                                "rocprofv3 --stats of the overlapped run is under profiles/" % nprof}
+    env.close()
+
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary and render and n_local == ENVS_PER_GPU:
+        secondary = secondary_workloads(torch, np, nat, BatchedREALRobotEnv, local_rank, min(args.steps, 100))
 
     if rank == 0:
+        rccl = None
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        cmd_txt = "full-range" if args.command_scale == 1.0 else "x%g-scaled" % args.command_scale
         out = {
             "metric": "env-steps/sec (whole node), 4096 envs, R2J3 3-obj + 128x128 cam",
             "value": round(total * args.steps / elapsed, 1), "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "REALRobot2020-R2J3-v0, %d envs/GPU, 3 objects + contact solver, %s" %
-                                   (n_local, "128x128 top-down RGB+depth render every step" if render else "no render"),
-                       "envs_total": total, "solver_iters": args.solver_iters, "dt": 0.005, "parallelism": "env-shard x%d" % world},
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "REALRobot2020-R2J%d-v0, %d envs/GPU, %d object(s) + contact solver, %s joint commands "
+                                   "(README resample-and-hold over the joint limits, robot.py:58-67), %s" %
+                                   (n_obj, n_local, n_obj, cmd_txt,
+                                    "128x128 top-down RGB+depth render every step" if render else "no render"),
+                       "envs_total": total, "envs_per_gpu": n_local, "command_scale": args.command_scale,
+                       "solver_iters": args.solver_iters, "dt": 0.005, "parallelism": "env-shard x%d" % world,
+                       "gather": args.gather, "gathered_bytes_per_step_per_rank": gathered_bytes,
+                       "world": world, "rccl_version": rccl if world > 1 else None,
+                       "device": torch.cuda.get_device_name(local_rank),
+                       "multi_gpu_note": None if world > 1 else "N>1 is unmeasured until the driver's SCALE run exists; "
+                                                                "the step path has no collective (DESIGN.md 6)"},
             "roofline": roofline}
+        if secondary is not None:
+            out["secondary"] = secondary
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    env.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -82,6 +82,9 @@ int rr_reset(rr_env *env, const uint8_t *env_mask_host);
 
 /* Replaces BodyPart.reset_pose via robot.object_bodies[name].reset_pose (env.py:159-162; zeroes velocity). */
 int rr_set_object_pose(rr_env *env, int32_t env_index, int32_t obj, const float *pose7);
+/* Batched rr_set_object_pose: poses f32 [N, n_obj, 7] (host) for the envs whose mask byte is non-zero (NULL: all envs).
+ * Replaces the per-object loop of REALRobotEnv.set_goal (env.py:159-162) for a whole batch with one upload. */
+int rr_set_object_poses(rr_env *env, const float *poses_host, const uint8_t *env_mask_host);
 /* The pose (xyz + xyzw quaternion, host) object `obj` of env `env_index` (< 0: every env) returns to on rr_reset and when the
  * out-of-bounds rule fires (env.py:257-264). Replaces in-place edits of Kuka.object_poses (robot.py:19-24; the reference's
  * tests/test_actions.py:95-98 parks the objects on the shelf that way). Defaults: the poses of the model blob. */
@@ -92,6 +95,13 @@ int rr_set_object_home(rr_env *env, int32_t env_index, int32_t obj, const float 
  *   (robot.py:188-201), scene.global_step() -> stepSimulation (env.py:340), calc_state/get_touch_sensors
  *   (robot.py:203-211,152-163) and, when render_mode != 0, get_retina (env.py:249-255).
  * joint_cmd: f32 [N, 9] (device pointer if cmd_on_device, else host; NULL -> zeros as env.py:333-334).
+ *   Host commands / flags are copied into a pinned staging ring before the call returns (the caller may reuse its
+ *   buffer at once; the call does not wait for the device).
+ *   STREAM CONTRACT for cmd_on_device: the buffer is read IN PLACE by the first kernel of the step, on the library's
+ *   stream (rr_create / rr_set_stream).  The caller must (1) have produced it on that same stream, or have made that
+ *   stream wait for the producer (event / synchronise), and (2) not overwrite it before the step has consumed it --
+ *   i.e. not before later work on the same stream, or rr_sync.  The zero-copy views of rr_get_buffer carry no stream
+ *   either: readers on another stream must order themselves after the step the same way.
  * render_mode: 0 none, 1 all envs, 2 per-env flags in render_flags_host (u8 [N]). */
 int rr_step(rr_env *env, const float *joint_cmd, int32_t cmd_on_device, int32_t render_mode,
             const uint8_t *render_flags_host);
@@ -135,6 +145,9 @@ int rr_get_plan(rr_env *env, int32_t env_index, float *plan_host);
 /* Replaces step_macro's next_step() + step_joints (env.py:404-412, 463-467): every env consumes the next row of its
  * plan (the last row repeats once the plan is exhausted; the host decides when to re-plan) and steps. */
 int rr_step_plan(rr_env *env, int32_t render_mode, const uint8_t *render_flags_host);
+/* Same, but the envs whose idle byte is non-zero (u8 [N], host; NULL: none) take the command zeros(9) for this step and
+ * keep their place in the plan: step_macro with macro_action None (env.py:391-393). */
+int rr_step_plan_masked(rr_env *env, const uint8_t *idle_mask_host, int32_t render_mode, const uint8_t *render_flags_host);
 
 /* Per-kernel device timing with HIP events on the library's stream (bench.py roofline leg).
  * After rr_set_timing(env, 1), each rr_step/rr_render records events; rr_get_timing returns accumulated

@@ -62,6 +62,7 @@ def _lib(f32=False):
         L.rro_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.rro_set_object_pose.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rro_mass_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rro_set_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rro_default_params.argtypes = [C.POINTER(Params)]
         _libs[f32] = L
     return _libs[f32]
@@ -105,6 +106,12 @@ class Oracle:
         mask = np.empty((self.H, self.W), np.int32)
         self.L.rro_render(self.h, rgb.ctypes.data, depth.ctypes.data, mask.ctypes.data)
         return rgb, depth, mask
+
+    def set_camera(self, view, proj):
+        """Row-major 4x4 OpenGL view / projection matrices replacing the eye camera (EnvCamera, env.py:470-513)."""
+        v = np.ascontiguousarray(view, dtype=np.float32).reshape(16)
+        p = np.ascontiguousarray(proj, dtype=np.float32).reshape(16)
+        self.L.rro_set_camera(self.h, v.ctypes.data, p.ctypes.data)
 
     @property
     def state(self):

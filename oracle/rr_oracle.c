@@ -122,6 +122,9 @@ struct rr_oracle {
     real touch[4];
     int ncontacts;
     contact_t contacts[MAXC];
+    /* camera override (EnvCamera, env.py:470-513): row-major proj * view, set by rro_set_camera */
+    int cam_custom;
+    float cam_VP[16];
     /* kinematics cache */
     real bR[NB][9], bp[NB][3], baxis[NB][3], bcom[NB][3], bIw[NB][9];
 };
@@ -156,9 +159,38 @@ static inline void m3_mul(real *o, const real *A, const real *B) {
         for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
     memcpy(o, t, sizeof t);
 }
+#ifdef RR_FLOAT
+/* The float build is the bit-level checker of the device's collision decisions (which contacts exist): joint rotations
+ * use this explicit sequence of IEEE single operations -- the same one as det_sincosf in csrc/realrobot.hip -- because
+ * glibc's sinf/cosf and the device's differ in the last bit.  Cody-Waite reduction by pi/2 in three parts, Cephes
+ * minimax polynomials on [-pi/4, pi/4]; < 2 ulp for |x| up to a few turns (joint angles).  The float64 build (the oracle
+ * proper) uses libm. */
+static void det_sincosf(float x, float *sn, float *cs) {
+    const float k = rintf(x * 0.63661977236758134308f);
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188216e-8f;
+    const float z = r * r;
+    float ps = -1.9515295891e-4f * z + 8.3321608736e-3f;
+    ps = ps * z - 1.6666654611e-1f;
+    const float s = r + r * z * ps;
+    float pc = 2.443315711809948e-5f * z - 1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    const float c = (1.0f - 0.5f * z) + z * z * pc;
+    const int n = (int)k & 3;
+    *sn = n == 0 ? s : (n == 1 ? c : (n == 2 ? -s : -c));
+    *cs = n == 0 ? c : (n == 1 ? -s : (n == 2 ? -c : s));
+}
+#endif
 /* Rodrigues: rotation about unit axis a by angle */
 static void m3_axis_angle(real *R, const real *a, real ang) {
+#ifdef RR_FLOAT
+    real c, s;
+    det_sincosf(ang, &s, &c);
+    real t = 1 - c;
+#else
     real c = RCOS(ang), s = RSIN(ang), t = 1 - c;
+#endif
     R[0] = t * a[0] * a[0] + c;        R[1] = t * a[0] * a[1] - s * a[2]; R[2] = t * a[0] * a[2] + s * a[1];
     R[3] = t * a[0] * a[1] + s * a[2]; R[4] = t * a[1] * a[1] + c;        R[5] = t * a[1] * a[2] - s * a[0];
     R[6] = t * a[0] * a[2] - s * a[1]; R[7] = t * a[1] * a[2] + s * a[0]; R[8] = t * a[2] * a[2] + c;
@@ -969,6 +1001,7 @@ void rro_mass_matrix(rr_oracle *o, double *M121, double *bias11) {
 typedef struct { float m[16]; } mat4;
 
 static void camera_matrices(const rr_oracle *o, float *VP /*16 row-major*/) {
+    if (o->cam_custom) { memcpy(VP, o->cam_VP, sizeof o->cam_VP); return; }
     float eye[3] = {0.01f, 0.0f, 1.2f};
     float tgt[3] = {(float)o->m.table_pos[0], (float)o->m.table_pos[1], (float)o->m.table_pos[2]};
     float up[3] = {0, 0, 1};
@@ -997,6 +1030,19 @@ static void camera_matrices(const rr_oracle *o, float *VP /*16 row-major*/) {
             for (int k = 0; k < 4; k++) a += P[4 * i + k] * V[4 * k + j];
             VP[4 * i + j] = a;
         }
+}
+
+/* Replaces the eye camera by an arbitrary one: row-major 4x4 OpenGL view and projection matrices (float), VP = proj * view
+ * with the same summation order as the product of the default camera above.  EnvCamera of render('rgb_array'):
+ * computeViewMatrixFromYawPitchRoll / computeProjectionMatrixFOV, env.py:480-499. */
+void rro_set_camera(rr_oracle *o, const float *view16, const float *proj16) {
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float a = 0;
+            for (int k = 0; k < 4; k++) a += proj16[4 * i + k] * view16[4 * k + j];
+            o->cam_VP[4 * i + j] = a;
+        }
+    o->cam_custom = 1;
 }
 
 static void instance_xform(const rr_oracle *o, int inst, float *R, float *p) {

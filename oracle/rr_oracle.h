@@ -61,6 +61,8 @@ void rro_reset(rr_oracle *o);
 int rro_step(rr_oracle *o, const double *action9);
 /* top-down eye camera (env.py:249-255, 536-567). rgb u8[H,W,3], depth f32[H,W] (GL depth 0..1), mask i32[H,W] */
 void rro_render(rr_oracle *o, uint8_t *rgb, float *depth, int32_t *mask);
+/* camera override for the following renders (row-major 4x4 OpenGL view / projection; EnvCamera env.py:470-513) */
+void rro_set_camera(rr_oracle *o, const float *view16, const float *proj16);
 void rro_get_state(const rr_oracle *o, double *state61);
 void rro_set_state(rr_oracle *o, const double *state61);
 void rro_get_obs(const rr_oracle *o, double *joints9, double *touch4, double *objpos /*[nobj*3]*/);

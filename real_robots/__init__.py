@@ -16,3 +16,6 @@ for _name, _mod in (('envs', envs), ('envs.env', _env), ('envs.robot', _robot), 
     sys.modules[__name__ + '.' + _name] = _mod
 sys.modules[__name__ + '.evaluate'] = sys.modules['real_robots_amd.evaluate']
 evaluate = _impl.evaluate
+# Goal datasets written here must load in the reference package (and anywhere `real_robots_amd` is not installed): the
+# class pickles under the reference's path, which this alias serves (env.py:15-24, generate_goals.py:435-436).
+_env.Goal.__module__ = __name__ + '.envs.env'

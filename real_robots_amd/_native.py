@@ -17,13 +17,15 @@ LINK_NAMES = open(os.path.join(_HERE, 'data', 'realrobot_model_links.txt')).read
 RR_ABI_VERSION = 1
 (F_JOINTS, F_TOUCH, F_OBJ_POSE, F_RGB, F_DEPTH, F_MASK, F_TIMESTEP, F_ERRFLAGS, F_STATE, F_FRAG_COUNT) = range(10)
 NUM_KERNELS = 7
-KERNEL_NAMES = ('k_prep', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster', 'k_restore', 'k_shade')
+# id 5 = image set-up outside the two render kernels: the full static copy of the first frame (and the earlier schemes
+# RR_FULL_COPY / RR_SEPARATE_RESTORE); it does not run in steady state
+KERNEL_NAMES = ('k_prep', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster', 'k_image_setup', 'k_shade')
 
 # every symbol include/realrobot.h declares (tests check the library exports all of them)
 SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_object_pose', 'rr_set_object_home', 'rr_step', 'rr_render',
            'rr_get_buffer', 'rr_copy_to_host', 'rr_set_state', 'rr_sync', 'rr_link_poses', 'rr_get_contacts',
            'rr_set_timing', 'rr_get_timing', 'rr_last_error', 'rr_abi_version', 'rr_ik', 'rr_plan_macro', 'rr_get_plan',
-           'rr_step_plan', 'rr_set_camera')
+           'rr_step_plan', 'rr_set_camera', 'rr_set_object_poses', 'rr_step_plan_masked')
 
 
 class Config(C.Structure):
@@ -89,6 +91,8 @@ def load_library():
     L.rr_get_plan.argtypes = [vp, i32, vp]
     L.rr_step_plan.argtypes = [vp, i32, vp]
     L.rr_set_camera.argtypes = [vp, vp, vp]
+    L.rr_set_object_poses.argtypes = [vp, vp, vp]
+    L.rr_step_plan_masked.argtypes = [vp, vp, i32, vp]
     L.rr_last_error.restype = C.c_char_p
     L.rr_abi_version.restype = i32
     for name in SYMBOLS:

@@ -116,6 +116,17 @@ class BatchedREALRobotEnv:
         assert p.shape == (7,)
         nat.check(self.L.rr_set_object_pose(self.h, int(env), int(obj), p.ctypes.data))
 
+    def set_object_poses(self, poses, env_mask=None):
+        """Teleports the objects of the masked envs (None: all): poses [N, n_objects, 7] (xyz + xyzw quaternion),
+        velocities zeroed -- one upload for the whole batch."""
+        p = np.ascontiguousarray(poses, dtype=np.float32)
+        assert p.shape == (self.N, self.n_objects, 7)
+        m = None
+        if env_mask is not None:
+            m = np.ascontiguousarray(env_mask, dtype=np.uint8)
+            assert m.shape == (self.N,)
+        nat.check(self.L.rr_set_object_poses(self.h, p.ctypes.data, m.ctypes.data if m is not None else None))
+
     def set_object_home(self, env, obj, pose7):
         """Pose object `obj` of env `env` (None: every env) returns to on reset / when it leaves the table
         (Kuka.object_poses, robot.py:19-24)."""
@@ -159,29 +170,45 @@ class BatchedREALRobotEnv:
         nat.check(self.L.rr_get_plan(self.h, int(env), out.ctypes.data))
         return out
 
-    def step_plan(self, render=False):
+    def step_plan(self, render=False, idle=None):
+        """Every env consumes the next row of its plan; envs flagged in `idle` (uint8 [N]) take zeros(9) instead and
+        keep their place (macro_action None, env.py:391-393)."""
         flags = None
         if isinstance(render, np.ndarray) and render.size > 1:
             flags = np.ascontiguousarray(render, dtype=np.uint8)
             mode = 2
         else:
             mode = 1 if np.any(render) else 0
-        nat.check(self.L.rr_step_plan(self.h, mode, flags.ctypes.data if flags is not None else None))
+        if idle is not None:
+            idle = np.ascontiguousarray(idle, dtype=np.uint8)
+            assert idle.shape == (self.N,)
+        nat.check(self.L.rr_step_plan_masked(self.h, idle.ctypes.data if idle is not None else None, mode,
+                                             flags.ctypes.data if flags is not None else None))
 
     def step_macro(self, macro_actions, render=False):
         """Batched REALRobotEnv.step_macro (env.py:388-412): a new macro action (or an exhausted plan) triggers
-        re-planning for that env; every env then consumes the next row of its plan."""
+        re-planning for that env; every env then consumes the next row of its plan.  `macro_actions` is an array
+        [N, 2, 2] or a sequence whose entries may be None (that env steps with zeros(9), env.py:391-393)."""
+        none = np.array([a is None for a in macro_actions], dtype=bool) if not isinstance(macro_actions, np.ndarray) \
+            else np.zeros(self.N, bool)
+        if none.any():
+            macro_actions = [np.zeros((2, 2)) if a is None else a for a in macro_actions]
         m = np.ascontiguousarray(macro_actions, dtype=np.float64).reshape(self.N, 4)
         if not hasattr(self, '_macro_req'):
             self._macro_req = np.full((self.N, 4), np.nan)
             self._macro_step = np.zeros(self.N, np.int64)
-        need = (~np.all(m == self._macro_req, axis=1)) | (self._macro_step >= 1000)
+        need = ((~np.all(m == self._macro_req, axis=1)) | (self._macro_step >= 1000)) & ~none
         if need.any():
+            if not hasattr(self, '_macro_any'):       # the plan buffers exist after the first plan_macro
+                self._macro_any = True
             self.plan_macro(m, need.astype(np.uint8))
             self._macro_req[need] = m[need]
             self._macro_step[need] = 0
-        self.step_plan(render)
-        self._macro_step += 1
+        if none.all() and not hasattr(self, '_macro_any'):
+            self.step(None, render=render)             # nobody has a plan yet: plain zeros step
+            return
+        self.step_plan(render, idle=none.astype(np.uint8) if none.any() else None)
+        self._macro_step[~none] += 1
 
     def set_camera(self, view, proj):
         """Row-major 4x4 OpenGL view / projection matrices replacing the eye camera of this batch."""

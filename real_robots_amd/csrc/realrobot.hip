@@ -225,26 +225,95 @@ __device__ __forceinline__ m3 inertia_world(const m3 &R, const float *I6) {
     return mul(mul(R, I), transpose(R));
 }
 
+
+// ---- contraction-free twins ------------------------------------------------------------------------------------------
+// Everything that decides WHICH contacts exist (forward kinematics, shape transforms, the sphere cull, vertex-in-polytope
+// distances, the manifold reduction) is evaluated without FMA contraction and with the operation order of
+// oracle/rr_oracle.c, and the joint rotations use det_sincosf below instead of the vendor sincosf: with the same state
+// in, the candidate set `best < margin`, the arg-max plane and the "farthest point" picks of symmetric configurations (a
+// cube flat on the table has four equally good corners) come out bit-identical to the oracle's float build.  clang
+// attaches the `contract` flag to each fmul / fadd where it is written, so helpers inlined from outside a pragma region
+// could still fuse: these twins are used instead of the operators above wherever that matters.
+#pragma clang fp contract(off)
+namespace nc {
+__device__ __forceinline__ v3 add(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 sub(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 scale(v3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ v3 cross(v3 a, v3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ v3 mulv(const m3 &M, v3 v) {
+    return mk(M.m[0] * v.x + M.m[1] * v.y + M.m[2] * v.z, M.m[3] * v.x + M.m[4] * v.y + M.m[5] * v.z,
+              M.m[6] * v.x + M.m[7] * v.y + M.m[8] * v.z);
+}
+__device__ __forceinline__ v3 tmulv(const m3 &M, v3 v) {
+    return mk(M.m[0] * v.x + M.m[3] * v.y + M.m[6] * v.z, M.m[1] * v.x + M.m[4] * v.y + M.m[7] * v.z,
+              M.m[2] * v.x + M.m[5] * v.y + M.m[8] * v.z);
+}
+__device__ __forceinline__ m3 mul(const m3 &A, const m3 &B) {
+    m3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+    return r;
+}
+// sin and cos of x (|x| up to a few turns: joint angles) from explicit IEEE single operations only -- the same sequence
+// as det_sincosf in oracle/rr_oracle.c, hence bit-identical results on both sides (the vendor sincosf and glibc's differ
+// in the last bit).  Cody-Waite reduction by pi/2 in three parts, Cephes minimax polynomials on [-pi/4, pi/4]; < 2 ulp.
+__device__ __forceinline__ void det_sincosf(float x, float *sn, float *cs) {
+    const float k = rintf(x * 0.63661977236758134308f);
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188216e-8f;
+    const float z = r * r;
+    float ps = -1.9515295891e-4f * z + 8.3321608736e-3f;
+    ps = ps * z - 1.6666654611e-1f;
+    const float s = r + r * z * ps;
+    float pc = 2.443315711809948e-5f * z - 1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    const float c = (1.0f - 0.5f * z) + z * z * pc;
+    const int n = (int)k & 3;
+    *sn = n == 0 ? s : (n == 1 ? c : (n == 2 ? -s : -c));
+    *cs = n == 0 ? c : (n == 1 ? -s : (n == 2 ? -c : s));
+}
+__device__ __forceinline__ m3 axis_angle(v3 a, float ang) {
+    float s, c;
+    det_sincosf(ang, &s, &c);
+    float t = 1.0f - c;
+    m3 R = {{t * a.x * a.x + c, t * a.x * a.y - s * a.z, t * a.x * a.z + s * a.y,
+             t * a.x * a.y + s * a.z, t * a.y * a.y + c, t * a.y * a.z - s * a.x,
+             t * a.x * a.z - s * a.y, t * a.y * a.z + s * a.x, t * a.z * a.z + c}};
+    return R;
+}
+__device__ __forceinline__ m3 quat_to_m3(float x, float y, float z, float w) {
+    m3 R = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+             2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+             2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+    return R;
+}
+}  // namespace nc
+#pragma clang fp contract(fast)
+
 #define SCR(slot) scratch[(size_t)(slot) * N + env]
 #define STT(slot) state[(size_t)(slot) * N + env]
 
-// Forward kinematics for all 11 bodies; results kept in registers/local arrays.
+// Forward kinematics for all 11 bodies; results kept in registers/local arrays.  Contraction-free (see nc above): the
+// transforms feed the collision tests, whose accept / reject decisions are compared bit for bit with the oracle.
 __device__ void fk_all(const BodyParams &bp_, const float *q, m3 *bR, v3 *bp, v3 *bax) {
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         m3 Rp = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
         v3 pp = mk(bp_.robot_pos[0], bp_.robot_pos[1], bp_.robot_pos[2]);
-        constexpr int dummy_ = 0; (void)dummy_;
         const int p = PARENT[b];
         if (p >= 0) { Rp = bR[p >= 0 ? p : 0]; pp = bp[p >= 0 ? p : 0]; }
         m3 jr;
 #pragma unroll
         for (int k = 0; k < 9; k++) jr.m[k] = bp_.jrot[b][k];
-        m3 Rj = mul(Rp, jr);
+        m3 Rj = nc::mul(Rp, jr);
         v3 ax = mk(bp_.axis[b][0], bp_.axis[b][1], bp_.axis[b][2]);
-        bp[b] = pp + mulv(Rp, mk(bp_.jpos[b][0], bp_.jpos[b][1], bp_.jpos[b][2]));
-        bR[b] = mul(Rj, axis_angle(ax, q[b]));
-        bax[b] = mulv(Rj, ax);
+        bp[b] = nc::add(pp, nc::mulv(Rp, mk(bp_.jpos[b][0], bp_.jpos[b][1], bp_.jpos[b][2])));
+        bR[b] = nc::mul(Rj, nc::axis_angle(ax, q[b]));
+        bax[b] = nc::mulv(Rj, ax);
     }
 }
 
@@ -432,7 +501,7 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
     if (PHASE == 2) return;
     // ---- objects: rotation, inverse inertia, unconstrained velocities
     for (int i = 0; i < P.nobj; i++) {
-        m3 R = quat_to_m3(STT(ST_OQUAT + 4 * i), STT(ST_OQUAT + 4 * i + 1), STT(ST_OQUAT + 4 * i + 2), STT(ST_OQUAT + 4 * i + 3));
+        m3 R = nc::quat_to_m3(STT(ST_OQUAT + 4 * i), STT(ST_OQUAT + 4 * i + 1), STT(ST_OQUAT + 4 * i + 2), STT(ST_OQUAT + 4 * i + 3));
         float I6[6] = {B.obj_inertia[i][0], B.obj_inertia[i][1], B.obj_inertia[i][2], 0, 0, 0};
         float Ii6[6] = {1.0f / B.obj_inertia[i][0], 1.0f / B.obj_inertia[i][1], 1.0f / B.obj_inertia[i][2], 0, 0, 0};
         m3 Iw = inertia_world(R, I6), Iinv = inertia_world(R, Ii6);
@@ -550,6 +619,8 @@ __device__ __forceinline__ float lane_f(float v, int src) {
 // the workgroup is a single wavefront: LDS traffic is ordered per wave, so a compiler-level fence replaces s_barrier
 #define CSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 static_assert(COLLIDE_THREADS == 64, "k_collide synchronises with wave-level fences");
+// (the whole kernel is contraction-free and uses the nc:: helpers: see "contraction-free twins" above)
+#pragma clang fp contract(off)
 __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtrs D, int ns) {
     const int N = P.N;
     const int env = blockIdx.x;
@@ -575,7 +646,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
 #pragma unroll
         for (int k = 0; k < 9; k++) xf[lane][k] = X.R.m[k];
         xf[lane][9] = X.p.x; xf[lane][10] = X.p.y; xf[lane][11] = X.p.z;
-        const v3 c = mulv(X.R, mk(S->sphere[lane][0], S->sphere[lane][1], S->sphere[lane][2])) + X.p;
+        const v3 c = nc::add(nc::mulv(X.R, mk(S->sphere[lane][0], S->sphere[lane][1], S->sphere[lane][2])), X.p);
         sph[lane] = make_float4(c.x, c.y, c.z, S->sphere[lane][3]);
     }
     CSYNC();
@@ -629,7 +700,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 // vertex of "mine" can be a candidate; with that true for both directions the pair has no contact.
                 // Evaluated on the plane each lane already holds in a register, before anything is staged in LDS.
                 const float4 cm = sph[sm];
-                const v3 cl = tmulv(Xo.R, mk(cm.x, cm.y, cm.z) - Xo.p);
+                const v3 cl = nc::tmulv(Xo.R, nc::sub(mk(cm.x, cm.y, cm.z), Xo.p));
                 const bool sep = v < nf && mypl.x * cl.x + mypl.y * cl.y + mypl.z * cl.z - mypl.w > cm.w + P.margin;
                 const unsigned long long sb_ = __ballot(sep);
                 if ((sb_ & 0xffffffffull) && (sb_ >> 32)) continue;        // S_PCOUNT is already 0
@@ -642,8 +713,8 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
             float cx = 0, cy = 0, cz = 0, cs = 0;
             int bf = 0;
             if (v < nv) {
-                const v3 xw = mulv(Xm.R, mk(mvx, mvy, mvz)) + Xm.p;
-                const v3 xl = tmulv(Xo.R, xw - Xo.p);
+                const v3 xw = nc::add(nc::mulv(Xm.R, mk(mvx, mvy, mvz)), Xm.p);
+                const v3 xl = nc::tmulv(Xo.R, nc::sub(xw, Xo.p));
                 float best = -1e30f;
                 // all FMAXC slots: padded planes are (0, 0, 0, 1e9), i.e. sd = -1e9, and never win against a real plane
 #pragma unroll 8
@@ -654,7 +725,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 }
                 if (best < P.margin) {
                     const float4 pl = planes[dirflag][bf];
-                    const v3 nw = mulv(Xo.R, mk(pl.x, pl.y, pl.z));
+                    const v3 nw = nc::mulv(Xo.R, mk(pl.x, pl.y, pl.z));
                     cx = xw.x - 0.5f * best * nw.x; cy = xw.y - 0.5f * best * nw.y; cz = xw.z - 0.5f * best * nw.z;
                     cs = best;
                     hit = true;
@@ -677,18 +748,18 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 const float sbest = lane_f(cs, sel0);
                 const float lim = sbest + 0.001f;
                 const v3 x0 = mk(lane_f(cx, sel0), lane_f(cy, sel0), lane_f(cz, sel0));
-                const v3 dd = mk(cx, cy, cz) - x0;
-                const float v1 = dot(dd, dd);
+                const v3 dd = nc::sub(mk(cx, cy, cz), x0);
+                const float v1 = nc::dot(dd, dd);
                 const bool t0 = cs < lim;
                 sel1 = wave_argmax_first(v1, hit && lane != sel0 && t0, -1.0f);
                 if (sel1 < 0) sel1 = wave_argmax_first(v1, hit && lane != sel0, -1.0f);
-                const v3 e = mk(lane_f(cx, sel1), lane_f(cy, sel1), lane_f(cz, sel1)) - x0;
-                const v3 cr = cross(dd, e);
-                const float v2 = dot(cr, cr);
+                const v3 e = nc::sub(mk(lane_f(cx, sel1), lane_f(cy, sel1), lane_f(cz, sel1)), x0);
+                const v3 cr = nc::cross(dd, e);
+                const float v2 = nc::dot(cr, cr);
                 sel2 = wave_argmax_first(v2, hit && lane != sel0 && lane != sel1 && t0, -1.0f);
                 if (sel2 < 0) sel2 = wave_argmax_first(v2, hit && lane != sel0 && lane != sel1, -1.0f);
                 const v3 cr2 = mk(lane_f(cr.x, sel2), lane_f(cr.y, sel2), lane_f(cr.z, sel2));
-                const float v3_ = -dot(cr, cr2);
+                const float v3_ = -nc::dot(cr, cr2);
                 const bool o3 = hit && lane != sel0 && lane != sel1 && lane != sel2;
                 sel3 = wave_argmax_first(v3_, o3 && t0, 0.0f);
                 if (sel3 < 0) sel3 = wave_argmax_first(v3_, o3, 0.0f);
@@ -699,8 +770,8 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
             const int slot = lane == sel0 ? 0 : (lane == sel1 ? 1 : (lane == sel2 ? 2 : (lane == sel3 ? 3 : -1)));
             if (hit && slot >= 0) {
                 const float4 pl = planes[dirflag][bf];
-                v3 nw = mulv(Xo.R, mk(pl.x, pl.y, pl.z));
-                if (dirflag) nw = nw * -1.0f;
+                v3 nw = nc::mulv(Xo.R, mk(pl.x, pl.y, pl.z));
+                if (dirflag) nw = nc::scale(nw, -1.0f);
                 float4 *pd = D.pdata + (((size_t)env * MAXPAIRS + pair) * 4 + slot) * 2;
                 pd[0] = make_float4(cx, cy, cz, nw.x);
                 pd[1] = make_float4(nw.y, nw.z, cs, 0.0f);
@@ -709,6 +780,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
     }
     if (lane == 0) D.demand[(size_t)P.par * N + env] = (unsigned)min(d_all, 255) | ((unsigned)min(d_rob, 255) << 8) | ((unsigned)min(d_oo, 255) << 16);
 }
+#pragma clang fp contract(fast)
 
 // ---------------------------------------------------------------------------------------------- k_solve
 __device__ __forceinline__ void plane_space(v3 n, v3 &p, v3 &q) {   // btPlaneSpace1
@@ -766,7 +838,7 @@ struct Slab { int fix, base, rob, bs, lc, lr, lb; };
 // beside k_collide; the order only decides where rows live and which envs wait for each other -- never a result.
 #define BAL_THREADS 1024
 __global__ void __launch_bounds__(BAL_THREADS) k_balance(SimParams P, DevPtrs D) {
-    __shared__ int s_wave[BAL_THREADS / 64];
+    __shared__ int s_wave[BAL_THREADS / 64], s_wave2[BAL_THREADS / 64];
     const int N = P.N, t = threadIdx.x, nblk = (N + SGRP - 1) / SGRP;
     const unsigned *dem = D.demand + (size_t)(P.par ^ 1) * N;
     if (N > 64 * BAL_THREADS) {                       // beyond the bit mask below: identity order
@@ -784,23 +856,30 @@ __global__ void __launch_bounds__(BAL_THREADS) k_balance(SimParams P, DevPtrs D)
         if (need > (P.pool * 3) / 10) { hm1 |= 1ull << j; n1++; }
         else if (need > (P.pool * 3) / 20) { hm2 |= 1ull << j; n2++; }
     }
-    // exclusive prefix of both counts over the workgroup (packed: 16 bits each)
-    int incl = n1 | (n2 << 16);
-    const int mine = incl;
+    // exclusive prefix of both counts over the workgroup (two plain ints: with N up to 65536 a packed 16+16-bit scan
+    // would carry from one field into the other)
+    int incl1 = n1, incl2 = n2;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if ((t & 63) >= d) incl += o; }
-    if ((t & 63) == 63) s_wave[t >> 6] = incl;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o1 = __shfl_up(incl1, d), o2 = __shfl_up(incl2, d);
+        if ((t & 63) >= d) { incl1 += o1; incl2 += o2; }
+    }
+    if ((t & 63) == 63) { s_wave[t >> 6] = incl1; s_wave2[t >> 6] = incl2; }
     for (int i = t; i < SGRP * nblk; i += BAL_THREADS) D.solve_order[i] = -1;     // N need not be a multiple of four: the
                                                                                   // positions left over stay empty, wherever they are
     __syncthreads();
-    int base = incl - mine, tot = 0;
-    for (int w = 0; w < BAL_THREADS / 64; w++) { const int c = s_wave[w]; if (w < (t >> 6)) base += c; tot += c; }
-    const int H1 = tot & 0xffff, H = H1 + (tot >> 16);
-    int r1 = base & 0xffff, r2 = H1 + (base >> 16);              // next rank of either class for this thread's envs
+    int base1 = incl1 - n1, base2 = incl2 - n2, H1 = 0, H2 = 0;
+    for (int w = 0; w < BAL_THREADS / 64; w++) {
+        const int c1 = s_wave[w], c2 = s_wave2[w];
+        if (w < (t >> 6)) { base1 += c1; base2 += c2; }
+        H1 += c1; H2 += c2;
+    }
+    const int H = H1 + H2;
+    int r1 = base1, r2 = H1 + base2;                             // next rank of either class for this thread's envs
     // heavy rank h -> workgroup h % nblk, position h / nblk; the light envs fill the remaining positions in order
     const int q = H / nblk, r = H % nblk;            // workgroups [0, r) hold q + 1 heavy envs, the others q
     const int ebase = (N / BAL_THREADS) * t + min(t, N % BAL_THREADS);     // envs owned by the threads before this one
-    const int hbefore = (base & 0xffff) + (base >> 16);                    // heavy envs (both classes) of those threads
+    const int hbefore = base1 + base2;                                     // heavy envs (both classes) of those threads
     int hseen = 0;
     for (int j = 0, e = t; e < N; e += BAL_THREADS, j++) {
         int slot;
@@ -1630,6 +1709,28 @@ __global__ void k_state_io(SimParams P, DevPtrs D, float *aos /*[N][61]*/, int t
             if (to_aos) b[3 + k] = STT(ST_OQUAT + 4 * o + k); else STT(ST_OQUAT + 4 * o + k) = b[3 + k];
         }
     }
+    if (!to_aos) {
+        // a restored state is a fresh start for everything derived from the previous step: the NaN guard's freeze bit, the
+        // contact list behind rr_get_contacts and the touch sensors (as k_reset does)
+        D.errflags[env] = 0;
+        for (int k = 0; k < 4; k++) D.touch[(size_t)env * 4 + k] = 0;
+        *(int *)&D.scratch[(size_t)S_NCT * N + env] = 0;
+    }
+}
+
+// rr_set_object_poses: poses [N][nobj][7] for the envs whose mask byte is set (nullptr: all); zeroes the velocities like
+// BodyPart.reset_pose -> resetBasePositionAndOrientation (env.py:159-162)
+__global__ void k_set_object_poses(SimParams P, DevPtrs D, const float *poses, const unsigned char *mask) {
+    const int N = P.N;
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    if (mask && !mask[env]) return;
+    float *state = D.state;
+    for (int i = 0; i < P.nobj; i++) {
+        const float *p7 = poses + ((size_t)env * P.nobj + i) * 7;
+        for (int k = 0; k < 3; k++) { STT(ST_OPOS + 3 * i + k) = p7[k]; STT(ST_OVEL + 3 * i + k) = 0; STT(ST_OANG + 3 * i + k) = 0; }
+        for (int k = 0; k < 4; k++) STT(ST_OQUAT + 4 * i + k) = p7[3 + k];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- render setup
@@ -1659,13 +1760,13 @@ __global__ void __launch_bounds__(64) k_render_setup(BodyParams B, SimParams P, 
             m3 jr;
 #pragma unroll
             for (int k = 0; k < 9; k++) jr.m[k] = B.jrot[b][k];
-            const m3 Rj = mul(R, jr);
+            const m3 Rj = nc::mul(R, jr);
             const v3 ax = mk(B.axis[b][0], B.axis[b][1], B.axis[b][2]);
-            p = p + mulv(R, mk(B.jpos[b][0], B.jpos[b][1], B.jpos[b][2]));
-            R = mul(Rj, axis_angle(ax, STT(ST_Q + b)));
+            p = nc::add(p, nc::mulv(R, mk(B.jpos[b][0], B.jpos[b][1], B.jpos[b][2])));
+            R = nc::mul(Rj, nc::axis_angle(ax, STT(ST_Q + b)));
         }
     } else if (ot == 2) {
-        R = quat_to_m3(STT(ST_OQUAT + 4 * oi), STT(ST_OQUAT + 4 * oi + 1), STT(ST_OQUAT + 4 * oi + 2), STT(ST_OQUAT + 4 * oi + 3));
+        R = nc::quat_to_m3(STT(ST_OQUAT + 4 * oi), STT(ST_OQUAT + 4 * oi + 1), STT(ST_OQUAT + 4 * oi + 2), STT(ST_OQUAT + 4 * oi + 3));
         p = mk(STT(ST_OPOS + 3 * oi), STT(ST_OPOS + 3 * oi + 1), STT(ST_OPOS + 3 * oi + 2));
     }
     // mvp = VP * [R p; 0 1] (same summation order as the oracle's 4x4 product, no FMA contraction), then the shading
@@ -1951,10 +2052,14 @@ __global__ void __launch_bounds__(64) k_plan_macro(IkModel M, SimParams P, DevPt
 }
 
 // command of this step = plan row plan_step (clamped to the last row); advances plan_step
-__global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *plan_step) {
+__global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *plan_step, const unsigned char *idle) {
     const int N = P.N;
     int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= N) return;
+    if (idle && idle[env]) {       // macro_action None: zeros(9), the plan keeps its position (env.py:391-393)
+        for (int k = 0; k < 9; k++) D.cmd[(size_t)env * 9 + k] = 0.0f;
+        return;
+    }
     int st = plan_step[env];
     int r = st < PLAN_LEN ? st : PLAN_LEN - 1;
     for (int k = 0; k < 9; k++) D.cmd[(size_t)env * 9 + k] = plan[((size_t)env * PLAN_LEN + r) * 9 + k];
@@ -2633,6 +2738,10 @@ struct rr_env {
     float t_ms[RR_NUM_KERNELS];
     int t_n[RR_NUM_KERNELS];
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+    // pinned staging ring for per-step host inputs (commands, render flags): a hipMemcpyAsync from pageable memory blocks
+    // the host until the copy is done; from these slots it is asynchronous, and a slot is reused only after the event
+    // recorded behind its copy has completed
+    char *pin_buf[4]; hipEvent_t pin_ev[4]; bool pin_used[4]; int pin_next; size_t pin_bytes;
 };
 
 template <typename T>
@@ -2699,6 +2808,7 @@ int rr_destroy(rr_env *e) {
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
     if (e->ev_dyn) hipEventDestroy(e->ev_dyn);
+    for (int i = 0; i < 4; i++) { if (e->pin_buf[i]) hipHostFree(e->pin_buf[i]); if (e->pin_ev[i]) hipEventDestroy(e->pin_ev[i]); }
     delete e;
     return RR_OK;
 }
@@ -2755,6 +2865,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     memset(&e->B, 0, sizeof e->B); memset(&e->RM, 0, sizeof e->RM); memset(&e->D, 0, sizeof e->D);
     memset(e->ev, 0, sizeof e->ev); memset(e->t_ms, 0, sizeof e->t_ms); memset(e->t_n, 0, sizeof e->t_n);
     e->timing = false;
+    memset(e->pin_buf, 0, sizeof e->pin_buf); memset(e->pin_ev, 0, sizeof e->pin_ev); memset(e->pin_used, 0, sizeof e->pin_used); e->pin_next = 0; e->pin_bytes = 0;
     e->full_copy = getenv("RR_FULL_COPY") != nullptr;
     e->sep_restore = getenv("RR_SEPARATE_RESTORE") != nullptr;
     e->plan = nullptr; e->plan_step = nullptr; e->ik_in = nullptr; e->ik_out = nullptr; e->ik_err = nullptr;
@@ -3040,6 +3151,22 @@ int rr_set_object_pose(rr_env *e, int32_t env_index, int32_t obj, const float *p
     return RR_OK;
 }
 
+// Batched form of rr_set_object_pose: one upload and one kernel for the whole batch (set_goal of N envs, env.py:151-166).
+int rr_set_object_poses(rr_env *e, const float *poses_host, const uint8_t *env_mask_host) {
+    if (!e || !poses_host) return fail(RR_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const int N = e->P.N;
+    static_assert(NSTATE >= NOBJ * 7, "the state staging buffer doubles as pose staging");
+    HIPCHK(hipMemcpyAsync(e->state_aos, poses_host, (size_t)N * e->P.nobj * 28, hipMemcpyHostToDevice, e->stream));
+    const unsigned char *m = nullptr;
+    if (env_mask_host) { HIPCHK(hipMemcpyAsync(e->mask_dev, env_mask_host, N, hipMemcpyHostToDevice, e->stream)); m = e->mask_dev; }
+    hipLaunchKernelGGL(k_set_object_poses, dim3((N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D, e->state_aos, m);
+    hipLaunchKernelGGL(k_obs, dim3((N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));   // the arguments are host memory
+    return RR_OK;
+}
+
 static bool g_debug_sync = getenv("RR_DEBUG_SYNC") != nullptr;
 static int g_skip = getenv("RR_SKIP") ? atoi(getenv("RR_SKIP")) : 0;
 #define TIMED(id, launch)                                                   \
@@ -3073,7 +3200,7 @@ static int do_render(rr_env *e, bool use_flags) {
         const int copy_blocks = std::min(16, (e->RM.W * e->RM.H / 4 + COPY_THREADS - 1) / COPY_THREADS);
         DevPtrs Dall = D;
         if (!e->images_valid) Dall.render_flags = nullptr;      // first frame: every env, flagged or not -- all images become valid
-        TIMED(5, hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, N), dim3(COPY_THREADS), 0, e->stream, e->RM_dev, Dall, io, 1, N));
+        TIMED(5, hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, std::min(N, 65535)), dim3(COPY_THREADS), 0, e->stream, e->RM_dev, Dall, io, 1, N));
         if (!e->images_valid) HIPCHK(hipMemsetAsync(e->D.frag_count, 0, (size_t)N * e->RM.ntiles * sizeof(unsigned), e->stream));
         e->images_valid = true;
         restore = 0;
@@ -3099,18 +3226,42 @@ static void launch_collide(rr_env *e) {
     hipLaunchKernelGGL(k_collide, dim3(e->P.N), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D, e->n_shapes);
 }
 
+// Next slot of the pinned ring (allocated on first use: N * 37 bytes per slot = commands + render flags).
+static int pin_acquire(rr_env *e, char **slot, int *idx) {
+    const int i = e->pin_next;
+    e->pin_next = (i + 1) & 3;
+    if (!e->pin_buf[i]) {
+        e->pin_bytes = (size_t)e->P.N * 37;
+        HIPCHK(hipHostMalloc((void **)&e->pin_buf[i], e->pin_bytes, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&e->pin_ev[i], hipEventDisableTiming));
+    }
+    if (e->pin_used[i]) HIPCHK(hipEventSynchronize(e->pin_ev[i]));
+    *slot = e->pin_buf[i]; *idx = i;
+    return RR_OK;
+}
+
 int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t render_mode, const uint8_t *render_flags_host) {
     if (!e) return fail(RR_EINVAL, "null env");
     if (render_mode < 0 || render_mode > 2 || (render_mode == 2 && !render_flags_host)) return fail(RR_EINVAL, "rr_step: bad render_mode");
     HIPCHK(hipSetDevice(e->cfg.device));
     const int N = e->P.N;
+    const bool host_cmd = joint_cmd && !cmd_on_device, host_flags = render_mode == 2;
+    char *pin = nullptr; int pin_idx = -1;
+    if (host_cmd || host_flags) { const int rc = pin_acquire(e, &pin, &pin_idx); if (rc != RR_OK) return rc; }
     if (!joint_cmd) HIPCHK(hipMemsetAsync(e->D.cmd, 0, (size_t)N * 36, e->stream));      // env.py:333-334
-    else if (!cmd_on_device) HIPCHK(hipMemcpyAsync(e->D.cmd, joint_cmd, (size_t)N * 36, hipMemcpyHostToDevice, e->stream));
+    else if (host_cmd) {
+        memcpy(pin, joint_cmd, (size_t)N * 36);
+        HIPCHK(hipMemcpyAsync(e->D.cmd, pin, (size_t)N * 36, hipMemcpyHostToDevice, e->stream));
+    }
     // a device-resident command buffer is read in place by k_prep (stream order protects it like a copy would)
     DevPtrs Dp = e->D;
     if (joint_cmd && cmd_on_device) Dp.cmd = const_cast<float *>(joint_cmd);
     e->P.par ^= 1;          // k_collide records this step's contact demand in one half, k_balance reads the other
-    if (render_mode == 2) HIPCHK(hipMemcpyAsync(e->D.render_flags, render_flags_host, N, hipMemcpyHostToDevice, e->stream));
+    if (host_flags) {
+        memcpy(pin + (size_t)N * 36, render_flags_host, N);
+        HIPCHK(hipMemcpyAsync(e->D.render_flags, pin + (size_t)N * 36, N, hipMemcpyHostToDevice, e->stream));
+    }
+    if (pin_idx >= 0) { HIPCHK(hipEventRecord(e->pin_ev[pin_idx], e->stream)); e->pin_used[pin_idx] = true; }
     bool dyn_forked = false;
     if (e->aux && !e->timing && !g_skip) {
         // phase 1 on the main stream, phase 2 (dynamics, needed by k_solve only) on the side stream beside k_collide
@@ -3253,12 +3404,18 @@ int rr_get_plan(rr_env *e, int32_t env_index, float *plan_host) {
     return RR_OK;
 }
 
-int rr_step_plan(rr_env *e, int32_t render_mode, const uint8_t *render_flags_host) {
+int rr_step_plan_masked(rr_env *e, const uint8_t *idle_mask_host, int32_t render_mode, const uint8_t *render_flags_host) {
     if (!e) return fail(RR_EINVAL, "null env");
     if (!e->plan) return fail(RR_EINVAL, "rr_step_plan: call rr_plan_macro first");
     HIPCHK(hipSetDevice(e->cfg.device));
-    hipLaunchKernelGGL(k_plan_fetch, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D, e->plan, e->plan_step);
+    const unsigned char *idle = nullptr;
+    if (idle_mask_host) { HIPCHK(hipMemcpyAsync(e->mask_dev, idle_mask_host, e->P.N, hipMemcpyHostToDevice, e->stream)); idle = e->mask_dev; }
+    hipLaunchKernelGGL(k_plan_fetch, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D, e->plan, e->plan_step, idle);
     return rr_step(e, e->D.cmd, 1, render_mode, render_flags_host);
+}
+
+int rr_step_plan(rr_env *e, int32_t render_mode, const uint8_t *render_flags_host) {
+    return rr_step_plan_masked(e, nullptr, render_mode, render_flags_host);
 }
 
 // Replaces the fixed eye camera by an arbitrary one (row-major 4x4 view and projection, OpenGL conventions) and rebuilds

@@ -47,3 +47,24 @@ def gather_observations(local_obs, group=None):
         dist.all_gather(parts, t.contiguous(), group=group)
         out[k] = torch.cat(parts, dim=0)
     return out
+
+
+def gather_images(rgb, depth, group=None):
+    """All-gather of the per-rank image slabs (RGB u8 [n, H, W, 3], depth f32 [n, H, W]) into [world * n, ...] tensors:
+    one collective per slab (470 MB per rank at 4096 envs x 128x128), which RCCL moves over the seven xGMI links of a
+    fully connected node directly -- bucket sizes far above the latency-bound regime.  Falls back to the
+    list form of all_gather on backends without all_gather_into_tensor."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    outs = []
+    for t in (rgb, depth):
+        t = t.contiguous()
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        try:
+            dist.all_gather_into_tensor(out, t, group=group)
+        except (RuntimeError, NotImplementedError, AttributeError):
+            parts = list(out.chunk(world, dim=0))
+            dist.all_gather(parts, t, group=group)
+        outs.append(out)
+    return outs[0], outs[1]

@@ -227,7 +227,7 @@ def evaluate_batched(Controller, num_envs, environment='R1', action_type='macro_
             acts = [c.step(o, 0, done) for c, o in zip(ctrls, obs)]
             rendered = bool(render_every) and (t % render_every == 0)
             if action_type == 'macro_action':
-                env.step_macro(np.array([a['macro_action'] for a in acts], dtype=np.float64), render=rendered)
+                env.step_macro([a['macro_action'] for a in acts], render=rendered)       # entries may be None (env.py:391-393)
             else:
                 env.step(np.array([np.zeros(9) if a['joint_command'] is None else a['joint_command'] for a in acts],
                                   dtype=np.float32), render=rendered)
@@ -249,9 +249,11 @@ def evaluate_batched(Controller, num_envs, environment='R1', action_type='macro_
     for trial in range(int(extrinsic_trials)):
         env.reset()
         goal_of_env = [goals[(i + trial) % len(goals)] for i in range(N)]
+        start = env.host(nat.F_OBJ_POSE)                     # one upload for the whole batch (env.py:159-162 per env)
         for i, g in enumerate(goal_of_env):
             for n in g.initial_state:
-                env.set_object_pose(i, names.index(n), np.asarray(g.initial_state[n], dtype=np.float32))
+                start[i, names.index(n)] = np.asarray(g.initial_state[n], dtype=np.float32)
+        env.set_object_poses(start)
         for c in ctrls:
             c.start_extrinsic_trial()
         obs = run_phase(extrinsic_timesteps, goal_of_env)

@@ -156,6 +156,8 @@ def generate_goals(n_2d_goals=25, n_25d_goals=15, n_3d_goals=10, n_obj=3, seed=N
 
 def save_goals(path, goals):
     """np.savez_compressed(path, list_of_goals) (generate_goals.py:435-436; env.py:143-145 reads items()[0][1])."""
+    import real_robots  # noqa: F401  the alias package makes Goal pickle as real_robots.envs.env.Goal (the reference's path)
+    assert Goal.__module__ == 'real_robots.envs.env'
     arr = np.empty(len(goals), dtype=object)
     for i, g in enumerate(goals):
         arr[i] = g

@@ -21,6 +21,14 @@ def _worker(rank, world, port, tmp):
     g = gather_observations({'act': acts[:n], 'id': ids[:n]})
     full = synthetic_actions(range(total), step=3)
     ok = bool((g['id'].numpy() == np.arange(total)).all() and (g['act'].numpy() == full).all())
+    # image slabs (bench.py --gather images): every rank contributes its envs' RGB + depth, order = global env id
+    from real_robots_amd.distributed import gather_images
+    rgb = torch.full((n, 4, 8, 3), rank + 1, dtype=torch.uint8) + ids[:n].to(torch.uint8).view(n, 1, 1, 1)
+    depth = torch.full((n, 4, 8), 0.25 * (rank + 1), dtype=torch.float32)
+    grgb, gdepth = gather_images(rgb, depth)
+    ok = ok and tuple(grgb.shape) == (total, 4, 8, 3) and tuple(gdepth.shape) == (total, 4, 8)
+    want = np.concatenate([np.full(n, r + 1) + np.arange(r * n, (r + 1) * n) for r in range(world)])
+    ok = ok and bool((grgb[:, 0, 0, 0].numpy() == want).all()) and bool((gdepth[n:, 0, 0].numpy() == 0.5).all())
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -1,0 +1,196 @@
+"""GPU parity tests (-m gpu) that pin WHICH contacts exist and what they carry, through the C ABI:
+
+* a seeded randomised differential run (batch sizes 1..130, 1-3 objects, five resolutions, full / shrunken / empty solver
+  row pool, random joint commands or macro plans, per-env render flags, resets and teleports): the envs with the most
+  contacts are checked one step at a time against the float build of the oracle started from the device state.  The
+  collision pipeline (forward kinematics, shape transforms, sphere cull, vertex-in-polytope tests, manifold reduction)
+  runs without FMA contraction and with a shared explicit sin/cos on both sides, so the contact LIST -- bodies, points,
+  normals, distances, friction -- must be bit-identical; the solver (fp32, contracted) is held to tolerances;
+* numeric parity of Kuka.get_touch_sensors / get_contacts normal forces (robot.py:131-163) in a grasp and in a pushing
+  sweep.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from real_robots_amd import _native as nat
+from real_robots_amd.batched import BatchedREALRobotEnv
+from real_robots_amd.distributed import synthetic_actions
+
+pytestmark = pytest.mark.gpu
+
+CRUSH_FORCE = 2000.0      # N; above this a finger is crushing an object into the table under the 100 kN position motors:
+                          # 50 Gauss-Seidel sweeps are far from converged there and fp32 / fp64 oracles disagree too
+
+
+def _lists_identical(c_dev, c_orc):
+    """Contact records {bodyA, bodyB, linkA, x, n, dist, force, mu}: everything but the force (column 10) bit for bit."""
+    if len(c_dev) != len(c_orc):
+        return False
+    if not len(c_dev):
+        return True
+    keep = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11]
+    return bool((c_dev[:, keep] == c_orc[:, keep].astype(np.float32)).all())
+
+
+def _fuzz_case(case, seed0, stats, bad):
+    rng = np.random.default_rng(seed0 * 1000 + case)
+    N = int(rng.choice([1, 3, 5, 17, 34, 63, 130]))
+    nobj = int(rng.integers(1, 4))
+    W, H = [(64, 48), (64, 64), (128, 128), (160, 120), (320, 240)][int(rng.integers(0, 5))]
+    pool = rng.choice([None, None, "0", "900", "2500"])
+    if pool:
+        os.environ['RR_SOLVER_POOL'] = str(pool)
+    try:
+        env = BatchedREALRobotEnv(N, objects=nobj, width=W, height=H)
+    finally:
+        os.environ.pop('RR_SOLVER_POOL', None)
+    o = Oracle(nobj, W, H, f32=True)
+    macro = rng.random() < 0.6
+    plans = None
+    if macro:
+        env.plan_macro(rng.uniform([-0.25, -0.5], [0.05, 0.5], size=(N, 2, 2)))
+        plans = [env.get_plan(i) for i in range(N)]
+    scale = rng.choice([0.5, 0.8, 1.0])
+    T = int(rng.integers(60, 200))
+    t_off = int(rng.integers(0, 400)) if macro else 0
+    if macro and t_off:
+        plans = [np.roll(p, -t_off, axis=0) for p in plans]
+    for t in range(T):
+        if macro:
+            cmd = np.stack([plans[i][t % 1000] for i in range(N)]).astype(np.float32)
+        else:
+            cmd = (synthetic_actions(range(N), t, seed=case) * scale).astype(np.float32)
+        if rng.random() < 0.01:
+            env.reset((rng.random(N) < 0.3).astype(np.uint8))
+        if rng.random() < 0.01:
+            env.set_object_pose(int(rng.integers(0, N)), int(rng.integers(0, nobj)),
+                                np.array([rng.uniform(-0.2, 0.0), rng.uniform(-0.3, 0.3), rng.uniform(0.3, 0.6), 0, 0, 0, 1], np.float32))
+        flags = (rng.random(N) < 0.5).astype(np.uint8)
+        chk = t % 20 == 19
+        if chk:
+            st0 = env.state
+            ncs = np.array([len(env.contacts(i)) for i in range(N)])
+            sel = sorted(set(list(np.argsort(-ncs)[:2]) + [int(rng.integers(0, N))]))
+            flags[sel] = 1
+        env.step(cmd, render=flags if N > 1 else bool(flags[0]))
+        if not chk:
+            continue
+        st1 = env.state
+        rgb, dep, msk = env.host(nat.F_RGB), env.host(nat.F_DEPTH), env.host(nat.F_MASK)
+        for i in sel:
+            o.state = st0[i].astype(np.float64)
+            o.step(cmd[i].astype(np.float64))
+            cd, co = env.contacts(i), o.contacts()
+            stats['checks'] += 1
+            stats['contacts'] += len(cd)
+            tag = (case, N, nobj, W, H, pool, bool(macro), t, int(i))
+            if not _lists_identical(cd, co):
+                bad.append(tag + ('contact list', len(cd), len(co)))
+                continue
+            fmax = float(cd[:, 10].max()) if len(cd) else 0.0
+            dj = float(np.abs(st1[i][:22] - o.state[:22]).max())
+            do = float(np.abs((st1[i][22:22 + 13 * nobj] - o.state[22:22 + 13 * nobj]).reshape(nobj, 13)[:, :3]).max())
+            if fmax > CRUSH_FORCE:
+                stats['crush'] += 1
+                if not np.isfinite(st1[i]).all():
+                    bad.append(tag + ('non-finite under crush',))
+            else:
+                stats['dj'] = max(stats['dj'], dj)
+                stats['do'] = max(stats['do'], do)
+                if dj > 2e-3 or do > 1e-3:
+                    bad.append(tag + ('state', dj, do, fmax))
+            o.state = st1[i].astype(np.float64)
+            r, d, m = o.render()
+            diff = np.abs(r.astype(int) - rgb[i].astype(int)).max(-1)
+            if (m != msk[i]).any() or (diff > 1).sum() > 0 or np.abs(d - dep[i]).max() > 1e-5:
+                bad.append(tag + ('image', int((m != msk[i]).sum()), int((diff > 1).sum()), float(np.abs(d - dep[i]).max())))
+    if (env.host(nat.F_ERRFLAGS) != 0).any() or (env.host(nat.F_TIMESTEP) > T).any():
+        bad.append((case, 'errflags/timestep'))
+    env.close()
+
+
+def test_seeded_differential_run_contact_lists_bit_identical():
+    """>= 300 seeded cases; zero disagreements in the contact lists (in particular no candidate that sits at the 2 cm margin
+    on one side only), states within the one-step tolerances outside crush scenarios, images exact."""
+    stats = dict(checks=0, contacts=0, crush=0, dj=0.0, do=0.0)
+    bad = []
+    n_cases = int(os.environ.get('RR_FUZZ_CASES', '300'))
+    for case in range(n_cases):
+        _fuzz_case(case, 2, stats, bad)
+    print("fuzz: %d cases, %d one-step checks, %d contacts compared, %d crush checks, worst joints %.2e objects %.2e; %d violations"
+          % (n_cases, stats['checks'], stats['contacts'], stats['crush'], stats['dj'], stats['do'], len(bad)))
+    assert not bad, bad[:20]
+    assert stats['checks'] >= 3 * n_cases and stats['contacts'] > 20 * n_cases
+    assert stats['crush'] <= 0.05 * stats['checks']
+
+
+def _grasp_script():
+    from real_robots_amd.kinematics import inverse_kinematics, quat_from_euler
+    orient = quat_from_euler(0, 3.14, -1.57)
+    q_hi = inverse_kinematics(np.zeros(11), [-0.1, 0.0, 0.55], orient)
+    q_lo = inverse_kinematics(q_hi, [-0.1, 0.0, 0.47], orient)
+    cmds = []
+    for q, g, n in [(q_hi, [0.5, 0.0], 150), (q_lo, [0.5, 0.0], 120), (q_lo, [0.0, 0.0], 60)]:
+        cmds += [np.concatenate([q[:7], g])] * n
+    return np.array(cmds, np.float32)
+
+
+def _check_forces(env, o, i, st0, cmd, where, stats):
+    """One step of env i from the device state st0: contact list identical, normal forces and the four touch sensors
+    (max normal force per skin link, robot.py:152-163) within 0.1 % (+ 0.02 N) of the float oracle."""
+    o.state = st0[i].astype(np.float64)
+    o.step(cmd.astype(np.float64))
+    cd, co = env.contacts(i), o.contacts()
+    assert _lists_identical(cd, co), where
+    if len(cd):
+        f_dev, f_orc = cd[:, 10].astype(np.float64), co[:, 10]
+        if f_orc.max() > CRUSH_FORCE:
+            return
+        assert np.abs(f_dev - f_orc).max() <= 1e-3 * f_orc.max() + 0.02, (where, float(np.abs(f_dev - f_orc).max()), float(f_orc.max()))
+        stats['forces'] += int((f_orc > 1.0).sum())
+    touch = env.host(nat.F_TOUCH)[i].astype(np.float64)
+    t_orc = o.obs()[1]
+    assert np.abs(touch - t_orc).max() <= 1e-3 * max(t_orc.max(), 1.0) + 0.02, (where, touch, t_orc)
+    stats['touch'] += int((t_orc > 1.0).sum())
+
+
+def test_touch_sensors_and_normal_forces_match_the_oracle():
+    """a7: get_touch_sensors / get_contacts (robot.py:131-163) compared numerically, one step at a time from the device
+    state, (i) while the fingers close on the cube and (ii) while a macro action pushes the objects over the table."""
+    stats = dict(forces=0, touch=0)
+    cmds = _grasp_script()
+    env = BatchedREALRobotEnv(4, objects=1, width=64, height=64)
+    o = Oracle(1, 64, 64, f32=True)
+    for _ in range(100):
+        env.step(None)
+    for t, c in enumerate(cmds):
+        chk = t >= 262 and t % 2 == 0
+        if chk:
+            st0 = env.state
+        env.step(np.tile(c, (4, 1)))
+        if chk:
+            _check_forces(env, o, 0, st0, c, ('grasp', t), stats)
+    assert stats['touch'] >= 20, stats                # the distal skins pressed on the cube in the steps that were checked
+    env.close()
+    N = 34
+    env = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    o = Oracle(3, 64, 64, f32=True)
+    rng = np.random.default_rng(5)
+    env.plan_macro(rng.uniform([-0.25, -0.5], [0.05, 0.5], size=(N, 2, 2)))
+    plans = [env.get_plan(i) for i in range(N)]
+    before = dict(stats)
+    for t in range(760):
+        chk = t >= 200 and t % 20 == 0
+        if chk:
+            ncs = np.array([len(env.contacts(i)) for i in range(N)])
+            sel = np.argsort(-ncs)[:4]
+            st0 = env.state
+        env.step_plan(render=False)
+        if chk:
+            for i in sel:
+                _check_forces(env, o, int(i), st0, plans[i][t], ('push', t, int(i)), stats)
+    assert stats['forces'] - before['forces'] > 200, stats
+    env.close()

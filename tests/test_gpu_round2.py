@@ -1,0 +1,161 @@
+"""GPU tests (-m gpu) added in round 2: EnvCamera view against the oracle, CLI demo, BASELINE config 2 at its size,
+checkpoint restore semantics, batched object teleport, macro steps with None actions."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from real_robots_amd import _native as nat
+from real_robots_amd.batched import BatchedREALRobotEnv
+from real_robots_amd.distributed import synthetic_actions
+
+pytestmark = pytest.mark.gpu
+
+
+def test_env_camera_view_matches_the_oracle_pixel_exact():
+    """render('rgb_array') (EnvCamera: distance 1.2, yaw 30, pitch -30, roll 0, target [0,0,.4], fov 80, 320x240;
+    env.py:83-90,470-513) against an oracle render through the same view / projection matrices: mask identical, RGB
+    within one grey level, depth within 1e-6 -- for the reset pose and after 80 steps of arm motion."""
+    import real_robots_amd as rr
+    from real_robots_amd.kinematics import perspective, view_from_yaw_pitch_roll
+    env = rr.make('REALRobot2020-R1J3-v0', eye_width=64, eye_height=64)
+    env.reset()
+    view = view_from_yaw_pitch_roll([0, 0, .4], 1.2, 30, -30, 0)
+    proj = perspective(80, 320.0 / 240.0, 0.1, 100.0)
+    o = Oracle(3, 320, 240)
+    o.set_camera(view, proj)
+    for phase in range(2):
+        img = env.render('rgb_array')
+        assert img.shape == (240, 320, 3) and img.dtype == np.uint8
+        be = env.envCamera._be
+        o.state = env._backend().state[0].astype(np.float64)
+        r, d, m = o.render()
+        assert (m == be.host(nat.F_MASK)[0]).all()
+        assert np.abs(r.astype(int) - img.astype(int)).max() <= 1
+        assert np.abs(d - be.host(nat.F_DEPTH)[0]).max() < 1e-6
+        assert set(np.unique(m).tolist()) >= {-1, 0, 1}            # background, robot and table are in the oblique view
+        for _ in range(80):
+            env.step({'joint_command': np.array([0.8, 0.6, 0, -1.0, 0, 0.5, 0, 0.3, 0.2]), 'render': False})
+    env.close()
+
+
+def test_cli_demo_runs(capsys):
+    """real-robots-demo (cli.py:23-64): a random policy on REALRobot2020-R2J3-v0, headless."""
+    from real_robots_amd import cli
+    cli.main(['--steps', '20'])
+    out = capsys.readouterr().out
+    assert 'ran 20 steps of REALRobot2020-R2J3-v0' in out
+
+
+def test_config2_1024_envs_one_object_no_render():
+    """BASELINE config 2 at its size: REALRobot2020-R2J1, 1024 envs, 1 object (cube), joint control, no render.
+    Full-range README-style commands for 400 steps; four envs are followed by the float64 oracle for the first 150 steps
+    (before contact switching amplifies rounding), every env must stay finite, keep its cube on the table or put it back
+    (env.py:257-264), and two runs must agree bit for bit."""
+    N, T = 1024, 400
+    ids = np.arange(N)
+
+    def run(follow):
+        env = BatchedREALRobotEnv(N, objects=1, width=64, height=64, want_mask=False)
+        orcs = [Oracle(1, 64, 64) for _ in range(4)] if follow else []
+        for t in range(T):
+            act = synthetic_actions(ids, t, seed=1234)
+            env.step(act)
+            if t < 150:
+                for k, o in enumerate(orcs):
+                    o.step(act[k * 300].astype(np.float64))
+            if t == 149 and follow:
+                st = env.state
+                for k, o in enumerate(orcs):
+                    assert np.abs(st[k * 300][:11] - o.state[:11]).max() < 2e-3, k
+                    assert np.abs(st[k * 300][22:25] - o.state[22:25]).max() < 2e-3, k
+        st, ef, ts = env.state, env.host(nat.F_ERRFLAGS), env.host(nat.F_TIMESTEP)
+        env.close()
+        return st, ef, ts
+
+    a, ef, ts = run(True)
+    assert np.isfinite(a).all() and (ef == 0).all() and (ts == T).all()
+    z = a[:, 24]
+    assert (z > 0.08 - 1e-3).all() and (z < 1.5).all()
+    b, _, _ = run(False)
+    assert (a == b).all()
+
+
+def test_set_state_clears_the_freeze_bit_contacts_and_touch():
+    """rr_set_state is a fresh start: an env frozen by the NaN guard steps again after a valid state is restored, and the
+    contact list / touch sensors of the previous step are gone until the next step."""
+    N = 3
+    env = BatchedREALRobotEnv(N, objects=2, width=64, height=64)
+    for _ in range(60):
+        env.step(None)
+    good = env.state
+    assert len(env.contacts(1)) > 0
+    bad = good.copy()
+    bad[1, 22] = np.nan                        # object position -> non-finite after the next integration
+    env.state = bad
+    env.step(None)
+    assert env.host(nat.F_ERRFLAGS)[1] & 1
+    frozen = env.state[1].copy()
+    env.step(None)
+    assert np.array_equal(env.state[1], frozen, equal_nan=True)          # frozen envs are skipped
+    env.state = good
+    assert (env.host(nat.F_ERRFLAGS) == 0).all()
+    assert len(env.contacts(1)) == 0 and (env.host(nat.F_TOUCH) == 0).all()
+    q_before = env.state[1].copy()
+    env.step(np.full((N, 9), 0.3, np.float32))
+    assert (env.host(nat.F_ERRFLAGS) == 0).all() and np.abs(env.state[1] - q_before).max() > 1e-4
+    assert len(env.contacts(1)) > 0
+    env.close()
+
+
+def test_batched_object_teleport_equals_the_per_object_calls():
+    N = 5
+    a = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    b = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    for e in (a, b):
+        for _ in range(20):
+            e.step(np.full((N, 9), 0.2, np.float32))
+    rng = np.random.default_rng(0)
+    poses = a.host(nat.F_OBJ_POSE)
+    mask = np.array([1, 0, 1, 1, 0], np.uint8)
+    for i in np.flatnonzero(mask):
+        for k in range(3):
+            poses[i, k] = [rng.uniform(-0.2, 0.0), rng.uniform(-0.3, 0.3), 0.4 + 0.1 * k, 0, 0, 0, 1]
+            a.set_object_pose(int(i), k, poses[i, k])
+    b.set_object_poses(poses, mask)
+    assert (a.state == b.state).all() and (a.host(nat.F_OBJ_POSE) == b.host(nat.F_OBJ_POSE)).all()
+    for e in (a, b):
+        e.step(None)
+    assert (a.state == b.state).all()
+    a.close()
+    b.close()
+
+
+def test_step_macro_with_none_actions_keeps_the_plan_position():
+    """step_macro with macro_action None: that env steps with zeros(9) and its plan does not advance (env.py:391-393)."""
+    N = 4
+    env = BatchedREALRobotEnv(N, objects=1, width=64, height=64)
+    ref = BatchedREALRobotEnv(N, objects=1, width=64, height=64)
+    m = np.tile(np.array([[-0.1, 0.2], [-0.2, -0.3]]), (N, 1, 1))
+    env.step_macro([None] * N)                         # nobody has a plan yet: zeros everywhere
+    ref.step(None)
+    assert (env.state == ref.state).all()
+    acts = [m[i] for i in range(N)]
+    for t in range(130):
+        env.step_macro(acts)
+        ref.step_macro(m)
+    assert (env.state == ref.state).all()
+    plan = env.get_plan(2)
+    acts[2] = None
+    env.step_macro(acts)                               # env 2 idles for one step ...
+    cmd = np.stack([plan[130]] * N)
+    cmd[2] = 0
+    ref.step(cmd.astype(np.float32))
+    assert (env.state == ref.state).all()
+    acts[2] = m[2]
+    env.step_macro(acts)                               # ... and resumes at the row it had reached
+    cmd = np.stack([plan[131]] * N)
+    cmd[2] = plan[130]
+    ref.step(cmd.astype(np.float32))
+    assert (env.state == ref.state).all()
+    env.close()
+    ref.close()

@@ -143,6 +143,23 @@ def test_goal_dataset_format_roundtrip(tmp_path):
     assert pickle.loads(pickle.dumps(g)).final_state['cube'].shape == (7,)
 
 
+def test_saved_goals_pickle_under_the_reference_module_path(tmp_path):
+    """A dataset written here must load where only the reference package exists: the Goal class pickles as
+    real_robots.envs.env.Goal (env.py:15-24; generate_goals.py:435-436), not under real_robots_amd."""
+    from real_robots_amd.envs.env import Goal
+    from real_robots_amd.generate_goals import save_goals
+    g = Goal(initial_state={'cube': np.arange(7.0)}, final_state={'cube': np.ones(7)}, retina=np.zeros((2, 2, 3), np.uint8),
+             challenge='2D', mask=np.zeros((2, 2), np.int32))
+    path = str(tmp_path / 'goals.npy')
+    save_goals(path, [g])
+    raw = pickle.dumps(g, protocol=2)
+    assert b'real_robots.envs.env' in raw and b'real_robots_amd' not in raw
+    arr = np.load(path + '.npz', allow_pickle=True)
+    assert list(arr.items())[0][1][0].challenge == '2D'
+    import real_robots.envs.env as ref_path
+    assert ref_path.Goal is Goal
+
+
 def test_spaces_standins():
     b = spaces.Box(low=np.zeros(3), high=np.ones(3), dtype=float)
     assert b.contains(b.sample()) and not b.contains(np.array([2.0, 0, 0]))
@@ -175,3 +192,29 @@ def test_shard_ranges_partition_and_actions_are_shard_invariant():
     assert (synthetic_actions(range(a, b), step=7) == full[a:b]).all()
     assert (synthetic_actions(range(16), step=8) == full).sum() > 0      # held
     assert not (synthetic_actions(range(16), step=60) == full).all()     # resampled
+
+
+def test_pybullet_harness_imports_without_pybullet_and_mirrors_the_protocol_constants():
+    """oracle/pybullet_ref.py is the route to `cpu_baseline.kind = "reference"` and to golden vectors from a real
+    PyBullet; here (no pybullet) it must import, report unavailable, refuse loudly -- and its protocol constants must be
+    the ones the compiled model carries."""
+    from oracle import pybullet_ref as pr
+    from real_robots_amd.model import load_model
+    m = load_model()
+    lo, hi = pr.joint_limits()
+    assert np.allclose(lo, m['act_min'], atol=1e-6) and np.allclose(hi, m['act_max'], atol=1e-6)
+    assert np.allclose(pr.MAX_DIFF, m['act_maxdiff'], atol=1e-7)
+    assert np.allclose(pr.ROBOT_POSITION, m['robot_pos'], atol=1e-7)
+    for k, name in enumerate(pr.OBJECTS):
+        assert np.allclose(pr.OBJECT_POSES[name][:3], m['obj_pose0'][k][:3], atol=1e-6)
+    assert len(pr.perimeter_pairs()) == 36 and pr.seeded_actions(3, 5).shape == (5, 9)
+    if not pr.available():
+        with pytest.raises(pr.PyBulletUnavailable):
+            pr.PyBulletRef()
+        with pytest.raises(pr.PyBulletUnavailable):
+            pr.cpu_baseline(seconds=0.1)
+    else:                                  # a box with pybullet: the harness must at least reset and step
+        ref = pr.PyBulletRef(1, 64, 64)
+        ref.step(np.zeros(9))
+        assert ref.state61().shape == (61,)
+        ref.close()

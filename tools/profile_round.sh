@@ -1,0 +1,49 @@
+#!/bin/bash
+# Collects a round's evidence on a GPU box (run through gpurun): the bench JSON (with cpu_baseline + secondary workloads),
+# rocprofv3 kernel stats, PMC HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes, never combined with other trace
+# domains), SQ VALU counters.  Output: gpurun_out/round/ ; traffic_latest.json and sq_latest.json carry the run
+# configuration so that bench.py only attaches them to runs of that configuration.  Usage: tools/profile_round.sh [tag]
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; mkdir -p $O
+cd $R && python bench.py --steps 200 --warmup 20 > $O/${TAG}_bench.json 2> $O/bench.err; tail -c 600 $O/${TAG}_bench.json
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --no-cpu-baseline --no-secondary"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- $B --steps 100 --warmup 10 > $O/stats_bench.log 2>&1
+cp $O/stats/run_kernel_stats.csv $O/${TAG}_kernel_stats.csv; head -12 $O/${TAG}_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o run -- $B --steps 20 --warmup 5 > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- $B --steps 20 --warmup 5 > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/sq -o run -- $B --steps 20 --warmup 5 > $O/sq.log 2>&1
+TAG=$TAG python3 - <<'PY'
+import csv, glob, os, json, collections
+R=os.environ['GRAFT_REPO_ROOT']; O=R+'/gpurun_out/round'; TAG=os.environ['TAG']
+cfg={"envs": 4096, "objects": 3, "width": 128, "height": 128, "render": True, "command_scale": 1.0, "solver_iters": 50}
+def means(d):
+    f=glob.glob(O+'/%s/*counter_collection.csv'%d)
+    acc=collections.defaultdict(list)
+    if not f: print('no counter csv in', d); return {}
+    for row in csv.DictReader(open(f[0])):
+        acc[(row['Kernel_Name'].split('(')[0], row['Counter_Name'])].append(float(row['Counter_Value']))
+    out={}
+    for (k,c),v in acc.items(): out.setdefault(k,{})[c]={'mean': sum(v)/len(v), 'n': len(v)}
+    return out
+fe, wr, sq = means('pmc_fetch'), means('pmc_write'), means('sq')
+json.dump({'fetch': fe, 'write': wr}, open(O+'/%s_pmc_summary.json'%TAG,'w'), indent=1)
+json.dump(sq, open(O+'/%s_sq_counters.json'%TAG,'w'), indent=1)
+# HBM bytes per launch: (2*FETCH_SIZE + WRITE_SIZE) KB (MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts half of wide coalesced reads)
+tr={}
+for k in set(fe)|set(wr):
+    f=fe.get(k,{}).get('FETCH_SIZE',{}).get('mean',0.0); w=wr.get(k,{}).get('WRITE_SIZE',{}).get('mean',0.0)
+    tr[k]=round((2*f+w)*1024)
+tr['render_stage']=tr.get('k_raster',0)+tr.get('k_shade',0)
+tr['k_prep']=tr.get('k_prep_a',0)+tr.get('k_prep_b',0)+tr.get('k_balance',0)
+tr['config']=cfg; tr['source']=TAG+'_pmc_summary.json'
+tr['_note']="HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), (2*FETCH_SIZE + WRITE_SIZE) * 1024; render_stage = k_raster + k_shade; only valid for `config`"
+json.dump(tr, open(O+'/traffic_latest.json','w'), indent=1)
+sv={'config': cfg, 'source': TAG+'_sq_counters.json', 'valu_wave_instr_per_launch': {k: round(v['SQ_INSTS_VALU']['mean']) for k,v in sq.items() if 'SQ_INSTS_VALU' in v}}
+json.dump(sv, open(O+'/sq_latest.json','w'), indent=1)
+for k in ('k_raster','k_shade','k_solve','k_collide','k_prep_a','k_prep_b','k_render_setup'):
+    r={c: x['mean'] for c,x in sq.get(k,{}).items()}
+    if not r: continue
+    wc=r.get('SQ_WAVE_CYCLES',0) or 1
+    print(k, 'traffic MB %.1f'%(tr.get(k,0)/1e6), 'VALU wave-instr %.3g'%r.get('SQ_INSTS_VALU',0), 'VALU active/wave-cycle %.3f wait_any %.3f'%(r.get('SQ_ACTIVE_INST_VALU',0)/wc, r.get('SQ_WAIT_ANY',0)/wc))
+PY
