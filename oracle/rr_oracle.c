@@ -24,7 +24,7 @@
 #define NB RRO_NB
 #define NOBJ RRO_NOBJ
 #define MAXC RRO_MAXC
-#define NROWS (3 * NB + 3 * MAXC)
+#define NROWS (3 * NB + 6 * MAXC)
 #define NDOF (NB + 6 * NOBJ)
 
 #ifdef RR_FLOAT
@@ -74,8 +74,8 @@ static const uint8_t *blob_u8(const void *blob, const char *name) {
 
 /* ------------------------------------------------------------------------------------------- model */
 #define MAXSHAPES 32
-#define VMAXC 32
-#define FMAXC 32
+#define VMAXC 192
+#define FMAXC 192
 #define MAXINST 32
 #define MAXLINKS 24
 
@@ -89,7 +89,7 @@ typedef struct {
     int sh_otype[MAXSHAPES], sh_oidx[MAXSHAPES], sh_link[MAXSHAPES], sh_uid[MAXSHAPES];
     int sh_nv[MAXSHAPES], sh_nf[MAXSHAPES];
     real sh_verts[MAXSHAPES][VMAXC][3], sh_planes[MAXSHAPES][FMAXC][4], sh_sphere[MAXSHAPES][4];
-    real sh_fric[MAXSHAPES], sh_rest[MAXSHAPES];
+    real sh_fric[MAXSHAPES], sh_rest[MAXSHAPES], sh_roll[MAXSHAPES], sh_spin[MAXSHAPES];
     int touch_links[4];
     int link_body[MAXLINKS];
     real link_pos[MAXLINKS][3], link_rot[MAXLINKS][9];
@@ -106,6 +106,7 @@ typedef struct {
     int bodyA, bodyB;   /* -1 static, 0..10 robot body, 16+i object i.  normal points from B to A */
     int linkA;          /* robot link id of the robot-side shape (or -1) */
     real x[3], n[3], dist, mu, rest;
+    real roll, spin;    /* combined rolling / spinning friction coefficients */
     real lambda_n;
 } contact_t;
 
@@ -274,6 +275,8 @@ rr_oracle *rro_create(const void *blob_in, size_t nbytes, int n_objects, int wid
     cpy_f(&m->sh_sphere[0][0], blob_f32(blob, "shape_sphere"), m->ns * 4);
     const float *sm = blob_f32(blob, "shape_mat");
     for (int s = 0; s < m->ns; s++) { m->sh_fric[s] = sm[2 * s]; m->sh_rest[s] = sm[2 * s + 1]; }
+    const float *sr = blob_f32(blob, "shape_roll");
+    for (int s = 0; s < m->ns; s++) { m->sh_roll[s] = sr[2 * s]; m->sh_spin[s] = sr[2 * s + 1]; }
     memcpy(m->touch_links, blob_i32(blob, "touch_links"), sizeof(int) * 4);
     memcpy(m->link_body, blob_i32(blob, "link_body"), sizeof(int) * m->nl);
     cpy_f(&m->link_pos[0][0], blob_f32(blob, "link_pos"), m->nl * 3);
@@ -481,6 +484,7 @@ static int shape_body(const model_t *m, int s) {
 }
 
 typedef struct { real x[3], n[3], s; } cand_t;
+#define CAND_MAX 128   /* candidates kept per pair, in candidate order (the device kernel has the same cap) */
 
 /* vertices of shape sa tested against the planes of shape sb. Appends candidates with normal pointing
  * from sb towards sa, multiplied by `sign` (so callers can keep the B->A convention). */
@@ -501,7 +505,7 @@ static int verts_in_planes(const rr_oracle *o, int sa, const xform_t *Xa, int sb
             real s = pl[0] * xl[0] + pl[1] * xl[1] + pl[2] * xl[2] - pl[3];
             if (s > best) { best = s; bf = f; }
         }
-        if (best < margin) {
+        if (best < margin && n < CAND_MAX) {
             real nw[3];
             m3_mulv(nw, Xb->R, m->sh_planes[sb][bf]);
             cand_t *c = &out[n++];
@@ -517,15 +521,30 @@ static int verts_in_planes(const rr_oracle *o, int sa, const xform_t *Xa, int sb
 }
 
 /* Manifold reduction to <= 4 points: deepest point first, then the three points that spread the manifold most
- * (farthest from the first, farthest from that line, farthest on the other side of it). Candidates within
+ * (farthest from the first, farthest from that line, farthest on the other side of it). "Deepest" is taken with a
+ * tolerance (TIE_TOL, see below). Candidates within
  * TIER_TOL of the deepest penetration ("tier 1": the features actually touching) are preferred at every pick;
  * the remaining speculative candidates are only used when tier 1 has no admissible point. */
 #define TIER_TOL ((real)0.001)
+#define TIE_TOL ((real)0.0005)
 static int reduce4(const cand_t *c, int n, int *sel) {
     if (n <= 4) { for (int i = 0; i < n; i++) sel[i] = i; return n; }
     int k0 = 0;
     for (int i = 1; i < n; i++) if (c[i].s < c[k0].s) k0 = i;
     real lim = c[k0].s + TIER_TOL;
+    /* the anchor of the manifold: the deepest candidate, with a tolerance TIE_TOL on "deepest" -- an
+     * object resting flat has a whole face within a fraction of a millimetre of the deepest vertex; anchoring on "the"
+     * deepest one would pick another quadruple of the face's vertices whenever the object rocks by a micro-radian, and
+     * without persistent manifolds that alone keeps a bevelled cube rocking for ever */
+    {   /* among the tied candidates the extreme one along a fixed skew direction: a corner of the face, so that the
+         * farthest-point picks below return the face's other corners */
+        real tl = c[k0].s + TIE_TOL, bestf = (real)-3.0e38;
+        for (int i = 0; i < n; i++) {
+            if (!(c[i].s < tl)) continue;
+            real f = c[i].x[0] + (real)0.618 * c[i].x[1] + (real)0.382 * c[i].x[2];
+            if (f > bestf) { bestf = f; k0 = i; }
+        }
+    }
     int k1 = -1, k2 = -1, k3 = -1;
     real e[3] = {0, 0, 0}, cr2[3] = {0, 0, 0};
     for (int tier = 0; tier < 2 && k1 < 0; tier++) {
@@ -572,7 +591,7 @@ static void collide_pair(rr_oracle *o, int sa, int sb, const xform_t *X) {
     v3_sub(d, ca, cb);
     real rr = m->sh_sphere[sa][3] + m->sh_sphere[sb][3] + (real)o->p.margin;
     if (v3_dot(d, d) > rr * rr) return;
-    cand_t cand[2 * VMAXC];
+    cand_t cand[CAND_MAX];
     int n = 0;
     n = verts_in_planes(o, sa, Xa, sb, Xb, (real)1, cand, n);   /* A's vertices in B: normal B->A */
     n = verts_in_planes(o, sb, Xb, sa, Xa, (real)-1, cand, n);  /* B's vertices in A: normal A->B, flipped */
@@ -589,6 +608,13 @@ static void collide_pair(rr_oracle *o, int sa, int sb, const xform_t *X) {
         c->dist = cand[sel[i]].s;
         c->mu = m->sh_fric[sa] * m->sh_fric[sb];
         c->rest = m->sh_rest[sa] * m->sh_rest[sb];
+        /* btManifoldResult::calculateCombinedRollingFriction / SpinningFriction: r_a mu_b + r_b mu_a, clamped to 10
+         * (URDF <rolling_friction>, <spinning_friction>: cube.urdf:6-7, tomato.urdf:6-7, mustard.urdf:6-7,
+         * kuka_gripper.urdf:292-296 ...) */
+        c->roll = m->sh_roll[sa] * m->sh_fric[sb] + m->sh_roll[sb] * m->sh_fric[sa];
+        c->spin = m->sh_spin[sa] * m->sh_fric[sb] + m->sh_spin[sb] * m->sh_fric[sa];
+        if (c->roll > 10) c->roll = 10;
+        if (c->spin > 10) c->spin = 10;
         c->lambda_n = 0;
     }
 }
@@ -679,6 +705,48 @@ static real build_row(const rr_oracle *o, row_t *r, const contact_t *c, const re
             v3_copy(MA, mang);
             diag += v3_dot(L, ML) + v3_dot(A, MA);
             rel += v3_dot(L, ovs[ob]) + v3_dot(A, ows[ob]);
+        }
+    }
+    r->dinv = diag > 0 ? 1 / diag : 0;
+    return rel;
+}
+
+/* Torsional friction row (btMultiBodyConstraintSolver::setupMultiBodyTorsionalFrictionConstraint): a purely angular
+ * Jacobian about `axis` -- joint j contributes axis_j . axis for the ancestors of the robot link, a free object
+ * (0, +-axis).  Returns the relative angular velocity A - B about the axis. */
+static real build_row_torsional(const rr_oracle *o, row_t *r, const contact_t *c, const real *axis, const real Minv[NB][NB],
+                                const real *qdstar, real ows[NOBJ][3], real oIinv[NOBJ][9]) {
+    const model_t *m = &o->m;
+    memset(r, 0, sizeof *r);
+    r->bodyA = c->bodyA; r->bodyB = c->bodyB;
+    r->normal_row = -1;
+    real diag = 0, rel = 0;
+    for (int side = 0; side < 2; side++) {
+        int body = side == 0 ? c->bodyA : c->bodyB;
+        real sg = side == 0 ? (real)1 : (real)-1;
+        if (body < 0) continue;
+        if (body < 16) {
+            int k = body;
+            while (k >= 0) {
+                r->Ja[k] = sg * v3_dot(axis, o->baxis[k]);
+                k = m->parent[k];
+            }
+            for (int i = 0; i < NB; i++) {
+                real s = 0;
+                for (int j = 0; j < NB; j++) s += Minv[i][j] * r->Ja[j];
+                r->MJa[i] = s;
+            }
+            for (int i = 0; i < NB; i++) { diag += r->Ja[i] * r->MJa[i]; rel += r->Ja[i] * qdstar[i]; }
+        } else {
+            int ob = body - 16;
+            real ang[3], mang[3];
+            v3_scale(ang, axis, sg);
+            m3_mulv(mang, oIinv[ob], ang);
+            real *A = side == 0 ? r->aa : r->ab, *MA = side == 0 ? r->maa : r->mab;
+            v3_copy(A, ang);
+            v3_copy(MA, mang);
+            diag += v3_dot(A, MA);
+            rel += v3_dot(A, ows[ob]);
         }
     }
     r->dinv = diag > 0 ? 1 / diag : 0;
@@ -782,6 +850,24 @@ static void solve_and_integrate(rr_oracle *o) {
         }
     }
     (void)first_fric;
+    /* torsional friction rows, after the lateral friction rows (Bullet keeps them in a list of their own, swept after the
+     * friction list): per contact one spinning row about the normal when the combined spinning coefficient is positive
+     * and two rolling rows about the tangents when the combined rolling coefficient is; bounds +- coefficient x normal
+     * impulse, velocity target zero */
+    for (int c = 0; c < o->ncontacts; c++) {
+        contact_t *ct = &o->contacts[c];
+        real t1[3], t2[3];
+        plane_space(ct->n, t1, t2);
+        for (int k = 0; k < 3; k++) {
+            real coef = k == 0 ? ct->spin : ct->roll;
+            if (!(coef > 0)) continue;
+            row_t *r = &rows[nr++];
+            real rel = build_row_torsional(o, r, ct, k == 0 ? ct->n : (k == 1 ? t1 : t2), Minv, qds, ows, oIinv);
+            r->rhs = -rel * r->dinv;
+            r->normal_row = first_normal + c;
+            r->mu = coef;
+        }
+    }
     /* projected Gauss-Seidel on velocity deltas */
     real dq[NB], dv[NOBJ][3], dw[NOBJ][3];
     memset(dq, 0, sizeof dq); memset(dv, 0, sizeof dv); memset(dw, 0, sizeof dw);

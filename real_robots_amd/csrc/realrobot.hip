@@ -8,8 +8,6 @@
 //   k_prep_b        1 thread / env : joint-space mass matrix (composite rigid bodies), bias (RNEA), Cholesky, M^-1,
 //                                    unconstrained joint velocities -- side stream, beside k_collide
 //   k_collide       1 wavefront / env: bounding spheres -> pair list -> lane-per-vertex convex tests -> <=4 points/pair
-//   k_balance       1 workgroup    : env -> solver group order (envs with many contacts dealt out over the solver
-//                                    workgroups) -- side stream, beside k_collide
 //   k_solve         16 lanes / env : row assembly (motors, joint limits, contact normal + 2 friction), PGS with the
 //                                    common rows in registers and the others streamed from a per-workgroup LDS row
 //                                    pool, semi-implicit Euler, touch sensors, observation pack (robot.py:152-163,203-211)
@@ -39,11 +37,10 @@
 #define MAXC 48
 #define NLINK_MAX 24
 #define MAXSHAPES 32
-#define VMAXC 32
-#define FMAXC 32
+#define VMAXC 192        // caps of collision vertices / planes per shape (tools/compile_model.py stops earlier at 0.3 mm)
+#define FMAXC 192
 #define MAXINST 32
 #define MAXPAIRS 96
-#define ROWF 40          // floats per contact row in scratch
 #define NSTATE 61
 
 // ---------------------------------------------------------------------------------------------- error handling
@@ -67,7 +64,7 @@ struct BodyParams {   // passed by value as kernel argument -> scalar loads, uni
 };
 
 struct SimParams {
-    int N, nobj, iters, npairs, ablate, small_area, par, pool;   // pool: floats of a solver workgroup's LDS row pool (<= SPOOL)    // par: step parity (double-buffered per-env contact demand)
+    int N, nobj, iters, npairs, ablate, small_area, os_cap;   // os_cap: object-vs-static contacts per env with rows in LDS (<= OS_CAP)
     float dt, gravity, erp, margin, kp, kd, max_impulse, lin_damp, ang_damp, rest_thresh;
 };
 
@@ -76,10 +73,10 @@ struct ShapeData {    // global memory, read uniformly
     float verts[MAXSHAPES][VMAXC][3];
     float planes[MAXSHAPES][FMAXC][4];
     float sphere[MAXSHAPES][4];
-    float fric[MAXSHAPES], rest[MAXSHAPES];
+    float fric[MAXSHAPES], rest[MAXSHAPES], roll[MAXSHAPES], spin[MAXSHAPES];
     int pair_a[MAXPAIRS], pair_b[MAXPAIRS];
     int pair_meta[MAXPAIRS][4];      // {bodyA, bodyB, link of shape a, 0}: body = -1 static, 0..15 robot body, 16+i object i
-    float pair_mat[MAXPAIRS][2];     // {friction, restitution} products of the two shapes
+    float pair_mat[MAXPAIRS][4];     // {friction, restitution} products of the two shapes, combined {rolling, spinning} friction
 };
 
 struct RenderModel {
@@ -106,9 +103,7 @@ enum {
     S_OVS = S_OIINV + 27,        // 9
     S_OWS = S_OVS + 9,           // 9
     S_PCOUNT = S_OWS + 9,        // MAXPAIRS (int)
-    S_ROWS = S_PCOUNT + MAXPAIRS,            // 3*MAXC*ROWF
-    S_RMETA = S_ROWS + 3 * MAXC * ROWF,      // MAXC (int: bodyA | bodyB<<8 | linkA<<16)
-    S_CT = S_RMETA + MAXC,                   // MAXC*12 (contact records for the API)
+    S_CT = S_PCOUNT + MAXPAIRS,              // MAXC*12 (contact records for the API)
     S_NCT = S_CT + MAXC * 12,                // 1 (int)
     S_MOT = S_NCT + 1,                       // 11 x {rhs, dinv, lambda}
     S_LIM = S_MOT + 33,                      // 22 x {rhs, lambda}
@@ -129,8 +124,7 @@ struct DevPtrs {
     int *timestep;     // [N]
     unsigned *errflags;// [N]
     float *obj_home;   // [NOBJ*7][N] per-env pose an object is put back to by reset / the out-of-bounds rule (robot.py:19-24, mutable there)
-    unsigned *demand;  // [2][N] candidate contacts of the env: all | robot involved << 8 | object-object << 16, written by k_collide
-    int *solve_order;  // [4 * ceil(N / 4)] env handled by each 16-lane group of k_solve (-1: none), written by k_balance
+    float4 *grows;     // [N * 6 MAXC + 1][16] generic solver rows in the slot layout {J_A, MJ_A, J_B, MJ_B} per lane; the last row is all zero
     float *cmd;        // [N][9]
     float *joints;     // [N][9]
     float *touch;      // [N][4]
@@ -571,17 +565,27 @@ extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
 #endif
 
 // ---- collision: one wavefront per env ------------------------------------------------------------------------------
-// The narrow phase of a pair is ~2 x 32 vertices against ~32 planes plus a manifold reduction: as a per-thread loop it is
-// a chain of ~20k dependent instructions and, with only three or four close pairs per env, a kernel built that way is
-// as slow as that chain.  Here a wavefront owns an env:
+// Every collision shape is the convex hull of its OBJ reduced to <= 192 vertices and <= 192 facet planes
+// (deviation from the full hull < 1 mm, tests/test_oracle_pins.py).  A contact candidate is a vertex of one shape whose
+// largest signed distance to the planes of the other is below the margin; <= 4 points per pair are kept.  A wavefront
+// owns an env:
 //   1. lanes 0..ns-1 load the transform of "their" shape and its world bounding-sphere centre into LDS (one round trip);
 //   2. the pairs are sphere-tested 64 at a time, survivors are collected with ballots;
-//   3. every surviving pair is handled by the whole wave: lanes 0..31 test the vertices of shape a against the planes
-//      of shape b (direction 0), lanes 32..63 the vertices of b against the planes of a (direction 1).
-// Candidate order (direction 0 by vertex index, then direction 1) equals lane order, so the "first best wins"
-// selections of the oracle's reduce4() become wave reductions with lowest-lane tie-breaks -- results are identical
-// to the serial formulation.  No atomics, no work list: results do not depend on scheduling.
+//   3. every surviving pair is handled by the whole wave, direction 0 (vertices of a against the planes of b) and then
+//      direction 1 (b against a):
+//        a. exact cull -- the bounding sphere of "mine" beyond one plane of "other" by more than the margin: nothing;
+//        b. the planes of "other" are staged in LDS; lane = vertex, 64 at a time: a vertex that is beyond one of the first
+//           six planes (the shape's extreme facets along +-x, +-y, +-z) by the margin cannot be a candidate and is dropped
+//           (exact: the candidate test is a maximum over ALL planes of the very same values); survivors are compacted,
+//           in vertex order, into an LDS list;
+//        c. lane = survivor: maximum over all planes (first maximum wins), candidates appended to the pair's list.
+//   4. manifold reduction over the candidate list (direction 0 by vertex index, then direction 1 -- the oracle's order):
+//      the "first best wins" selections of the oracle's reduce4() are wave reductions with lowest-index tie-breaks.
+// The whole kernel is contraction-free (see "contraction-free twins"): results are bit-identical to the oracle's float
+// build.  No atomics, no work list: results do not depend on scheduling.
 #define COLLIDE_THREADS 64
+#define NPREF 6          // leading planes of every shape used by the prefilter (tools/compile_model.py orders them)
+#define CAND_MAX 128     // candidates kept per pair (the oracle applies the same cap)
 #ifdef RR_RASTER_STATS
 #define CABL(bit) (P.ablate & (bit))      // development build: phase ablations (256 stage only, 512 no pairs, 1024 cull only)
 #else
@@ -605,12 +609,6 @@ __device__ __forceinline__ float wave_max(float m) {
     const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 48));
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
-__device__ __forceinline__ int wave_argmax_first(float v, bool ok, float floor_) {
-    const float m = wave_max(ok ? v : -3.0e38f);
-    if (!(m > floor_)) return -1;
-    const unsigned long long b = __ballot(ok && v == m);
-    return b ? __ffsll((long long)b) - 1 : -1;
-}
 // value of lane src (wave-uniform) in every lane
 __device__ __forceinline__ float lane_f(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
@@ -619,8 +617,28 @@ __device__ __forceinline__ float lane_f(float v, int src) {
 // the workgroup is a single wavefront: LDS traffic is ordered per wave, so a compiler-level fence replaces s_barrier
 #define CSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 static_assert(COLLIDE_THREADS == 64, "k_collide synchronises with wave-level fences");
+static_assert(VMAXC % 64 == 0 && FMAXC % 64 == 0 && VMAXC < 256 && FMAXC < 256, "vertex / plane passes of 64, counts packed in bytes");
 // (the whole kernel is contraction-free and uses the nc:: helpers: see "contraction-free twins" above)
 #pragma clang fp contract(off)
+// index of the first maximum of val(i) over the candidates i < n with ok(i), or -1 when there is none above `floor_`;
+// candidates are visited 64 at a time, a later chunk only replaces the winner when it is strictly greater
+#define CAND_ARGMAX(RESULT, FLOOR, OKEXPR, VALEXPR)                                                   \
+    {                                                                                                 \
+        float bestv_ = (FLOOR); int besti_ = -1;                                                      \
+        for (int c0_ = 0; c0_ < ncand; c0_ += 64) {                                                   \
+            const int ci = c0_ + lane;                                                                \
+            const bool in_ = ci < ncand;                                                              \
+            const float4 ca = cand_a[in_ ? ci : 0];                                                   \
+            const bool ok_ = in_ && (OKEXPR);                                                         \
+            const float val_ = (VALEXPR);                                                             \
+            const float m_ = wave_max(ok_ ? val_ : -3.0e38f);                                         \
+            if (m_ > bestv_) {                                                                        \
+                const unsigned long long bb_ = __ballot(ok_ && val_ == m_);                           \
+                if (bb_) { bestv_ = m_; besti_ = c0_ + __ffsll((long long)bb_) - 1; }                 \
+            }                                                                                         \
+        }                                                                                             \
+        RESULT = besti_;                                                                              \
+    }
 __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtrs D, int ns) {
     const int N = P.N;
     const int env = blockIdx.x;
@@ -630,16 +648,19 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
     const ShapeData *S = D.shapes;
     __shared__ float xf[MAXSHAPES][12];        // R (row-major 9), p (3) of every shape's owner
     __shared__ float4 sph[MAXSHAPES];          // world bounding sphere
-    __shared__ float4 planes[2][FMAXC];
+    __shared__ float4 planes[FMAXC];           // planes of "other" in the current direction
+    __shared__ float surv[VMAXC][3];           // world position of the vertices that survive the prefilter, in vertex order
+    __shared__ float4 cand_a[CAND_MAX];        // candidates of the pair: contact point, signed distance
+    __shared__ float4 cand_b[CAND_MAX];        //                         normal (B -> A)
     __shared__ int pair_ab[MAXPAIRS];          // shape a | shape b << 8 of every pair   } staged once: no global load of
     __shared__ int shape_n[MAXSHAPES];         // vertex count | plane count << 8        } metadata inside the pair loop
     const int lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int pr = lane; pr < P.npairs; pr += COLLIDE_THREADS) {
         const int ba = S->pair_meta[pr][0], bb = S->pair_meta[pr][1];
         const int cls = (((ba >= 0 && ba < 16) || (bb >= 0 && bb < 16)) ? 1 : 0) | ((ba >= 16 && bb >= 16) ? 2 : 0);
         pair_ab[pr] = S->pair_a[pr] | (S->pair_b[pr] << 8) | (cls << 16);      // + robot involved (bit 16), object-object (bit 17)
     }
-    int d_all = 0, d_rob = 0, d_oo = 0;        // candidate contacts of this env (wave-uniform), for k_balance
     if (lane < ns) {
         shape_n[lane] = S->nv[lane] | (S->nf[lane] << 8);
         const Xf X = load_xf(S, lane, state, scratch, N, env);
@@ -660,126 +681,145 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
             close = !(dx * dx + dy * dy + dz * dz > rr * rr);
             *(int *)&SCR(S_PCOUNT + pr) = 0;
         }
-        const int dirflag = lane >> 5, v = lane & 31;
         unsigned long long todo = CABL(512) ? 0ull : __ballot(close);
-        // plane (lane & 31) of the "other" shape of this lane's direction; the planes of the next pair are fetched while
-        // the current one is processed
-        float4 nextpl = make_float4(0, 0, 0, 0);
-        float nvx = 0, nvy = 0, nvz = 0;       // vertex v of "mine", fetched one pair ahead as well
-        if (todo) {
-            const int pn = p0 + __ffsll((long long)todo) - 1;
-            const int pa = pair_ab[pn] & 255, pb = (pair_ab[pn] >> 8) & 255;
-            nextpl = *(const float4 *)S->planes[dirflag ? pa : pb][v];
-            const float *vp = S->verts[dirflag ? pb : pa][v];
-            nvx = vp[0]; nvy = vp[1]; nvz = vp[2];
-        }
         for (; todo; todo &= todo - 1) {
             const int pair = p0 + __ffsll((long long)todo) - 1;
             const int sa = pair_ab[pair] & 255, sb = (pair_ab[pair] >> 8) & 255;
-            // "mine" = the shape whose vertex this lane tests, "other" = the shape whose planes it is tested against
-            const int sm = dirflag ? sb : sa, so = dirflag ? sa : sb;
-            const float4 mypl = nextpl;     // plane v of "other"
-            const float mvx = nvx, mvy = nvy, mvz = nvz;
-            {
-                const unsigned long long rest = todo & (todo - 1);
-                if (rest) {
-                    const int pn = p0 + __ffsll((long long)rest) - 1;
-                    const int pa = pair_ab[pn] & 255, pb = (pair_ab[pn] >> 8) & 255;
-                    nextpl = *(const float4 *)S->planes[dirflag ? pa : pb][v];
-                    const float *vp = S->verts[dirflag ? pb : pa][v];
-                    nvx = vp[0]; nvy = vp[1]; nvz = vp[2];
-                }
-            }
-            Xf Xm, Xo;
+            int ncand = 0;                      // wave-uniform
+            for (int dirflag = 0; dirflag < 2; dirflag++) {
+                // "mine" = the shape whose vertices are tested, "other" = the shape whose planes they are tested against
+                const int sm = dirflag ? sb : sa, so = dirflag ? sa : sb;
+                Xf Xm, Xo;
 #pragma unroll
-            for (int kk = 0; kk < 9; kk++) { Xm.R.m[kk] = xf[sm][kk]; Xo.R.m[kk] = xf[so][kk]; }
-            Xm.p = mk(xf[sm][9], xf[sm][10], xf[sm][11]);
-            Xo.p = mk(xf[so][9], xf[so][10], xf[so][11]);
-            const int nv = shape_n[sm] & 255, nf = shape_n[so] >> 8;
-            {   // exact cull: when the bounding sphere of "mine" lies beyond one plane of "other" by more than the margin, no
-                // vertex of "mine" can be a candidate; with that true for both directions the pair has no contact.
-                // Evaluated on the plane each lane already holds in a register, before anything is staged in LDS.
-                const float4 cm = sph[sm];
-                const v3 cl = nc::tmulv(Xo.R, nc::sub(mk(cm.x, cm.y, cm.z), Xo.p));
-                const bool sep = v < nf && mypl.x * cl.x + mypl.y * cl.y + mypl.z * cl.z - mypl.w > cm.w + P.margin;
-                const unsigned long long sb_ = __ballot(sep);
-                if ((sb_ & 0xffffffffull) && (sb_ >> 32)) continue;        // S_PCOUNT is already 0
+                for (int kk = 0; kk < 9; kk++) { Xm.R.m[kk] = xf[sm][kk]; Xo.R.m[kk] = xf[so][kk]; }
+                Xm.p = mk(xf[sm][9], xf[sm][10], xf[sm][11]);
+                Xo.p = mk(xf[so][9], xf[so][10], xf[so][11]);
+                const int nv = shape_n[sm] & 255, nf = shape_n[so] >> 8;
+                CSYNC();            // the previous direction's reads of planes / surv are done
+                bool sep = false;
+                {   // a. exact cull + b. plane staging (lane = plane)
+                    const float4 cm = sph[sm];
+                    const v3 cl = nc::tmulv(Xo.R, nc::sub(mk(cm.x, cm.y, cm.z), Xo.p));
+                    for (int f = lane; f < nf; f += 64) {
+                        const float4 pl = *(const float4 *)S->planes[so][f];
+                        planes[f] = pl;
+                        sep = sep || (pl.x * cl.x + pl.y * cl.y + pl.z * cl.z - pl.w > cm.w + P.margin);
+                    }
+                }
+                if (__ballot(sep)) continue;
+                if (CABL(1024)) continue;
+                CSYNC();
+                const int npre = min(NPREF, nf);
+                int nsurv = 0;                  // wave-uniform
+                for (int v0 = 0; v0 < nv; v0 += 64) {
+                    const int v = v0 + lane;
+                    bool keep = false;
+                    v3 xw = mk(0, 0, 0);
+                    if (v < nv) {
+                        const float *vp = S->verts[sm][v];
+                        xw = nc::add(nc::mulv(Xm.R, mk(vp[0], vp[1], vp[2])), Xm.p);
+                        const v3 xl = nc::tmulv(Xo.R, nc::sub(xw, Xo.p));
+                        float best = -1e30f;
+                        for (int f = 0; f < npre; f++) {
+                            const float4 pl = planes[f];
+                            const float sd = pl.x * xl.x + pl.y * xl.y + pl.z * xl.z - pl.w;
+                            best = fmaxf(best, sd);
+                        }
+                        keep = best < P.margin;
+                    }
+                    const unsigned long long km = __ballot(keep);
+                    if (keep) {
+                        const int pos = nsurv + __popcll(km & lt_mask);
+                        surv[pos][0] = xw.x; surv[pos][1] = xw.y; surv[pos][2] = xw.z;
+                    }
+                    nsurv += __popcll(km);
+                }
+                if (nsurv == 0) continue;
+                CSYNC();
+                for (int k0 = 0; k0 < nsurv; k0 += 64) {
+                    const int k = k0 + lane;
+                    bool hit = false;
+                    float cx = 0, cy = 0, cz = 0, cs = 0;
+                    v3 nw = mk(0, 0, 0);
+                    if (k < nsurv) {
+                        const v3 xw = mk(surv[k][0], surv[k][1], surv[k][2]);
+                        const v3 xl = nc::tmulv(Xo.R, nc::sub(xw, Xo.p));
+                        float best = -1e30f;
+                        int bf = 0;
+                        for (int f = 0; f < nf; f++) {
+                            const float4 pl = planes[f];
+                            const float sd = pl.x * xl.x + pl.y * xl.y + pl.z * xl.z - pl.w;
+                            if (sd > best) { best = sd; bf = f; }
+                        }
+                        if (best < P.margin) {
+                            const float4 pl = planes[bf];
+                            nw = nc::mulv(Xo.R, mk(pl.x, pl.y, pl.z));
+                            cx = xw.x - 0.5f * best * nw.x; cy = xw.y - 0.5f * best * nw.y; cz = xw.z - 0.5f * best * nw.z;
+                            cs = best;
+                            if (dirflag) nw = nc::scale(nw, -1.0f);
+                            hit = true;
+                        }
+                    }
+                    const unsigned long long hm = __ballot(hit);
+                    const int pos = ncand + __popcll(hm & lt_mask);
+                    if (hit && pos < CAND_MAX) {
+                        cand_a[pos] = make_float4(cx, cy, cz, cs);
+                        cand_b[pos] = make_float4(nw.x, nw.y, nw.z, 0.0f);
+                    }
+                    ncand = min(ncand + __popcll(hm), CAND_MAX);
+                }
             }
-            if (CABL(1024)) continue;
-            CSYNC();        // previous item's plane reads are done
-            planes[dirflag][v] = mypl;
+            if (ncand == 0) continue;           // S_PCOUNT is already 0
             CSYNC();
-            bool hit = false;
-            float cx = 0, cy = 0, cz = 0, cs = 0;
-            int bf = 0;
-            if (v < nv) {
-                const v3 xw = nc::add(nc::mulv(Xm.R, mk(mvx, mvy, mvz)), Xm.p);
-                const v3 xl = nc::tmulv(Xo.R, nc::sub(xw, Xo.p));
-                float best = -1e30f;
-                // all FMAXC slots: padded planes are (0, 0, 0, 1e9), i.e. sd = -1e9, and never win against a real plane
-#pragma unroll 8
-                for (int f = 0; f < FMAXC; f++) {
-                    const float4 pl = planes[dirflag][f];
-                    const float sd = pl.x * xl.x + pl.y * xl.y + pl.z * xl.z - pl.w;
-                    if (sd > best) { best = sd; bf = f; }
-                }
-                if (best < P.margin) {
-                    const float4 pl = planes[dirflag][bf];
-                    const v3 nw = nc::mulv(Xo.R, mk(pl.x, pl.y, pl.z));
-                    cx = xw.x - 0.5f * best * nw.x; cy = xw.y - 0.5f * best * nw.y; cz = xw.z - 0.5f * best * nw.z;
-                    cs = best;
-                    hit = true;
-                }
-            }
-            const unsigned long long hmask = __ballot(hit);
-            if (CABL(2048)) { if (hmask == 0x123456789ull) *(int *)&SCR(S_PCOUNT + pair) = 1; continue; }
-            const int n = __popcll(hmask);
+            if (CABL(2048)) { if (ncand == 12345) *(int *)&SCR(S_PCOUNT + pair) = 1; continue; }
             // manifold reduction, same rule as the oracle's reduce4(): deepest first, then maximal spread, preferring the
             // candidates within TIER_TOL (1 mm) of the deepest penetration at every pick; ties go to the first candidate
             int sel0 = -1, sel1 = -1, sel2 = -1, sel3 = -1, k = 0;
-            if (n <= 4) {
-                unsigned long long r = hmask;
-                if (r) { sel0 = __ffsll((long long)r) - 1; r &= r - 1; k = 1; }
-                if (r) { sel1 = __ffsll((long long)r) - 1; r &= r - 1; k = 2; }
-                if (r) { sel2 = __ffsll((long long)r) - 1; r &= r - 1; k = 3; }
-                if (r) { sel3 = __ffsll((long long)r) - 1; k = 4; }
+            if (ncand <= 4) {
+                sel0 = 0; sel1 = ncand > 1 ? 1 : -1; sel2 = ncand > 2 ? 2 : -1; sel3 = ncand > 3 ? 3 : -1;
+                k = ncand;
             } else {
-                sel0 = wave_argmax_first(-cs, hit, -3.0e38f);         // smallest s, first one
-                const float sbest = lane_f(cs, sel0);
-                const float lim = sbest + 0.001f;
-                const v3 x0 = mk(lane_f(cx, sel0), lane_f(cy, sel0), lane_f(cz, sel0));
-                const v3 dd = nc::sub(mk(cx, cy, cz), x0);
-                const float v1 = nc::dot(dd, dd);
-                const bool t0 = cs < lim;
-                sel1 = wave_argmax_first(v1, hit && lane != sel0 && t0, -1.0f);
-                if (sel1 < 0) sel1 = wave_argmax_first(v1, hit && lane != sel0, -1.0f);
-                const v3 e = nc::sub(mk(lane_f(cx, sel1), lane_f(cy, sel1), lane_f(cz, sel1)), x0);
-                const v3 cr = nc::cross(dd, e);
-                const float v2 = nc::dot(cr, cr);
-                sel2 = wave_argmax_first(v2, hit && lane != sel0 && lane != sel1 && t0, -1.0f);
-                if (sel2 < 0) sel2 = wave_argmax_first(v2, hit && lane != sel0 && lane != sel1, -1.0f);
-                const v3 cr2 = mk(lane_f(cr.x, sel2), lane_f(cr.y, sel2), lane_f(cr.z, sel2));
-                const float v3_ = -nc::dot(cr, cr2);
-                const bool o3 = hit && lane != sel0 && lane != sel1 && lane != sel2;
-                sel3 = wave_argmax_first(v3_, o3 && t0, 0.0f);
-                if (sel3 < 0) sel3 = wave_argmax_first(v3_, o3, 0.0f);
+                CAND_ARGMAX(sel0, -3.0e38f, true, -ca.w)                       // smallest s, first one
+                const float smin = cand_a[sel0].w, lim = smin + 0.001f, tie = smin + 0.0005f;
+                // anchor = a candidate within TIE_TOL (0.5 mm) of the deepest (oracle reduce4(): a resting face must give
+                // the same quadruple whichever of its vertices happens to be deepest by a micrometre)
+                // -- and among those the extreme one along a fixed skew direction, i.e. a corner of the face
+                CAND_ARGMAX(sel0, -3.0e38f, ca.w < tie, ca.x + 0.618f * ca.y + 0.382f * ca.z)
+                const float4 c0 = cand_a[sel0];
+                const v3 x0 = mk(c0.x, c0.y, c0.z);
+#define V1_ nc::dot(nc::sub(mk(ca.x, ca.y, ca.z), x0), nc::sub(mk(ca.x, ca.y, ca.z), x0))
+                CAND_ARGMAX(sel1, -1.0f, ci != sel0 && ca.w < lim, V1_)
+                if (sel1 < 0) CAND_ARGMAX(sel1, -1.0f, ci != sel0, V1_)
+                const float4 c1 = cand_a[sel1];
+                const v3 e = nc::sub(mk(c1.x, c1.y, c1.z), x0);
+#define CR_ nc::cross(nc::sub(mk(ca.x, ca.y, ca.z), x0), e)
+#define V2_ nc::dot(CR_, CR_)
+                CAND_ARGMAX(sel2, -1.0f, ci != sel0 && ci != sel1 && ca.w < lim, V2_)
+                if (sel2 < 0) CAND_ARGMAX(sel2, -1.0f, ci != sel0 && ci != sel1, V2_)
+                const float4 c2 = cand_a[sel2];
+                const v3 cr2 = nc::cross(nc::sub(mk(c2.x, c2.y, c2.z), x0), e);
+#define V3_ (-nc::dot(CR_, cr2))
+                CAND_ARGMAX(sel3, 0.0f, ci != sel0 && ci != sel1 && ci != sel2 && ca.w < lim, V3_)
+                if (sel3 < 0) CAND_ARGMAX(sel3, 0.0f, ci != sel0 && ci != sel1 && ci != sel2, V3_)
+#undef V1_
+#undef CR_
+#undef V2_
+#undef V3_
                 k = sel3 >= 0 ? 4 : 3;
             }
             if (lane == 0) *(int *)&SCR(S_PCOUNT + pair) = k;
-            d_all += k; d_rob += ((pair_ab[pair] >> 16) & 1) ? k : 0; d_oo += ((pair_ab[pair] >> 17) & 1) ? k : 0;
-            const int slot = lane == sel0 ? 0 : (lane == sel1 ? 1 : (lane == sel2 ? 2 : (lane == sel3 ? 3 : -1)));
-            if (hit && slot >= 0) {
-                const float4 pl = planes[dirflag][bf];
-                v3 nw = nc::mulv(Xo.R, mk(pl.x, pl.y, pl.z));
-                if (dirflag) nw = nc::scale(nw, -1.0f);
-                float4 *pd = D.pdata + (((size_t)env * MAXPAIRS + pair) * 4 + slot) * 2;
-                pd[0] = make_float4(cx, cy, cz, nw.x);
-                pd[1] = make_float4(nw.y, nw.z, cs, 0.0f);
+            if (lane < k) {
+                const int ci = lane == 0 ? sel0 : (lane == 1 ? sel1 : (lane == 2 ? sel2 : sel3));
+                const float4 a = cand_a[ci], b = cand_b[ci];
+                float4 *pd = D.pdata + (((size_t)env * MAXPAIRS + pair) * 4 + lane) * 2;
+                pd[0] = make_float4(a.x, a.y, a.z, b.x);
+                pd[1] = make_float4(b.y, b.z, a.w, 0.0f);
             }
+            CSYNC();            // the candidate list is reused by the next pair
         }
     }
-    if (lane == 0) D.demand[(size_t)P.par * N + env] = (unsigned)min(d_all, 255) | ((unsigned)min(d_rob, 255) << 8) | ((unsigned)min(d_oo, 255) << 16);
 }
+#undef CAND_ARGMAX
 #pragma clang fp contract(fast)
 
 // ---------------------------------------------------------------------------------------------- k_solve
@@ -798,114 +838,48 @@ __device__ __forceinline__ void plane_space(v3 n, v3 &p, v3 &q) {   // btPlaneSp
 }
 
 // ---- solver ------------------------------------------------------------------------------------------------------
-// One env per 16-lane group (4 envs per wavefront, SGRP groups per workgroup). The PGS chain of an env is sequential
-// (Gauss-Seidel), so the lanes of a group split each row instead:
-//   lanes 0..10  own joint velocity delta dq[lane]; a robot row contributes Ja[lane]*dq[lane] and applies MJa[lane]*dl
-//   lanes 11..13 own the velocity delta (dv, dw) of object lane-11
-//   J.v is a 16-lane butterfly sum (ds_swizzle/dpp via __shfl_xor); clamping is done redundantly by every lane.
-// All rows a sweep touches live in LDS.  Per env a fixed part:
-//   Minv (121), motor rows (11 x {rhs, dinv, lambda}), joint-limit rows (22 x {rhs, lambda}), contact meta (48 ints),
-//   friction coefficients (48)
-// and per contact row, taken from the workgroup's row pool according to the env's contact population (the four envs
-// of a workgroup share 8 912 floats: an env pushing an object with 30 robot contacts borrows what its neighbours with
-// a dozen resting contacts do not need):
-//     base  part (12): dir[3], aa[3], maa[3], rhs, dinv, lambda          -- lc contacts
-//     robot part (22): Ja[11], MJa[11]                                   -- lr robot-involved contacts
-//     Bside part  (6): ab[3], mab[3]                                     -- lb object-object contacts
-// Contacts the pool cannot hold (rare) keep their rows in the global scratch slab with the ROWF layout
-// (0..10 Ja, 11..21 MJa, 22..24 dir, 25..27 aa, 28..30 maa, 31..33 ab, 34..36 mab, 37 rhs, 38 dinv, 39 lambda);
-// arithmetic and row order are the same on both paths.
+// One env per 16-lane group (4 envs per wavefront, SGRP groups per workgroup).  The PGS chain of an env is sequential
+// (Gauss-Seidel, Bullet's order: motors, limits, all normals, all lateral frictions, all torsional frictions), each SIMD
+// runs a single wave, so the kernel lasts as long as the longest chain: what counts is the number of (dependent)
+// instructions per row step.  Three kinds of rows:
+//   * motor / joint-limit rows: lane j < 11 owns joint j (dq), rows in registers (MOTOR_STEP, LIMIT_STEP);
+//   * object-vs-static contacts (objects resting on table / shelf), the first P.os_cap of them: lane 11 + o owns the
+//     velocity change (dv, dw) of object o and sweeps that object's rows on its own -- rows of different objects touch
+//     disjoint variables, so the three object lanes run side by side and no cross-lane sum is needed; the rows of the first
+//     KOS contacts per object live in registers, further ones and the torsional rows stream from LDS;
+//   * generic contacts (robot involved, two objects, object-static beyond os_cap): SLOT LAYOUT.  Every scalar velocity
+//     variable of the env has a fixed (lane, slot):
+//         slot A: lanes 0..10 joint velocities dq (the same register as the motor rows'), lanes 11..15 object 2 (v.xyz, w.xy)
+//         slot B: lanes 0..5 object 0 (v.xyz, w.xyz), lanes 6..11 object 1, lane 12 object 2 (w.z)
+//     and a row is one float4 per lane {J_A, (M^-1 J^T)_A, J_B, (M^-1 J^T)_B} (zeros where the row does not act): a row
+//     step is one 16-byte load, two multiply-adds, a four-step DPP sum, the clamp, one DPP broadcast and two
+//     multiply-adds -- no role logic, no per-row scalars in memory: rows are swept in blocks of 16, lane k of the group
+//     holds {rhs, 1/diag, lambda, bounds} of the block's row k in registers, computes the clamp of "its" row from the
+//     common J.v, and the impulse change of row k is lane k's value (DPP row_newbcast k).  The row data (256 B per row,
+//     up to 6 rows per contact) does not fit LDS for an env with dozens of contacts; it lives in global memory
+//     (D.grows, L2 resident), written once by the row builder and streamed through a register queue eight rows ahead.
+//     Object velocities are moved between the object lanes and the slots around each generic sweep, only for the objects
+//     that some generic contact of the wave touches.
+//   Rows of contacts without normal impulse whose friction impulses are zero have the bounds [-0, 0] and cannot move
+//   anything: the friction and torsional sweeps run over compacted lists of the other rows, rebuilt after every normal
+//   sweep (94 % of the robot contacts of a pushing gripper are speculative: inside the margin, not touching).
+// LDS per env (LF_TOTAL floats): Minv (121), motor rows (11 x {rhs, dinv, lambda}), joint-limit rows (22 x {rhs, lambda}),
+// contact meta (48 ints), friction / spinning / rolling coefficients (3 x 48), object-vs-static rows (os_cap x (3 x 12
+// linear + 3 x 8 torsional)), generic row scalars (288 x {rhs, dinv, lambda}), the two row lists.
 #define SGRP 4           // envs per workgroup (64 threads)
-enum { LF_MINV = 0, LF_MOT = LF_MINV + 124, LF_LIM = LF_MOT + 36, LF_META = LF_LIM + 44, LF_MU = LF_META + MAXC, LF_TOTAL = LF_MU + MAXC };
-#define SLDS_FLOATS 10112                      // 40 448 B per workgroup: four workgroups (16 envs) per CU
-#define SPOOL (SLDS_FLOATS - SGRP * LF_TOTAL - 128)  // floats of the row pool (the pipelined sweep fetches one row past the end)
+#define OS_CAP 18        // object-vs-static contacts per env with rows in LDS (a resting object has 3..4)
+#define GROWS (6 * MAXC) // generic row ids: 6 j + k for generic contact j; k = 0 normal, 1 2 lateral, 3 spinning, 4 5 rolling
+enum { LF_MINV = 0, LF_MOT = LF_MINV + 124, LF_LIM = LF_MOT + 36, LF_META = LF_LIM + 44, LF_MU = LF_META + MAXC, LF_SPIN = LF_MU + MAXC,
+       LF_ROLL = LF_SPIN + MAXC, LF_OSL = LF_ROLL + MAXC, LF_OST = LF_OSL + OS_CAP * 36, LF_GRHS = LF_OST + OS_CAP * 24,
+       LF_GDINV = LF_GRHS + GROWS, LF_GLAM = LF_GDINV + GROWS, LF_LISTF = LF_GLAM + GROWS, LF_LISTT = LF_LISTF + MAXC,
+       LF_TOTAL = LF_LISTT + (3 * MAXC) / 2 };
+#define SLDS_FLOATS (SGRP * LF_TOTAL)
 static_assert(SLDS_FLOATS * 4 * 4 <= 163840, "four solver workgroups must fit the 160 KiB LDS of a CU");
-static_assert(LF_TOTAL % 4 == 0, "row parts must be 16-byte aligned");
+static_assert(LF_TOTAL % 4 == 0 && LF_OSL % 4 == 0 && LF_OST % 4 == 0, "row parts must be 16-byte aligned");
 __shared__ __attribute__((aligned(16))) float g_slds[SLDS_FLOATS];
-// LDS offsets (floats) of one env's sections and the number of contacts each row section holds
-struct Slab { int fix, base, rob, bs, lc, lr, lb; };
-#define SLAB_NAMES(sl)                                                                                              \
-    const int L_MINV = (sl).fix + LF_MINV, L_MOT = (sl).fix + LF_MOT, L_LIM = (sl).fix + LF_LIM, L_META = (sl).fix + LF_META, \
-              L_MU = (sl).fix + LF_MU, L_BASE = (sl).base, L_ROB = (sl).rob, L_BS = (sl).bs;                          \
-    (void)L_MINV; (void)L_MOT; (void)L_LIM; (void)L_META; (void)L_MU; (void)L_BASE; (void)L_ROB; (void)L_BS;
 #define LD(slot) g_slds[(slot)]
-// ---- k_balance: which env goes to which 16-lane group of k_solve ------------------------------------------------------
-// The four envs of a solver workgroup share one row pool and one instruction stream, so a workgroup is as slow as its
-// heaviest env and envs that ask for more LDS rows than the pool holds fall back to rows in global memory.  One
-// workgroup of this kernel deals the "heavy" envs (an env that alone needs a large share of the pool: a gripper
-// pushing an object) out over the solver workgroups round-robin and fills up with the light ones.  It uses the contact
-// demand k_collide recorded in the PREVIOUS step (contacts persist from step to step), so it runs on the side stream
-// beside k_collide; the order only decides where rows live and which envs wait for each other -- never a result.
-#define BAL_THREADS 1024
-__global__ void __launch_bounds__(BAL_THREADS) k_balance(SimParams P, DevPtrs D) {
-    __shared__ int s_wave[BAL_THREADS / 64], s_wave2[BAL_THREADS / 64];
-    const int N = P.N, t = threadIdx.x, nblk = (N + SGRP - 1) / SGRP;
-    const unsigned *dem = D.demand + (size_t)(P.par ^ 1) * N;
-    if (N > 64 * BAL_THREADS) {                       // beyond the bit mask below: identity order
-        for (int i = t; i < SGRP * nblk; i += BAL_THREADS) D.solve_order[i] = i < N ? i : -1;
-        return;
-    }
-    // thread t owns envs t, t + 1024, ... (coalesced reads).  Two heavy classes, dealt in that order: an env that alone
-    // needs more than ~30 % of the pool, and one that needs more than ~15 % (a typical env with a dozen resting contacts
-    // and a few robot contacts needs 10 %)
-    unsigned long long hm1 = 0, hm2 = 0;
-    int n1 = 0, n2 = 0;
-    for (int j = 0, e = t; e < N; e += BAL_THREADS, j++) {
-        const unsigned d = dem[e];
-        const int need = min((int)(d & 255), MAXC) * 36 + min((int)((d >> 8) & 255), MAXC) * 66 + min((int)((d >> 16) & 255), MAXC) * 18;
-        if (need > (P.pool * 3) / 10) { hm1 |= 1ull << j; n1++; }
-        else if (need > (P.pool * 3) / 20) { hm2 |= 1ull << j; n2++; }
-    }
-    // exclusive prefix of both counts over the workgroup (two plain ints: with N up to 65536 a packed 16+16-bit scan
-    // would carry from one field into the other)
-    int incl1 = n1, incl2 = n2;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o1 = __shfl_up(incl1, d), o2 = __shfl_up(incl2, d);
-        if ((t & 63) >= d) { incl1 += o1; incl2 += o2; }
-    }
-    if ((t & 63) == 63) { s_wave[t >> 6] = incl1; s_wave2[t >> 6] = incl2; }
-    for (int i = t; i < SGRP * nblk; i += BAL_THREADS) D.solve_order[i] = -1;     // N need not be a multiple of four: the
-                                                                                  // positions left over stay empty, wherever they are
-    __syncthreads();
-    int base1 = incl1 - n1, base2 = incl2 - n2, H1 = 0, H2 = 0;
-    for (int w = 0; w < BAL_THREADS / 64; w++) {
-        const int c1 = s_wave[w], c2 = s_wave2[w];
-        if (w < (t >> 6)) { base1 += c1; base2 += c2; }
-        H1 += c1; H2 += c2;
-    }
-    const int H = H1 + H2;
-    int r1 = base1, r2 = H1 + base2;                             // next rank of either class for this thread's envs
-    // heavy rank h -> workgroup h % nblk, position h / nblk; the light envs fill the remaining positions in order
-    const int q = H / nblk, r = H % nblk;            // workgroups [0, r) hold q + 1 heavy envs, the others q
-    const int ebase = (N / BAL_THREADS) * t + min(t, N % BAL_THREADS);     // envs owned by the threads before this one
-    const int hbefore = base1 + base2;                                     // heavy envs (both classes) of those threads
-    int hseen = 0;
-    for (int j = 0, e = t; e < N; e += BAL_THREADS, j++) {
-        int slot;
-        if (((hm1 | hm2) >> j) & 1ull) {
-            const int h = ((hm1 >> j) & 1ull) ? r1++ : r2++;
-            hseen++;
-            slot = (h % nblk) * SGRP + h / nblk;
-        } else {
-            int k = ebase + j - (hbefore + hseen);   // rank among the light envs
-            if (k < (SGRP - 1 - q) * r) slot = (k / (SGRP - 1 - q)) * SGRP + q + 1 + k % (SGRP - 1 - q);
-            else { k -= (SGRP - 1 - q) * r; slot = (r + k / (SGRP - q)) * SGRP + q + k % (SGRP - q); }
-        }
-        D.solve_order[slot] = e;
-    }
-}
 
-// Overflow rows in global memory: the immutable part (Jacobians, directions, rhs, dinv) is written during the row build
-// and made visible to the other lanes of the group with ONE agent-scope fence before the sweeps; the mutable part
-// (lambda) is owned by lane 0, which alone reads and writes it and broadcasts the impulse change with a DPP row
-// broadcast -- plain cached loads and stores, no atomics or fences inside the sweeps.
-#define ROW_ADDR(r, f) (&SCR(S_ROWS + (r) * ROWF + (f)))
-#define ROWL(r, f) (*ROW_ADDR(r, f))
-#define ROWS(r, f, v) (*ROW_ADDR(r, f) = (v))
-#define ROW_FENCE()
-
-// meta word: bodyA (8) | bodyB (8) | linkA (8) | rows in LDS (1)
+// meta word: bodyA (8) | bodyB (8) | linkA (8) | rows in LDS, object-vs-static (1)
 __device__ __forceinline__ int meta_bodyA(int m) { return (signed char)(m & 255); }
 __device__ __forceinline__ int meta_bodyB(int m) { return (signed char)((m >> 8) & 255); }
 __device__ __forceinline__ int meta_link(int m) { return (signed char)((m >> 16) & 255); }
@@ -922,6 +896,7 @@ __device__ __forceinline__ float dpp_ror(float v) {
 template <int J> __device__ __forceinline__ float row_bcast(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xf, 0xf, false));
 }
+template <int J> __device__ __forceinline__ int row_bcast_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false); }
 // value of an arbitrary lane of the wavefront (ds_bpermute; the source lane must be active)
 __device__ __forceinline__ float lane_gather(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
@@ -941,78 +916,63 @@ __device__ constexpr unsigned ANC[NB] = {0x001, 0x003, 0x007, 0x00f, 0x01f, 0x03
 // Per-object data a contact row needs (pose, world inverse inertia, unconstrained velocities), fetched once per pair.
 struct ObjData { v3 op, vs, ws; m3 Iinv; float imass; };
 
-// Builds row k (0 normal, 1, 2 tangents) of contact c along `dir`; returns the relative velocity A - B along dir.
-// Executed by all 16 lanes of the env's group; `l` is the lane index within the group.  Nothing is read from global
-// memory here: the lane's joint frame (pk, ak), its unconstrained velocity qds and the objects' data are passed in.
-__device__ float build_row(const SimParams &P, const DevPtrs &D, int env, const Slab &sl, int l, int c, int k,
-                           bool fast, int rslot, int bslot, int bodyA, int bodyB, v3 x, v3 dir,
-                           v3 pk, v3 ak, float qds, const ObjData &oA, const ObjData &oB) {
-    const int N = P.N;
-    SLAB_NAMES(sl)
-    float *scratch = D.scratch;
-    const int row = 3 * c + k;
-    float diag = 0, rel = 0;
+// What a lane owns in the slot layout: its object (or -1) and the unit vectors that pick its component out of a
+// (linear, angular) pair -- J = lin . el + ang . ea.
+struct SlotOwner { int objA, objB; v3 elA, eaA, elB, eaB; };
+__device__ __forceinline__ v3 unit3(int c) { return mk(c == 0 ? 1.0f : 0.0f, c == 1 ? 1.0f : 0.0f, c == 2 ? 1.0f : 0.0f); }
+__device__ __forceinline__ SlotOwner slot_owner(int l) {
+    SlotOwner s;
+    const int cA = l - NB;                                   // slot A, lanes 11..15: object 2, components 0..4
+    s.objA = l >= NB ? 2 : -1;
+    s.elA = unit3(cA < 3 ? cA : -1); s.eaA = unit3(cA >= 3 ? cA - 3 : -1);
+    const int cB = l < 6 ? l : (l < 12 ? l - 6 : 5);         // slot B: object 0 | object 1 | object 2 component 5
+    s.objB = l < 6 ? 0 : (l < 12 ? 1 : (l == 12 ? 2 : -1));
+    s.elB = unit3(cB < 3 ? cB : -1); s.eaB = unit3(cB >= 3 ? cB - 3 : -1);
+    return s;
+}
+
+// Builds generic row `r` (= 6 j + k) of a contact along `dir` (linear rows: the constraint direction at point x;
+// torsional rows, `tors`: the rotation axis) in the slot layout; returns the relative velocity A - B along it.  Executed
+// by all 16 lanes of the env's group.  Nothing is read from global memory here.
+__device__ __forceinline__ float build_grow(const DevPtrs &D, int env, int fix, int l, int lj, int r, bool tors, int bodyA, int bodyB, v3 x, v3 dir,
+                                            v3 pk, v3 ak, float ua, float ub, const SlotOwner &so, const ObjData &oA, const ObjData &oB) {
+    float ja = 0, mja = 0, jb = 0, mjb = 0;
 #pragma unroll
     for (int side = 0; side < 2; side++) {
-        int body = side == 0 ? bodyA : bodyB;
-        float sg = side == 0 ? 1.0f : -1.0f;
+        const int body = side == 0 ? bodyA : bodyB;
+        const float sg = side == 0 ? 1.0f : -1.0f;
         if (body < 0) continue;
         if (body < 16) {
             // lane l < 11: Jacobian entry of joint l (zero unless joint l is an ancestor-or-self of the body)
-            float ja = 0;
-            const int lj = l < NB ? l : 0;
-            if (l < NB && ((ANC[body] >> l) & 1u)) ja = sg * dot(dir, cross(ak, x - pk));
-            float mja = 0;
-#define MJA_STEP(J) mja += LD(L_MINV + lj * NB + (J)) * row_bcast<J>(ja);
+            float jj = 0;
+            if (l < NB && ((ANC[body] >> l) & 1u)) jj = tors ? sg * dot(dir, ak) : sg * dot(dir, cross(ak, x - pk));
+            float mj = 0;
+#define MJA_STEP(J) mj += LD(fix + LF_MINV + lj * NB + (J)) * row_bcast<J>(jj);
             MJA_STEP(0) MJA_STEP(1) MJA_STEP(2) MJA_STEP(3) MJA_STEP(4) MJA_STEP(5) MJA_STEP(6) MJA_STEP(7) MJA_STEP(8) MJA_STEP(9) MJA_STEP(10)
 #undef MJA_STEP
-            if (l < NB) {
-                if (fast) { LD(L_ROB + (rslot * 3 + k) * 22 + l) = ja; LD(L_ROB + (rslot * 3 + k) * 22 + 11 + l) = mja; }
-                else { ROWS(row, l, ja); ROWS(row, 11 + l, mja); }
-            } else mja = 0;
-            diag += group_sum(ja * mja);
-            rel += group_sum(l < NB ? ja * qds : 0.0f);
+            ja = l < NB ? jj : ja;
+            mja = l < NB ? mj : mja;
         } else {
             const ObjData &o = side == 0 ? oA : oB;
-            v3 lin = dir * sg;
-            v3 ang = cross(x - o.op, lin);
-            v3 mang = mulv(o.Iinv, ang);
-            if (l == 0) {
-                if (fast) {
-                    // the base part holds the angular data of the contact's (first) object; the Bside part exists
-                    // only for object-object contacts
-                    const int oo = (side == 0 || bodyA < 16) ? L_BASE + row * 12 + 3 : L_BS + (bslot * 3 + k) * 6;
-                    LD(oo) = ang.x; LD(oo + 1) = ang.y; LD(oo + 2) = ang.z; LD(oo + 3) = mang.x; LD(oo + 4) = mang.y; LD(oo + 5) = mang.z;
-                } else {
-                    int oo = side == 0 ? 25 : 31;
-                    ROWS(row, oo, ang.x); ROWS(row, oo + 1, ang.y); ROWS(row, oo + 2, ang.z);
-                    ROWS(row, oo + 3, mang.x); ROWS(row, oo + 4, mang.y); ROWS(row, oo + 5, mang.z);
-                }
-            }
-            diag += dot(lin, lin) * o.imass + dot(ang, mang);
-            rel += dot(lin, o.vs) + dot(ang, o.ws);
+            const int ob = body - 16;
+            const v3 lin = tors ? mk(0, 0, 0) : dir * sg;
+            const v3 ang = tors ? dir * sg : cross(x - o.op, lin);
+            const v3 mlin = lin * o.imass, mang = mulv(o.Iinv, ang);
+            const float ca = dot(lin, so.elA) + dot(ang, so.eaA), cma = dot(mlin, so.elA) + dot(mang, so.eaA);
+            const float cb = dot(lin, so.elB) + dot(ang, so.eaB), cmb = dot(mlin, so.elB) + dot(mang, so.eaB);
+            ja = so.objA == ob ? ca : ja; mja = so.objA == ob ? cma : mja;
+            jb = so.objB == ob ? cb : jb; mjb = so.objB == ob ? cmb : mjb;
         }
     }
-    float dinv = diag > 0 ? 1.0f / diag : 0.0f;
-    if (l == 0) {
-        if (fast) {
-            const int o = L_BASE + row * 12;
-            // a robot contact stores the direction as its object sees it (negated when the object is body B): the
-            // pipelined sweep needs no sign logic; object-object rows keep the plain direction for both owners
-            const float ds = (bodyA >= 0 && bodyA < 16 && bodyB >= 16) ? -1.0f : 1.0f;
-            LD(o) = ds * dir.x; LD(o + 1) = ds * dir.y; LD(o + 2) = ds * dir.z; LD(o + 10) = dinv; LD(o + 11) = 0.0f;
-            if (bodyA < 16 && bodyB < 16) { LD(o + 3) = 0.0f; LD(o + 4) = 0.0f; LD(o + 5) = 0.0f; LD(o + 6) = 0.0f; LD(o + 7) = 0.0f; LD(o + 8) = 0.0f; }
-        } else {
-            ROWS(row, 22, dir.x); ROWS(row, 23, dir.y); ROWS(row, 24, dir.z); ROWS(row, 38, dinv); ROWS(row, 39, 0.0f);
-        }
-    }
-    if (!fast) ROW_FENCE();
+    const float diag = group_sum(ja * mja + jb * mjb);
+    const float rel = group_sum(ja * ua + jb * ub);
+    D.grows[((size_t)env * GROWS + r) * 16 + l] = make_float4(ja, mja, jb, mjb);
+    if (l == 0) { LD(fix + LF_GDINV + r) = diag > 0 ? 1.0f / diag : 0.0f; LD(fix + LF_GLAM + r) = 0.0f; }
     return rel;
 }
 
-// Row step of an object-vs-static contact row, executed by the lane that owns the object only (such a row touches no
-// other body, so the three object lanes sweep their own contacts side by side and no cross-lane sum is needed):
-// b0,b1,b2 = the row's base part (dir.xyz ang.x | ang.yz mang.xy | mang.z rhs dinv lambda), bounds [lo, hi].
+// Row step of an object-vs-static contact row, executed by the lane that owns the object only:
+// b0,b1,b2 = the row's linear part (dir.xyz ang.x | ang.yz mang.xy | mang.z rhs dinv lambda), bounds [lo, hi].
 #define OS_ROW_STEP(b0, b1, b2, lo, hi, rowidx)                                                                   \
     do {                                                                                                          \
         const float jv_ = ((b0).x * dv.x + (b0).y * dv.y + (b0).z * dv.z) + ((b0).w * dw.x + (b1).x * dw.y + (b1).y * dw.z);    \
@@ -1020,7 +980,7 @@ __device__ float build_row(const SimParams &P, const DevPtrs &D, int env, const 
         const float s0_ = fmaf(-jv_, (b2).z, lam_ + (b2).y);        /* (lambda + rhs) - dinv * J.v */             \
         const float sum_ = fminf(fmaxf(s0_, (lo)), (hi));                                                         \
         const float dl_ = sum_ - lam_;                                                                            \
-        LD(L_BASE + (rowidx) * 12 + 11) = sum_;                                                                   \
+        LD(L_OSL + (rowidx) * 12 + 11) = sum_;                                                                    \
         const float sm_ = dl_ * inv_mass;                                                                         \
         dv.x += (b0).x * sm_; dv.y += (b0).y * sm_; dv.z += (b0).z * sm_;                                            \
         dw.x += (b1).z * dl_; dw.y += (b1).w * dl_; dw.z += (b2).x * dl_;                                            \
@@ -1049,19 +1009,20 @@ __device__ __forceinline__ float4 sel4(bool has, float4 v) {
 __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs D) {
     const int N = P.N;
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
-    const int env_raw = D.solve_order[blockIdx.x * SGRP + grp];       // k_balance: heavy envs are dealt out over the workgroups
-    const int env = (env_raw >= 0 && env_raw < N) ? env_raw : N - 1;  // groups without an env stay until the row pool is divided
+    const int env_raw = blockIdx.x * SGRP + grp;
+    const int env = env_raw < N ? env_raw : N - 1;                    // groups without an env run along as no-ops
     float *state = D.state, *scratch = D.scratch;
-    const bool dead = env_raw < 0 || env_raw >= N || D.errflags[env] != 0;
+    const bool dead = env_raw >= N || D.errflags[env] != 0;
     const ShapeData *S = D.shapes;
-    Slab sl;
-    sl.fix = grp * LF_TOTAL;
-    const int L_MINV = sl.fix + LF_MINV, L_MOT = sl.fix + LF_MOT, L_LIM = sl.fix + LF_LIM, L_META = sl.fix + LF_META, L_MU = sl.fix + LF_MU;
+    const int fix = grp * LF_TOTAL;
+    const int L_MINV = fix + LF_MINV, L_MOT = fix + LF_MOT, L_LIM = fix + LF_LIM, L_META = fix + LF_META, L_MU = fix + LF_MU,
+              L_SPIN = fix + LF_SPIN, L_ROLL = fix + LF_ROLL, L_OSL = fix + LF_OSL, L_OST = fix + LF_OST, L_GRHS = fix + LF_GRHS,
+              L_GDINV = fix + LF_GDINV, L_GLAM = fix + LF_GLAM;
+    unsigned short *listF = (unsigned short *)&LD(fix + LF_LISTF), *listT = (unsigned short *)&LD(fix + LF_LISTT);
     const float dt = P.dt;
     const int lj = l < NB ? l : 0;               // joint owned by this lane (lanes >= 11 alias joint 0, masked)
     const int lo_ = (l >= NB && l < NB + NOBJ) ? l - NB : -1;   // object owned by this lane
     SPROF_INIT
-    SBLK_BEGIN
     // ---- stage Minv in LDS; the lane's joint frame and unconstrained velocity go to registers (same round trip)
     for (int i = l; i < NB * NB; i += 16) LD(L_MINV + i) = SCR(S_MINV + i);
     const v3 pk_l = mk(SCR(S_BP + 3 * lj), SCR(S_BP + 3 * lj + 1), SCR(S_BP + 3 * lj + 2));
@@ -1079,50 +1040,41 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         myobj.ws = mk(SCR(S_OWS + 3 * ob), SCR(S_OWS + 3 * ob + 1), SCR(S_OWS + 3 * ob + 2));
         myobj.imass = 1.0f / (ob == 0 ? B.obj_mass[0] : (ob == 1 ? B.obj_mass[1] : B.obj_mass[2]));
     }
+    // row l of Minv in registers (motor rows, and M^-1 J^T of the generic rows)
+    float minv_l[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) minv_l[j] = l < NB ? LD(L_MINV + lj * NB + j) : 0.0f;
+    // the unconstrained velocities in the slot layout (relative velocity of a generic row = sum over lanes of J . u)
+    const SlotOwner so = slot_owner(l);
+    float ua = l < NB ? qds_l : 0.0f, ub = 0.0f;
+    {
+#define U_FROM(O)                                                                                                  \
+        {                                                                                                          \
+            const v3 vs_ = mk(row_bcast<NB + (O)>(myobj.vs.x), row_bcast<NB + (O)>(myobj.vs.y), row_bcast<NB + (O)>(myobj.vs.z));     \
+            const v3 ws_ = mk(row_bcast<NB + (O)>(myobj.ws.x), row_bcast<NB + (O)>(myobj.ws.y), row_bcast<NB + (O)>(myobj.ws.z));     \
+            ua = so.objA == (O) ? dot(vs_, so.elA) + dot(ws_, so.eaA) : ua;                                        \
+            ub = so.objB == (O) ? dot(vs_, so.elB) + dot(ws_, so.eaB) : ub;                                        \
+        }
+        U_FROM(0) U_FROM(1) U_FROM(2)
+#undef U_FROM
+    }
     SPROF(0);
     // ---- gather contacts in pair order, build rows (all lanes of the group run the control flow redundantly)
-    // The 92 per-pair candidate counts are fetched in one go: lane l loads the counts of pairs l, l+16, ... and the
+    // The per-pair candidate counts are fetched in one go: lane l loads the counts of pairs l, l+16, ... and the
     // non-empty pairs are collected into per-group bit masks with wave ballots (no chain of dependent global loads).
     unsigned pmask[MAXPAIRS / 16];
-    float need_c = 0, need_r = 0, need_b = 0;    // candidate contacts of this env: all / robot involved / object-object
 #pragma unroll
     for (int k = 0; k < MAXPAIRS / 16; k++) {
         const int pr = 16 * k + l;
         const bool in = pr < P.npairs && !dead;
         const int cntl = in ? *(const int *)&SCR(S_PCOUNT + pr) : 0;
-        const int2 ab = *(const int2 *)S->pair_meta[in ? pr : 0];
         const unsigned long long bal = __ballot(cntl > 0);
         pmask[k] = (unsigned)(bal >> (16 * grp)) & 0xffffu;
-        need_c += (float)cntl;
-        need_r += ((ab.x >= 0 && ab.x < 16) || (ab.y >= 0 && ab.y < 16)) ? (float)cntl : 0.0f;
-        need_b += (ab.x >= 16 && ab.y >= 16) ? (float)cntl : 0.0f;
     }
-    // ---- divide the workgroup's row pool: every env asks for what its candidate contacts need, served in env order
-    {
-        const int want_c = min((int)group_sum(need_c), MAXC), want_r = min((int)group_sum(need_r), MAXC), want_b = min((int)group_sum(need_b), MAXC);
-        int cursor = SGRP * LF_TOTAL, avail = P.pool;
-        sl.base = sl.rob = sl.bs = cursor; sl.lc = sl.lr = sl.lb = 0;
-#pragma unroll
-        for (int g = 0; g < SGRP; g++) {
-            const int wc = __builtin_amdgcn_readlane(want_c, 16 * g), wr = __builtin_amdgcn_readlane(want_r, 16 * g), wb = __builtin_amdgcn_readlane(want_b, 16 * g);
-            const int ac = min(wc, avail / 36); avail -= ac * 36;
-            const int ar = min(wr, avail / 66); avail -= ar * 66;
-            const int ab_ = min(wb, avail / 18); avail -= ab_ * 18;
-            if (g == grp) { sl.base = cursor; sl.rob = cursor + ac * 36; sl.bs = sl.rob + ar * 66; sl.lc = ac; sl.lr = ar; sl.lb = ab_; }
-            const int used = ac * 36 + ar * 66 + ab_ * 18, pad = (4 - (used & 3)) & 3;      // base parts stay 16-byte aligned
-            cursor += used + pad;
-            avail = max(avail - pad, 0);
-        }
-    }
-    if (dead) return;
-    const int L_BASE = sl.base, L_ROB = sl.rob, L_BS = sl.bs;
-    int n_os = 0;
-    unsigned own_os = 0;
-    bool any_slow = false;            // some contact of this env keeps its rows in global memory
-    int c_lf = 0;                     // end of the run of generic contacts whose rows are in LDS (they precede any overflow)
-    unsigned long long g_rob = 0, g_own = 0, g_ownB = 0;   // generic contact j (bit j): robot involved / this lane owns an object of it / ... as body B of an object-object contact
-    int nc = 0, gidx = 0, n_oo = 0;   // gidx: index among the generic (not object-vs-static) contacts, which all follow the
-                                      // object-vs-static ones; n_oo: object-object contacts (their pairs precede the robot pairs)
+    int n_os = 0;                     // leading object-vs-static contacts, rows in LDS
+    unsigned own_os = 0;              // this lane's share of them (bit = contact index)
+    unsigned gobj = 0;                // objects touched by generic contacts of this env (bit o)
+    int nc = 0, ng = 0;               // contacts; generic contacts (they follow the n_os leading ones: contact c = n_os + j)
     static_assert(MAXPAIRS / 16 == 6, "pair-mask select chain below");
 #pragma unroll 1        // one copy of the (large) row-building body: the kernel must stay inside the instruction cache
     for (int k = 0; k < MAXPAIRS / 16; k++)
@@ -1133,7 +1085,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         // objects' data comes from the object lanes.  Nothing is fetched inside the contact loop.
         const int cnt = *(const int *)&SCR(S_PCOUNT + pair);
         const int4 pm = *(const int4 *)S->pair_meta[pair];
-        const float2 pmat = *(const float2 *)S->pair_mat[pair];
+        const float4 pmat = *(const float4 *)S->pair_mat[pair];
         float cd[4][7];
         {
             const float4 *pd = D.pdata + ((size_t)env * MAXPAIRS + pair) * 8;
@@ -1144,9 +1096,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             }
         }
         const int bodyA = pm.x, bodyB = pm.y, linkA = pm.z;
-        const float mu = pmat.x, rest = pmat.y;
-        const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
-        const bool objobj = bodyA >= 16 && bodyB >= 16;
+        const float mu = pmat.x, rest = pmat.y, roll = pmat.z, spin = pmat.w;
         const bool ospair = bodyA >= 16 && bodyB < 0;
         ObjData oA, oB;
 #pragma unroll
@@ -1162,7 +1112,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             o.imass = lane_gather(myobj.imass, src);
         }
         // every value fetched above is waited for here, once: with no load in flight the contact loop below needs no
-        // vmcnt waits, which on gfx9 would also wait for the acknowledgement of the contact-record stores it issues
+        // vmcnt waits, which on gfx9 would also wait for the acknowledgement of the stores it issues
 #pragma unroll
         for (int i = 0; i < 4; i++)
             asm volatile("" : "+v"(cd[i][0]), "+v"(cd[i][1]), "+v"(cd[i][2]), "+v"(cd[i][3]), "+v"(cd[i][4]), "+v"(cd[i][5]), "+v"(cd[i][6]));
@@ -1172,40 +1122,24 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             for (int kk = 0; kk < 7; kk++) c7[kk] = i == 0 ? cd[0][kk] : (i == 1 ? cd[1][kk] : (i == 2 ? cd[2][kk] : cd[3][kk]));
             const v3 x = mk(c7[0], c7[1], c7[2]), n = mk(c7[3], c7[4], c7[5]);
             const float dist = c7[6];
-            int rslot = 15, bslot = 15;
-            bool fast = nc < sl.lc && !any_slow;      // rows in LDS form a prefix of the contact list
-            // the Bside part of generic contact j lives in slot j, its robot part in slot j - n_oo of the LDS sections
-            // (object-object pairs precede the robot pairs): sweep code finds them without reading the meta word
-            if (robot) { if (gidx - n_oo < sl.lr && fast) rslot = gidx - n_oo; else fast = false; }
-            if (objobj) { if (gidx < sl.lb && fast) bslot = gidx; else fast = false; n_oo = gidx + 1; }
-            if ((robot || objobj) && fast) {
-                // loop-invariant roles of this lane in generic contact gidx, one bit each (no meta decoding in the sweeps)
-                const unsigned long long bit = 1ull << gidx;
-                if (robot) g_rob |= bit;
-                if (lo_ >= 0 && (bodyA == 16 + lo_ || bodyB == 16 + lo_)) g_own |= bit;
-                if (objobj && lo_ >= 0 && bodyB == 16 + lo_) g_ownB |= bit;
-                c_lf = nc + 1;
-            }
-            if (robot || objobj) gidx++;
-            else if (gidx == 0 && nc < sl.lc) {       // still inside the leading run of object-vs-static contacts
-                n_os = nc + 1;
-                if (lo_ >= 0 && bodyA == 16 + lo_) own_os |= 1u << nc;
-            }
-            int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | ((fast ? 1 : 0) << 24);
-            any_slow = any_slow || !fast;
+            // object-vs-static contacts keep their rows in LDS while they form the head of the contact list
+            const bool fast = ospair && ng == 0 && nc < P.os_cap;
+            const int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | ((fast ? 1 : 0) << 24);
             if (l == 0) {
                 *(int *)&LD(L_META + nc) = meta;
-                LD(L_MU + nc) = mu;
+                LD(L_MU + nc) = mu; LD(L_SPIN + nc) = spin; LD(L_ROLL + nc) = roll;
             }
             if (l < 12) {   // contact record (rr_get_contacts, touch sensors): field l is stored by lane l, one instruction
                 const float fld = l == 0 ? (float)bodyA : l == 1 ? (float)bodyB : l == 2 ? (float)linkA : l == 3 ? x.x : l == 4 ? x.y :
                                   l == 5 ? x.z : l == 6 ? n.x : l == 7 ? n.y : l == 8 ? n.z : l == 9 ? dist : l == 10 ? 0.0f : mu;
                 SCR(S_CT + nc * 12 + l) = fld;
             }
-            if (fast && bodyA >= 16 && bodyB < 0) {
-                // object-vs-static contact: the three rows (n, t1, t2) are built by lanes 0, 1, 2 in parallel
-                v3 t1, t2;
-                plane_space(n, t1, t2);
+            v3 t1, t2;
+            plane_space(n, t1, t2);
+            if (fast) {
+                // the three linear rows (n, t1, t2) and the three torsional rows about the same axes are built by lanes 0, 1, 2
+                n_os = nc + 1;
+                if (lo_ >= 0 && bodyA == 16 + lo_) own_os |= 1u << nc;
                 const v3 dir = l == 0 ? n : (l == 1 ? t1 : t2);
                 const v3 ang = cross(x - oA.op, dir);
                 const v3 mang = mulv(oA.Iinv, ang);
@@ -1218,41 +1152,57 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                 if (dist > 0) verr -= dist / dt;
                 else perr = -dist * P.erp / dt;
                 const float rhs = l == 0 ? (perr + verr) * dinv : -rel * dinv;
+                // torsional: pure rotation about dir; absent (coefficient 0) rows are all-zero
+                const float coef = l == 0 ? spin : roll;
+                const v3 tm = mulv(oA.Iinv, dir);
+                const float tdiag = dot(dir, tm);
+                const float tdinv = (coef > 0 && tdiag > 0) ? 1.0f / tdiag : 0.0f;
+                const float trhs = -dot(dir, oA.ws) * tdinv;
                 if (l < 3) {
-                    float4 *bp4 = (float4 *)&LD(L_BASE + (3 * nc + l) * 12);
+                    float4 *bp4 = (float4 *)&LD(L_OSL + (3 * nc + l) * 12);
                     bp4[0] = make_float4(dir.x, dir.y, dir.z, ang.x);
                     bp4[1] = make_float4(ang.y, ang.z, mang.x, mang.y);
                     bp4[2] = make_float4(mang.z, rhs, dinv, 0.0f);
+                    float4 *tp4 = (float4 *)&LD(L_OST + (3 * nc + l) * 8);
+                    tp4[0] = make_float4(tm.x, tm.y, tm.z, trhs);
+                    tp4[1] = make_float4(tdinv, 0.0f, 0.0f, 0.0f);
                 }
                 continue;
             }
-            // normal row
-            float rel = build_row(P, D, env, sl, l, nc, 0, fast, rslot, bslot, bodyA, bodyB, x, n, pk_l, ak_l, qds_l, oA, oB);
-            float r = 0;
-            if (fabsf(rel) >= P.rest_thresh) { r = rest * -rel; if (r < 0) r = 0; }
-            float verr = r - rel, perr = 0;
-            if (dist > 0) verr -= dist / dt;
-            else perr = -dist * P.erp / dt;
-            v3 t1, t2;
-            plane_space(n, t1, t2);
-            float rel1 = build_row(P, D, env, sl, l, nc, 1, fast, rslot, bslot, bodyA, bodyB, x, t1, pk_l, ak_l, qds_l, oA, oB);
-            float rel2 = build_row(P, D, env, sl, l, nc, 2, fast, rslot, bslot, bodyA, bodyB, x, t2, pk_l, ak_l, qds_l, oA, oB);
-            if (l == 0) {
-                if (fast) {
-                    LD(L_BASE + (3 * nc) * 12 + 9) = (perr + verr) * LD(L_BASE + (3 * nc) * 12 + 10);
-                    LD(L_BASE + (3 * nc + 1) * 12 + 9) = -rel1 * LD(L_BASE + (3 * nc + 1) * 12 + 10);
-                    LD(L_BASE + (3 * nc + 2) * 12 + 9) = -rel2 * LD(L_BASE + (3 * nc + 2) * 12 + 10);
-                } else {
-                    ROWS(3 * nc, 37, (perr + verr) * ROWL(3 * nc, 38));
-                    ROWS(3 * nc + 1, 37, -rel1 * ROWL(3 * nc + 1, 38));
-                    ROWS(3 * nc + 2, 37, -rel2 * ROWL(3 * nc + 2, 38));
+            // generic contact j = ng: six rows in the slot layout
+            const int r0 = 6 * ng;
+            if (bodyA >= 16) gobj |= 1u << (bodyA - 16);
+            if (bodyB >= 16) gobj |= 1u << (bodyB - 16);
+            float rel0 = 0;
+#pragma unroll 1        // one inlined copy of the row builder
+            for (int kr = 0; kr < 6; kr++) {
+                const bool tors = kr >= 3;
+                const int ka = tors ? kr - 3 : kr;
+                const v3 d = ka == 0 ? n : (ka == 1 ? t1 : t2);
+                const bool present = !tors || (kr == 3 ? spin > 0 : roll > 0);
+                float rhsn = 0;
+                if (present) {
+                    const float rel = build_grow(D, env, fix, l, lj, r0 + kr, tors, bodyA, bodyB, x, d, pk_l, ak_l, ua, ub, so, oA, oB);
+                    if (kr == 0) {
+                        float r = 0;
+                        if (fabsf(rel) >= P.rest_thresh) { r = rest * -rel; if (r < 0) r = 0; }
+                        float verr = r - rel, perr = 0;
+                        if (dist > 0) verr -= dist / dt;
+                        else perr = -dist * P.erp / dt;
+                        rhsn = perr + verr;
+                    } else rhsn = -rel;
+                }
+                if (l == 0) {
+                    if (!present) { LD(L_GDINV + r0 + kr) = 0.0f; LD(L_GLAM + r0 + kr) = 0.0f; }
+                    LD(L_GRHS + r0 + kr) = rhsn * LD(L_GDINV + r0 + kr);
                 }
             }
-            if (!fast) ROW_FENCE();
+            (void)rel0;
+            ng++;
         }
     }
     SPROF(1);
-    if (l == 0) *(int *)&SCR(S_NCT) = nc;
+    if (l == 0 && !dead) *(int *)&SCR(S_NCT) = nc;
     // ---- motor + limit rows: lane j < 11 builds the rows of joint j
     if (l < NB) {
         float dinv = 1.0f / LD(L_MINV + l * NB + l);
@@ -1275,31 +1225,22 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         }
     }
     SPROF(2);
+    // the rows written to global memory above are read back by the same wave in the sweeps
+    __threadfence();
     // compact list of the limit rows that exist (usually the two finger lower limits), in row order
     unsigned limmask = 0;
 #pragma unroll
     for (int js = 0; js < 2 * NB; js++) if (LD(L_LIM + 2 * js) > -1e29f) limmask |= 1u << js;    // 22 independent LDS reads
-    // ---- PGS.  Lane state: dq (lanes 0..10) or (dv, dw) of object lane-11 (lanes 11..13)
-    float dq = 0;
+    // ---- PGS.  Lane state: dq (slot A: lanes 0..10 joints, lanes 11..15 object 2 during generic sweeps), vb (slot B), and
+    // (dv, dw) of object lane-11 on lanes 11..13
+    float dq = 0, vb = 0;
     v3 dv = mk(0, 0, 0), dw = mk(0, 0, 0);
     const float inv_mass = lo_ >= 0 ? 1.0f / B.obj_mass[lo_ >= 0 ? lo_ : 0] : 0.0f;
     const float max_imp = P.max_impulse;
-    // Motor row j lives in the registers of lane j (rhs, dinv, lambda) and row l of Minv in the registers of lane l:
-    // lane j computes its impulse change from its own dq, one DPP sum broadcasts it, every joint lane applies
-    // Minv[l][j] * dl -- no LDS traffic on the 11 motor rows.
-    float minv_l[NB];
-#pragma unroll
-    for (int j = 0; j < NB; j++) minv_l[j] = l < NB ? LD(L_MINV + lj * NB + j) : 0.0f;
     const float m_rhs = l < NB ? LD(L_MOT + 3 * lj) : 0.0f, m_dinv = l < NB ? LD(L_MOT + 3 * lj + 1) : 0.0f;
     float m_lam = 0.0f, m_c = m_rhs;        // m_c = lambda + rhs of this lane's motor row, kept up to date off the critical chain
-    // Leading object-vs-static contacts (the common case: objects resting on the table) get a specialised sweep:
-    // ownership of contact c by this lane is one bit of `own_os`, rows are prefetched one step ahead.
-    // (n_os = number of leading object-vs-static contacts and own_os = this lane's share of them were collected by the gather)
-#define LDB4(r, off) (*(const float4 *)&LD(L_BASE + (r) * 12 + (off)))
-    // Each SIMD runs a single wave of this kernel (4 envs), so the sweep is a chain of dependent operations and its LDS
-    // round trips are fully exposed.  Rows that are the same in every iteration are therefore lifted into registers
-    // (occupancy cannot drop below the one wave there is): the first KLIM joint-limit rows and, on the object lanes, the
-    // rows of the object's first KOS object-vs-static contacts.  Anything beyond stays in LDS and uses the loops below.
+#define LDB4(r, off) (*(const float4 *)&LD(L_OSL + (r) * 12 + (off)))
+#define LDT4(r, off) (*(const float4 *)&LD(L_OST + (r) * 8 + (off)))
 #define LDZ4(has, r, off) sel4((has), LDB4((r), (off)))
     int lim_j[KLIM]; float lim_sg[KLIM], lim_rhs[KLIM], lim_dinv[KLIM], lim_col[KLIM], lim_lam[KLIM];
     {
@@ -1316,6 +1257,7 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         }
         limmask = rem;                                   // rows left for the LDS loop
     }
+    const unsigned own_all = own_os;                     // every object-vs-static contact of this lane (torsional sweep)
     unsigned os_cs = 0;                                  // contact indices of the register rows, one byte each
     float os_mu[KOS], os_ln[KOS], os_l1[KOS], os_l2[KOS];
     float4 os_n0[KOS], os_n1[KOS], os_n2[KOS], os_a0[KOS], os_a1[KOS], os_a2[KOS], os_b0[KOS], os_b1[KOS], os_b2[KOS];
@@ -1364,50 +1306,57 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             REG_ROW_STEP(os_a0[i], os_a1[i], os_a2[i], os_l1[i], -hi_, hi_);                          \
             REG_ROW_STEP(os_b0[i], os_b1[i], os_b2[i], os_l2[i], -hi_, hi_);                          \
         }
+    // the normal impulse of a register-resident contact is published to its LDS slot after the normal sweep: the torsional
+    // sweep (rows in LDS) bounds its rows with it
+#define OSN_PUBLISH(i) { const int c_ = (os_cs >> (8 * (i))) & 255; if (c_ != 255) LD(L_OSL + (3 * c_) * 12 + 11) = os_ln[i]; }
+    // Torsional rows of this lane's object-vs-static contacts (all of them, register-resident linear rows or not): rotation
+    // about the axis of linear row k of the same contact; {M^-1 J^T (3), rhs | dinv, lambda} in LDS, the next row is
+    // fetched while the current one is swept.  A row with bounds [-0, 0] and no impulse is skipped.
+#define OS_TORSIONAL_SWEEP                                                                                             \
+    if (own_all) {                                                                                                     \
+        unsigned rem_ = own_all;                                                                                       \
+        int c_ = __ffs(rem_) - 1, k_ = 0;                                                                              \
+        float4 nd_ = LDB4(3 * c_, 0), nt_ = LDT4(3 * c_, 0);                                                           \
+        float2 ns_ = *(const float2 *)&LD(L_OST + (3 * c_) * 8 + 4);                                                   \
+        float nln_ = LD(L_OSL + (3 * c_) * 12 + 11), nsp_ = LD(L_SPIN + c_), nro_ = LD(L_ROLL + c_);                   \
+        for (;;) {                                                                                                     \
+            const float4 d_ = nd_, t_ = nt_; const float2 s_ = ns_;                                                    \
+            const float hi_ = (k_ == 0 ? nsp_ : nro_) * nln_;                                                          \
+            const int row_ = 3 * c_ + k_;                                                                              \
+            if (++k_ == 3) { k_ = 0; rem_ &= rem_ - 1; if (!rem_) { k_ = 3; } else { c_ = __ffs(rem_) - 1; nln_ = LD(L_OSL + (3 * c_) * 12 + 11); nsp_ = LD(L_SPIN + c_); nro_ = LD(L_ROLL + c_); } } \
+            if (k_ < 3) { nd_ = LDB4(3 * c_ + k_, 0); nt_ = LDT4(3 * c_ + k_, 0); ns_ = *(const float2 *)&LD(L_OST + (3 * c_ + k_) * 8 + 4); } \
+            if (hi_ > 0.0f || s_.y != 0.0f) {                                                                          \
+                const float jv_ = d_.x * dw.x + d_.y * dw.y + d_.z * dw.z;                                             \
+                const float s0_ = fmaf(-jv_, s_.x, s_.y + t_.w);                                                       \
+                const float sum_ = fminf(fmaxf(s0_, -hi_), hi_);                                                       \
+                const float dl_ = sum_ - s_.y;                                                                         \
+                LD(L_OST + row_ * 8 + 5) = sum_;                                                                       \
+                dw.x += t_.x * dl_; dw.y += t_.y * dl_; dw.z += t_.z * dl_;                                            \
+            }                                                                                                          \
+            if (k_ == 3) break;                                                                                        \
+        }                                                                                                              \
+    }
     SPROF(3);
-    // Generic contacts (robot involved, or two objects) follow the object-vs-static ones in contact order: first the
-    // object-object contacts [n_os, c_r0), then the robot contacts [c_r0, nc); [n_os, c_lf) have their rows in LDS.
-    // Row step of a generic contact for any number of contacts: rows streamed from LDS, two register sets taking turns.
-    // Roles come from the bit masks collected by the gather.  A robot row stores its direction as its object sees it
-    // and zeros in the object slots of a robot-static row; lanes >= 11 have dq == 0 and take MJa = 0.  The second owner
-    // of an object-object row (body B) reads its angular part from the Bside slot and negates the direction.
-    if (c_lf < n_os) c_lf = n_os;
-    const int base4 = L_BASE >> 2;          // base parts are float4-aligned (the pool cursor advances in multiples of 4 floats)
-#define LEAN_LOAD(B, J, K)   /* fetch row K of generic contact J (= contact n_os + J) into register set B */       \
-    {                                                                                                              \
-        B##row = (base4 + (3 * (n_os + (J)) + (K)) * 3) << 2;                                                      \
-        const int rr_ = L_ROB + (((J) - n_oo) * 3 + (K)) * 22 + lj;      /* (a valid LDS address for any J) */     \
-        const int oa_ = (B##row + 3) + (-(int)((g_ownB >> (J)) & 1ull) & (L_BS + ((J) * 3 + (K)) * 6 - (B##row + 3)));   /* branch-free select */ \
-        B##p = *(const float4 *)&LD(B##row); B##r = *(const float4 *)&LD(B##row + 8);                              \
-        B##a0 = LD(oa_); B##a1 = LD(oa_ + 1); B##a2 = LD(oa_ + 2); B##m0 = LD(oa_ + 3); B##m1 = LD(oa_ + 4); B##m2 = LD(oa_ + 5); \
-        B##j = LD(rr_); B##m = LD(rr_ + 11);                                                                       \
-    }
-#define LEAN_ROLE(J)   /* one mask test per lane: a joint lane of a robot contact, or the object lane of an owner */ \
-    const bool act_ = (g_act >> (J)) & 1ull, own_ = act_ && l >= NB, rob_ = act_ && l < NB;                        \
-    const float sg_ = ((g_ownB >> (J)) & 1ull) ? -1.0f : 1.0f, sgim_ = sg_ * inv_mass;
-#define LEAN_STEP(B, LOB, HIB, OUT)                                                                                \
-    {                                                                                                              \
-        const float pobj_ = fmaf(sg_, B##p.x * dv.x + B##p.y * dv.y + B##p.z * dv.z, B##a0 * dw.x + B##a1 * dw.y + B##a2 * dw.z); \
-        const float jv_ = group_sum(own_ ? pobj_ : (rob_ ? B##j * dq : 0.0f));                                     \
-        const float lam_ = B##r.w;                                                                                 \
-        const float s0_ = fmaf(-jv_, B##r.z, lam_ + B##r.y);                                                       \
-        const float sum_ = __builtin_amdgcn_fmed3f(s0_, (LOB), (HIB));     /* = min(max(s0, lo), hi) for lo <= hi */ \
-        const float dl_ = sum_ - lam_;                                                                             \
-        LD(B##row + 11) = sum_; OUT = sum_;                                                                        \
-        dq += rob_ ? B##m * dl_ : 0.0f;                                                                            \
-        const float so_ = own_ ? dl_ : 0.0f;                                                                       \
-        const float sm_ = so_ * sgim_;                                                                             \
-        dv.x += B##p.x * sm_; dv.y += B##p.y * sm_; dv.z += B##p.z * sm_;                                          \
-        dw.x += B##m0 * so_; dw.y += B##m1 * so_; dw.z += B##m2 * so_;                                             \
-    }
-    const unsigned long long g_act = l < NB ? g_rob : g_own;
-    if (__ballot(any_slow)) __threadfence();       // rows built in global memory become visible to the group's other lanes
     static_assert(KLIM == 2 && KOS == 4, "the sweeps below are written out for KLIM = 2, KOS = 4");
-    // When no env of this wave has a row outside the registers (no robot or object-object contact, no further limit
-    // or contact rows), an iteration is one straight-line block: the robot chain (motors, limits) and the object chain
-    // (normals, frictions) are independent and the scheduler overlaps them.
-    const bool simple = __ballot(!(nc == n_os && own_os == 0 && limmask == 0)) == 0ull;
-    unsigned long long ln_pos = 0, fr_nz = 0;   // generic contacts in LDS: normal impulse > 0 after this sweep / a friction impulse != 0
+    // When no env of this wave has a row outside the registers / the torsional LDS sweep (no generic contact, no further
+    // limit or contact rows), an iteration is one straight-line block: the robot chain (motors, limits) and the object chain
+    // (normals, frictions, torsional) are independent and the scheduler overlaps them.
+    const bool simple = __ballot(!(ng == 0 && own_os == 0 && limmask == 0)) == 0ull;
+    // generic sweeps: trip counts and the objects to move between the object lanes and the slots, over the whole wave
+    const int ng_max = max(max(__builtin_amdgcn_readlane(ng, 0), __builtin_amdgcn_readlane(ng, 16)),
+                           max(__builtin_amdgcn_readlane(ng, 32), __builtin_amdgcn_readlane(ng, 48)));
+    const unsigned gobj_w = (unsigned)__builtin_amdgcn_readlane((int)gobj, 0) | (unsigned)__builtin_amdgcn_readlane((int)gobj, 16) |
+                            (unsigned)__builtin_amdgcn_readlane((int)gobj, 32) | (unsigned)__builtin_amdgcn_readlane((int)gobj, 48);
+    const int grow_base = env * GROWS * 16;               // float4 index of row 0 of this env (fits an int: N <= 2^31 / 4608)
+    const int zrow = P.N * GROWS * 16;                    // an all-zero row behind the last env's rows
+    // object lane (11 + O) -> slots, and back; comps 0..5 = dv.xyz, dw.xyz
+#define TO_SLOT(O, C, REG, SLOTREG, LANE) { const float t_ = row_bcast<NB + (O)>(REG); SLOTREG = (l == (LANE)) ? t_ : SLOTREG; }
+#define FROM_SLOT(O, C, REG, SLOTREG, LANE) { const float t_ = row_bcast<LANE>(SLOTREG); REG = (l == NB + (O)) ? t_ : REG; }
+#define OBJ_SLOTS(OP)                                                                                                  \
+    if (gobj_w & 1u) { OP(0, 0, dv.x, vb, 0) OP(0, 1, dv.y, vb, 1) OP(0, 2, dv.z, vb, 2) OP(0, 3, dw.x, vb, 3) OP(0, 4, dw.y, vb, 4) OP(0, 5, dw.z, vb, 5) } \
+    if (gobj_w & 2u) { OP(1, 0, dv.x, vb, 6) OP(1, 1, dv.y, vb, 7) OP(1, 2, dv.z, vb, 8) OP(1, 3, dw.x, vb, 9) OP(1, 4, dw.y, vb, 10) OP(1, 5, dw.z, vb, 11) } \
+    if (gobj_w & 4u) { OP(2, 0, dv.x, dq, 11) OP(2, 1, dv.y, dq, 12) OP(2, 2, dv.z, dq, 13) OP(2, 3, dw.x, dq, 14) OP(2, 4, dw.y, dq, 15) OP(2, 5, dw.z, vb, 12) }
+    int nF = 0, nT = 0;                                   // entries of this env's lateral / torsional row lists
     for (int it = 0; it < P.iters; it++) {
         // compiler barrier: the row data in LDS / global memory is loop invariant, but hoisting hundreds of such loads out
         // of the sweep loop exhausts the register file (everything that should live in registers is held explicitly)
@@ -1416,7 +1365,9 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             SWEEP_MOTORS
             LIMIT_STEP(0) LIMIT_STEP(1)
             OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3)
+            OSN_PUBLISH(0) OSN_PUBLISH(1) OSN_PUBLISH(2) OSN_PUBLISH(3)
             OSF_STEP(0) OSF_STEP(1) OSF_STEP(2) OSF_STEP(3)
+            OS_TORSIONAL_SWEEP
             continue;
         }
         SWEEP_MOTORS
@@ -1436,152 +1387,150 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             if (l == 0) LD(L_LIM + 2 * js + 1) = sum;
             if (l < NB) dq += LD(L_MINV + l * NB + j) * (sg * dl);
         }
-        // ---- object-vs-static contacts, normals (rows 3c): every object lane walks its own contacts in contact order
-        //      (divergent loop; rows of different objects are independent, so this equals the sequential sweep)
-        OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3)
-        if (own_os) {
-            unsigned rem = own_os;
-            int c = __ffs(rem) - 1;
-            float4 n0 = LDB4(3 * c, 0), n1 = LDB4(3 * c, 4), n2 = LDB4(3 * c, 8);
-            while (rem) {
-                const float4 b0 = n0, b1 = n1, b2 = n2;
-                const int cc = c;
-                rem &= rem - 1;
-                if (rem) { c = __ffs(rem) - 1; n0 = LDB4(3 * c, 0); n1 = LDB4(3 * c, 4); n2 = LDB4(3 * c, 8); }
-                OS_ROW_STEP(b0, b1, b2, 0.0f, 1e10f, 3 * cc);
+#pragma unroll 1
+        for (int pass = 0; pass < 3; pass++) {    // all normals, then all lateral frictions, then all torsional frictions
+            // ---- the generic sweep of this pass: its first rows are requested before the object lanes' own work
+            const int cnt = pass == 0 ? ng : (pass == 1 ? nF : nT);
+            const int cmax = pass == 0 ? ng_max : max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
+                                                      max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
+            const unsigned short *lst = pass == 1 ? listF : listT;
+#define ENTRY(I) ((I) < cnt ? (pass == 0 ? ((I) << 3) : (int)lst[(I) < cnt ? (I) : 0]) : 0xffff)
+#define ENTRY_IDX(E) ((E) == 0xffff ? zrow : grow_base + (6 * ((E) >> 3) + ((E) & 7)) * 16)
+            int e_cur = ENTRY(l), e_nxt = ENTRY(16 + l);
+            int idx_cur = ENTRY_IDX(e_cur), idx_nxt = ENTRY_IDX(e_nxt);
+            float4 Q0, Q1, Q2, Q3, Q4, Q5, Q6, Q7;
+            if (cmax > 0) {
+                Q0 = D.grows[row_bcast_i<0>(idx_cur) + l]; Q1 = D.grows[row_bcast_i<1>(idx_cur) + l]; Q2 = D.grows[row_bcast_i<2>(idx_cur) + l];
+                Q3 = D.grows[row_bcast_i<3>(idx_cur) + l]; Q4 = D.grows[row_bcast_i<4>(idx_cur) + l]; Q5 = D.grows[row_bcast_i<5>(idx_cur) + l];
+                Q6 = D.grows[row_bcast_i<6>(idx_cur) + l]; Q7 = D.grows[row_bcast_i<7>(idx_cur) + l];
             }
-        }
-        // ---- object-vs-static contacts, frictions (rows 3c+1, 3c+2) are swept after ALL normals (Bullet's order),
-        //      i.e. after the generic normals below; see the friction pass.
-        for (int pass = 0; pass < 2; pass++) {  // all normals, then all frictions
-            if (pass == 1) { OSF_STEP(0) OSF_STEP(1) OSF_STEP(2) OSF_STEP(3) }
-            if (pass == 1 && own_os) {
-                // frictions of this lane's further object-vs-static contacts; the rows of the next one are prefetched
-                unsigned rem = own_os;
-                int c = __ffs(rem) - 1;
-                float nln = LD(L_BASE + (3 * c) * 12 + 11), nmu = LD(L_MU + c);
-                float4 na0 = LDB4(3 * c + 1, 0), na1 = LDB4(3 * c + 1, 4), na2 = LDB4(3 * c + 1, 8);
-                float4 nc0 = LDB4(3 * c + 2, 0), nc1 = LDB4(3 * c + 2, 4), nc2 = LDB4(3 * c + 2, 8);
-                while (rem) {
-                    const float hi = nmu * nln;
-                    const float4 a0 = na0, a1 = na1, a2 = na2, c0 = nc0, c1 = nc1, c2 = nc2;
-                    const int cc = c;
-                    rem &= rem - 1;
-                    if (rem) {
-                        c = __ffs(rem) - 1;
-                        nln = LD(L_BASE + (3 * c) * 12 + 11); nmu = LD(L_MU + c);
-                        na0 = LDB4(3 * c + 1, 0); na1 = LDB4(3 * c + 1, 4); na2 = LDB4(3 * c + 1, 8);
-                        nc0 = LDB4(3 * c + 2, 0); nc1 = LDB4(3 * c + 2, 4); nc2 = LDB4(3 * c + 2, 8);
-                    }
-                    if (!(hi > 0.0f) && a2.w == 0.0f && c2.w == 0.0f) continue;   // bounds [-0, 0] and lambda already 0: nothing moves
-                    OS_ROW_STEP(a0, a1, a2, -hi, hi, 3 * cc + 1);
-                    OS_ROW_STEP(c0, c1, c2, -hi, hi, 3 * cc + 2);
-                }
-            }
-            // ---- generic contacts with rows in LDS [n_os, c_lf): software-pipelined row steps, the next row is fetched
-            //      while the current one is swept (one wave per SIMD: LDS latency is otherwise exposed).  The four envs
-            //      of the wave run this loop together.
-            if (c_lf > n_os) {
-                const int ng = c_lf - n_os;
-                float4 Ap, Ar, Bp, Br; float Aa0, Aa1, Aa2, Am0, Am1, Am2, Aj, Am, Ba0, Ba1, Ba2, Bm0, Bm1, Bm2, Bj, Bm; int Arow, Brow;
-                if (pass == 0) {
-                    // normals of all contacts; the ones that carry an impulse afterwards are noted for the friction pass
-                    unsigned long long pos = 0;
-                    float sA_, sB_;
-                    LEAN_LOAD(A, 0, 0)
-                    for (int j = 0; j < ng; j += 2) {
-                        LEAN_LOAD(B, j + 1, 0)                 // (one row past the end at most: inside the pool's tail pad)
-                        { LEAN_ROLE(j) LEAN_STEP(A, 0.0f, 1e10f, sA_) }
-                        pos |= sA_ > 0.0f ? 1ull << j : 0ull;
-                        if (j + 1 < ng) {
-                            LEAN_LOAD(A, j + 2, 0)
-                            { LEAN_ROLE(j + 1) LEAN_STEP(B, 0.0f, 1e10f, sB_) }
-                            pos |= sB_ > 0.0f ? 2ull << j : 0ull;
-                        }
-                    }
-                    ln_pos = pos;
-                } else {
-                    // frictions: a contact without normal impulse (94 % of the robot contacts of a pushing gripper are
-                    // speculative: inside the margin, not touching) whose friction impulses are zero has the bounds
-                    // [-0, 0] and cannot move anything -- only the others are swept, every env walking its own list
-                    unsigned long long todo = ln_pos | fr_nz;
-                    fr_nz = 0;
-                    if (todo) {
-                        int j = __ffsll((long long)todo) - 1;
-                        todo &= todo - 1;
-                        LEAN_LOAD(A, j, 1)
-                        float nmu_ = LD(L_MU + n_os + j), nln_ = LD(L_BASE + (3 * (n_os + j)) * 12 + 11);
-                        for (;;) {
-                            const float hi_ = nmu_ * nln_;
-                            LEAN_ROLE(j)
-                            const bool more = todo != 0;
-                            const int jn = more ? __ffsll((long long)todo) - 1 : j;
-                            todo &= todo - 1;
-                            // the next contact's scalars first: they are multiplied at the top of the next trip
-                            nmu_ = LD(L_MU + n_os + jn); nln_ = LD(L_BASE + (3 * (n_os + jn)) * 12 + 11);
-                            float s1_, s2_;
-                            LEAN_LOAD(B, j, 2)
-                            LEAN_STEP(A, -hi_, hi_, s1_)
-                            LEAN_LOAD(A, jn, 1)
-                            LEAN_STEP(B, -hi_, hi_, s2_)
-                            fr_nz |= (s1_ != 0.0f || s2_ != 0.0f) ? 1ull << j : 0ull;
-                            if (!more) break;
-                            j = jn;
-                        }
+            // ---- object-vs-static rows of this pass (object lanes, side by side)
+            if (pass == 0) {
+                OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3)
+                OSN_PUBLISH(0) OSN_PUBLISH(1) OSN_PUBLISH(2) OSN_PUBLISH(3)
+                if (own_os) {
+                    unsigned rem = own_os;
+                    int c = __ffs(rem) - 1;
+                    float4 n0 = LDB4(3 * c, 0), n1 = LDB4(3 * c, 4), n2 = LDB4(3 * c, 8);
+                    while (rem) {
+                        const float4 b0 = n0, b1 = n1, b2 = n2;
+                        const int cc = c;
+                        rem &= rem - 1;
+                        if (rem) { c = __ffs(rem) - 1; n0 = LDB4(3 * c, 0); n1 = LDB4(3 * c, 4); n2 = LDB4(3 * c, 8); }
+                        OS_ROW_STEP(b0, b1, b2, 0.0f, 1e10f, 3 * cc);
                     }
                 }
-            }
-            // ---- overflow contacts [c_lf, nc): rows in global memory (same arithmetic; lane 0 owns rhs / dinv / lambda)
-            for (int c = c_lf; c < nc; c++) {
-                const int meta = *(const int *)&LD(L_META + c);
-                const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta);
-                const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
-                const int r0 = pass == 0 ? 3 * c : 3 * c + 1, r1 = pass == 0 ? 3 * c + 1 : 3 * c + 3;
-                const bool mineA = (lo_ >= 0) && (bodyA == 16 + lo_), mineB = (lo_ >= 0) && (bodyB == 16 + lo_);
-                const float mu = SCR(S_CT + c * 12 + 11);
-                float ln = 0.0f;
-                if (l == 0) ln = ROWL(3 * c, 39);
-                for (int r = r0; r < r1; r++) {
-                    float lo = 0, hi = 1e10f;
-                    if (pass == 1) { hi = mu * ln; lo = -hi; }
-                    float part = 0;
-                    v3 ang = mk(0, 0, 0), mang = mk(0, 0, 0);
-                    float mja = 0;
-                    const v3 dir = mk(ROWL(r, 22), ROWL(r, 23), ROWL(r, 24));
-                    if (robot && l < NB) { part = ROWL(r, l) * dq; mja = ROWL(r, 11 + l); }
-                    if (mineA) { ang = mk(ROWL(r, 25), ROWL(r, 26), ROWL(r, 27)); mang = mk(ROWL(r, 28), ROWL(r, 29), ROWL(r, 30)); }
-                    if (mineB) { ang = mk(ROWL(r, 31), ROWL(r, 32), ROWL(r, 33)); mang = mk(ROWL(r, 34), ROWL(r, 35), ROWL(r, 36)); }
-                    if (mineA) part = dot(dir, dv) + dot(ang, dw);
-                    if (mineB) part = -dot(dir, dv) + dot(ang, dw);
-                    const float jv = group_sum(part);
-                    float dl = 0.0f;
-                    if (l == 0) {
-                        const float rhs = ROWL(r, 37), dinv = ROWL(r, 38), lam = ROWL(r, 39);
-                        const float s0 = fmaf(-jv, dinv, lam + rhs);
-                        const float sum = fminf(fmaxf(s0, lo), hi);
-                        dl = sum - lam;
-                        ROWS(r, 39, sum);
+            } else if (pass == 1) {
+                OSF_STEP(0) OSF_STEP(1) OSF_STEP(2) OSF_STEP(3)
+                if (own_os) {
+                    // frictions of this lane's further object-vs-static contacts; the rows of the next one are prefetched
+                    unsigned rem = own_os;
+                    int c = __ffs(rem) - 1;
+                    float nln = LD(L_OSL + (3 * c) * 12 + 11), nmu = LD(L_MU + c);
+                    float4 na0 = LDB4(3 * c + 1, 0), na1 = LDB4(3 * c + 1, 4), na2 = LDB4(3 * c + 1, 8);
+                    float4 nc0 = LDB4(3 * c + 2, 0), nc1 = LDB4(3 * c + 2, 4), nc2 = LDB4(3 * c + 2, 8);
+                    while (rem) {
+                        const float hi = nmu * nln;
+                        const float4 a0 = na0, a1 = na1, a2 = na2, c0 = nc0, c1 = nc1, c2 = nc2;
+                        const int cc = c;
+                        rem &= rem - 1;
+                        if (rem) {
+                            c = __ffs(rem) - 1;
+                            nln = LD(L_OSL + (3 * c) * 12 + 11); nmu = LD(L_MU + c);
+                            na0 = LDB4(3 * c + 1, 0); na1 = LDB4(3 * c + 1, 4); na2 = LDB4(3 * c + 1, 8);
+                            nc0 = LDB4(3 * c + 2, 0); nc1 = LDB4(3 * c + 2, 4); nc2 = LDB4(3 * c + 2, 8);
+                        }
+                        if (!(hi > 0.0f) && a2.w == 0.0f && c2.w == 0.0f) continue;   // bounds [-0, 0] and lambda already 0: nothing moves
+                        OS_ROW_STEP(a0, a1, a2, -hi, hi, 3 * cc + 1);
+                        OS_ROW_STEP(c0, c1, c2, -hi, hi, 3 * cc + 2);
                     }
-                    dl = row_bcast<0>(dl);
-                    dq += mja * dl;
-                    if (mineA) { dv = dv + dir * (dl * inv_mass); dw = dw + mang * dl; }
-                    if (mineB) { dv = dv + dir * (-dl * inv_mass); dw = dw + mang * dl; }
+                }
+            } else {
+                OS_TORSIONAL_SWEEP
+            }
+            if (cmax == 0) continue;
+            // ---- generic rows of this pass, blocks of 16 rows: lane k of the group holds the scalars of the block's row k
+            OBJ_SLOTS(TO_SLOT)
+            for (int i0 = 0; i0 < cmax; i0 += 16) {
+                const int e = e_cur;
+                const bool valid = e != 0xffff;
+                const int jc = e >> 3, kk = e & 7, r = valid ? 6 * jc + kk : 0;
+                const float rhs = valid ? LD(L_GRHS + r) : 0.0f, dinv = valid ? LD(L_GDINV + r) : 0.0f;
+                float lam = valid ? LD(L_GLAM + r) : 0.0f;
+                const float coef = kk == 0 ? 0.0f : (kk < 3 ? LD(L_MU + n_os + (valid ? jc : 0)) : (kk == 3 ? LD(L_SPIN + n_os + (valid ? jc : 0)) : LD(L_ROLL + n_os + (valid ? jc : 0))));
+                const float lnorm = valid ? LD(L_GLAM + 6 * jc) : 0.0f;
+                const float hi = !valid ? 0.0f : (kk == 0 ? 1e10f : coef * lnorm), lo = kk == 0 ? 0.0f : -hi;
+                const int idx_a = idx_cur, idx_b = idx_nxt;        // this block's rows 8..15 and the next block's rows 0..7 are requested below
+                e_cur = e_nxt; idx_cur = idx_nxt;
+                e_nxt = ENTRY(i0 + 32 + l); idx_nxt = ENTRY_IDX(e_nxt);
+#define GROW_STEP(S, Q, NEXTIDX)                                                                                       \
+                {                                                                                                      \
+                    const float4 rw_ = Q;                                                                              \
+                    Q = D.grows[(NEXTIDX) + l];                                                                              \
+                    const float p_ = fmaf(rw_.z, vb, rw_.x * dq);                                                      \
+                    const float jv_ = group_sum(p_);                                                                   \
+                    const float s0_ = fmaf(-jv_, dinv, lam + rhs);                                                     \
+                    const float sum_ = __builtin_amdgcn_fmed3f(s0_, lo, hi);                                           \
+                    const float dl_ = sum_ - lam;                                                                      \
+                    lam = (l == (S)) ? sum_ : lam;                                                                     \
+                    const float dlb_ = row_bcast<S>(dl_);                                                              \
+                    dq = fmaf(rw_.y, dlb_, dq); vb = fmaf(rw_.w, dlb_, vb);                                            \
+                }
+                GROW_STEP(0, Q0, row_bcast_i<8>(idx_a))   GROW_STEP(1, Q1, row_bcast_i<9>(idx_a))
+                GROW_STEP(2, Q2, row_bcast_i<10>(idx_a))  GROW_STEP(3, Q3, row_bcast_i<11>(idx_a))
+                GROW_STEP(4, Q4, row_bcast_i<12>(idx_a))  GROW_STEP(5, Q5, row_bcast_i<13>(idx_a))
+                GROW_STEP(6, Q6, row_bcast_i<14>(idx_a))  GROW_STEP(7, Q7, row_bcast_i<15>(idx_a))
+                GROW_STEP(8, Q0, row_bcast_i<0>(idx_b))   GROW_STEP(9, Q1, row_bcast_i<1>(idx_b))
+                GROW_STEP(10, Q2, row_bcast_i<2>(idx_b))  GROW_STEP(11, Q3, row_bcast_i<3>(idx_b))
+                GROW_STEP(12, Q4, row_bcast_i<4>(idx_b))  GROW_STEP(13, Q5, row_bcast_i<5>(idx_b))
+                GROW_STEP(14, Q6, row_bcast_i<6>(idx_b))  GROW_STEP(15, Q7, row_bcast_i<7>(idx_b))
+#undef GROW_STEP
+                if (valid) LD(L_GLAM + r) = lam;
+            }
+#undef ENTRY
+#undef ENTRY_IDX
+            OBJ_SLOTS(FROM_SLOT)
+            if (pass == 0) {
+                // ---- the lateral and torsional rows that can move something: contacts with a normal impulse, or with a
+                //      lateral / torsional impulse left from the previous sweep
+                nF = 0; nT = 0;
+                for (int j0 = 0; j0 < ng_max; j0 += 16) {
+                    const int j = j0 + l;
+                    bool act = false, hs = false, hr = false;
+                    if (j < ng) {
+                        const int r = 6 * j;
+                        act = LD(L_GLAM + r) > 0.0f || LD(L_GLAM + r + 1) != 0.0f || LD(L_GLAM + r + 2) != 0.0f ||
+                              LD(L_GLAM + r + 3) != 0.0f || LD(L_GLAM + r + 4) != 0.0f || LD(L_GLAM + r + 5) != 0.0f;
+                        hs = act && LD(L_SPIN + n_os + j) > 0.0f;
+                        hr = act && LD(L_ROLL + n_os + j) > 0.0f;
+                    }
+                    const unsigned lt = (1u << l) - 1u;
+                    const unsigned ma = (unsigned)(__ballot(act) >> (16 * grp)) & 0xffffu, ms = (unsigned)(__ballot(hs) >> (16 * grp)) & 0xffffu,
+                                   mr = (unsigned)(__ballot(hr) >> (16 * grp)) & 0xffffu;
+                    if (act) {
+                        const int pf = nF + 2 * __popc(ma & lt);
+                        listF[pf] = (unsigned short)((j << 3) | 1); listF[pf + 1] = (unsigned short)((j << 3) | 2);
+                        int pt = nT + __popc(ms & lt) + 2 * __popc(mr & lt);
+                        if (hs) listT[pt++] = (unsigned short)((j << 3) | 3);
+                        if (hr) { listT[pt] = (unsigned short)((j << 3) | 4); listT[pt + 1] = (unsigned short)((j << 3) | 5); }
+                    }
+                    nF += 2 * __popc(ma); nT += __popc(ms) + 2 * __popc(mr);
                 }
             }
         }
     }
     SPROF(4);
-    SBLK_END(nc, nc - n_os, nc - c_lf, c_lf - n_os);
     // impulses of the register-resident contact rows go back to their LDS slots (contact forces / touch sensors below)
 #pragma unroll
     for (int i = 0; i < KOS; i++) {
         const int c = (os_cs >> (8 * i)) & 255;
         if (c != 255) {
-            LD(L_BASE + (3 * c) * 12 + 11) = os_ln[i];
-            LD(L_BASE + (3 * c + 1) * 12 + 11) = os_l1[i];
-            LD(L_BASE + (3 * c + 2) * 12 + 11) = os_l2[i];
+            LD(L_OSL + (3 * c) * 12 + 11) = os_ln[i];
+            LD(L_OSL + (3 * c + 1) * 12 + 11) = os_l1[i];
+            LD(L_OSL + (3 * c + 2) * 12 + 11) = os_l2[i];
         }
     }
+    if (dead) return;
     // ---- integrate: lanes 0..10 joints, lanes 11..13 objects
     bool finite = true;
     if (l < NB) {
@@ -1637,10 +1586,8 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         float touch[4] = {0, 0, 0, 0};
         for (int c = 0; c < nc; c++) {
             const int meta = *(const int *)&LD(L_META + c);
-            const int bodyA = meta_bodyA(meta), bodyB = meta_bodyB(meta), link = meta_link(meta);
-            const bool robot = (bodyA >= 0 && bodyA < 16) || (bodyB >= 0 && bodyB < 16);
-            const bool fast = meta_fast(meta);
-            float lam = fast ? LD(L_BASE + (3 * c) * 12 + 11) : ROWL(3 * c, 39);
+            const int bodyA = meta_bodyA(meta), link = meta_link(meta);
+            const float lam = meta_fast(meta) ? LD(L_OSL + (3 * c) * 12 + 11) : LD(L_GLAM + 6 * (c - n_os));
             float f = lam / dt;
             SCR(S_CT + c * 12 + 10) = f;
             if (bodyA < 0 || bodyA >= 16) continue;
@@ -2913,7 +2860,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     P.margin = cfg->margin > 0 ? cfg->margin : 0.02f; P.kp = 0.1f; P.kd = 1.0f; P.max_impulse = 100000.0f * P.dt;
     P.ablate = getenv("RR_ABLATE") ? atoi(getenv("RR_ABLATE")) : 0;
     P.small_area = getenv("RR_SMALL_AREA") ? atoi(getenv("RR_SMALL_AREA")) : SMALL_AREA;
-    P.pool = getenv("RR_SOLVER_POOL") ? std::max(0, std::min(atoi(getenv("RR_SOLVER_POOL")), (int)SPOOL)) : SPOOL;   // tests shrink it to reach the overflow rows
+    // RR_SOLVER_POOL (tests): LDS floats for object-vs-static rows, 60 per contact; contacts beyond it take the generic (slot layout) path
+    P.os_cap = getenv("RR_SOLVER_POOL") ? std::max(0, std::min(atoi(getenv("RR_SOLVER_POOL")) / 60, (int)OS_CAP)) : OS_CAP;
     P.lin_damp = 0.04f; P.ang_damp = 0.04f; P.rest_thresh = 0.2f;
     e->epb = cfg->envs_per_block > 0 ? cfg->envs_per_block : 64;
     if (e->epb > 64) e->epb = 64;   // physics kernels are compiled with __launch_bounds__(64)
@@ -2931,6 +2879,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     NEED(f = b.f32("shape_sphere", ns * 4)); memcpy(S.sphere, f, (size_t)ns * 4 * 4);
     NEED(f = b.f32("shape_mat", ns * 2));
     for (int s = 0; s < ns; s++) { S.fric[s] = f[2 * s]; S.rest[s] = f[2 * s + 1]; }
+    NEED(f = b.f32("shape_roll", ns * 2));       // URDF <rolling_friction>, <spinning_friction> (cube.urdf:6-7, kuka_gripper.urdf:292-296 ...)
+    for (int s = 0; s < ns; s++) { S.roll[s] = f[2 * s]; S.spin[s] = f[2 * s + 1]; }
     int np = 0, s_obj0 = n_static + n_robot;
     for (int i = 0; i < P.nobj; i++) for (int s = 0; s < n_static; s++) { S.pair_a[np] = s_obj0 + i; S.pair_b[np++] = s; }
     for (int i = 0; i < P.nobj; i++) for (int j = i + 1; j < P.nobj; j++) { S.pair_a[np] = s_obj0 + i; S.pair_b[np++] = s_obj0 + j; }
@@ -2944,6 +2894,9 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         S.pair_meta[k][1] = S.otype[sb] == 0 ? -1 : (S.otype[sb] == 1 ? S.oidx[sb] : 16 + S.oidx[sb]);
         S.pair_meta[k][2] = S.link[sa]; S.pair_meta[k][3] = 0;
         S.pair_mat[k][0] = S.fric[sa] * S.fric[sb]; S.pair_mat[k][1] = S.rest[sa] * S.rest[sb];
+        // btManifoldResult::calculateCombinedRollingFriction / SpinningFriction: r_a mu_b + r_b mu_a, at most 10
+        S.pair_mat[k][2] = std::min(S.roll[sa] * S.fric[sb] + S.roll[sb] * S.fric[sa], 10.0f);
+        S.pair_mat[k][3] = std::min(S.spin[sa] * S.fric[sb] + S.spin[sb] * S.fric[sa], 10.0f);
     }
 
     // render model
@@ -2982,8 +2935,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     ALLOC(D.timestep, (size_t)N);
     ALLOC(D.errflags, (size_t)N);
     ALLOC(D.obj_home, (size_t)NOBJ * 7 * N);
-    ALLOC(D.demand, (size_t)2 * N);
-    ALLOC(D.solve_order, (size_t)4 * ((N + 3) / 4));
+    ALLOC(D.grows, ((size_t)N * GROWS + 1) * 16);
     ALLOC(D.cmd, (size_t)N * 9);
     ALLOC(D.joints, (size_t)N * 9);
     ALLOC(D.touch, (size_t)N * 4);
@@ -3082,7 +3034,6 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         e->field_ptr[RR_F_FRAG_COUNT] = e->D.frag_count;
         if ((r = build_static_layer(e)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
     }
-    hipLaunchKernelGGL(k_balance, dim3(1), dim3(BAL_THREADS), 0, e->stream, e->P, e->D);     // identity order until contacts appear
     HIPCHK(hipGetLastError());
     return RR_OK;
 }
@@ -3219,7 +3170,6 @@ static int do_render(rr_env *e, bool use_flags) {
 static void launch_prep_serial(rr_env *e, const DevPtrs &Dp) {
     hipLaunchKernelGGL(k_prep_a, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp);
     hipLaunchKernelGGL(k_prep_b, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp);
-    hipLaunchKernelGGL(k_balance, dim3(1), dim3(BAL_THREADS), 0, e->stream, e->P, e->D);
 }
 
 static void launch_collide(rr_env *e) {
@@ -3256,7 +3206,6 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     // a device-resident command buffer is read in place by k_prep (stream order protects it like a copy would)
     DevPtrs Dp = e->D;
     if (joint_cmd && cmd_on_device) Dp.cmd = const_cast<float *>(joint_cmd);
-    e->P.par ^= 1;          // k_collide records this step's contact demand in one half, k_balance reads the other
     if (host_flags) {
         memcpy(pin + (size_t)N * 36, render_flags_host, N);
         HIPCHK(hipMemcpyAsync(e->D.render_flags, pin + (size_t)N * 36, N, hipMemcpyHostToDevice, e->stream));
@@ -3269,7 +3218,6 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
         hipLaunchKernelGGL(k_prep_b, env_grid(e), dim3(e->epb), 0, e->aux, e->B, e->P, Dp);
-        hipLaunchKernelGGL(k_balance, dim3(1), dim3(BAL_THREADS), 0, e->aux, e->P, e->D);
         hipEventRecord(e->ev_dyn, e->aux);
         dyn_forked = true;
     } else {

@@ -32,8 +32,8 @@ from scipy.spatial import ConvexHull
 
 REF = os.environ.get("RR_REFERENCE_DATA",
                      "/root/reference/real_robots/data/kuka_gripper_description")
-VMAX = 32     # collision vertices per shape
-FMAX = 32     # collision planes per shape
+VMAX = 192    # cap of collision vertices per shape (the greedy reduction stops earlier when HULL_TOL is met)
+FMAX = 192    # cap of collision planes per shape
 MARGIN = 0.001  # Bullet gUrdfDefaultCollisionMargin, used for the inertia AABB only
 CLUSTER = 64    # triangles per raster cluster (= one wavefront iteration)
 
@@ -144,74 +144,93 @@ def mtl_info(obj_path):
 
 
 # ----------------------------------------------------------------------------- hull simplification
-def support_dirs():
-    dirs = []
-    e = 0.15
-    for ax in range(3):
-        for s0 in (1, -1):
-            for s1 in (1, -1):
-                for s2 in (1, -1):
-                    d = np.zeros(3)
-                    d[ax] = s0
-                    d[(ax + 1) % 3] = s1 * e
-                    d[(ax + 2) % 3] = s2 * e
-                    dirs.append(d)
-    for s0 in (1, -1):
-        for s1 in (1, -1):
-            for s2 in (1, -1):
-                dirs.append(np.array([s0, s1, s2], dtype=float))
-    return [d / np.linalg.norm(d) for d in dirs]
+# Bullet collides the full convex hull of every OBJ (link_1 has 1 407 vertices).  The device kernel works on
+# a reduced vertex set (an inner approximation: a subset of the hull's vertices) and a reduced plane set (an outer
+# approximation: a subset of the hull's facet planes), both chosen greedily by the error they remove, until the
+# deviation from the full hull is below HULL_TOL or the caps are reached.  The remaining deviations are stored in the
+# blob (`shape_dev`) and bounded by tests/test_oracle_pins.py::test_collision_hull_reduction_error.
+HULL_TOL = 3.0e-4   # m
+NPREF = 6           # the first NPREF planes of every shape are its extreme planes along +-x, +-y, +-z (cheap exact rejection)
+
+
+def hull_facets(pts):
+    """(vertices [H,3], unique facet planes [F,4] with n.x + d <= 0 inside) of the convex hull of pts."""
+    hull = ConvexHull(pts)
+    eq = hull.equations
+    keep, seen = [], set()
+    for i, e in enumerate(np.round(eq, 7)):          # coplanar triangles of one facet
+        k = e.tobytes()
+        if k not in seen:
+            seen.add(k)
+            keep.append(i)
+    return pts[hull.vertices], eq[keep]
+
+
+def vertex_deviation(hv, sub):
+    """How far the full hull sticks out of the hull of the subset `sub` (m), and the vertex that sticks out most."""
+    h = ConvexHull(sub)
+    out = (hv @ h.equations[:, :3].T + h.equations[:, 3]).max(1)
+    i = int(np.argmax(out))
+    return max(float(out[i]), 0.0), i
+
+
+def plane_deviation(hv, eq, chosen):
+    """How far the polytope of the plane subset `chosen` sticks out of the full hull (m), and the facet to add."""
+    from scipy.spatial import HalfspaceIntersection
+    pv = HalfspaceIntersection(eq[chosen], hv.mean(0)).intersections
+    viol = pv @ eq[:, :3].T + eq[:, 3]
+    viol[:, chosen] = -1.0
+    _, fi = np.unravel_index(np.argmax(viol), viol.shape)
+    return max(float(viol.max()), 0.0), int(fi)
 
 
 def simplify_hull(pts):
-    """pts [V,3] (already in the owner's frame). Returns verts[<=VMAX,3], planes[<=FMAX,4] (n, c: n.x<=c inside)."""
-    hull = ConvexHull(pts)
-    hv = pts[hull.vertices]
-    # --- vertices
-    if len(hv) <= VMAX:
-        verts = hv.copy()
+    """pts [V,3] (already in the owner's frame). Returns verts[<=VMAX,3], planes[<=FMAX,4] (n, c: n.x<=c inside),
+    (vertex deviation, plane deviation) in metres."""
+    hv, eq = hull_facets(pts)
+    axes = np.vstack([np.eye(3), -np.eye(3)])
+    # --- vertices: extremes first, then always the hull vertex farthest outside the current subset's hull
+    chosen = []
+    for d in axes:
+        i = int(np.argmax(hv @ d))
+        if i not in chosen:
+            chosen.append(i)
+    while len(chosen) < 4:
+        chosen.append(int(np.argmax(np.min(np.linalg.norm(hv[:, None] - hv[None, chosen], axis=2), axis=1))))
+    if len(hv) <= VMAX and len(hv) <= 24:
+        chosen, vdev = list(range(len(hv))), 0.0
     else:
-        chosen = []
-        for d in support_dirs():
-            i = int(np.argmax(hv @ d))
-            if i not in chosen:
-                chosen.append(i)
-        while len(chosen) < VMAX:   # farthest point fill
-            dmin = np.min(np.linalg.norm(hv[:, None, :] - hv[None, chosen, :], axis=2), axis=1)
-            chosen.append(int(np.argmax(dmin)))
-        verts = hv[chosen[:VMAX]]
-    # --- planes: merge facets by normal, area weighted, then cluster until <= FMAX
-    eq = hull.equations  # n.x + d <= 0
-    simp = hull.simplices
-    areas = 0.5 * np.linalg.norm(np.cross(pts[simp[:, 1]] - pts[simp[:, 0]],
-                                          pts[simp[:, 2]] - pts[simp[:, 0]]), axis=1)
-    order = np.argsort(-areas)
-    theta = 1.0  # degrees
-    while True:
-        cth = np.cos(np.radians(theta))
-        seeds, acc = [], []
-        for i in order:
-            n = eq[i, :3]
-            hit = -1
-            best = cth
-            for k, s in enumerate(seeds):
-                c = float(n @ s)
-                if c > best:
-                    best, hit = c, k
-            if hit < 0:
-                seeds.append(n.copy())
-                acc.append(n * areas[i])
-            else:
-                acc[hit] += n * areas[i]
-        if len(seeds) <= FMAX:
-            break
-        theta *= 1.3
-    planes = []
-    for a in acc:
-        n = a / np.linalg.norm(a)
-        c = float(np.max(hv @ n))
-        planes.append([n[0], n[1], n[2], c])
-    return verts, np.array(planes), theta
+        while True:
+            try:
+                vdev, i = vertex_deviation(hv, hv[chosen])
+            except Exception:                            # degenerate start: spread by distance
+                vdev, i = 1.0, int(np.argmax(np.min(np.linalg.norm(hv[:, None] - hv[None, chosen], axis=2), axis=1)))
+            if vdev < HULL_TOL or len(chosen) >= VMAX or i in chosen:
+                break
+            chosen.append(i)
+    verts = hv[chosen]
+    # --- planes: the six extreme facets first (kernel prefilter), then always the facet that cuts off the worst corner
+    pch = []
+    for d in axes:
+        i = int(np.argmax(eq[:, :3] @ d))
+        if i not in pch:
+            pch.append(i)
+    k = 0
+    while len(pch) < min(NPREF, len(eq)):                # boxes etc.: fewer than six distinct extremes -> fill in order
+        if k not in pch:
+            pch.append(k)
+        k += 1
+    if len(eq) <= 24:
+        pch += [i for i in range(len(eq)) if i not in pch]
+        pdev = 0.0
+    else:
+        while True:
+            pdev, fi = plane_deviation(hv, eq, pch)
+            if pdev < HULL_TOL or len(pch) >= FMAX:
+                break
+            pch.append(fi)
+    planes = np.array([[eq[i, 0], eq[i, 1], eq[i, 2], -eq[i, 3]] for i in pch])
+    return verts, planes, (vdev, pdev)
 
 
 # ----------------------------------------------------------------------------- URDF
@@ -543,13 +562,14 @@ def main(out_path):
     shapes = []
 
     def add_shape(name, owner_type, owner_idx, lid, pts_owner_frame, L, body_uid):
-        verts, planes, theta = simplify_hull(pts_owner_frame)
+        verts, planes, dev = simplify_hull(pts_owner_frame)
         c = 0.5 * (pts_owner_frame.min(0) + pts_owner_frame.max(0))
         r = float(np.max(np.linalg.norm(pts_owner_frame - c, axis=1)))
         shapes.append(dict(name=name, otype=owner_type, oidx=owner_idx, link=lid, verts=verts, planes=planes,
-                           center=c, radius=r, friction=L.friction, restitution=L.restitution, uid=body_uid))
-        print('shape %-12s owner(%d,%2d) link %2d  V=%2d F=%2d  merge-angle %.1f deg  r=%.3f' %
-              (name, owner_type, owner_idx, lid, len(verts), len(planes), theta, r))
+                           center=c, radius=r, friction=L.friction, restitution=L.restitution, uid=body_uid, dev=dev,
+                           rolling=L.rolling, spinning=L.spinning))
+        print('shape %-12s owner(%d,%2d) link %2d  V=%3d F=%3d  deviation from the full hull: vertices %.2f mm, planes %.2f mm  r=%.3f' %
+              (name, owner_type, owner_idx, lid, len(verts), len(planes), dev[0] * 1e3, dev[1] * 1e3, r))
 
     # statics first: table, shelf, robot base link_0
     for ln in ('table_base', 'table_upper'):
@@ -577,6 +597,8 @@ def main(out_path):
     sh_planes[:, :, 3] = 1e9                    # padded planes never bind (n=0, c=+big)
     sh_sphere = np.zeros((NS, 4))
     sh_mat = np.zeros((NS, 2))
+    sh_roll = np.zeros((NS, 2))                 # rolling, spinning friction coefficients (URDF <contact>)
+    sh_dev = np.zeros((NS, 2))                  # deviation of the reduced vertex / plane set from the full hull (m)
     for s, S in enumerate(shapes):
         sh_owner[s] = [S['otype'], S['oidx'], S['link'], S['uid']]
         nv, nf = len(S['verts']), len(S['planes'])
@@ -587,6 +609,8 @@ def main(out_path):
         sh_sphere[s, :3] = S['center']
         sh_sphere[s, 3] = S['radius']
         sh_mat[s] = [S['friction'], S['restitution']]
+        sh_roll[s] = [S['rolling'], S['spinning']]
+        sh_dev[s] = S['dev']
 
     # touch sensor links: skin_00, skin_01, skin_10, skin_11  (robot.py:156)
     touch_links = np.array([link_id[n] for n in ('skin_00', 'skin_01', 'skin_10', 'skin_11')], np.int32)
@@ -792,6 +816,8 @@ def main(out_path):
     B.add('shape_planes', sh_planes, F)
     B.add('shape_sphere', sh_sphere, F)
     B.add('shape_mat', sh_mat, F)
+    B.add('shape_roll', sh_roll, F)
+    B.add('shape_dev', sh_dev, F)
     B.add('touch_links', touch_links, I32)
     B.add('link_body', link_body, I32)
     B.add('link_pos', link_pos, F)
