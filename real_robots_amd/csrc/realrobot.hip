@@ -102,10 +102,7 @@ enum {
     S_OIINV = S_OR + 27,         // 3*9
     S_OVS = S_OIINV + 27,        // 9
     S_OWS = S_OVS + 9,           // 9
-    S_PCOUNT = S_OWS + 9,        // MAXPAIRS (int)
-    S_CT = S_PCOUNT + MAXPAIRS,              // MAXC*12 (contact records for the API)
-    S_NCT = S_CT + MAXC * 12,                // 1 (int)
-    S_MOT = S_NCT + 1,                       // 11 x {rhs, dinv, lambda}
+    S_MOT = S_OWS + 9,                       // 11 x {rhs, dinv, lambda}
     S_LIM = S_MOT + 33,                      // 22 x {rhs, lambda}
     S_TOTAL = S_LIM + 44
 };
@@ -118,9 +115,11 @@ enum {
 struct DevPtrs {
     float *state;      // [ST_TOTAL][N]
     float *scratch;    // [S_TOTAL][N]
-    float4 *pdata;     // [N][MAXPAIRS][4][2]  contact candidates per env and pair: {x, y, z, nx | ny, nz, depth, -}: written by one
-                       // k_collide workgroup, read by one k_solve group -- contiguous per env (the SoA slab would spread a
-                       // pair's 28 floats over 28 cache lines shared with 31 other envs)
+    float4 *clist;     // [N][MAXC][3]  the env's contacts in pair order {x, y, z, nx | ny, nz, distance, meta | mu, restitution, rolling,
+                       // spinning}; meta = bodyA | bodyB << 8 | linkA << 16 (bytes; -1 static, 0..15 robot body, 16+i object i).
+                       // Written by the env's k_collide wavefront, read by its k_solve group in one round trip.
+    int *ccount;       // [N] number of contacts in clist
+    float *cforce;     // [N][MAXC] normal force of every contact of the last step (rr_get_contacts, touch sensors)
     int *timestep;     // [N]
     unsigned *errflags;// [N]
     float *obj_home;   // [NOBJ*7][N] per-env pose an object is put back to by reset / the out-of-bounds rule (robot.py:19-24, mutable there)
@@ -544,13 +543,15 @@ __device__ __forceinline__ Xf load_xf(const ShapeData *S, int s, const float *st
 __device__ unsigned long long g_sprof[16];
 #define SPROF(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && (!(P.ablate & 0x4000) || (int)blockIdx.x == (P.ablate >> 16))) atomicAdd(&g_sprof[i], now_ - sp_t0); sp_t0 = now_; } while (0)   /* RR_ABLATE = block << 16 | 0x4000: one block only */
 #define SPROF_INIT unsigned long long sp_t0 = __builtin_readcyclecounter();
-// per solver workgroup: {cycles, and per env nc | generic << 8 | overflow rows << 16 | LDS robot rows << 24}
-__device__ unsigned g_sblk[4096 * 5];
-#define SBLK_BEGIN const unsigned long long sb_t0 = __builtin_readcyclecounter();
-#define SBLK_END(ncv, gv, ovf, lean) do { if (blockIdx.x < 4096) { if (l == 0) g_sblk[blockIdx.x * 5 + 1 + grp] = (unsigned)(ncv) | ((unsigned)(gv) << 8) | ((unsigned)(ovf) << 16) | ((unsigned)(lean) << 24); \
-    if (threadIdx.x == 0) g_sblk[blockIdx.x * 5] = (unsigned)(__builtin_readcyclecounter() - sb_t0); } } while (0)
+// per solver workgroup: {total cycles, cycles up to the end of the row build, cycles of the PGS loop, -, then per env
+// nc | generic contacts << 8 | leading object-vs-static contacts << 16 | last F-list length << 24}
+__device__ unsigned g_sblk[4096 * 8];
+#define SBLK_BEGIN const unsigned long long sb_t0 = __builtin_readcyclecounter(); unsigned long long sb_t1 = sb_t0, sb_t2 = sb_t0;
+#define SBLK_MARK(v) v = __builtin_readcyclecounter();
+#define SBLK_END(ncv, gv, osv, nfv) do { if (blockIdx.x < 4096) { if (l == 0) g_sblk[blockIdx.x * 8 + 4 + grp] = (unsigned)(ncv) | ((unsigned)(gv) << 8) | ((unsigned)(osv) << 16) | ((unsigned)(nfv) << 24); \
+    if (threadIdx.x == 0) { g_sblk[blockIdx.x * 8] = (unsigned)(__builtin_readcyclecounter() - sb_t0); g_sblk[blockIdx.x * 8 + 1] = (unsigned)(sb_t1 - sb_t0); g_sblk[blockIdx.x * 8 + 2] = (unsigned)(sb_t2 - sb_t1); } } } while (0)
 extern "C" int rr_debug_solver_blocks(unsigned *out, int nblocks) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sblk), sizeof(unsigned) * 5 * (size_t)nblocks) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sblk), sizeof(unsigned) * 8 * (size_t)nblocks) == hipSuccess ? 0 : -1;
 }
 extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sprof), sizeof(g_sprof)) != hipSuccess) return -1;
@@ -561,7 +562,8 @@ extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
 #define SPROF(i)
 #define SPROF_INIT
 #define SBLK_BEGIN
-#define SBLK_END(ncv, gv, ovf, lean)
+#define SBLK_MARK(v)
+#define SBLK_END(ncv, gv, osv, nfv)
 #endif
 
 // ---- collision: one wavefront per env ------------------------------------------------------------------------------
@@ -672,6 +674,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
     }
     CSYNC();
     if (CABL(256)) return;
+    int nct = 0;                                // contacts of this env so far (wave-uniform)
     for (int p0 = 0; p0 < P.npairs; p0 += 64) {
         const int pr = p0 + lane;
         bool close = false;
@@ -679,10 +682,9 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
             const float4 a = sph[pair_ab[pr] & 255], b = sph[(pair_ab[pr] >> 8) & 255];
             const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, rr = a.w + b.w + P.margin;
             close = !(dx * dx + dy * dy + dz * dz > rr * rr);
-            *(int *)&SCR(S_PCOUNT + pr) = 0;
         }
         unsigned long long todo = CABL(512) ? 0ull : __ballot(close);
-        for (; todo; todo &= todo - 1) {
+        for (; todo && nct < MAXC; todo &= todo - 1) {
             const int pair = p0 + __ffsll((long long)todo) - 1;
             const int sa = pair_ab[pair] & 255, sb = (pair_ab[pair] >> 8) & 255;
             int ncand = 0;                      // wave-uniform
@@ -769,9 +771,9 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                     ncand = min(ncand + __popcll(hm), CAND_MAX);
                 }
             }
-            if (ncand == 0) continue;           // S_PCOUNT is already 0
+            if (ncand == 0) continue;
             CSYNC();
-            if (CABL(2048)) { if (ncand == 12345) *(int *)&SCR(S_PCOUNT + pair) = 1; continue; }
+            if (CABL(2048)) continue;
             // manifold reduction, same rule as the oracle's reduce4(): deepest first, then maximal spread, preferring the
             // candidates within TIER_TOL (1 mm) of the deepest penetration at every pick; ties go to the first candidate
             int sel0 = -1, sel1 = -1, sel2 = -1, sel3 = -1, k = 0;
@@ -807,17 +809,22 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
 #undef V3_
                 k = sel3 >= 0 ? 4 : 3;
             }
-            if (lane == 0) *(int *)&SCR(S_PCOUNT + pair) = k;
+            k = min(k, MAXC - nct);             // the env's list holds MAXC contacts (the oracle stops there too)
             if (lane < k) {
                 const int ci = lane == 0 ? sel0 : (lane == 1 ? sel1 : (lane == 2 ? sel2 : sel3));
                 const float4 a = cand_a[ci], b = cand_b[ci];
-                float4 *pd = D.pdata + (((size_t)env * MAXPAIRS + pair) * 4 + lane) * 2;
-                pd[0] = make_float4(a.x, a.y, a.z, b.x);
-                pd[1] = make_float4(b.y, b.z, a.w, 0.0f);
+                const int4 pm = *(const int4 *)S->pair_meta[pair];
+                const int meta = (pm.x & 255) | ((pm.y & 255) << 8) | ((pm.z & 255) << 16);
+                float4 *rec = D.clist + ((size_t)env * MAXC + nct + lane) * 3;
+                rec[0] = make_float4(a.x, a.y, a.z, b.x);
+                rec[1] = make_float4(b.y, b.z, a.w, __int_as_float(meta));
+                rec[2] = *(const float4 *)S->pair_mat[pair];
             }
+            nct += k;
             CSYNC();            // the candidate list is reused by the next pair
         }
     }
+    if (lane == 0) D.ccount[env] = nct;
 }
 #undef CAND_ARGMAX
 #pragma clang fp contract(fast)
@@ -843,10 +850,10 @@ __device__ __forceinline__ void plane_space(v3 n, v3 &p, v3 &q) {   // btPlaneSp
 // runs a single wave, so the kernel lasts as long as the longest chain: what counts is the number of (dependent)
 // instructions per row step.  Three kinds of rows:
 //   * motor / joint-limit rows: lane j < 11 owns joint j (dq), rows in registers (MOTOR_STEP, LIMIT_STEP);
-//   * object-vs-static contacts (objects resting on table / shelf), the first P.os_cap of them: lane 11 + o owns the
+//   * object-vs-static contacts (objects resting on table / shelf): lane 11 + o owns the
 //     velocity change (dv, dw) of object o and sweeps that object's rows on its own -- rows of different objects touch
-//     disjoint variables, so the three object lanes run side by side and no cross-lane sum is needed; the rows of the first
-//     KOS contacts per object live in registers, further ones and the torsional rows stream from LDS;
+//     disjoint variables, so the three object lanes run side by side and no cross-lane sum is needed; up to KOS contacts
+//     per object, all six rows of each in registers (an object's further contacts with statics take the generic path);
 //   * generic contacts (robot involved, two objects, object-static beyond os_cap): SLOT LAYOUT.  Every scalar velocity
 //     variable of the env has a fixed (lane, slot):
 //         slot A: lanes 0..10 joint velocities dq (the same register as the motor rows'), lanes 11..15 object 2 (v.xyz, w.xy)
@@ -864,26 +871,27 @@ __device__ __forceinline__ void plane_space(v3 n, v3 &p, v3 &q) {   // btPlaneSp
 //   anything: the friction and torsional sweeps run over compacted lists of the other rows, rebuilt after every normal
 //   sweep (94 % of the robot contacts of a pushing gripper are speculative: inside the margin, not touching).
 // LDS per env (LF_TOTAL floats): Minv (121), motor rows (11 x {rhs, dinv, lambda}), joint-limit rows (22 x {rhs, lambda}),
-// contact meta (48 ints), friction / spinning / rolling coefficients (3 x 48), object-vs-static rows (os_cap x (3 x 12
-// linear + 3 x 8 torsional)), generic row scalars (288 x {rhs, dinv, lambda}), the two row lists.
+// contact meta (48 ints), friction / spinning / rolling coefficients of the object-lane contacts (3 x 12), the objects' data (3 x 20),
+// a staging area for 16 contact records, object-lane rows (12 x (3 x 12 linear + 3 x 8 torsional)), generic row scalars (288 x {rhs, dinv, bound coefficient, lambda}), the two row lists.
 #define SGRP 4           // envs per workgroup (64 threads)
-#define OS_CAP 18        // object-vs-static contacts per env with rows in LDS (a resting object has 3..4)
+#define OS_CAP 12        // object-vs-static contacts per env on the object lanes: KOS per object, rows staged in LDS
 #define GROWS (6 * MAXC) // generic row ids: 6 j + k for generic contact j; k = 0 normal, 1 2 lateral, 3 spinning, 4 5 rolling
-enum { LF_MINV = 0, LF_MOT = LF_MINV + 124, LF_LIM = LF_MOT + 36, LF_META = LF_LIM + 44, LF_MU = LF_META + MAXC, LF_SPIN = LF_MU + MAXC,
-       LF_ROLL = LF_SPIN + MAXC, LF_OSL = LF_ROLL + MAXC, LF_OST = LF_OSL + OS_CAP * 36, LF_GRHS = LF_OST + OS_CAP * 24,
-       LF_GDINV = LF_GRHS + GROWS, LF_GLAM = LF_GDINV + GROWS, LF_LISTF = LF_GLAM + GROWS, LF_LISTT = LF_LISTF + MAXC,
-       LF_TOTAL = LF_LISTT + (3 * MAXC) / 2 };
+enum { LF_MINV = 0, LF_MOT = LF_MINV + 124, LF_LIM = LF_MOT + 36, LF_META = LF_LIM + 44, LF_MU = LF_META + MAXC, LF_SPIN = LF_MU + OS_CAP,
+       LF_ROLL = LF_SPIN + OS_CAP, LF_OBJ = LF_ROLL + OS_CAP, LF_CST = LF_OBJ + NOBJ * 20, LF_OSL = LF_CST + 16 * 12, LF_OST = LF_OSL + OS_CAP * 36,
+       LF_GSC = LF_OST + OS_CAP * 24, LF_LISTF = LF_GSC + 4 * GROWS, LF_LISTT = LF_LISTF + MAXC, LF_TOTAL = LF_LISTT + (3 * MAXC) / 2 };
 #define SLDS_FLOATS (SGRP * LF_TOTAL)
 static_assert(SLDS_FLOATS * 4 * 4 <= 163840, "four solver workgroups must fit the 160 KiB LDS of a CU");
-static_assert(LF_TOTAL % 4 == 0 && LF_OSL % 4 == 0 && LF_OST % 4 == 0, "row parts must be 16-byte aligned");
+static_assert(LF_TOTAL % 4 == 0 && LF_OSL % 4 == 0 && LF_OST % 4 == 0 && LF_GSC % 4 == 0 && LF_OBJ % 4 == 0 && LF_CST % 4 == 0, "row parts must be 16-byte aligned");
 __shared__ __attribute__((aligned(16))) float g_slds[SLDS_FLOATS];
 #define LD(slot) g_slds[(slot)]
 
-// meta word: bodyA (8) | bodyB (8) | linkA (8) | rows in LDS, object-vs-static (1)
+// meta word: bodyA (8) | bodyB (8) | linkA (8) | swept by the object lane (1) | object-lane slot or generic contact index (6)
 __device__ __forceinline__ int meta_bodyA(int m) { return (signed char)(m & 255); }
 __device__ __forceinline__ int meta_bodyB(int m) { return (signed char)((m >> 8) & 255); }
 __device__ __forceinline__ int meta_link(int m) { return (signed char)((m >> 16) & 255); }
 __device__ __forceinline__ bool meta_fast(int m) { return (m >> 24) & 1; }
+__device__ __forceinline__ int meta_slot(int m) { return (m >> 25) & 63; }
+__device__ __forceinline__ bool meta_near(int m) { return m < 0; }     // |distance| < 0.1 (robot.py:136)
 
 // Sum over the 16 lanes of a group (= one DPP row), result in every lane: four rotate-and-add steps on the VALU
 // (v_add_f32 with row_ror:8/4/2/1), no LDS crossbar traffic. Every lane performs the same commutative pairings, so
@@ -894,9 +902,9 @@ __device__ __forceinline__ float dpp_ror(float v) {
 }
 // value of lane J of each 16-lane row, in every lane of that row (gfx90a+ DPP row_newbcast)
 template <int J> __device__ __forceinline__ float row_bcast(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x150 + J, 0xf, 0xf, false));
 }
-template <int J> __device__ __forceinline__ int row_bcast_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false); }
+template <int J> __device__ __forceinline__ int row_bcast_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xf, 0xf, false); }
 // value of an arbitrary lane of the wavefront (ds_bpermute; the source lane must be active)
 __device__ __forceinline__ float lane_gather(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
@@ -931,68 +939,44 @@ __device__ __forceinline__ SlotOwner slot_owner(int l) {
     return s;
 }
 
-// Builds generic row `r` (= 6 j + k) of a contact along `dir` (linear rows: the constraint direction at point x;
-// torsional rows, `tors`: the rotation axis) in the slot layout; returns the relative velocity A - B along it.  Executed
-// by all 16 lanes of the env's group.  Nothing is read from global memory here.
-__device__ __forceinline__ float build_grow(const DevPtrs &D, int env, int fix, int l, int lj, int r, bool tors, int bodyA, int bodyB, v3 x, v3 dir,
-                                            v3 pk, v3 ak, float ua, float ub, const SlotOwner &so, const ObjData &oA, const ObjData &oB) {
-    float ja = 0, mja = 0, jb = 0, mjb = 0;
+// Generic rows in the slot layout, built per contact in two stages so that a row costs a handful of dot products:
+//   stage 1 (once per contact): for this lane's slot-A and slot-B variable the vectors g, h with
+//       J = dir . g,   (M^-1 J^T) = dir . h        for a linear row along `dir` at the contact point
+//     and gt, ht likewise for a torsional row about `dir`.  Joint lane l (slot A): g = +-(a_l x (x - p_l)) for the ancestors
+//     of the contact's robot body, gt = +-a_l, M^-1 J^T by the row of Minv; an object component lane: with e the unit vector
+//     of its component, r = x - object position, s = +1 (body A) / -1 (body B):
+//       linear component    g = s e,            h = s e / m
+//       angular component   g = s (e x r),      h = s ((I^-1 e) x r)      [(r x d) . e = d . (e x r), I^-1 symmetric]
+//     torsional row:        gt = s e (angular components only), ht = s I^-1 e
+//   stage 2 (per row): four dot products, the 11-step Minv product for the joint lanes, two group sums, one store.
+// Branch-free: the four envs of a wave have different body types.
+struct GrowCtx { v3 gA, hA, gtA, htA, gB, hB, gtB, htB; };
+__device__ __forceinline__ void grow_slot(int myobj, v3 el, v3 ea, int bodyA, int bodyB, v3 x, const ObjData &oA, const ObjData &oB,
+                                          v3 &g, v3 &h, v3 &gt, v3 &ht) {
+    const bool isA = myobj >= 0 && bodyA == 16 + myobj, isB = myobj >= 0 && bodyB == 16 + myobj;
+    const float s = isA ? 1.0f : (isB ? -1.0f : 0.0f);
+    const v3 op = isA ? oA.op : oB.op;
+    const float im = isA ? oA.imass : oB.imass;
+    m3 Ii;
 #pragma unroll
-    for (int side = 0; side < 2; side++) {
-        const int body = side == 0 ? bodyA : bodyB;
-        const float sg = side == 0 ? 1.0f : -1.0f;
-        if (body < 0) continue;
-        if (body < 16) {
-            // lane l < 11: Jacobian entry of joint l (zero unless joint l is an ancestor-or-self of the body)
-            float jj = 0;
-            if (l < NB && ((ANC[body] >> l) & 1u)) jj = tors ? sg * dot(dir, ak) : sg * dot(dir, cross(ak, x - pk));
-            float mj = 0;
-#define MJA_STEP(J) mj += LD(fix + LF_MINV + lj * NB + (J)) * row_bcast<J>(jj);
-            MJA_STEP(0) MJA_STEP(1) MJA_STEP(2) MJA_STEP(3) MJA_STEP(4) MJA_STEP(5) MJA_STEP(6) MJA_STEP(7) MJA_STEP(8) MJA_STEP(9) MJA_STEP(10)
-#undef MJA_STEP
-            ja = l < NB ? jj : ja;
-            mja = l < NB ? mj : mja;
-        } else {
-            const ObjData &o = side == 0 ? oA : oB;
-            const int ob = body - 16;
-            const v3 lin = tors ? mk(0, 0, 0) : dir * sg;
-            const v3 ang = tors ? dir * sg : cross(x - o.op, lin);
-            const v3 mlin = lin * o.imass, mang = mulv(o.Iinv, ang);
-            const float ca = dot(lin, so.elA) + dot(ang, so.eaA), cma = dot(mlin, so.elA) + dot(mang, so.eaA);
-            const float cb = dot(lin, so.elB) + dot(ang, so.eaB), cmb = dot(mlin, so.elB) + dot(mang, so.eaB);
-            ja = so.objA == ob ? ca : ja; mja = so.objA == ob ? cma : mja;
-            jb = so.objB == ob ? cb : jb; mjb = so.objB == ob ? cmb : mjb;
-        }
-    }
-    const float diag = group_sum(ja * mja + jb * mjb);
-    const float rel = group_sum(ja * ua + jb * ub);
-    D.grows[((size_t)env * GROWS + r) * 16 + l] = make_float4(ja, mja, jb, mjb);
-    if (l == 0) { LD(fix + LF_GDINV + r) = diag > 0 ? 1.0f / diag : 0.0f; LD(fix + LF_GLAM + r) = 0.0f; }
-    return rel;
+    for (int k = 0; k < 9; k++) Ii.m[k] = isA ? oA.Iinv.m[k] : oB.Iinv.m[k];
+    const v3 r = x - op;
+    const v3 Iea = mulv(Ii, ea);
+    g = (el + cross(ea, r)) * s;
+    h = (el * im + cross(Iea, r)) * s;
+    gt = ea * s;
+    ht = Iea * s;
 }
 
-// Row step of an object-vs-static contact row, executed by the lane that owns the object only:
-// b0,b1,b2 = the row's linear part (dir.xyz ang.x | ang.yz mang.xy | mang.z rhs dinv lambda), bounds [lo, hi].
-#define OS_ROW_STEP(b0, b1, b2, lo, hi, rowidx)                                                                   \
-    do {                                                                                                          \
-        const float jv_ = ((b0).x * dv.x + (b0).y * dv.y + (b0).z * dv.z) + ((b0).w * dw.x + (b1).x * dw.y + (b1).y * dw.z);    \
-        const float lam_ = (b2).w;                                                                                \
-        const float s0_ = fmaf(-jv_, (b2).z, lam_ + (b2).y);        /* (lambda + rhs) - dinv * J.v */             \
-        const float sum_ = fminf(fmaxf(s0_, (lo)), (hi));                                                         \
-        const float dl_ = sum_ - lam_;                                                                            \
-        LD(L_OSL + (rowidx) * 12 + 11) = sum_;                                                                    \
-        const float sm_ = dl_ * inv_mass;                                                                         \
-        dv.x += (b0).x * sm_; dv.y += (b0).y * sm_; dv.z += (b0).z * sm_;                                            \
-        dw.x += (b1).z * dl_; dw.y += (b1).w * dl_; dw.z += (b2).x * dl_;                                            \
-    } while (0)
-
-// Same step for a row held in registers (b0, b1, b2 as above but lambda in `lam`).  An all-zero row with lam = 0 is a
+// Row step of an object-vs-static contact row held in registers, executed by the lane that owns the object only:
+// b0,b1,b2 = the row's linear part (dir.xyz ang.x | ang.yz mang.xy | mang.z rhs dinv -), lambda in `lam`, bounds [lo, hi].
+// An all-zero row with lam = 0 is a
 // no-op (dl = 0), which is how absent rows are represented -- no predicates, no scalar mask registers.
 #define REG_ROW_STEP(b0, b1, b2, lam, lo, hi)                                                                     \
     do {                                                                                                          \
         const float jv_ = ((b0).x * dv.x + (b0).y * dv.y + (b0).z * dv.z) + ((b0).w * dw.x + (b1).x * dw.y + (b1).y * dw.z);    \
         const float s0_ = fmaf(-jv_, (b2).z, (lam) + (b2).y);       /* (lambda + rhs) - dinv * J.v */             \
-        const float sum_ = fminf(fmaxf(s0_, (lo)), (hi));                                                         \
+        const float sum_ = __builtin_amdgcn_fmed3f(s0_, (lo), (hi));                                              \
         const float dl_ = sum_ - (lam);                                                                           \
         (lam) = sum_;                                                                                             \
         const float sm_ = dl_ * inv_mass;                                                                         \
@@ -1016,20 +1000,30 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
     const ShapeData *S = D.shapes;
     const int fix = grp * LF_TOTAL;
     const int L_MINV = fix + LF_MINV, L_MOT = fix + LF_MOT, L_LIM = fix + LF_LIM, L_META = fix + LF_META, L_MU = fix + LF_MU,
-              L_SPIN = fix + LF_SPIN, L_ROLL = fix + LF_ROLL, L_OSL = fix + LF_OSL, L_OST = fix + LF_OST, L_GRHS = fix + LF_GRHS,
-              L_GDINV = fix + LF_GDINV, L_GLAM = fix + LF_GLAM;
+              L_SPIN = fix + LF_SPIN, L_ROLL = fix + LF_ROLL, L_OSL = fix + LF_OSL, L_OST = fix + LF_OST, L_GSC = fix + LF_GSC,
+              L_OBJ = fix + LF_OBJ, L_CST = fix + LF_CST;
     unsigned short *listF = (unsigned short *)&LD(fix + LF_LISTF), *listT = (unsigned short *)&LD(fix + LF_LISTT);
-    const float dt = P.dt;
+    const float dt = P.dt, inv_dt = 1.0f / P.dt;
     const int lj = l < NB ? l : 0;               // joint owned by this lane (lanes >= 11 alias joint 0, masked)
     const int lo_ = (l >= NB && l < NB + NOBJ) ? l - NB : -1;   // object owned by this lane
     SPROF_INIT
+    SBLK_BEGIN
     // ---- stage Minv in LDS; the lane's joint frame and unconstrained velocity go to registers (same round trip)
     for (int i = l; i < NB * NB; i += 16) LD(L_MINV + i) = SCR(S_MINV + i);
     const v3 pk_l = mk(SCR(S_BP + 3 * lj), SCR(S_BP + 3 * lj + 1), SCR(S_BP + 3 * lj + 2));
     const v3 ak_l = mk(SCR(S_BAX + 3 * lj), SCR(S_BAX + 3 * lj + 1), SCR(S_BAX + 3 * lj + 2));
     const float q_l = STT(ST_Q + lj), qds_l = SCR(S_QDS + lj);
-    // lanes 11..13 also fetch "their" object's pose / inverse inertia / unconstrained velocities here; the row builder
-    // pulls the data of a pair's objects from those lanes with ds_bpermute instead of a round trip to memory per pair
+    // the env's contact list (k_collide): count and all MAXC records are requested here, in the same round trip as the rest
+    // of the stage-in -- lane l holds float4 #(l + 16 i) of the 144; records beyond the count are never looked at
+    const int nct = dead ? 0 : min(D.ccount[env], MAXC);
+    float4 crec[9];
+    {
+        const float4 *cl = D.clist + (size_t)env * MAXC * 3;
+#pragma unroll
+        for (int i = 0; i < 9; i++) crec[i] = cl[16 * i + l];
+    }
+    // lanes 11..13 fetch "their" object's pose / inverse inertia / unconstrained velocities and publish them in LDS: the row
+    // builder reads the data of a contact's objects from there (20 floats per object: position, 1/mass, I^-1, v*, w*)
     ObjData myobj;
     {
         const int ob = (l >= NB && l < NB + NOBJ && l - NB < P.nobj) ? l - NB : 0;
@@ -1039,6 +1033,14 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         myobj.vs = mk(SCR(S_OVS + 3 * ob), SCR(S_OVS + 3 * ob + 1), SCR(S_OVS + 3 * ob + 2));
         myobj.ws = mk(SCR(S_OWS + 3 * ob), SCR(S_OWS + 3 * ob + 1), SCR(S_OWS + 3 * ob + 2));
         myobj.imass = 1.0f / (ob == 0 ? B.obj_mass[0] : (ob == 1 ? B.obj_mass[1] : B.obj_mass[2]));
+        if (lo_ >= 0) {
+            float4 *od = (float4 *)&LD(L_OBJ + 20 * lo_);
+            od[0] = make_float4(myobj.op.x, myobj.op.y, myobj.op.z, myobj.imass);
+            od[1] = make_float4(myobj.Iinv.m[0], myobj.Iinv.m[1], myobj.Iinv.m[2], myobj.Iinv.m[3]);
+            od[2] = make_float4(myobj.Iinv.m[4], myobj.Iinv.m[5], myobj.Iinv.m[6], myobj.Iinv.m[7]);
+            od[3] = make_float4(myobj.Iinv.m[8], myobj.vs.x, myobj.vs.y, myobj.vs.z);
+            od[4] = make_float4(myobj.ws.x, myobj.ws.y, myobj.ws.z, 0.0f);
+        }
     }
     // row l of Minv in registers (motor rows, and M^-1 J^T of the generic rows)
     float minv_l[NB];
@@ -1059,87 +1061,67 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
 #undef U_FROM
     }
     SPROF(0);
-    // ---- gather contacts in pair order, build rows (all lanes of the group run the control flow redundantly)
-    // The per-pair candidate counts are fetched in one go: lane l loads the counts of pairs l, l+16, ... and the
-    // non-empty pairs are collected into per-group bit masks with wave ballots (no chain of dependent global loads).
-    unsigned pmask[MAXPAIRS / 16];
-#pragma unroll
-    for (int k = 0; k < MAXPAIRS / 16; k++) {
-        const int pr = 16 * k + l;
-        const bool in = pr < P.npairs && !dead;
-        const int cntl = in ? *(const int *)&SCR(S_PCOUNT + pr) : 0;
-        const unsigned long long bal = __ballot(cntl > 0);
-        pmask[k] = (unsigned)(bal >> (16 * grp)) & 0xffffu;
-    }
-    int n_os = 0;                     // leading object-vs-static contacts, rows in LDS
-    unsigned own_os = 0;              // this lane's share of them (bit = contact index)
+    // ---- walk the contact list in order, build rows (all lanes of the group run the control flow redundantly): 16 records at
+    // a time go through the LDS staging area, from where every lane reads the record of the contact at hand
+    int n_os = 0;                     // object-vs-static contacts swept by the object lanes (slots 0 .. n_os-1 of the LDS staging area)
+    unsigned own_os = 0;              // this lane's share of them (bit = slot)
+    unsigned fcnt = 0;                // ... per object, 4 bits each
     unsigned gobj = 0;                // objects touched by generic contacts of this env (bit o)
-    int nc = 0, ng = 0;               // contacts; generic contacts (they follow the n_os leading ones: contact c = n_os + j)
-    static_assert(MAXPAIRS / 16 == 6, "pair-mask select chain below");
+    int nc = 0, ng = 0;               // contacts; generic contacts
+    const int nct_max = max(max(__builtin_amdgcn_readlane(nct, 0), __builtin_amdgcn_readlane(nct, 16)),
+                            max(__builtin_amdgcn_readlane(nct, 32), __builtin_amdgcn_readlane(nct, 48)));
 #pragma unroll 1        // one copy of the (large) row-building body: the kernel must stay inside the instruction cache
-    for (int k = 0; k < MAXPAIRS / 16; k++)
-    for (unsigned rem = k == 0 ? pmask[0] : (k == 1 ? pmask[1] : (k == 2 ? pmask[2] : (k == 3 ? pmask[3] : (k == 4 ? pmask[4] : pmask[5]))));
-         rem && nc < MAXC; rem &= rem - 1) {
-        const int pair = 16 * k + __ffs(rem) - 1;
-        // One round trip per non-empty pair: its count, metadata and (unconditionally) all four candidate slots; the
-        // objects' data comes from the object lanes.  Nothing is fetched inside the contact loop.
-        const int cnt = *(const int *)&SCR(S_PCOUNT + pair);
-        const int4 pm = *(const int4 *)S->pair_meta[pair];
-        const float4 pmat = *(const float4 *)S->pair_mat[pair];
-        float cd[4][7];
-        {
-            const float4 *pd = D.pdata + ((size_t)env * MAXPAIRS + pair) * 8;
+    for (int bt = 0; 16 * bt < nct_max; bt++) {
+        {   // batch bt = records 16 bt .. 16 bt + 15 = float4 48 bt .. 48 bt + 47 of the list = crec[3 bt .. 3 bt + 2] of the lanes
+            float4 *st = (float4 *)&LD(L_CST);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float4 a = pd[2 * i], b = pd[2 * i + 1];
-                cd[i][0] = a.x; cd[i][1] = a.y; cd[i][2] = a.z; cd[i][3] = a.w; cd[i][4] = b.x; cd[i][5] = b.y; cd[i][6] = b.z;
+            for (int i = 0; i < 3; i++) {
+                const float4 a = crec[i], b = crec[3 + i], c = crec[6 + i];
+                st[16 * i + l] = make_float4(bt == 0 ? a.x : (bt == 1 ? b.x : c.x), bt == 0 ? a.y : (bt == 1 ? b.y : c.y),
+                                             bt == 0 ? a.z : (bt == 1 ? b.z : c.z), bt == 0 ? a.w : (bt == 1 ? b.w : c.w));
             }
         }
-        const int bodyA = pm.x, bodyB = pm.y, linkA = pm.z;
-        const float mu = pmat.x, rest = pmat.y, roll = pmat.z, spin = pmat.w;
-        const bool ospair = bodyA >= 16 && bodyB < 0;
-        ObjData oA, oB;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int ci = 0; ci < 16 && 16 * bt + ci < nct; ci++, nc++) {
+            const float4 ra = *(const float4 *)&LD(L_CST + 12 * ci), rb_ = *(const float4 *)&LD(L_CST + 12 * ci + 4), rc = *(const float4 *)&LD(L_CST + 12 * ci + 8);
+            const v3 x = mk(ra.x, ra.y, ra.z), n = mk(ra.w, rb_.x, rb_.y);
+            const float dist = rb_.z;
+            const int cm = __float_as_int(rb_.w);
+            const int bodyA = (signed char)(cm & 255), bodyB = (signed char)((cm >> 8) & 255), linkA = (signed char)((cm >> 16) & 255);
+            const float mu = rc.x, rest = rc.y, roll = rc.z, spin = rc.w;
+            const bool ospair = bodyA >= 16 && bodyB < 0;
+            ObjData oA, oB;
 #pragma unroll
-        for (int side = 0; side < 2; side++) {
-            ObjData &o = side == 0 ? oA : oB;
-            const int body = side == 0 ? bodyA : bodyB;
-            const int src = (threadIdx.x & ~15) + NB + (body >= 16 ? body - 16 : 0);     // the object's lane in this group
-            o.op = mk(lane_gather(myobj.op.x, src), lane_gather(myobj.op.y, src), lane_gather(myobj.op.z, src));
-#pragma unroll
-            for (int kk = 0; kk < 9; kk++) o.Iinv.m[kk] = lane_gather(myobj.Iinv.m[kk], src);
-            o.vs = mk(lane_gather(myobj.vs.x, src), lane_gather(myobj.vs.y, src), lane_gather(myobj.vs.z, src));
-            o.ws = mk(lane_gather(myobj.ws.x, src), lane_gather(myobj.ws.y, src), lane_gather(myobj.ws.z, src));
-            o.imass = lane_gather(myobj.imass, src);
-        }
-        // every value fetched above is waited for here, once: with no load in flight the contact loop below needs no
-        // vmcnt waits, which on gfx9 would also wait for the acknowledgement of the stores it issues
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            asm volatile("" : "+v"(cd[i][0]), "+v"(cd[i][1]), "+v"(cd[i][2]), "+v"(cd[i][3]), "+v"(cd[i][4]), "+v"(cd[i][5]), "+v"(cd[i][6]));
-        for (int i = 0; i < cnt && nc < MAXC; i++, nc++) {
-            float c7[7];
-#pragma unroll
-            for (int kk = 0; kk < 7; kk++) c7[kk] = i == 0 ? cd[0][kk] : (i == 1 ? cd[1][kk] : (i == 2 ? cd[2][kk] : cd[3][kk]));
-            const v3 x = mk(c7[0], c7[1], c7[2]), n = mk(c7[3], c7[4], c7[5]);
-            const float dist = c7[6];
-            // object-vs-static contacts keep their rows in LDS while they form the head of the contact list
-            const bool fast = ospair && ng == 0 && nc < P.os_cap;
-            const int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | ((fast ? 1 : 0) << 24);
+            for (int side = 0; side < 2; side++) {
+                ObjData &o = side == 0 ? oA : oB;
+                const int body = side == 0 ? bodyA : bodyB;
+                const float4 *od = (const float4 *)&LD(L_OBJ + 20 * (body >= 16 ? body - 16 : 0));
+                const float4 d0 = od[0], d1 = od[1], d2 = od[2], d3 = od[3], d4 = od[4];
+                o.op = mk(d0.x, d0.y, d0.z); o.imass = d0.w;
+                o.Iinv.m[0] = d1.x; o.Iinv.m[1] = d1.y; o.Iinv.m[2] = d1.z; o.Iinv.m[3] = d1.w;
+                o.Iinv.m[4] = d2.x; o.Iinv.m[5] = d2.y; o.Iinv.m[6] = d2.z; o.Iinv.m[7] = d2.w;
+                o.Iinv.m[8] = d3.x; o.vs = mk(d3.y, d3.z, d3.w); o.ws = mk(d4.x, d4.y, d4.z);
+            }
+            // the first KOS object-vs-static contacts of an object are swept by the object's lane, any further ones take the
+            // generic path (rows of different objects commute, and an object's own rows keep their order: its pairs with
+            // the statics precede every other pair)
+            const int obA = bodyA >= 16 ? bodyA - 16 : 0;
+            const bool fast = ospair && ((fcnt >> (4 * obA)) & 15u) < KOS && n_os < P.os_cap;
+            const int slot = fast ? n_os : ng;
+            const int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | ((fast ? 1 : 0) << 24) | (slot << 25) |
+                             (fabsf(dist) < 0.1f ? (int)0x80000000u : 0);        // robot.py:136 contact_threshold
             if (l == 0) {
                 *(int *)&LD(L_META + nc) = meta;
-                LD(L_MU + nc) = mu; LD(L_SPIN + nc) = spin; LD(L_ROLL + nc) = roll;
-            }
-            if (l < 12) {   // contact record (rr_get_contacts, touch sensors): field l is stored by lane l, one instruction
-                const float fld = l == 0 ? (float)bodyA : l == 1 ? (float)bodyB : l == 2 ? (float)linkA : l == 3 ? x.x : l == 4 ? x.y :
-                                  l == 5 ? x.z : l == 6 ? n.x : l == 7 ? n.y : l == 8 ? n.z : l == 9 ? dist : l == 10 ? 0.0f : mu;
-                SCR(S_CT + nc * 12 + l) = fld;
+                if (fast) { LD(L_MU + slot) = mu; LD(L_SPIN + slot) = spin; LD(L_ROLL + slot) = roll; }      // (generic rows carry their coefficient)
             }
             v3 t1, t2;
             plane_space(n, t1, t2);
             if (fast) {
                 // the three linear rows (n, t1, t2) and the three torsional rows about the same axes are built by lanes 0, 1, 2
-                n_os = nc + 1;
-                if (lo_ >= 0 && bodyA == 16 + lo_) own_os |= 1u << nc;
+                n_os++;
+                fcnt += 1u << (4 * obA);
+                if (lo_ >= 0 && bodyA == 16 + lo_) own_os |= 1u << slot;
                 const v3 dir = l == 0 ? n : (l == 1 ? t1 : t2);
                 const v3 ang = cross(x - oA.op, dir);
                 const v3 mang = mulv(oA.Iinv, ang);
@@ -1159,11 +1141,11 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                 const float tdinv = (coef > 0 && tdiag > 0) ? 1.0f / tdiag : 0.0f;
                 const float trhs = -dot(dir, oA.ws) * tdinv;
                 if (l < 3) {
-                    float4 *bp4 = (float4 *)&LD(L_OSL + (3 * nc + l) * 12);
+                    float4 *bp4 = (float4 *)&LD(L_OSL + (3 * slot + l) * 12);
                     bp4[0] = make_float4(dir.x, dir.y, dir.z, ang.x);
                     bp4[1] = make_float4(ang.y, ang.z, mang.x, mang.y);
                     bp4[2] = make_float4(mang.z, rhs, dinv, 0.0f);
-                    float4 *tp4 = (float4 *)&LD(L_OST + (3 * nc + l) * 8);
+                    float4 *tp4 = (float4 *)&LD(L_OST + (3 * slot + l) * 8);
                     tp4[0] = make_float4(tm.x, tm.y, tm.z, trhs);
                     tp4[1] = make_float4(tdinv, 0.0f, 0.0f, 0.0f);
                 }
@@ -1173,36 +1155,53 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             const int r0 = 6 * ng;
             if (bodyA >= 16) gobj |= 1u << (bodyA - 16);
             if (bodyB >= 16) gobj |= 1u << (bodyB - 16);
-            float rel0 = 0;
-#pragma unroll 1        // one inlined copy of the row builder
+            GrowCtx gc;
+            {
+                const int rb = bodyA >= 0 && bodyA < 16 ? bodyA : (bodyB >= 0 && bodyB < 16 ? bodyB : -1);
+                const float sgr = rb < 0 ? 0.0f : (rb == bodyA ? 1.0f : -1.0f);
+                const float jm = (l < NB && rb >= 0 && ((ANC[rb >= 0 ? rb : 0] >> l) & 1u)) ? sgr : 0.0f;     // joint lanes: sign x ancestor mask
+                v3 gA, hA, gtA, htA;
+                grow_slot(so.objA, so.elA, so.eaA, bodyA, bodyB, x, oA, oB, gA, hA, gtA, htA);
+                grow_slot(so.objB, so.elB, so.eaB, bodyA, bodyB, x, oA, oB, gc.gB, gc.hB, gc.gtB, gc.htB);
+                const v3 cj = cross(ak_l, x - pk_l) * jm, aj = ak_l * jm;
+                gc.gA = l < NB ? cj : gA; gc.gtA = l < NB ? aj : gtA; gc.hA = hA; gc.htA = htA;
+            }
+#pragma unroll 1        // one copy of the row evaluation
             for (int kr = 0; kr < 6; kr++) {
                 const bool tors = kr >= 3;
                 const int ka = tors ? kr - 3 : kr;
                 const v3 d = ka == 0 ? n : (ka == 1 ? t1 : t2);
                 const bool present = !tors || (kr == 3 ? spin > 0 : roll > 0);
-                float rhsn = 0;
-                if (present) {
-                    const float rel = build_grow(D, env, fix, l, lj, r0 + kr, tors, bodyA, bodyB, x, d, pk_l, ak_l, ua, ub, so, oA, oB);
-                    if (kr == 0) {
-                        float r = 0;
-                        if (fabsf(rel) >= P.rest_thresh) { r = rest * -rel; if (r < 0) r = 0; }
-                        float verr = r - rel, perr = 0;
-                        if (dist > 0) verr -= dist / dt;
-                        else perr = -dist * P.erp / dt;
-                        rhsn = perr + verr;
-                    } else rhsn = -rel;
-                }
+                const float ja = dot(d, tors ? gc.gtA : gc.gA), jb = dot(d, tors ? gc.gtB : gc.gB);
+                const float mjb = dot(d, tors ? gc.htB : gc.hB);
+                float mja = 0;
+#define MJA_STEP(J) mja += minv_l[J] * row_bcast<J>(ja);
+                MJA_STEP(0) MJA_STEP(1) MJA_STEP(2) MJA_STEP(3) MJA_STEP(4) MJA_STEP(5) MJA_STEP(6) MJA_STEP(7) MJA_STEP(8) MJA_STEP(9) MJA_STEP(10)
+#undef MJA_STEP
+                mja = l < NB ? mja : dot(d, tors ? gc.htA : gc.hA);
+                const float diag = group_sum(ja * mja + jb * mjb);
+                const float rel = group_sum(ja * ua + jb * ub);
+                if (present) D.grows[((size_t)env * GROWS + r0 + kr) * 16 + l] = make_float4(ja, mja, jb, mjb);
+                float rhsn;
+                if (kr == 0) {
+                    float r = 0;
+                    if (fabsf(rel) >= P.rest_thresh) { r = rest * -rel; if (r < 0) r = 0; }
+                    float verr = r - rel, perr = 0;
+                    if (dist > 0) verr -= dist * inv_dt;
+                    else perr = -dist * P.erp * inv_dt;
+                    rhsn = perr + verr;
+                } else rhsn = -rel;
                 if (l == 0) {
-                    if (!present) { LD(L_GDINV + r0 + kr) = 0.0f; LD(L_GLAM + r0 + kr) = 0.0f; }
-                    LD(L_GRHS + r0 + kr) = rhsn * LD(L_GDINV + r0 + kr);
+                    const float dinv = (present && diag > 0) ? 1.0f / diag : 0.0f;
+                    *(float4 *)&LD(L_GSC + 4 * (r0 + kr)) = make_float4(rhsn * dinv, dinv, kr == 0 ? 0.0f : (kr < 3 ? mu : (kr == 3 ? spin : roll)), 0.0f);
                 }
             }
-            (void)rel0;
             ng++;
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // the staging area is rewritten by the next batch
+        __builtin_amdgcn_wave_barrier();
     }
     SPROF(1);
-    if (l == 0 && !dead) *(int *)&SCR(S_NCT) = nc;
     // ---- motor + limit rows: lane j < 11 builds the rows of joint j
     if (l < NB) {
         float dinv = 1.0f / LD(L_MINV + l * NB + l);
@@ -1225,8 +1224,6 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         }
     }
     SPROF(2);
-    // the rows written to global memory above are read back by the same wave in the sweeps
-    __threadfence();
     // compact list of the limit rows that exist (usually the two finger lower limits), in row order
     unsigned limmask = 0;
 #pragma unroll
@@ -1257,7 +1254,6 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         }
         limmask = rem;                                   // rows left for the LDS loop
     }
-    const unsigned own_all = own_os;                     // every object-vs-static contact of this lane (torsional sweep)
     unsigned os_cs = 0;                                  // contact indices of the register rows, one byte each
     float os_mu[KOS], os_ln[KOS], os_l1[KOS], os_l2[KOS];
     float4 os_n0[KOS], os_n1[KOS], os_n2[KOS], os_a0[KOS], os_a1[KOS], os_a2[KOS], os_b0[KOS], os_b1[KOS], os_b2[KOS];
@@ -1274,7 +1270,21 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             os_a0[i] = LDZ4(has, 3 * c + 1, 0); os_a1[i] = LDZ4(has, 3 * c + 1, 4); os_a2[i] = LDZ4(has, 3 * c + 1, 8);
             os_b0[i] = LDZ4(has, 3 * c + 2, 0); os_b1[i] = LDZ4(has, 3 * c + 2, 4); os_b2[i] = LDZ4(has, 3 * c + 2, 8);
         }
-        own_os = rem;                                    // contacts left for the LDS loops
+    }
+    // torsional rows of the same contacts: rotation about the axis of linear row k (its dir), {M^-1 J^T (3), rhs}, 1/diag, lambda
+    float4 ot_m[KOS][3]; float ot_d[KOS][3], ot_l[KOS][3], os_sp[KOS], os_ro[KOS];
+#pragma unroll
+    for (int i = 0; i < KOS; i++) {
+        const int c = (os_cs >> (8 * i)) & 255;
+        const bool has = c != 255;
+        const int cc = has ? c : 0;
+        os_sp[i] = has ? LD(L_SPIN + cc) : 0.0f; os_ro[i] = has ? LD(L_ROLL + cc) : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            ot_m[i][k] = sel4(has, LDT4(3 * cc + k, 0));
+            ot_d[i][k] = has ? LD(L_OST + (3 * cc + k) * 8 + 4) : 0.0f;
+            ot_l[i][k] = 0.0f;
+        }
     }
     // motors: every lane evaluates the step of "its" row from its own dq; row J's impulse change is lane J's value,
     // broadcast to the 16 lanes of the env with one DPP row_newbcast (branch-free clamp, same values as if/else)
@@ -1306,47 +1316,35 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             REG_ROW_STEP(os_a0[i], os_a1[i], os_a2[i], os_l1[i], -hi_, hi_);                          \
             REG_ROW_STEP(os_b0[i], os_b1[i], os_b2[i], os_l2[i], -hi_, hi_);                          \
         }
-    // the normal impulse of a register-resident contact is published to its LDS slot after the normal sweep: the torsional
-    // sweep (rows in LDS) bounds its rows with it
-#define OSN_PUBLISH(i) { const int c_ = (os_cs >> (8 * (i))) & 255; if (c_ != 255) LD(L_OSL + (3 * c_) * 12 + 11) = os_ln[i]; }
-    // Torsional rows of this lane's object-vs-static contacts (all of them, register-resident linear rows or not): rotation
-    // about the axis of linear row k of the same contact; {M^-1 J^T (3), rhs | dinv, lambda} in LDS, the next row is
-    // fetched while the current one is swept.  A row with bounds [-0, 0] and no impulse is skipped.
-#define OS_TORSIONAL_SWEEP                                                                                             \
-    if (own_all) {                                                                                                     \
-        unsigned rem_ = own_all;                                                                                       \
-        int c_ = __ffs(rem_) - 1, k_ = 0;                                                                              \
-        float4 nd_ = LDB4(3 * c_, 0), nt_ = LDT4(3 * c_, 0);                                                           \
-        float2 ns_ = *(const float2 *)&LD(L_OST + (3 * c_) * 8 + 4);                                                   \
-        float nln_ = LD(L_OSL + (3 * c_) * 12 + 11), nsp_ = LD(L_SPIN + c_), nro_ = LD(L_ROLL + c_);                   \
-        for (;;) {                                                                                                     \
-            const float4 d_ = nd_, t_ = nt_; const float2 s_ = ns_;                                                    \
-            const float hi_ = (k_ == 0 ? nsp_ : nro_) * nln_;                                                          \
-            const int row_ = 3 * c_ + k_;                                                                              \
-            if (++k_ == 3) { k_ = 0; rem_ &= rem_ - 1; if (!rem_) { k_ = 3; } else { c_ = __ffs(rem_) - 1; nln_ = LD(L_OSL + (3 * c_) * 12 + 11); nsp_ = LD(L_SPIN + c_); nro_ = LD(L_ROLL + c_); } } \
-            if (k_ < 3) { nd_ = LDB4(3 * c_ + k_, 0); nt_ = LDT4(3 * c_ + k_, 0); ns_ = *(const float2 *)&LD(L_OST + (3 * c_ + k_) * 8 + 4); } \
-            if (hi_ > 0.0f || s_.y != 0.0f) {                                                                          \
-                const float jv_ = d_.x * dw.x + d_.y * dw.y + d_.z * dw.z;                                             \
-                const float s0_ = fmaf(-jv_, s_.x, s_.y + t_.w);                                                       \
-                const float sum_ = fminf(fmaxf(s0_, -hi_), hi_);                                                       \
-                const float dl_ = sum_ - s_.y;                                                                         \
-                LD(L_OST + row_ * 8 + 5) = sum_;                                                                       \
-                dw.x += t_.x * dl_; dw.y += t_.y * dl_; dw.z += t_.z * dl_;                                            \
-            }                                                                                                          \
-            if (k_ == 3) break;                                                                                        \
-        }                                                                                                              \
-    }
+#define REG_TORS_STEP(AX, i, k, HI)                                                                  \
+        {                                                                                             \
+            const float jv_ = (AX).x * dw.x + (AX).y * dw.y + (AX).z * dw.z;                          \
+            const float s0_ = fmaf(-jv_, ot_d[i][k], ot_l[i][k] + ot_m[i][k].w);                      \
+            const float sum_ = __builtin_amdgcn_fmed3f(s0_, -(HI), (HI));                             \
+            const float dl_ = sum_ - ot_l[i][k];                                                      \
+            ot_l[i][k] = sum_;                                                                        \
+            dw.x += ot_m[i][k].x * dl_; dw.y += ot_m[i][k].y * dl_; dw.z += ot_m[i][k].z * dl_;       \
+        }
+#define OST_STEP(i)                                                                                   \
+        {                                                                                             \
+            const float hs_ = os_sp[i] * os_ln[i], hr_ = os_ro[i] * os_ln[i];                         \
+            REG_TORS_STEP(os_n0[i], i, 0, hs_) REG_TORS_STEP(os_a0[i], i, 1, hr_) REG_TORS_STEP(os_b0[i], i, 2, hr_) \
+        }
     SPROF(3);
+    SBLK_MARK(sb_t1)
     static_assert(KLIM == 2 && KOS == 4, "the sweeps below are written out for KLIM = 2, KOS = 4");
-    // When no env of this wave has a row outside the registers / the torsional LDS sweep (no generic contact, no further
-    // limit or contact rows), an iteration is one straight-line block: the robot chain (motors, limits) and the object chain
+    // When no env of this wave has a row outside the registers (no generic contact, no further limit rows), an iteration is one straight-line block: the robot chain (motors, limits) and the object chain
     // (normals, frictions, torsional) are independent and the scheduler overlaps them.
-    const bool simple = __ballot(!(ng == 0 && own_os == 0 && limmask == 0)) == 0ull;
+    const bool simple = __ballot(!(ng == 0 && limmask == 0)) == 0ull;
     // generic sweeps: trip counts and the objects to move between the object lanes and the slots, over the whole wave
     const int ng_max = max(max(__builtin_amdgcn_readlane(ng, 0), __builtin_amdgcn_readlane(ng, 16)),
                            max(__builtin_amdgcn_readlane(ng, 32), __builtin_amdgcn_readlane(ng, 48)));
     const unsigned gobj_w = (unsigned)__builtin_amdgcn_readlane((int)gobj, 0) | (unsigned)__builtin_amdgcn_readlane((int)gobj, 16) |
                             (unsigned)__builtin_amdgcn_readlane((int)gobj, 32) | (unsigned)__builtin_amdgcn_readlane((int)gobj, 48);
+    // the generic rows written to global memory by the builder are read back by this same wave: its stores must have
+    // completed (workgroup scope: the CU's vector L1 is write-through and shared by the workgroup -- no cache maintenance;
+    // an agent-scope fence would write back the XCD's L2)
+    if (ng_max > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const int grow_base = env * GROWS * 16;               // float4 index of row 0 of this env (fits an int: N <= 2^31 / 4608)
     const int zrow = P.N * GROWS * 16;                    // an all-zero row behind the last env's rows
     // object lane (11 + O) -> slots, and back; comps 0..5 = dv.xyz, dw.xyz
@@ -1365,9 +1363,8 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             SWEEP_MOTORS
             LIMIT_STEP(0) LIMIT_STEP(1)
             OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3)
-            OSN_PUBLISH(0) OSN_PUBLISH(1) OSN_PUBLISH(2) OSN_PUBLISH(3)
             OSF_STEP(0) OSF_STEP(1) OSF_STEP(2) OSF_STEP(3)
-            OS_TORSIONAL_SWEEP
+            OST_STEP(0) OST_STEP(1) OST_STEP(2) OST_STEP(3)
             continue;
         }
         SWEEP_MOTORS
@@ -1394,8 +1391,8 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
             const int cmax = pass == 0 ? ng_max : max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
                                                       max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
             const unsigned short *lst = pass == 1 ? listF : listT;
-#define ENTRY(I) ((I) < cnt ? (pass == 0 ? ((I) << 3) : (int)lst[(I) < cnt ? (I) : 0]) : 0xffff)
-#define ENTRY_IDX(E) ((E) == 0xffff ? zrow : grow_base + (6 * ((E) >> 3) + ((E) & 7)) * 16)
+#define ENTRY(I) ((I) < cnt ? (pass == 0 ? 6 * (I) : (int)lst[(I) < cnt ? (I) : 0]) : 0xffff)        /* row id | k << 9 */
+#define ENTRY_IDX(E) ((E) == 0xffff ? zrow : grow_base + ((E) & 511) * 16)
             int e_cur = ENTRY(l), e_nxt = ENTRY(16 + l);
             int idx_cur = ENTRY_IDX(e_cur), idx_nxt = ENTRY_IDX(e_nxt);
             float4 Q0, Q1, Q2, Q3, Q4, Q5, Q6, Q7;
@@ -1404,62 +1401,22 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                 Q3 = D.grows[row_bcast_i<3>(idx_cur) + l]; Q4 = D.grows[row_bcast_i<4>(idx_cur) + l]; Q5 = D.grows[row_bcast_i<5>(idx_cur) + l];
                 Q6 = D.grows[row_bcast_i<6>(idx_cur) + l]; Q7 = D.grows[row_bcast_i<7>(idx_cur) + l];
             }
-            // ---- object-vs-static rows of this pass (object lanes, side by side)
-            if (pass == 0) {
-                OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3)
-                OSN_PUBLISH(0) OSN_PUBLISH(1) OSN_PUBLISH(2) OSN_PUBLISH(3)
-                if (own_os) {
-                    unsigned rem = own_os;
-                    int c = __ffs(rem) - 1;
-                    float4 n0 = LDB4(3 * c, 0), n1 = LDB4(3 * c, 4), n2 = LDB4(3 * c, 8);
-                    while (rem) {
-                        const float4 b0 = n0, b1 = n1, b2 = n2;
-                        const int cc = c;
-                        rem &= rem - 1;
-                        if (rem) { c = __ffs(rem) - 1; n0 = LDB4(3 * c, 0); n1 = LDB4(3 * c, 4); n2 = LDB4(3 * c, 8); }
-                        OS_ROW_STEP(b0, b1, b2, 0.0f, 1e10f, 3 * cc);
-                    }
-                }
-            } else if (pass == 1) {
-                OSF_STEP(0) OSF_STEP(1) OSF_STEP(2) OSF_STEP(3)
-                if (own_os) {
-                    // frictions of this lane's further object-vs-static contacts; the rows of the next one are prefetched
-                    unsigned rem = own_os;
-                    int c = __ffs(rem) - 1;
-                    float nln = LD(L_OSL + (3 * c) * 12 + 11), nmu = LD(L_MU + c);
-                    float4 na0 = LDB4(3 * c + 1, 0), na1 = LDB4(3 * c + 1, 4), na2 = LDB4(3 * c + 1, 8);
-                    float4 nc0 = LDB4(3 * c + 2, 0), nc1 = LDB4(3 * c + 2, 4), nc2 = LDB4(3 * c + 2, 8);
-                    while (rem) {
-                        const float hi = nmu * nln;
-                        const float4 a0 = na0, a1 = na1, a2 = na2, c0 = nc0, c1 = nc1, c2 = nc2;
-                        const int cc = c;
-                        rem &= rem - 1;
-                        if (rem) {
-                            c = __ffs(rem) - 1;
-                            nln = LD(L_OSL + (3 * c) * 12 + 11); nmu = LD(L_MU + c);
-                            na0 = LDB4(3 * c + 1, 0); na1 = LDB4(3 * c + 1, 4); na2 = LDB4(3 * c + 1, 8);
-                            nc0 = LDB4(3 * c + 2, 0); nc1 = LDB4(3 * c + 2, 4); nc2 = LDB4(3 * c + 2, 8);
-                        }
-                        if (!(hi > 0.0f) && a2.w == 0.0f && c2.w == 0.0f) continue;   // bounds [-0, 0] and lambda already 0: nothing moves
-                        OS_ROW_STEP(a0, a1, a2, -hi, hi, 3 * cc + 1);
-                        OS_ROW_STEP(c0, c1, c2, -hi, hi, 3 * cc + 2);
-                    }
-                }
-            } else {
-                OS_TORSIONAL_SWEEP
-            }
+            // ---- object-vs-static rows of this pass (object lanes, side by side; all register resident)
+            if (pass == 0) { OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3) }
+            else if (pass == 1) { OSF_STEP(0) OSF_STEP(1) OSF_STEP(2) OSF_STEP(3) }
+            else { OST_STEP(0) OST_STEP(1) OST_STEP(2) OST_STEP(3) }
             if (cmax == 0) continue;
             // ---- generic rows of this pass, blocks of 16 rows: lane k of the group holds the scalars of the block's row k
             OBJ_SLOTS(TO_SLOT)
             for (int i0 = 0; i0 < cmax; i0 += 16) {
                 const int e = e_cur;
                 const bool valid = e != 0xffff;
-                const int jc = e >> 3, kk = e & 7, r = valid ? 6 * jc + kk : 0;
-                const float rhs = valid ? LD(L_GRHS + r) : 0.0f, dinv = valid ? LD(L_GDINV + r) : 0.0f;
-                float lam = valid ? LD(L_GLAM + r) : 0.0f;
-                const float coef = kk == 0 ? 0.0f : (kk < 3 ? LD(L_MU + n_os + (valid ? jc : 0)) : (kk == 3 ? LD(L_SPIN + n_os + (valid ? jc : 0)) : LD(L_ROLL + n_os + (valid ? jc : 0))));
-                const float lnorm = valid ? LD(L_GLAM + 6 * jc) : 0.0f;
-                const float hi = !valid ? 0.0f : (kk == 0 ? 1e10f : coef * lnorm), lo = kk == 0 ? 0.0f : -hi;
+                const int r = valid ? (e & 511) : 0, kk = valid ? (e >> 9) : 0;
+                const float4 sc = sel4(valid, *(const float4 *)&LD(L_GSC + 4 * r));          // rhs, 1/diag, bound coefficient, lambda
+                const float lnorm = LD(L_GSC + 4 * (r - kk) + 3);                            // normal impulse of the row's contact
+                const float rhs = sc.x, dinv = sc.y;
+                float lam = sc.w;
+                const float hi = pass == 0 ? (valid ? 1e10f : 0.0f) : sc.z * lnorm, lo = pass == 0 ? 0.0f : -hi;
                 const int idx_a = idx_cur, idx_b = idx_nxt;        // this block's rows 8..15 and the next block's rows 0..7 are requested below
                 e_cur = e_nxt; idx_cur = idx_nxt;
                 e_nxt = ENTRY(i0 + 32 + l); idx_nxt = ENTRY_IDX(e_nxt);
@@ -1476,16 +1433,21 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     const float dlb_ = row_bcast<S>(dl_);                                                              \
                     dq = fmaf(rw_.y, dlb_, dq); vb = fmaf(rw_.w, dlb_, vb);                                            \
                 }
+                // (the last block of a sweep stops after the quadruple that holds the wave's last row)
                 GROW_STEP(0, Q0, row_bcast_i<8>(idx_a))   GROW_STEP(1, Q1, row_bcast_i<9>(idx_a))
                 GROW_STEP(2, Q2, row_bcast_i<10>(idx_a))  GROW_STEP(3, Q3, row_bcast_i<11>(idx_a))
+                if (i0 + 4 < cmax) {
                 GROW_STEP(4, Q4, row_bcast_i<12>(idx_a))  GROW_STEP(5, Q5, row_bcast_i<13>(idx_a))
                 GROW_STEP(6, Q6, row_bcast_i<14>(idx_a))  GROW_STEP(7, Q7, row_bcast_i<15>(idx_a))
+                if (i0 + 8 < cmax) {
                 GROW_STEP(8, Q0, row_bcast_i<0>(idx_b))   GROW_STEP(9, Q1, row_bcast_i<1>(idx_b))
                 GROW_STEP(10, Q2, row_bcast_i<2>(idx_b))  GROW_STEP(11, Q3, row_bcast_i<3>(idx_b))
+                if (i0 + 12 < cmax) {
                 GROW_STEP(12, Q4, row_bcast_i<4>(idx_b))  GROW_STEP(13, Q5, row_bcast_i<5>(idx_b))
                 GROW_STEP(14, Q6, row_bcast_i<6>(idx_b))  GROW_STEP(15, Q7, row_bcast_i<7>(idx_b))
+                } } }
 #undef GROW_STEP
-                if (valid) LD(L_GLAM + r) = lam;
+                if (valid) LD(L_GSC + 4 * r + 3) = lam;
             }
 #undef ENTRY
 #undef ENTRY_IDX
@@ -1498,21 +1460,20 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                     const int j = j0 + l;
                     bool act = false, hs = false, hr = false;
                     if (j < ng) {
-                        const int r = 6 * j;
-                        act = LD(L_GLAM + r) > 0.0f || LD(L_GLAM + r + 1) != 0.0f || LD(L_GLAM + r + 2) != 0.0f ||
-                              LD(L_GLAM + r + 3) != 0.0f || LD(L_GLAM + r + 4) != 0.0f || LD(L_GLAM + r + 5) != 0.0f;
-                        hs = act && LD(L_SPIN + n_os + j) > 0.0f;
-                        hr = act && LD(L_ROLL + n_os + j) > 0.0f;
+                        const int r = L_GSC + 24 * j;
+                        act = LD(r + 3) > 0.0f || LD(r + 7) != 0.0f || LD(r + 11) != 0.0f || LD(r + 15) != 0.0f || LD(r + 19) != 0.0f || LD(r + 23) != 0.0f;
+                        hs = act && LD(r + 14) > 0.0f;          // coefficient of the spinning row
+                        hr = act && LD(r + 18) > 0.0f;          // ... of the rolling rows
                     }
                     const unsigned lt = (1u << l) - 1u;
                     const unsigned ma = (unsigned)(__ballot(act) >> (16 * grp)) & 0xffffu, ms = (unsigned)(__ballot(hs) >> (16 * grp)) & 0xffffu,
                                    mr = (unsigned)(__ballot(hr) >> (16 * grp)) & 0xffffu;
                     if (act) {
                         const int pf = nF + 2 * __popc(ma & lt);
-                        listF[pf] = (unsigned short)((j << 3) | 1); listF[pf + 1] = (unsigned short)((j << 3) | 2);
+                        listF[pf] = (unsigned short)((6 * j + 1) | (1 << 9)); listF[pf + 1] = (unsigned short)((6 * j + 2) | (2 << 9));
                         int pt = nT + __popc(ms & lt) + 2 * __popc(mr & lt);
-                        if (hs) listT[pt++] = (unsigned short)((j << 3) | 3);
-                        if (hr) { listT[pt] = (unsigned short)((j << 3) | 4); listT[pt + 1] = (unsigned short)((j << 3) | 5); }
+                        if (hs) listT[pt++] = (unsigned short)((6 * j + 3) | (3 << 9));
+                        if (hr) { listT[pt] = (unsigned short)((6 * j + 4) | (4 << 9)); listT[pt + 1] = (unsigned short)((6 * j + 5) | (5 << 9)); }
                     }
                     nF += 2 * __popc(ma); nT += __popc(ms) + 2 * __popc(mr);
                 }
@@ -1520,15 +1481,13 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         }
     }
     SPROF(4);
-    // impulses of the register-resident contact rows go back to their LDS slots (contact forces / touch sensors below)
+    SBLK_MARK(sb_t2)
+    SBLK_END(nc, ng, n_os, nF);
+    // normal impulses of the register-resident contact rows go back to their LDS slots (contact forces below)
 #pragma unroll
     for (int i = 0; i < KOS; i++) {
         const int c = (os_cs >> (8 * i)) & 255;
-        if (c != 255) {
-            LD(L_OSL + (3 * c) * 12 + 11) = os_ln[i];
-            LD(L_OSL + (3 * c + 1) * 12 + 11) = os_l1[i];
-            LD(L_OSL + (3 * c + 2) * 12 + 11) = os_l2[i];
-        }
+        if (c != 255) LD(L_OSL + (3 * c) * 12 + 11) = os_ln[i];
     }
     if (dead) return;
     // ---- integrate: lanes 0..10 joints, lanes 11..13 objects
@@ -1587,11 +1546,11 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
         for (int c = 0; c < nc; c++) {
             const int meta = *(const int *)&LD(L_META + c);
             const int bodyA = meta_bodyA(meta), link = meta_link(meta);
-            const float lam = meta_fast(meta) ? LD(L_OSL + (3 * c) * 12 + 11) : LD(L_GLAM + 6 * (c - n_os));
+            const float lam = meta_fast(meta) ? LD(L_OSL + (3 * meta_slot(meta)) * 12 + 11) : LD(L_GSC + 24 * meta_slot(meta) + 3);
             float f = lam / dt;
-            SCR(S_CT + c * 12 + 10) = f;
+            D.cforce[(size_t)env * MAXC + c] = f;
             if (bodyA < 0 || bodyA >= 16) continue;
-            if (fabsf(SCR(S_CT + c * 12 + 9)) >= 0.1f) continue;
+            if (!meta_near(meta)) continue;
 #pragma unroll
             for (int k = 0; k < 4; k++) if (link == B.touch_links[k]) touch[k] = fmaxf(touch[k], f);
         }
@@ -1633,7 +1592,7 @@ __global__ void k_reset(BodyParams B, SimParams P, DevPtrs D, const unsigned cha
     D.timestep[env] = 0;
     D.errflags[env] = 0;
     for (int k = 0; k < 4; k++) D.touch[(size_t)env * 4 + k] = 0;
-    *(int *)&D.scratch[(size_t)S_NCT * N + env] = 0;
+    D.ccount[env] = 0;
 }
 
 __global__ void k_state_io(SimParams P, DevPtrs D, float *aos /*[N][61]*/, int to_aos) {
@@ -1661,7 +1620,7 @@ __global__ void k_state_io(SimParams P, DevPtrs D, float *aos /*[N][61]*/, int t
         // contact list behind rr_get_contacts and the touch sensors (as k_reset does)
         D.errflags[env] = 0;
         for (int k = 0; k < 4; k++) D.touch[(size_t)env * 4 + k] = 0;
-        *(int *)&D.scratch[(size_t)S_NCT * N + env] = 0;
+        D.ccount[env] = 0;
     }
 }
 
@@ -2931,7 +2890,9 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
 #define ALLOC(ptr, count) if ((rc = dev_alloc(e, &(ptr), (count))) != RR_OK) { rr_destroy(e); return rc; }
     ALLOC(D.state, (size_t)ST_TOTAL * N);
     ALLOC(D.scratch, (size_t)S_TOTAL * N);
-    ALLOC(D.pdata, (size_t)N * MAXPAIRS * 8);
+    ALLOC(D.clist, (size_t)N * MAXC * 3);
+    ALLOC(D.ccount, (size_t)N);
+    ALLOC(D.cforce, (size_t)N * MAXC);
     ALLOC(D.timestep, (size_t)N);
     ALLOC(D.errflags, (size_t)N);
     ALLOC(D.obj_home, (size_t)NOBJ * 7 * N);
@@ -3286,15 +3247,21 @@ int rr_get_contacts(rr_env *e, int32_t env_index, float *out_host, int32_t max_c
     if (!e || !out_host || !count) return fail(RR_EINVAL, "null argument");
     if (env_index < 0 || env_index >= e->P.N) return fail(RR_EINVAL, "rr_get_contacts: env out of range");
     HIPCHK(hipSetDevice(e->cfg.device));
-    const size_t N = e->P.N;
     int nc = 0;
-    HIPCHK(hipMemcpyAsync(&nc, e->D.scratch + (size_t)S_NCT * N + env_index, 4, hipMemcpyDeviceToHost, e->stream));
+    float rec[MAXC * 12], force[MAXC];
+    HIPCHK(hipMemcpyAsync(&nc, e->D.ccount + env_index, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(rec, e->D.clist + (size_t)env_index * MAXC * 3, sizeof rec, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(force, e->D.cforce + (size_t)env_index * MAXC, sizeof force, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (nc > max_contacts) nc = max_contacts;
-    if (nc > 0)   // strided gather: element (c, f) lives at scratch[(S_CT + c*12 + f) * N + env]
-        HIPCHK(hipMemcpy2DAsync(out_host, 4, e->D.scratch + (size_t)S_CT * N + env_index, N * 4, 4, (size_t)nc * 12,
-                                hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    nc = std::max(0, std::min(nc, std::min((int)MAXC, (int)max_contacts)));
+    for (int c = 0; c < nc; c++) {      // device record {x y z nx | ny nz dist meta | mu rest roll spin} -> {bodyA, bodyB, linkA, x, n, dist, force, mu}
+        const float *r = rec + 12 * c;
+        int meta;
+        memcpy(&meta, r + 7, 4);
+        float *o = out_host + 12 * c;
+        o[0] = (float)(signed char)(meta & 255); o[1] = (float)(signed char)((meta >> 8) & 255); o[2] = (float)(signed char)((meta >> 16) & 255);
+        o[3] = r[0]; o[4] = r[1]; o[5] = r[2]; o[6] = r[3]; o[7] = r[4]; o[8] = r[5]; o[9] = r[6]; o[10] = force[c]; o[11] = r[8];
+    }
     *count = nc;
     return RR_OK;
 }

@@ -1,32 +1,34 @@
-"""Which solver workgroups are slow during a macro-action episode (development build): cycles per block against the
-contact population of its four envs."""
+"""Development build (make -C real_robots_amd/csrc stats): cycles of every solver workgroup against the contact population
+of its four envs, for the headline workload (full-range commands) or the macro workload (argv[1] == 'macro')."""
 import os, sys, ctypes
 sys.path.insert(0, '/root/repo')
-os.environ['RR_LIB'] = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'real_robots_amd', 'csrc', 'librealrobot_hip_stats.so')
-import numpy as np
+os.environ['RR_LIB'] = os.path.join(os.path.dirname(__file__), '..', 'real_robots_amd', 'csrc', 'librealrobot_hip_stats.so')
+import numpy as np, torch
 from real_robots_amd import _native as nat
 from real_robots_amd.batched import BatchedREALRobotEnv
+from real_robots_amd.distributed import synthetic_actions
 N = 4096
+macro = len(sys.argv) > 1 and sys.argv[1] == 'macro'
+scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 env = BatchedREALRobotEnv(N, objects=3, width=128, height=128, want_mask=False)
 lib = nat.load_library()
-rng = np.random.default_rng(0)
-m = rng.uniform([-0.25, -0.5], [0.05, 0.5], size=(N, 2, 2))
-env.plan_macro(m)
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 600
-for t in range(T): env.step_plan(render=False)
-env.sync()
-out = (ctypes.c_uint * (5 * (N // 4)))()
-assert lib.rr_debug_solver_blocks(out, N // 4) == 0
-a = np.array(list(out), dtype=np.int64).reshape(N // 4, 5)
-cyc = a[:, 0]
-order = np.argsort(-cyc)
-print("block cycles: mean %.0f median %.0f p90 %.0f p99 %.0f max %d" % (cyc.mean(), np.median(cyc), np.percentile(cyc, 90), np.percentile(cyc, 99), cyc.max()))
-for b in order[:12]:
-    d = a[b, 1:]
-    print("block %4d cycles %8d  " % (b, cyc[b]) + "  ".join("nc %2d gen %2d ovf %2d lean %2d" % (x & 255, (x >> 8) & 255, (x >> 16) & 255, (x >> 24) & 255) for x in d))
-gen = (a[:, 1:] >> 8) & 255; ovf = (a[:, 1:] >> 16) & 255
-print("envs with overflow contacts:", int((ovf > 0).sum()), " max generic per block -> mean cycles:")
-mg = gen.max(1)
-for lo, hi in ((0, 1), (1, 5), (5, 13), (13, 21), (21, 29), (29, 49)):
-    sel = (mg >= lo) & (mg < hi)
-    if sel.any(): print("   max generic in [%2d,%2d): %4d blocks, mean %8.0f cycles, max %8d" % (lo, hi, sel.sum(), cyc[sel].mean(), cyc[sel].max()))
+ids = list(range(N))
+if macro:
+    env.plan_macro(np.random.default_rng(0).uniform([-0.25, -0.5], [0.05, 0.5], size=(N, 2, 2)))
+    for t in range(420): env.step_plan()
+else:
+    for t in range(200): env.step(synthetic_actions(ids, (t // 20) * 20) * scale)
+torch.cuda.synchronize()
+nb = N // 4
+buf = (ctypes.c_uint * (8 * nb))()
+lib.rr_debug_solver_blocks(buf, nb)
+a = np.array(list(buf), dtype=np.int64).reshape(nb, 8)
+cyc, build, pgs = a[:, 0], a[:, 1], a[:, 2]
+print("workgroups %d: total cycles mean %.0f median %.0f p99 %.0f max %.0f | build mean %.0f max %.0f | pgs mean %.0f max %.0f" % (
+    nb, cyc.mean(), np.median(cyc), np.percentile(cyc, 99), cyc.max(), build.mean(), build.max(), pgs.mean(), pgs.max()))
+order = np.argsort(-cyc)[:12]
+for b in order:
+    envs = [(int(x & 255), int((x >> 8) & 255), int((x >> 16) & 255), int(x >> 24)) for x in a[b, 4:8]]
+    print("  wg %4d cycles %7d build %6d pgs %7d  envs (nc, generic, os, F-list): %s" % (b, cyc[b], build[b], pgs[b], envs))
+ng = ((a[:, 4:8] >> 8) & 255)
+print("generic contacts per env: mean %.2f, share of envs with any %.3f, max %d; waves with any %.3f" % (ng.mean(), (ng > 0).mean(), ng.max(), (ng.max(1) > 0).mean()))

@@ -7,21 +7,23 @@ from real_robots_amd import _native as nat
 from real_robots_amd.batched import BatchedREALRobotEnv
 from real_robots_amd.distributed import synthetic_actions
 N = 4096
+SCALE = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
 env = BatchedREALRobotEnv(N, objects=3, width=128, height=128)
 lib = nat.load_library()
 ids = list(range(N))
 for t in range(160):
-    env.step(synthetic_actions(ids, (t // 20) * 20) * 0.5, render=False)
+    env.step(synthetic_actions(ids, (t // 20) * 20) * SCALE, render=False)
 out = (ctypes.c_ulonglong * 16)()
 torch.cuda.synchronize()
 lib.rr_debug_solver_prof(out, 1)
 K = 20
 for t in range(K):
-    env.step(synthetic_actions(ids, 160) * 0.5, render=False)
+    env.step(synthetic_actions(ids, 160) * SCALE, render=False)
 torch.cuda.synchronize()
 lib.rr_debug_solver_prof(out, 0)
 v = np.array(list(out), dtype=np.float64) / (K * N / 4)
-names = ['stage Minv', 'gather contacts + build rows', 'motor+limit rows', 'limmask + register rows', 'PGS iterations', 'integrate', 'touch/forces']
-tot = v[:7].sum()
+names = ['stage Minv', 'pair loop: tail after the last stamp', 'motor+limit rows', 'limmask + register rows', 'PGS iterations', 'integrate', 'touch/forces',
+         'pair header: loads + object gathers', 'pair: wait + contact setup', 'object-lane contact rows', 'generic contact stage 1', 'generic contact rows', '-', '-', '-', '-']
+tot = v[:12].sum()
 for n, x in zip(names, v): print(f'{n:28s} {x:10.0f} ticks  {100 * x / tot:5.1f} %')
 print('total', tot, 'ticks (shader clock cycles)')
