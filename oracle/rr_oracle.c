@@ -1082,7 +1082,8 @@ void rro_mass_matrix(rr_oracle *o, double *M121, double *bias11) {
  *   shading  : ambient 0.6 + diffuse 0.35 max(0,n.l) + specular 0.05 max(r.z,0)^2, light dir (-50,30,100),
  *              nearest texel x instance colour, background white, depth = GL depth in [0,1], mask = body uid / -1
  *   ties     : equal depth -> lowest triangle id wins
- *   clipping : triangles with any vertex closer than the near plane are dropped (documented in DESIGN.md)
+ *   clipping : triangles that cross the near plane (w = 0.1) are clipped against it (clip_near), fragments outside the depth
+ *              range are discarded
  */
 typedef struct { float m[16]; } mat4;
 
@@ -1141,22 +1142,58 @@ static void instance_xform(const rr_oracle *o, int inst, float *R, float *p) {
 }
 
 typedef struct { float sx[3], sy[3], sz[3], w[3]; int ok; } stri_t;
+#define NEAR_W 0.1f      /* clip-space w of the near plane (env.py:548-551 nearVal 0.1) */
 
-static void project_tri(const float *MVP, const float *tp, int W, int H, stri_t *s) {
-    s->ok = 1;
+/* clip coordinates of the three corners: c[k] = {x, y, z, w} */
+static void clip_coords(const float *MVP, const float *tp, float c[3][4]) {
     for (int k = 0; k < 3; k++) {
         const float *v = tp + 3 * k;
-        float cx = MVP[0] * v[0] + MVP[1] * v[1] + MVP[2] * v[2] + MVP[3];
-        float cy = MVP[4] * v[0] + MVP[5] * v[1] + MVP[6] * v[2] + MVP[7];
-        float cz = MVP[8] * v[0] + MVP[9] * v[1] + MVP[10] * v[2] + MVP[11];
-        float cw = MVP[12] * v[0] + MVP[13] * v[1] + MVP[14] * v[2] + MVP[15];
-        if (cw < 0.1f) { s->ok = 0; return; }
-        float iw = 1.0f / cw;
-        s->sx[k] = (cx * iw + 1.0f) * (0.5f * (float)W);
-        s->sy[k] = (cy * iw + 1.0f) * (0.5f * (float)H);
-        s->sz[k] = cz * iw;
-        s->w[k] = cw;
+        c[k][0] = MVP[0] * v[0] + MVP[1] * v[1] + MVP[2] * v[2] + MVP[3];
+        c[k][1] = MVP[4] * v[0] + MVP[5] * v[1] + MVP[6] * v[2] + MVP[7];
+        c[k][2] = MVP[8] * v[0] + MVP[9] * v[1] + MVP[10] * v[2] + MVP[11];
+        c[k][3] = MVP[12] * v[0] + MVP[13] * v[1] + MVP[14] * v[2] + MVP[15];
     }
+}
+/* perspective division + viewport of one clip-space vertex (TinyRenderer viewport(): integer sample points in a
+ * (x+1)*W/2 window) */
+static void to_screen(const float *c, int W, int H, float *sx, float *sy, float *sz, float *w) {
+    float iw = 1.0f / c[3];
+    *sx = (c[0] * iw + 1.0f) * (0.5f * (float)W);
+    *sy = (c[1] * iw + 1.0f) * (0.5f * (float)H);
+    *sz = c[2] * iw;
+    *w = c[3];
+}
+static void project_tri(const float *MVP, const float *tp, int W, int H, stri_t *s) {
+    float c[3][4];
+    clip_coords(MVP, tp, c);
+    s->ok = 1;
+    for (int k = 0; k < 3; k++) {
+        if (c[k][3] < NEAR_W) { s->ok = 0; return; }
+        to_screen(c[k], W, H, &s->sx[k], &s->sy[k], &s->sz[k], &s->w[k]);
+    }
+}
+/* Sutherland-Hodgman against the near plane w >= NEAR_W: a triangle with one or two corners nearer than the plane becomes
+ * a triangle or a quadrilateral (a fan of two triangles) -- TinyRenderer clips the triangles that cross the eye plane and
+ * discards the fragments nearer than the near plane, which is the same coverage.  An intersection is always computed from
+ * the inside corner a towards the outside corner b, t = (near - w_a) / (w_b - w_a), and gets w = near exactly.
+ * Returns the number of polygon vertices (0, 3 or 4) in out[][4]. */
+static int clip_near(float c[3][4], float out[4][4]) {
+    int n = 0;
+    for (int i = 0; i < 3; i++) {
+        int j = (i + 1) % 3;
+        int in_i = c[i][3] >= NEAR_W, in_j = c[j][3] >= NEAR_W;
+        if (in_i) { for (int k = 0; k < 4; k++) out[n][k] = c[i][k]; n++; }
+        if (in_i != in_j) {
+            const float *a = in_i ? c[i] : c[j], *b = in_i ? c[j] : c[i];
+            float t = (NEAR_W - a[3]) / (b[3] - a[3]);
+            out[n][0] = a[0] + t * (b[0] - a[0]);
+            out[n][1] = a[1] + t * (b[1] - a[1]);
+            out[n][2] = a[2] + t * (b[2] - a[2]);
+            out[n][3] = NEAR_W;
+            n++;
+        }
+    }
+    return n;
 }
 
 static inline int bary(const stri_t *s, float px, float py, float *b) {
@@ -1197,27 +1234,36 @@ void rro_render(rr_oracle *o, uint8_t *rgb, float *depth, int32_t *mask) {
     for (int t = 0; t < m->nt; t++) {
         int inst = m->tri_inst[t];
         if (inst >= n_inst_used) continue;   /* unused objects are the trailing instances */
-        stri_t s;
-        project_tri(MVPs[inst], m->tri_pos + 9 * t, W, H, &s);
-        if (!s.ok) continue;
-        float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
-        float ymin = fminf(s.sy[0], fminf(s.sy[1], s.sy[2])), ymax = fmaxf(s.sy[0], fmaxf(s.sy[1], s.sy[2]));
-        if (xmax < 0 || ymax < 0 || xmin > (float)(W - 1) || ymin > (float)(H - 1)) continue;
-        int x0 = (int)ceilf(fmaxf(xmin, 0.0f)), x1 = (int)floorf(fminf(xmax, (float)(W - 1)));
-        int y0 = (int)ceilf(fmaxf(ymin, 0.0f)), y1 = (int)floorf(fminf(ymax, (float)(H - 1)));
-        for (int py = y0; py <= y1; py++)
-            for (int px = x0; px <= x1; px++) {
-                float b[3];
-                if (!bary(&s, (float)px, (float)py, b)) continue;
-                float z = b[0] * s.sz[0] + b[1] * s.sz[1] + b[2] * s.sz[2];
-                float d = 0.5f * z + 0.5f;
-                if (!(d >= 0.0f && d <= 1.0f)) continue;
-                uint32_t db;
-                memcpy(&db, &d, 4);
-                uint64_t key = ((uint64_t)db << 32) | (uint32_t)t;
-                int idx = (H - 1 - py) * W + px;
-                if (key < vis[idx]) vis[idx] = key;
-            }
+        float cc[3][4], poly[4][4];
+        clip_coords(MVPs[inst], m->tri_pos + 9 * t, cc);
+        int n_in = (cc[0][3] >= NEAR_W) + (cc[1][3] >= NEAR_W) + (cc[2][3] >= NEAR_W);
+        if (n_in == 0) continue;
+        int npoly = 3;
+        if (n_in == 3) memcpy(poly, cc, sizeof cc);
+        else npoly = clip_near(cc, poly);
+        for (int sub = 0; sub + 2 < npoly; sub++) {      /* fan: (0, 1, 2), (0, 2, 3) */
+            stri_t s;
+            const int vi[3] = {0, sub + 1, sub + 2};
+            for (int k = 0; k < 3; k++) to_screen(poly[vi[k]], W, H, &s.sx[k], &s.sy[k], &s.sz[k], &s.w[k]);
+            float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
+            float ymin = fminf(s.sy[0], fminf(s.sy[1], s.sy[2])), ymax = fmaxf(s.sy[0], fmaxf(s.sy[1], s.sy[2]));
+            if (xmax < 0 || ymax < 0 || xmin > (float)(W - 1) || ymin > (float)(H - 1)) continue;
+            int x0 = (int)ceilf(fmaxf(xmin, 0.0f)), x1 = (int)floorf(fminf(xmax, (float)(W - 1)));
+            int y0 = (int)ceilf(fmaxf(ymin, 0.0f)), y1 = (int)floorf(fminf(ymax, (float)(H - 1)));
+            for (int py = y0; py <= y1; py++)
+                for (int px = x0; px <= x1; px++) {
+                    float b[3];
+                    if (!bary(&s, (float)px, (float)py, b)) continue;
+                    float z = b[0] * s.sz[0] + b[1] * s.sz[1] + b[2] * s.sz[2];
+                    float d = 0.5f * z + 0.5f;
+                    if (!(d >= 0.0f && d <= 1.0f)) continue;
+                    uint32_t db;
+                    memcpy(&db, &d, 4);
+                    uint64_t key = ((uint64_t)db << 32) | (uint32_t)t;
+                    int idx = (H - 1 - py) * W + px;
+                    if (key < vis[idx]) vis[idx] = key;
+                }
+        }
     }
     /* resolve / shade */
     float L[3] = {-50.0f, 30.0f, 100.0f};
@@ -1241,9 +1287,22 @@ void rro_render(rr_oracle *o, uint8_t *rgb, float *depth, int32_t *mask) {
             int inst = m->tri_inst[t];
             stri_t s;
             project_tri(MVPs[inst], m->tri_pos + 9 * t, W, H, &s);
-            float b[3] = {0, 0, 0};
-            bary(&s, (float)px, (float)(H - 1 - row), b);
-            float c0 = b[0] / s.w[0], c1 = b[1] / s.w[1], c2 = b[2] / s.w[2];
+            float c0, c1, c2;
+            if (s.ok) {
+                float b[3] = {0, 0, 0};
+                bary(&s, (float)px, (float)(H - 1 - row), b);
+                c0 = b[0] / s.w[0]; c1 = b[1] / s.w[1]; c2 = b[2] / s.w[2];
+            } else {
+                /* a corner is nearer than the near plane (the triangle was clipped): perspective-correct weights straight
+                 * from the clip coordinates -- the point sum c_i V_i projects onto the sample iff c is orthogonal to
+                 * u_i = x_i - xn w_i and v_i = y_i - yn w_i, i.e. c ~ u x v */
+                float cc[3][4];
+                clip_coords(MVPs[inst], m->tri_pos + 9 * t, cc);
+                float xn = (float)px * (2.0f / (float)W) - 1.0f, yn = (float)(H - 1 - row) * (2.0f / (float)H) - 1.0f;
+                float u0 = cc[0][0] - xn * cc[0][3], u1 = cc[1][0] - xn * cc[1][3], u2 = cc[2][0] - xn * cc[2][3];
+                float v0 = cc[0][1] - yn * cc[0][3], v1 = cc[1][1] - yn * cc[1][3], v2 = cc[2][1] - yn * cc[2][3];
+                c0 = u1 * v2 - u2 * v1; c1 = u2 * v0 - u0 * v2; c2 = u0 * v1 - u1 * v0;
+            }
             float cs = 1.0f / (c0 + c1 + c2);
             c0 *= cs; c1 *= cs; c2 *= cs;
             const float *nn = m->tri_nrm + 9 * t, *uv = m->tri_uv + 6 * t;

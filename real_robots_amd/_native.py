@@ -122,3 +122,76 @@ class DeviceBuffer:
     @property
     def __cuda_array_interface__(self):
         return {'shape': self.shape, 'typestr': self.typestr, 'data': (self.ptr, False), 'version': 2, 'strides': None}
+
+
+# ---------------------------------------------------------------------------------------------- DLPack export
+class _DLDevice(C.Structure):
+    _fields_ = [('device_type', C.c_int32), ('device_id', C.c_int32)]
+
+
+class _DLDataType(C.Structure):
+    _fields_ = [('code', C.c_uint8), ('bits', C.c_uint8), ('lanes', C.c_uint16)]
+
+
+class _DLTensor(C.Structure):
+    _fields_ = [('data', C.c_void_p), ('device', _DLDevice), ('ndim', C.c_int32), ('dtype', _DLDataType),
+                ('shape', C.POINTER(C.c_int64)), ('strides', C.POINTER(C.c_int64)), ('byte_offset', C.c_uint64)]
+
+
+class _DLManagedTensor(C.Structure):
+    pass
+
+
+_DLDeleter = C.CFUNCTYPE(None, C.POINTER(_DLManagedTensor))
+_DLManagedTensor._fields_ = [('dl_tensor', _DLTensor), ('manager_ctx', C.c_void_p), ('deleter', _DLDeleter)]
+KDL_ROCM = 10                       # DLDeviceType kDLROCM
+_dl_alive = {}                      # address of a DLManagedTensor handed out -> (struct, shape array, owner)
+
+
+@_DLDeleter
+def _dl_deleter(ptr):
+    _dl_alive.pop(C.addressof(ptr.contents), None)
+
+
+_PyCapsuleDestructor = C.CFUNCTYPE(None, C.c_void_p)
+
+
+@_PyCapsuleDestructor
+def _dl_capsule_destructor(capsule):
+    # a capsule nobody consumed is still called "dltensor": its tensor is ours to release
+    api = C.pythonapi
+    api.PyCapsule_IsValid.argtypes, api.PyCapsule_IsValid.restype = [C.c_void_p, C.c_char_p], C.c_int
+    api.PyCapsule_GetPointer.argtypes, api.PyCapsule_GetPointer.restype = [C.c_void_p, C.c_char_p], C.c_void_p
+    if api.PyCapsule_IsValid(capsule, b'dltensor'):
+        _dl_alive.pop(api.PyCapsule_GetPointer(capsule, b'dltensor'), None)
+
+
+def _dlpack_capsule(ptr, shape, np_dtype, device_id, owner):
+    dt = np.dtype(np_dtype)
+    code = {'f': 2, 'i': 0, 'u': 1}[dt.kind]
+    m = _DLManagedTensor()
+    shp = (C.c_int64 * len(shape))(*shape)
+    m.dl_tensor.data = ptr
+    m.dl_tensor.device = _DLDevice(KDL_ROCM, device_id)
+    m.dl_tensor.ndim = len(shape)
+    m.dl_tensor.dtype = _DLDataType(code, dt.itemsize * 8, 1)
+    m.dl_tensor.shape = shp
+    m.dl_tensor.strides = None          # compact row-major
+    m.dl_tensor.byte_offset = 0
+    m.manager_ctx = None
+    m.deleter = _dl_deleter
+    _dl_alive[C.addressof(m)] = (m, shp, owner)
+    api = C.pythonapi
+    api.PyCapsule_New.argtypes, api.PyCapsule_New.restype = [C.c_void_p, C.c_char_p, _PyCapsuleDestructor], C.py_object
+    return api.PyCapsule_New(C.addressof(m), b'dltensor', _dl_capsule_destructor)
+
+
+def _dlpack(self, stream=None, **kwargs):
+    """DLPack export of a device buffer (zero-copy into torch / cupy / jax on ROCm).  The buffer belongs to the env handle
+    (kept alive by the capsule) and is rewritten by every step on the library's stream: `stream` is accepted for protocol
+    compatibility, ordering follows the stream contract of include/realrobot.h."""
+    return _dlpack_capsule(self.ptr, self.shape, self.typestr, getattr(self._owner, 'device', 0), self._owner)
+
+
+DeviceBuffer.__dlpack__ = _dlpack
+DeviceBuffer.__dlpack_device__ = lambda self: (KDL_ROCM, getattr(self._owner, 'device', 0))

@@ -1981,6 +1981,7 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 #define TILE_PIX 16384
 #endif
 #define MAXWIN 1024      // 64-triangle windows per model (rr_create checks nt)
+#define CLIPQ 2048        // triangles crossing the near plane per (env, tile) that are clipped (a link cut by the plane has a few hundred)
 #ifndef INLINE_PIX
 #define INLINE_PIX 2     // sample points of a small triangle walked by its own lane; the rest is redistributed over the wave
 #endif
@@ -2022,6 +2023,33 @@ __device__ __forceinline__ void project_vertex(const float *mvp, float vx, float
     sy = (cy * iw + 1.0f) * (0.5f * (float)H);
     sz = cz * iw;
 }
+// Near-plane clipping (oracle clip_near / to_screen, identical arithmetic): clip coordinates of one vertex, the screen
+// position of a clip-space point, and the intersection of an edge with w = NEAR_W computed from the inside end a towards
+// the outside end b.
+#define NEAR_W 0.1f
+__device__ __forceinline__ void clip_vertex(const float *mvp, float vx, float vy, float vz, float *c) {
+#pragma clang fp contract(off)
+    c[0] = mvp[0] * vx + mvp[1] * vy + mvp[2] * vz + mvp[3];
+    c[1] = mvp[4] * vx + mvp[5] * vy + mvp[6] * vz + mvp[7];
+    c[2] = mvp[8] * vx + mvp[9] * vy + mvp[10] * vz + mvp[11];
+    c[3] = mvp[12] * vx + mvp[13] * vy + mvp[14] * vz + mvp[15];
+}
+__device__ __forceinline__ void clip_to_screen(const float *c, int W, int H, float &sx, float &sy, float &sz) {
+#pragma clang fp contract(off)
+    const float iw = 1.0f / c[3];
+    sx = (c[0] * iw + 1.0f) * (0.5f * (float)W);
+    sy = (c[1] * iw + 1.0f) * (0.5f * (float)H);
+    sz = c[2] * iw;
+}
+__device__ __forceinline__ void clip_edge(const float *a, const float *b, float *o) {
+#pragma clang fp contract(off)
+    const float t = (NEAR_W - a[3]) / (b[3] - a[3]);
+    o[0] = a[0] + t * (b[0] - a[0]);
+    o[1] = a[1] + t * (b[1] - a[1]);
+    o[2] = a[2] + t * (b[2] - a[2]);
+    o[3] = NEAR_W;
+}
+
 // exclusive prefix sum over the 64 lanes of a wave (DPP row_shr scan inside each 16-lane row + the row totals)
 template <int SHR> __device__ __forceinline__ int dpp_shr0(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + SHR, 0xf, 0xf, true); }
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
@@ -2128,11 +2156,25 @@ __device__ __forceinline__ void shade_pixel(const ShadeCtx &c, int t, int px, in
     const float *tp = rec, *nn = rec + 9, *uv = rec + 18;
     const int inst = __float_as_int(rec[24]);
     STri s;
-    project_tri(c.mvp + inst * 16, tp, W, H, s);
-    float b[3] = {0, 0, 0};
-    bary(s, (float)px, (float)(H - 1 - row), b);
-    // perspective-correct weights b_k / w_k: s.w holds 1 / w_k (the reciprocal the projection computed anyway)
-    float c0 = b[0] * s.w[0], c1 = b[1] * s.w[1], c2 = b[2] * s.w[2];
+    float c0, c1, c2;
+    if (project_tri(c.mvp + inst * 16, tp, W, H, s)) {
+        float b[3] = {0, 0, 0};
+        bary(s, (float)px, (float)(H - 1 - row), b);
+        // perspective-correct weights b_k / w_k: s.w holds 1 / w_k (the reciprocal the projection computed anyway)
+        c0 = b[0] * s.w[0]; c1 = b[1] * s.w[1]; c2 = b[2] * s.w[2];
+    } else {
+        // a corner is nearer than the near plane (the triangle was clipped by k_raster): perspective-correct weights straight
+        // from the clip coordinates, c ~ u x v with u_i = x_i - xn w_i, v_i = y_i - yn w_i (oracle rro_render, same arithmetic)
+#pragma clang fp contract(off)
+        float k0[4], k1[4], k2[4];
+        clip_vertex(c.mvp + inst * 16, tp[0], tp[1], tp[2], k0);
+        clip_vertex(c.mvp + inst * 16, tp[3], tp[4], tp[5], k1);
+        clip_vertex(c.mvp + inst * 16, tp[6], tp[7], tp[8], k2);
+        const float xn = (float)px * (2.0f / (float)W) - 1.0f, yn = (float)(H - 1 - row) * (2.0f / (float)H) - 1.0f;
+        const float u0 = k0[0] - xn * k0[3], u1 = k1[0] - xn * k1[3], u2 = k2[0] - xn * k2[3];
+        const float v0 = k0[1] - yn * k0[3], v1 = k1[1] - yn * k1[3], v2 = k2[1] - yn * k2[3];
+        c0 = u1 * v2 - u2 * v1; c1 = u2 * v0 - u0 * v2; c2 = u0 * v1 - u1 * v0;
+    }
     float cs = 1.0f / (c0 + c1 + c2);
     c0 *= cs; c1 *= cs; c2 *= cs;
     float n0 = c0 * nn[0] + c1 * nn[3] + c2 * nn[6], n1 = c0 * nn[1] + c1 * nn[4] + c2 * nn[7], n2 = c0 * nn[2] + c1 * nn[5] + c2 * nn[8];
@@ -2205,6 +2247,8 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     __shared__ unsigned nlist, wcount, wnext;
     __shared__ unsigned short wlist[MAXWIN];
     __shared__ int wends[RASTER_THREADS / 64][64];      // per wave: running ends of the lanes' left-over points
+    __shared__ int clipq[CLIPQ];                        // triangles that cross the near plane (rare), clipped after the window loop
+    __shared__ unsigned nclipq;
     const int env = blockIdx.x + env0, tile = blockIdx.y;
     if (pass == 0 && D.render_flags && !D.render_flags[env]) return;
     const int W = RM.W, H = RM.H;
@@ -2221,7 +2265,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     // The tile starts empty (an LDS-only fill); the static layer's keys are compared at compaction time and only for the
     // few pixels a moving triangle reached (min is associative) -- no 128 KB read of the static keys per env.
     for (int i = tid; i < npix; i += RASTER_THREADS) vis[i] = ~0ull;
-    if (tid == 0) { nlist = 0; wcount = 0; wnext = 0; }
+    if (tid == 0) { nlist = 0; wcount = 0; wnext = 0; nclipq = 0; }
     stage_instances(RM, D, env, tid, RASTER_THREADS, mvp, nullptr);
     __syncthreads();
     // tile bounds in screen y (py = H-1-row)
@@ -2287,6 +2331,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         const int inst = D.tri_inst[tb];
         STri s;
         int x0 = 0, y0 = 0, x1 = -1, y1 = -1, area = 0;
+        bool needs_clip = false;
         float ia = 0.0f;
         {
             // The window is one cluster: lane l projects the cluster's vertex l (<= 64 distinct positions for its 64
@@ -2302,7 +2347,11 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
                 s.sx[k] = lane_gather(psx, src); s.sy[k] = lane_gather(psy, src); s.sz[k] = lane_gather(psz, src);
                 s.w[k] = 1.0f;
             }
-            live = live && !(s.sx[0] != s.sx[0] || s.sx[1] != s.sx[1] || s.sx[2] != s.sx[2]);
+            // corners nearer than the near plane (sx = NaN): none -> the ordinary paths below; all -> nothing to draw;
+            // one or two -> the triangle is clipped against the plane by the whole wave (rare, see the end of the loop body)
+            const int nnear = (s.sx[0] != s.sx[0] ? 1 : 0) + (s.sx[1] != s.sx[1] ? 1 : 0) + (s.sx[2] != s.sx[2] ? 1 : 0);
+            needs_clip = live && nnear > 0 && nnear < 3;
+            live = live && nnear == 0;
         }
         if (live) {
             float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
@@ -2433,6 +2482,105 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
                 }
             }
         }
+        // triangles that cross the near plane are rare: they are queued and clipped after the window loop
+        if (needs_clip && !ABL(16)) { const unsigned qi = atomicAdd(&nclipq, 1u); if (qi < CLIPQ) clipq[qi] = t; }
+    }
+    // ---- triangles that cross the near plane (queued above): clipped against w = NEAR_W (Sutherland-Hodgman, the oracle's
+    // clip_near()) into a triangle or a fan of two, which a whole wave rasterises under the original triangle id
+    __syncthreads();
+    for (unsigned qi = tid >> 6; qi < min(nclipq, (unsigned)CLIPQ); qi += RASTER_THREADS / 64) {
+        const int bt = clipq[qi];
+        const int tb = bt & ~63;
+        const int inst = D.tri_inst[tb];
+        STri ta, tb2;
+        int nsub = 0;
+        {
+            const int cvi = D.tri_vidx[bt];
+                const float *cv = D.cluster_verts + (size_t)(tb >> 6) * 192;
+            float c0[4], c1[4], c2[4];
+            { const int i0 = cvi & 63, i1 = (cvi >> 8) & 63, i2 = (cvi >> 16) & 63;
+              clip_vertex(mvp[inst], cv[i0], cv[64 + i0], cv[128 + i0], c0);
+              clip_vertex(mvp[inst], cv[i1], cv[64 + i1], cv[128 + i1], c1);
+              clip_vertex(mvp[inst], cv[i2], cv[64 + i2], cv[128 + i2], c2); }
+            const bool in0 = c0[3] >= NEAR_W, in1 = c1[3] >= NEAR_W, in2 = c2[3] >= NEAR_W;
+            float e01[4] = {0, 0, 0, 1}, e12[4] = {0, 0, 0, 1}, e20[4] = {0, 0, 0, 1};
+            if (in0 != in1) { if (in0) clip_edge(c0, c1, e01); else clip_edge(c1, c0, e01); }
+            if (in1 != in2) { if (in1) clip_edge(c1, c2, e12); else clip_edge(c2, c1, e12); }
+            if (in2 != in0) { if (in2) clip_edge(c2, c0, e20); else clip_edge(c0, c2, e20); }
+            // polygon in Sutherland-Hodgman order: [v0] [x01] [v1] [x12] [v2] [x20] with the absent ones left out (values
+            // are copied, not pointed to: private arrays behind pointers would live in scratch memory)
+            float p0[4], p1[4], p2[4], p3[4];
+#define CP4(D_, S_) { D_[0] = S_[0]; D_[1] = S_[1]; D_[2] = S_[2]; D_[3] = S_[3]; }
+            CP4(p0, c0) CP4(p1, c0) CP4(p2, c0) CP4(p3, c0)
+            const int msk = (in0 ? 1 : 0) | (in1 ? 2 : 0) | (in2 ? 4 : 0);       // wave-uniform
+            if (msk == 1) { CP4(p0, c0) CP4(p1, e01) CP4(p2, e20) nsub = 1; }
+            else if (msk == 2) { CP4(p0, e01) CP4(p1, c1) CP4(p2, e12) nsub = 1; }
+            else if (msk == 4) { CP4(p0, e12) CP4(p1, c2) CP4(p2, e20) nsub = 1; }
+            else if (msk == 3) { CP4(p0, c0) CP4(p1, c1) CP4(p2, e12) CP4(p3, e20) nsub = 2; }
+            else if (msk == 6) { CP4(p0, e01) CP4(p1, c1) CP4(p2, c2) CP4(p3, e20) nsub = 2; }
+            else if (msk == 5) { CP4(p0, c0) CP4(p1, e01) CP4(p2, e12) CP4(p3, c2) nsub = 2; }
+#undef CP4
+            clip_to_screen(p0, W, H, ta.sx[0], ta.sy[0], ta.sz[0]);          // fan (0, 1, 2), (0, 2, 3)
+            clip_to_screen(p1, W, H, ta.sx[1], ta.sy[1], ta.sz[1]);
+            clip_to_screen(p2, W, H, ta.sx[2], ta.sy[2], ta.sz[2]);
+            tb2.sx[0] = ta.sx[0]; tb2.sy[0] = ta.sy[0]; tb2.sz[0] = ta.sz[0];
+            tb2.sx[1] = ta.sx[2]; tb2.sy[1] = ta.sy[2]; tb2.sz[1] = ta.sz[2];
+            clip_to_screen(p3, W, H, tb2.sx[2], tb2.sy[2], tb2.sz[2]);
+            ta.w[0] = ta.w[1] = ta.w[2] = tb2.w[0] = tb2.w[1] = tb2.w[2] = 1.0f;
+        }
+        for (int sub = 0; sub < nsub; sub++) {
+            STri bs;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { bs.sx[k] = sub ? tb2.sx[k] : ta.sx[k]; bs.sy[k] = sub ? tb2.sy[k] : ta.sy[k]; bs.sz[k] = sub ? tb2.sz[k] : ta.sz[k]; bs.w[k] = 1.0f; }
+            // clipped bounding box and reciprocal area: the same arithmetic as the per-lane set-up above
+            const float xmin = fminf(bs.sx[0], fminf(bs.sx[1], bs.sx[2])), xmax = fmaxf(bs.sx[0], fmaxf(bs.sx[1], bs.sx[2]));
+            const float ymin = fminf(bs.sy[0], fminf(bs.sy[1], bs.sy[2])), ymax = fmaxf(bs.sy[0], fmaxf(bs.sy[1], bs.sy[2]));
+            if (xmax < 0 || ymax < ty0 || xmin > (float)(W - 1) || ymin > ty1) continue;
+            const int bx0 = (int)ceilf(fmaxf(xmin, 0.0f)), bx1 = (int)floorf(fminf(xmax, (float)(W - 1)));
+            const int by0 = (int)ceilf(fmaxf(ymin, ty0)), by1 = (int)floorf(fminf(ymax, ty1));
+            if (bx1 < bx0 || by1 < by0) continue;
+            const TriEdge te = tri_edge(bs);
+            if (!te.ok) continue;
+            const float bia = te.ia;
+            const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+            const int nbx = (bw + 7) >> 3, nby = (bh + 7) >> 3, nblk = nbx * nby;
+            if (nblk <= 4) {
+                for (int by = 0; by < bh; by += 8)
+                    for (int bx = 0; bx < bw; bx += 8) {
+                        const int ox = bx + lx, oy = by + ly;
+                        if (ox < bw && oy < bh) raster_pixel_hoisted(bs, bia, bt, bx0 + ox, by0 + oy, H, W, row0, vis);
+                    }
+                continue;
+            }
+            // Hierarchical: each lane first classifies one 8x8 block (64 blocks per step) with the conservative corner
+            // test; only blocks that may hold covered sample points are rasterised.  Triangles close to the near plane
+            // project to slivers whose clipped bounding box is the whole image -- without this they dominate the kernel.
+            // delta bounds |float - exact| of a barycentric anywhere in the tile: each edge function is a difference of
+            // two products of magnitude <= X*Y (X = max|sx|+W, Y = max|sy|+H), evaluated with <= 4 roundings.
+            const float X = fmaxf(fabsf(bs.sx[0]), fmaxf(fabsf(bs.sx[1]), fabsf(bs.sx[2]))) + (float)W;
+            const float Y = fmaxf(fabsf(bs.sy[0]), fmaxf(fabsf(bs.sy[1]), fabsf(bs.sy[2]))) + (float)H;
+            const float delta2 = 2.0f * (8.0e-6f * X * Y * fabsf(bia) + 1.0e-6f);
+            const float inbx = 1.0f / (float)nbx;
+            if (lane == 0) { RSTAT(10, 1); RSTAT(11, nblk); }
+            for (int c0 = 0; c0 < nblk; c0 += 64) {
+                const int bi = c0 + lane;
+                bool keep = false;
+                if (bi < nblk) {
+                    const int byi = (int)(((float)bi + 0.5f) * inbx), bxi = bi - byi * nbx;
+                    const int px0 = bx0 + 8 * bxi, py0 = by0 + 8 * byi;
+                    keep = block_may_overlap(bs, bia, px0, min(px0 + 7, bx0 + bw - 1), py0, min(py0 + 7, by0 + bh - 1), delta2);
+                }
+                unsigned long long km = __ballot(keep);
+                while (km) {
+                    const int j = c0 + __ffsll((long long)km) - 1;
+                    km &= km - 1;
+                    const int byi = (int)(((float)j + 0.5f) * inbx), bxi = j - byi * nbx;
+                    const int ox = 8 * bxi + lx, oy = 8 * byi + ly;
+                    if (lane == 0) RSTAT(9, 1);     // 8x8 blocks rasterised by the hierarchical path
+                    if (ox < bw && oy < bh) raster_pixel_hoisted(bs, bia, bt, bx0 + ox, by0 + oy, H, W, row0, vis);
+                }
+            }
+        }
     }
 #ifdef RR_RASTER_STATS
     const unsigned long long t_exit_ = __builtin_readcyclecounter();
@@ -2460,7 +2608,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
         }
     }
     __syncthreads();
-    if (tid == 0) { D.frag_count[(size_t)env * RM.ntiles + tile] = nlist; RSTAT(12, nlist); RSTAT(13, 1); }
+    if (tid == 0) { D.frag_count[(size_t)env * RM.ntiles + tile] = nlist; RSTAT(12, nlist); RSTAT(13, 1); RSTAT(14, nclipq); RSTAT(15, nclipq > 0 ? 1 : 0); }
 }
 
 // Image targets of k_static_copy / k_shade: the per-env observation buffers (pass 0) or the shared static layer (pass 1).

@@ -1,0 +1,78 @@
+"""Vector-env adapter: N REALRobot envs behind the gymnasium `VectorEnv` calling convention (reset(seed, options) ->
+(obs, info); step(actions) -> (obs, rewards, terminations, truncations, infos)), on top of BatchedREALRobotEnv.
+
+The reference has no vectorised env (one env per process); this is the adoption surface SURVEY 8(f4) asks for.
+When `gymnasium` is importable the class derives from `gymnasium.vector.VectorEnv`, otherwise it is a plain class with
+the same methods and attributes (`num_envs`, `single_action_space`, `single_observation_space`, `action_space`,
+`observation_space`).  Episodes end like the reference's (env.py:345-352): `truncated` once `timestep >=
+max_episode_steps`; truncated envs are reset at the start of the next step (gymnasium's next-step autoreset).
+Observations are batched numpy arrays; with `device_obs=True` the image / low-dim entries are the library's device
+buffers instead (DLPack / __cuda_array_interface__, zero copy into torch on ROCm).
+"""
+import numpy as np
+
+from . import _native as nat
+from . import spaces
+from .batched import BatchedREALRobotEnv
+from .envs.robot import Kuka
+
+try:                                    # optional dependency
+    from gymnasium.vector import VectorEnv as _Base
+except Exception:                       # pragma: no cover - gymnasium is not installed in the build container
+    _Base = object
+
+
+class REALRobotVectorEnv(_Base):
+    def __init__(self, num_envs, objects=3, additional_obs=False, eye_width=320, eye_height=240, device=0,
+                 max_episode_steps=int(15e6), render_every_step=True, device_obs=False):
+        self.num_envs = int(num_envs)
+        self._robot = Kuka(additional_obs, objects, eye_width, eye_height, env=None)
+        self.single_action_space = spaces.Dict({"joint_command": self._robot.action_space, "render": spaces.MultiBinary(1)})
+        self.single_observation_space = self._robot.observation_space
+        self.action_space = spaces.Box(low=np.tile(self._robot.min_joints, (self.num_envs, 1)),
+                                       high=np.tile(self._robot.max_joints, (self.num_envs, 1)), dtype=float)
+        self.observation_space = self.single_observation_space
+        self.max_episode_steps = int(max_episode_steps)
+        self.render_every_step, self.device_obs, self.additional_obs = bool(render_every_step), bool(device_obs), bool(additional_obs)
+        self._be = BatchedREALRobotEnv(self.num_envs, objects=objects, width=eye_width, height=eye_height, device=device,
+                                       want_mask=additional_obs)
+        self._pending_reset = np.zeros(self.num_envs, np.uint8)
+
+    # ------------------------------------------------------------------ observations
+    def _obs(self, rendered):
+        be = self._be
+        get = be.device_buffer if self.device_obs else be.host
+        obs = {"joint_positions": get(nat.F_JOINTS), "touch_sensors": get(nat.F_TOUCH)}
+        if rendered:
+            obs["retina"], obs["depth"] = get(nat.F_RGB), get(nat.F_DEPTH)
+            if self.additional_obs:
+                obs["mask"] = get(nat.F_MASK)
+        if self.additional_obs:
+            obs["object_positions"] = get(nat.F_OBJ_POSE)
+        return obs
+
+    def reset(self, *, seed=None, options=None):
+        self._be.reset()
+        self._pending_reset[:] = 0
+        if self.render_every_step:
+            self._be.render()
+        return self._obs(self.render_every_step), {}
+
+    def step(self, actions):
+        """actions: float array [N, 9] of joint commands (or a dict with "joint_command" [N, 9] and optional "render")."""
+        render = self.render_every_step
+        if isinstance(actions, dict):
+            render = bool(np.any(actions.get("render", render)))
+            actions = actions["joint_command"]
+        if self._pending_reset.any():
+            self._be.reset(self._pending_reset)
+            self._pending_reset[:] = 0
+        self._be.step(np.asarray(actions, dtype=np.float32), render=render)
+        ts = self._be.host(nat.F_TIMESTEP)
+        truncated = ts >= self.max_episode_steps
+        self._pending_reset = truncated.astype(np.uint8)
+        n = self.num_envs
+        return self._obs(render), np.zeros(n), np.zeros(n, bool), truncated, {}
+
+    def close(self, **kwargs):
+        self._be.close()

@@ -218,3 +218,23 @@ def test_pybullet_harness_imports_without_pybullet_and_mirrors_the_protocol_cons
         ref.step(np.zeros(9))
         assert ref.state61().shape == (61,)
         ref.close()
+
+
+def test_dlpack_capsule_lifecycle_without_a_gpu():
+    """DeviceBuffer.__dlpack__ builds a DLManagedTensor by hand (ctypes): kDLROCM device, compact row-major shape, and the
+    bookkeeping entry that keeps the struct alive goes away when an unconsumed capsule is dropped."""
+    import gc
+
+    class Owner:
+        device = 3
+    b = nat.DeviceBuffer(0x1000, (4, 9), '<f4', Owner())
+    assert b.__dlpack_device__() == (nat.KDL_ROCM, 3)
+    n0 = len(nat._dl_alive)
+    cap = b.__dlpack__()
+    assert len(nat._dl_alive) == n0 + 1
+    m = next(iter(nat._dl_alive.values()))[0]
+    assert m.dl_tensor.ndim == 2 and [m.dl_tensor.shape[i] for i in range(2)] == [4, 9]
+    assert (m.dl_tensor.dtype.code, m.dl_tensor.dtype.bits) == (2, 32) and m.dl_tensor.data == 0x1000
+    del cap, m
+    gc.collect()
+    assert len(nat._dl_alive) == n0
