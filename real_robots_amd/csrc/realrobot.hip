@@ -120,6 +120,9 @@ struct DevPtrs {
                        // Written by the env's k_collide wavefront, read by its k_solve group in one round trip.
     int *ccount;       // [N] number of contacts in clist
     float *cforce;     // [N][MAXC] normal force of every contact of the last step (rr_get_contacts, touch sensors)
+    int *hgflag;       // [ceil(N/4)] != 0: this solver group (four consecutive envs) holds an env with generic contacts -- "heavy"
+    int *hlist;        // [ceil(N/4)] the heavy groups of this step (in arrival order: placement only, never a result)
+    int *hcount;       // [1] their number
     int *timestep;     // [N]
     unsigned *errflags;// [N]
     float *obj_home;   // [NOBJ*7][N] per-env pose an object is put back to by reset / the out-of-bounds rule (robot.py:19-24, mutable there)
@@ -145,6 +148,15 @@ struct DevPtrs {
     uint2 *frag_list;       // [N*ntiles][TILE_PIX] pixels won by moving triangles: {depth bits, pixel-in-tile << 18 | triangle}
     unsigned *frag_count;   // [N*ntiles]
 };
+
+// Which envs a launch handles: 0 all; 1 the envs of light solver groups; 2 the envs of heavy ones (rr_step runs the few
+// heavy groups -- an arm pressed on the table, a gripper pushing objects: dozens of generic contact rows -- and their
+// render on the side stream, beside the render of the others).
+__device__ __forceinline__ bool env_selected(const int *hgflag, int env, int sel) {
+    if (sel == 0) return true;
+    const bool heavy = hgflag[env >> 2] != 0;
+    return sel == 1 ? !heavy : heavy;
+}
 
 // Kinematic tree of the 11 moving bodies (lbr_iiwa_link_1..7 [+gripper base], finger_00, finger_01, finger_10,
 // finger_11); compile-time so that per-body register arrays are statically indexed. rr_create verifies the blob.
@@ -548,8 +560,8 @@ __device__ unsigned long long g_sprof[16];
 __device__ unsigned g_sblk[4096 * 8];
 #define SBLK_BEGIN const unsigned long long sb_t0 = __builtin_readcyclecounter(); unsigned long long sb_t1 = sb_t0, sb_t2 = sb_t0;
 #define SBLK_MARK(v) v = __builtin_readcyclecounter();
-#define SBLK_END(ncv, gv, osv, nfv) do { if (blockIdx.x < 4096) { if (l == 0) g_sblk[blockIdx.x * 8 + 4 + grp] = (unsigned)(ncv) | ((unsigned)(gv) << 8) | ((unsigned)(osv) << 16) | ((unsigned)(nfv) << 24); \
-    if (threadIdx.x == 0) { g_sblk[blockIdx.x * 8] = (unsigned)(__builtin_readcyclecounter() - sb_t0); g_sblk[blockIdx.x * 8 + 1] = (unsigned)(sb_t1 - sb_t0); g_sblk[blockIdx.x * 8 + 2] = (unsigned)(sb_t2 - sb_t1); } } } while (0)
+#define SBLK_END(ncv, gv, osv, nfv) do { if (unit < 4096) { if (l == 0) g_sblk[unit * 8 + 4 + (grp & 3)] = (unsigned)(ncv) | ((unsigned)(gv) << 8) | ((unsigned)(osv) << 16) | ((unsigned)(nfv) << 24); \
+    if ((threadIdx.x & 63) == 0) { g_sblk[unit * 8] = (unsigned)(__builtin_readcyclecounter() - sb_t0); g_sblk[unit * 8 + 1] = (unsigned)(sb_t1 - sb_t0); g_sblk[unit * 8 + 2] = (unsigned)(sb_t2 - sb_t1); } } } while (0)
 extern "C" int rr_debug_solver_blocks(unsigned *out, int nblocks) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sblk), sizeof(unsigned) * 8 * (size_t)nblocks) == hipSuccess ? 0 : -1;
 }
@@ -675,6 +687,8 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
     CSYNC();
     if (CABL(256)) return;
     int nct = 0;                                // contacts of this env so far (wave-uniform)
+    bool heavy = false;                         // some contact is not an object-vs-static one the object lanes take (wave-uniform)
+    unsigned oscnt = 0;                         // object-vs-static contacts per object, 4 bits each
     for (int p0 = 0; p0 < P.npairs; p0 += 64) {
         const int pr = p0 + lane;
         bool close = false;
@@ -810,6 +824,12 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 k = sel3 >= 0 ? 4 : 3;
             }
             k = min(k, MAXC - nct);             // the env's list holds MAXC contacts (the oracle stops there too)
+            {   // the solver's object lanes take up to four object-vs-static contacts per object; anything else is a generic row
+                const int cls = (pair_ab[pair] >> 16) & 3;
+                const int ob = sa - (ns - NOBJ);                        // object index of shape a for the object-vs-static pairs
+                if (cls != 0 || ob < 0) heavy = heavy || k > 0;
+                else { oscnt += (unsigned)k << (4 * ob); heavy = heavy || ((oscnt >> (4 * ob)) & 15u) > 4u; }
+            }
             if (lane < k) {
                 const int ci = lane == 0 ? sel0 : (lane == 1 ? sel1 : (lane == 2 ? sel2 : sel3));
                 const float4 a = cand_a[ci], b = cand_b[ci];
@@ -824,7 +844,10 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
             CSYNC();            // the candidate list is reused by the next pair
         }
     }
-    if (lane == 0) D.ccount[env] = nct;
+    if (lane == 0) {
+        D.ccount[env] = nct;
+        if (heavy && atomicOr(&D.hgflag[env >> 2], 1) == 0) D.hlist[atomicAdd(D.hcount, 1)] = env >> 2;
+    }
 }
 #undef CAND_ARGMAX
 #pragma clang fp contract(fast)
@@ -880,9 +903,9 @@ enum { LF_MINV = 0, LF_MOT = LF_MINV + 124, LF_LIM = LF_MOT + 36, LF_META = LF_L
        LF_ROLL = LF_SPIN + OS_CAP, LF_OBJ = LF_ROLL + OS_CAP, LF_CST = LF_OBJ + NOBJ * 20, LF_OSL = LF_CST + 16 * 12, LF_OST = LF_OSL + OS_CAP * 36,
        LF_GSC = LF_OST + OS_CAP * 24, LF_LISTF = LF_GSC + 4 * GROWS, LF_LISTT = LF_LISTF + MAXC, LF_TOTAL = LF_LISTT + (3 * MAXC) / 2 };
 #define SLDS_FLOATS (SGRP * LF_TOTAL)
-static_assert(SLDS_FLOATS * 4 * 4 <= 163840, "four solver workgroups must fit the 160 KiB LDS of a CU");
+static_assert(SLDS_FLOATS * 4 * 4 <= 163840, "sixteen envs (four 64-thread workgroups or one 256-thread workgroup) must fit the 160 KiB LDS of a CU");
 static_assert(LF_TOTAL % 4 == 0 && LF_OSL % 4 == 0 && LF_OST % 4 == 0 && LF_GSC % 4 == 0 && LF_OBJ % 4 == 0 && LF_CST % 4 == 0, "row parts must be 16-byte aligned");
-__shared__ __attribute__((aligned(16))) float g_slds[SLDS_FLOATS];
+extern __shared__ __attribute__((aligned(16))) float g_slds[];      // (blockDim.x / 16) x LF_TOTAL floats
 #define LD(slot) g_slds[(slot)]
 
 // meta word: bodyA (8) | bodyB (8) | linkA (8) | swept by the object lane (1) | object-lane slot or generic contact index (6)
@@ -990,10 +1013,18 @@ __device__ __forceinline__ float4 sel4(bool has, float4 v) {
     return make_float4(has ? v.x : 0.0f, has ? v.y : 0.0f, has ? v.z : 0.0f, has ? v.w : 0.0f);
 }
 
-__global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs D) {
+// sel 0: workgroup b handles the solver group b (envs 4 b .. 4 b + 3); 1: the same, but heavy groups are left out; 2: wave w of
+// the launch handles the w-th heavy group of D.hlist (256-thread workgroups: four heavy groups fill a CU's LDS and leave
+// the other CUs to the render of the light envs).
+__global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtrs D, int sel) {
     const int N = P.N;
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
-    const int env_raw = blockIdx.x * SGRP + grp;
+    int unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // solver group = the four envs of this wave
+    bool skip = false;
+    if (sel == 2) { skip = unit >= *D.hcount; unit = skip ? 0 : D.hlist[unit]; }
+    else if (sel == 1) skip = 4 * unit < N && D.hgflag[unit] != 0;
+    if (skip) return;                                                 // (wave-uniform; the kernel has no workgroup barrier)
+    const int env_raw = 4 * unit + (grp & 3);
     const int env = env_raw < N ? env_raw : N - 1;                    // groups without an env run along as no-ops
     float *state = D.state, *scratch = D.scratch;
     const bool dead = env_raw >= N || D.errflags[env] != 0;
@@ -1466,8 +1497,8 @@ __global__ void __launch_bounds__(64) k_solve(BodyParams B, SimParams P, DevPtrs
                         hr = act && LD(r + 18) > 0.0f;          // ... of the rolling rows
                     }
                     const unsigned lt = (1u << l) - 1u;
-                    const unsigned ma = (unsigned)(__ballot(act) >> (16 * grp)) & 0xffffu, ms = (unsigned)(__ballot(hs) >> (16 * grp)) & 0xffffu,
-                                   mr = (unsigned)(__ballot(hr) >> (16 * grp)) & 0xffffu;
+                    const unsigned ma = (unsigned)(__ballot(act) >> (16 * (grp & 3))) & 0xffffu, ms = (unsigned)(__ballot(hs) >> (16 * (grp & 3))) & 0xffffu,
+                                   mr = (unsigned)(__ballot(hr) >> (16 * (grp & 3))) & 0xffffu;
                     if (act) {
                         const int pf = nF + 2 * __popc(ma & lt);
                         listF[pf] = (unsigned short)((6 * j + 1) | (1 << 9)); listF[pf + 1] = (unsigned short)((6 * j + 2) | (2 << 9));
@@ -1644,13 +1675,13 @@ __global__ void k_set_object_poses(SimParams P, DevPtrs D, const float *poses, c
 // transforms of its body's ancestors only (same operations, in the same order, as fk_all() for that chain), an object
 // thread converts the object's quaternion; the 12 floats of an instance are stored as three 16-byte words, so a wave
 // writes a contiguous span.  (One thread per env needed 264 stores with a 1.5 KB stride between lanes.)
-__global__ void __launch_bounds__(64) k_render_setup(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D) {
+__global__ void __launch_bounds__(64) k_render_setup(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D, int sel) {
     const RenderModel &RM = *RMp;
     const int N = P.N;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int env = gid >> 5, i = gid & (MAXINST - 1);
     static_assert(MAXINST == 32, "thread -> (env, instance) mapping");
-    if (env >= N || i >= RM.ni) return;
+    if (env >= N || i >= RM.ni || !env_selected(D.hgflag, env, sel)) return;
     const float *state = D.state;
     m3 R = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
     v3 p = mk(0, 0, 0);
@@ -2240,8 +2271,7 @@ extern "C" int rr_debug_raster_stats(unsigned long long *out16, int reset) {
 // rasterised triangle {depth bits, pixel-in-tile << 18 | triangle}, shaded by k_shade; everything else in the image is the
 // static layer, copied by k_static_copy.
 struct ImageOut { unsigned char *rgb; float *depth; int *mask; size_t env_stride; /* pixels between envs */ };
-__global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int pass, int env0, int restore) {
-    const RenderModel &RM = *RMp;
+__device__ __forceinline__ void raster_tile(const SimParams &P, const RenderModel &RM, const DevPtrs &D, int n_inst_used, int pass, int env, int tile, int restore) {
     __shared__ unsigned long long vis[TILE_PIX];
     __shared__ __attribute__((aligned(16))) float mvp[MAXINST][16];
     __shared__ unsigned nlist, wcount, wnext;
@@ -2249,8 +2279,6 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     __shared__ int wends[RASTER_THREADS / 64][64];      // per wave: running ends of the lanes' left-over points
     __shared__ int clipq[CLIPQ];                        // triangles that cross the near plane (rare), clipped after the window loop
     __shared__ unsigned nclipq;
-    const int env = blockIdx.x + env0, tile = blockIdx.y;
-    if (pass == 0 && D.render_flags && !D.render_flags[env]) return;
     const int W = RM.W, H = RM.H;
     const int row0 = tile * RM.tile_h;
     const int rows = min(RM.tile_h, H - row0);
@@ -2611,6 +2639,32 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     if (tid == 0) { D.frag_count[(size_t)env * RM.ntiles + tile] = nlist; RSTAT(12, nlist); RSTAT(13, 1); RSTAT(14, nclipq); RSTAT(15, nclipq > 0 ? 1 : 0); }
 }
 
+// One workgroup per (env, tile); sel (env_selected): all envs, or only those of light solver groups.
+__global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int pass, int env0, int restore, int sel) {
+    const int env = blockIdx.x + env0, tile = blockIdx.y;
+    if (pass == 0 && D.render_flags && !D.render_flags[env]) return;
+    if (!env_selected(D.hgflag, env, sel)) return;
+    raster_tile(P, *RMp, D, n_inst_used, pass, env, tile, restore);
+}
+
+// The envs of the heavy solver groups (D.hlist, D.hcount -- known on the device only): a fixed number of workgroups walk the
+// list, so that no LDS-filling workgroup is launched just to find that its env is not on it.
+__global__ void __launch_bounds__(RASTER_THREADS) k_raster_list(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int restore) {
+    const RenderModel &RM = *RMp;
+    const int nitems = D.hcount[0] * 4 * RM.ntiles;
+    __shared__ int s_item;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&D.hcount[1], 1);      // dynamic assignment: tiles differ a lot in cost
+        __syncthreads();
+        const int it = s_item;
+        if (it >= nitems) break;
+        const int tile = it % RM.ntiles, ge = it / RM.ntiles;
+        const int env = 4 * D.hlist[ge >> 2] + (ge & 3);
+        if (env < P.N && !(D.render_flags && !D.render_flags[env])) raster_tile(P, RM, D, n_inst_used, 0, env, tile, restore);
+        __syncthreads();        // the LDS of the tile is reused
+    }
+}
+
 // Image targets of k_static_copy / k_shade: the per-env observation buffers (pass 0) or the shared static layer (pass 1).
 
 // Copies the static layer (or the background when there is none) into the images of every rendered env: 4 pixels per
@@ -2684,12 +2738,13 @@ __global__ void k_background(const RenderModel *RMp, DevPtrs D) {
 // staging of the instance constants outweighs the tail of long lists.
 #define SHADE_THREADS 256
 #define SHADE_SPLIT 8
-__global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags, int env0) {
+__global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags, int env0, int sel) {
     const RenderModel &RM = *RMp;
     __shared__ __attribute__((aligned(16))) float mvp[MAXINST][16];
     __shared__ __attribute__((aligned(16))) float sinst[MAXINST][16];
     const int env = blockIdx.x + env0, tile = blockIdx.y;
     if (use_flags && D.render_flags && !D.render_flags[env]) return;
+    if (!env_selected(D.hgflag, env, sel)) return;
     const unsigned n = D.frag_count[(size_t)env * RM.ntiles + tile];
     if (blockIdx.z * SHADE_THREADS >= n) return;
     stage_instances(RM, D, env, threadIdx.x, SHADE_THREADS, mvp, sinst);
@@ -2784,6 +2839,8 @@ struct rr_env {
     std::vector<void *> allocs;
     bool timing;
     bool full_copy, sep_restore;   // RR_FULL_COPY / RR_SEPARATE_RESTORE at create: the two earlier image-update schemes (tests, A/B)
+    int *h_hcount;                 // pinned host copy of D.hcount[0], refreshed asynchronously every step
+    bool split_heavy;              // heavy solver groups + their render on the side stream (RR_NO_SPLIT=1 turns it off: A/B, tests)
     bool images_valid;       // every env's image holds its previous frame (static layer + the pixels of its fragment list)
     hipEvent_t ev[2 * RR_NUM_KERNELS];
     hipStream_t aux;         // side stream: the HBM-bound static-layer copy runs beside the VALU-bound physics / visibility kernels
@@ -2863,6 +2920,7 @@ int rr_destroy(rr_env *e) {
     if (e->ev_join) hipEventDestroy(e->ev_join);
     if (e->ev_dyn) hipEventDestroy(e->ev_dyn);
     for (int i = 0; i < 4; i++) { if (e->pin_buf[i]) hipHostFree(e->pin_buf[i]); if (e->pin_ev[i]) hipEventDestroy(e->pin_ev[i]); }
+    if (e->h_hcount) hipHostFree(e->h_hcount);
     delete e;
     return RR_OK;
 }
@@ -2882,9 +2940,9 @@ static int build_static_layer(rr_env *e) {
         ImageOut so;
         so.rgb = e->D.static_rgb; so.depth = e->D.static_depth; so.mask = e->D.static_mask; so.env_stride = 0;
         e->D.static_vis = nullptr;
-        hipLaunchKernelGGL(k_render_setup, dim3((e->P.N * MAXINST + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D);
-        hipLaunchKernelGGL(k_raster, dim3(1, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1, 0, 0);
-        hipLaunchKernelGGL(k_shade, dim3(1, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, e->D, so, 0, 0);
+        hipLaunchKernelGGL(k_render_setup, dim3((e->P.N * MAXINST + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D, 0);
+        hipLaunchKernelGGL(k_raster, dim3(1, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1, 0, 0, 0);
+        hipLaunchKernelGGL(k_shade, dim3(1, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, e->D, so, 0, 0, 0);
     }
     // the pass above used env 0's fragment list; from here on the lists describe what differs from the static layer
     if (hipMemsetAsync(e->D.frag_count, 0, (size_t)e->P.N * e->RM.ntiles * sizeof(unsigned), e->stream) != hipSuccess ||
@@ -2922,6 +2980,9 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     memset(e->pin_buf, 0, sizeof e->pin_buf); memset(e->pin_ev, 0, sizeof e->pin_ev); memset(e->pin_used, 0, sizeof e->pin_used); e->pin_next = 0; e->pin_bytes = 0;
     e->full_copy = getenv("RR_FULL_COPY") != nullptr;
     e->sep_restore = getenv("RR_SEPARATE_RESTORE") != nullptr;
+    e->split_heavy = getenv("RR_NO_SPLIT") == nullptr;
+    e->h_hcount = nullptr;
+    if (hipHostMalloc((void **)&e->h_hcount, sizeof(int), hipHostMallocDefault) == hipSuccess) *e->h_hcount = 0; else e->h_hcount = nullptr;
     e->plan = nullptr; e->plan_step = nullptr; e->ik_in = nullptr; e->ik_out = nullptr; e->ik_err = nullptr;
     e->cfg = *cfg;
     e->stream = (hipStream_t)stream;
@@ -3041,6 +3102,9 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     ALLOC(D.clist, (size_t)N * MAXC * 3);
     ALLOC(D.ccount, (size_t)N);
     ALLOC(D.cforce, (size_t)N * MAXC);
+    ALLOC(D.hgflag, (size_t)(N + 3) / 4);
+    ALLOC(D.hlist, (size_t)(N + 3) / 4);
+    ALLOC(D.hcount, (size_t)4);
     ALLOC(D.timestep, (size_t)N);
     ALLOC(D.errflags, (size_t)N);
     ALLOC(D.obj_home, (size_t)NOBJ * 7 * N);
@@ -3143,6 +3207,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         e->field_ptr[RR_F_FRAG_COUNT] = e->D.frag_count;
         if ((r = build_static_layer(e)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
     }
+    // the 256-thread form of k_solve (heavy solver groups, four per workgroup) asks for 158 KiB of dynamic LDS
+    HIPCHK(hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * SGRP * LF_TOTAL * sizeof(float))));
     HIPCHK(hipGetLastError());
     return RR_OK;
 }
@@ -3243,35 +3309,48 @@ static int g_skip = getenv("RR_SKIP") ? atoi(getenv("RR_SKIP")) : 0;
         }                                                                   \
     } while (0)
 
-static int do_render(rr_env *e, bool use_flags) {
-    DevPtrs D = e->D;
-    if (!use_flags) D.render_flags = nullptr;
+// Image set-up that precedes the first frame after create / a new static layer: full copy of the static layer (all envs).
+static int ensure_images(rr_env *e, DevPtrs &D) {
     const int N = e->P.N;
-    TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, D));
     const ImageOut io = env_images(e);
-    // The images persist in HBM from frame to frame: after the first frame (or a new static layer) only the pixels of
-    // the previous frame's fragment lists are put back to the static layer (k_restore) instead of copying the static
-    // layer into every env's image (470 MB per frame at 4096 envs, and a side stream with two fork/join bubbles).
-    // (Earlier design, kept for RR_FULL_COPY=1: the full copy throttled to ~one workgroup per CU on the side stream beside
-    // k_raster; pipelining k_shade of one env chunk against k_raster of the next was tried too, +7 % .. +50 % step time.)
-    const bool full_copy = e->full_copy, sep_restore = e->sep_restore;
-    int restore = 1;
-    if (!e->images_valid || full_copy) {
+    if (!e->images_valid || e->full_copy) {
         const int copy_blocks = std::min(16, (e->RM.W * e->RM.H / 4 + COPY_THREADS - 1) / COPY_THREADS);
         DevPtrs Dall = D;
         if (!e->images_valid) Dall.render_flags = nullptr;      // first frame: every env, flagged or not -- all images become valid
         TIMED(5, hipLaunchKernelGGL(k_static_copy, dim3(copy_blocks, std::min(N, 65535)), dim3(COPY_THREADS), 0, e->stream, e->RM_dev, Dall, io, 1, N));
         if (!e->images_valid) HIPCHK(hipMemsetAsync(e->D.frag_count, 0, (size_t)N * e->RM.ntiles * sizeof(unsigned), e->stream));
         e->images_valid = true;
-        restore = 0;
-    } else if (sep_restore) {
-        // (Also measured: these stores at the head / tail of k_raster's workgroups -- the same +30 us as this pass: that
-        // kernel holds one LDS-filling workgroup per CU, and a workgroup retires only when its stores are acknowledged.)
-        TIMED(5, hipLaunchKernelGGL(k_restore, dim3(N, e->RM.ntiles), dim3(RESTORE_THREADS), 0, e->stream, e->RM_dev, D, io, 1));
-        restore = 0;
+        return 0;           // the lists are empty: nothing to restore
     }
-    TIMED(4, hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, D, e->n_inst_used, 0, 0, restore));
-    TIMED(6, hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, D, io, 1, 0));
+    if (e->sep_restore) {
+        TIMED(5, hipLaunchKernelGGL(k_restore, dim3(N, e->RM.ntiles), dim3(RESTORE_THREADS), 0, e->stream, e->RM_dev, D, io, 1));
+        return 0;
+    }
+    return 1;
+}
+
+// The three render kernels for the envs selected by `sel` (env_selected) on `st`.  The images persist in HBM from frame to
+// frame: only the pixels of the previous frame's fragment lists are put back to the static layer (`restore`), DESIGN.md 5.
+static void launch_render(rr_env *e, const DevPtrs &D, int restore, int sel, hipStream_t st, bool timed) {
+    const int N = e->P.N;
+    const ImageOut io = env_images(e);
+    if (timed) {
+        TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, st, e->B, e->P, e->RM_dev, D, sel));
+        TIMED(4, hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, 0, 0, restore, sel));
+        TIMED(6, hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel));
+    } else {
+        hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, st, e->B, e->P, e->RM_dev, D, sel);
+        if (sel == 2) hipLaunchKernelGGL(k_raster_list, dim3(std::min(N * e->RM.ntiles, 256)), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, restore);
+        else hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, 0, 0, restore, sel);
+        hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel);
+    }
+}
+
+static int do_render(rr_env *e, bool use_flags) {
+    DevPtrs D = e->D;
+    if (!use_flags) D.render_flags = nullptr;
+    const int restore = ensure_images(e, D);
+    launch_render(e, D, restore, 0, e->stream, true);
     HIPCHK(hipGetLastError());
     return RR_OK;
 }
@@ -3332,9 +3411,36 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     } else {
         TIMED(0, launch_prep_serial(e, Dp));
     }
+    HIPCHK(hipMemsetAsync(e->D.hgflag, 0, (size_t)((N + 3) / 4) * sizeof(int), e->stream));     // k_collide classifies the solver groups
+    HIPCHK(hipMemsetAsync(e->D.hcount, 0, 4 * sizeof(int), e->stream));      // [0] heavy groups, [1] work counter of k_raster_list
     TIMED(1, launch_collide(e));
     if (dyn_forked) hipStreamWaitEvent(e->stream, e->ev_dyn, 0);
-    TIMED(2, hipLaunchKernelGGL(k_solve, dim3((N + SGRP - 1) / SGRP), dim3(SGRP * 16), 0, e->stream, e->B, e->P, e->D));
+    const int ngroups = (N + SGRP - 1) / SGRP;
+    const size_t lds64 = (size_t)SGRP * LF_TOTAL * sizeof(float);
+    // (the number of heavy groups of a recent step, copied to pinned host memory without waiting for it: when most groups are
+    // heavy -- macro actions, every gripper pushing -- there is nothing to gain from the split)
+    if (e->h_hcount) HIPCHK(hipMemcpyAsync(e->h_hcount, e->D.hcount, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    const bool mostly_heavy = e->h_hcount && *(volatile int *)e->h_hcount * 4 > ngroups;
+    if (dyn_forked && render_mode && e->split_heavy && !mostly_heavy) {
+        // The few solver groups with generic contact rows take several times as long as the others (the kernel lasts as long
+        // as its longest Gauss-Seidel chain).  They are solved and rendered on the side stream -- four groups per 256-thread
+        // workgroup, so that they fill the LDS of a few CUs and leave the rest to the raster workgroups of the light envs --
+        // while the main stream solves and renders everybody else.
+        DevPtrs D = e->D;
+        if (render_mode != 2) D.render_flags = nullptr;
+        const int restore = ensure_images(e, D);
+        hipEventRecord(e->ev_fork, e->stream);
+        hipStreamWaitEvent(e->aux, e->ev_fork, 0);
+        hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->aux, e->B, e->P, e->D, 2);
+        launch_render(e, D, restore, 2, e->aux, false);
+        hipEventRecord(e->ev_join, e->aux);
+        hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1);
+        launch_render(e, D, restore, 1, e->stream, false);
+        hipStreamWaitEvent(e->stream, e->ev_join, 0);
+        HIPCHK(hipGetLastError());
+        return RR_OK;
+    }
+    TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 0));
     HIPCHK(hipGetLastError());
     if (render_mode) return do_render(e, render_mode == 2);
     return RR_OK;

@@ -73,8 +73,12 @@ def test_all_36_perimeter_pairs_of_the_reference_script():
       * (p1, 0.6) at t = 199: < 0.01 m when p1 is not at the reach limit, < 0.012 m for (-0.25, 0) (1.8 rad of joint
         travel from home2 in 100 steps is marginal), < 0.08 m for the corners (0.05, +-0.5) where the arm is stretched
         out and the IK solution is a long way round;
-      * home2 at t = 849 is 50 steps after a way point up to 1.6 rad away: not reachable at 0.03 rad per step, recorded
-        only (a real pybullet run of the script would settle whether its motor is faster)."""
+      * t = 849: the script's check point there is raw_xy[849] = home2 (-0.41, 0, 1.14) -- its xy_parts list holds 500 rows of
+        (p2, 0.46) and 50 of (p2, 0.6), so index 849 falls 50 steps INTO the home2 segment (test_actions.py:62-71) -- i.e.
+        50 steps after a way point up to 1.6 rad away, which 0.02-0.03 rad per step cannot cover.  What IS asserted: from
+        the joints at t = 799 the joints at t = 849 follow the documented recursion q <- q + 0.1 clip(home2 - q, +-maxDiff)
+        (rate limit env.py:314-321, 10 % per step position motor SURVEY A.1.4) to 0.02 rad (0.03 rad at t = 899, where the
+        median pair is within 1 cm of home2).  A real pybullet run of the script would settle whether its motor is faster."""
     perimeter = [(a, b) for a in (-0.25, 0.05) for b in (-0.5, 0.0, 0.5)]
     pairs = [(p1, p2) for p1 in perimeter for p2 in perimeter]
     N = len(pairs)
@@ -87,8 +91,25 @@ def test_all_36_perimeter_pairs_of_the_reference_script():
     base = nat.LINK_NAMES.index('base')
     home = np.array([-0.55, 0.0, 1.27])
     dist = {}
+    home2_q = np.zeros(9)
+    home2_q[5] = home2_q[6] = np.pi / 2
+    max_diff = np.array([0.2, 0.2, 0.2, 0.2, 0.2, 0.3, 0.3, 0.1, 0.1])
+    q_pred = None
     for t in range(1000):
         env.step_plan()
+        if t == 799:
+            q_pred = env.host(nat.F_JOINTS).astype(np.float64)
+        elif 799 < t <= 899:
+            q_pred = q_pred + 0.1 * np.clip(home2_q - q_pred, -max_diff, max_diff)
+        if t == 849:
+            dq = np.abs(env.host(nat.F_JOINTS) - q_pred).max()
+            assert dq < 0.02, dq
+            far = np.linalg.norm(env.link_poses()[:, base, :3] - np.array([-0.41, 0.0, 1.14]), axis=1)
+            print("t=849: gripper base %.3f .. %.3f m from home2 (the reference script's 1 cm check point)" % (far.min(), far.max()))
+        if t == 899:
+            assert np.abs(env.host(nat.F_JOINTS) - q_pred).max() < 0.03
+            far = np.linalg.norm(env.link_poses()[:, base, :3] - np.array([-0.419, 0.0, 1.14]), axis=1)
+            assert np.median(far) < 0.01 and far.max() < 0.12       # a joint with more than 2 rad to go is still on its way
         if t in (199, 249, 999):
             lp = env.link_poses()[:, base, :3]
             for i, (p1, p2) in enumerate(pairs):

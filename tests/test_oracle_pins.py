@@ -410,3 +410,104 @@ def test_resting_objects_come_to_complete_rest():
     assert np.abs(ob[0, 7:]).max() < 1e-6 and np.abs(ob[2, 7:]).max() < 1e-6      # cube, mustard: all velocities
     assert np.abs(ob[1, 7:10]).max() < 2e-3 and np.abs(ob[1, 10:]).max() < 1e-2   # the 12-gon can keeps a residual creep
     assert np.abs(ob[0, 3:6]).max() < 1e-6                                        # the cube lies flat on its face
+
+
+def _numpy_step_free_body(state13, contacts, mass, inertia_diag, coefs, dt=0.005, iters=50, erp=0.2, g=9.81, torsional=True):
+    """Independent numpy restatement of one solver step for ONE free body against statics: rows per contact = normal, two
+    lateral frictions (btPlaneSpace1 tangents), one spinning and two rolling friction rows (pure rotation about normal /
+    tangents, bounds +- coefficient x normal impulse); projected Gauss-Seidel in Bullet's order (all normals, all lateral
+    frictions, all torsional frictions); semi-implicit Euler.  `contacts`: rows {x, n, dist, mu}; coefs = (rest, roll, spin)."""
+    pos, q, v, w = state13[:3].copy(), state13[3:7].copy(), state13[7:10].copy(), state13[10:13].copy()
+    x, y, z, s = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * s), 2 * (x * z + y * s)],
+                  [2 * (x * y + z * s), 1 - 2 * (x * x + z * z), 2 * (y * z - x * s)],
+                  [2 * (x * z - y * s), 2 * (y * z + x * s), 1 - 2 * (x * x + y * y)]])
+    Iw, Iinv = R @ np.diag(inertia_diag) @ R.T, R @ np.diag(1.0 / np.asarray(inertia_diag)) @ R.T
+    vs = v + dt * (-v * (0.04 + 0.04 * np.linalg.norm(v)))
+    vs[2] -= dt * g
+    ws = w + dt * (-Iinv @ np.cross(w, Iw @ w) - w * (0.04 + 0.04 * np.linalg.norm(w)))
+    rest, roll, spin = coefs
+
+    def tangents(n):
+        if abs(n[2]) > 0.7071067811865475244:
+            a = n[1] * n[1] + n[2] * n[2]
+            k = 1 / np.sqrt(a)
+            p = np.array([0, -n[2] * k, n[1] * k])
+            return p, np.array([a * k, -n[0] * p[2], n[0] * p[1]])
+        a = n[0] * n[0] + n[1] * n[1]
+        k = 1 / np.sqrt(a)
+        p = np.array([-n[1] * k, n[0] * k, 0])
+        return p, np.array([-n[2] * p[1], n[2] * p[0], a * k])
+
+    rows = []       # [J_lin, J_ang, rhs, dinv, normal index or -1, coefficient]
+    normals, fric, tors = [], [], []
+    for ci, c in enumerate(contacts):
+        xc, n, dist, mu = c[0:3], c[3:6], c[6], c[7]
+        t1, t2 = tangents(n)
+        r = xc - pos
+
+        def row(lin, ang):
+            diag = lin @ lin / mass + ang @ (Iinv @ ang)
+            return lin, ang, lin @ vs + ang @ ws, (1 / diag if diag > 0 else 0.0)
+        lin, ang, rel, dinv = row(n, np.cross(r, n))
+        rr = max(rest * -rel, 0.0) if abs(rel) >= 0.2 else 0.0
+        verr, perr = rr - rel, 0.0
+        if dist > 0:
+            verr -= dist / dt
+        else:
+            perr = -dist * erp / dt
+        normals.append([lin, ang, (perr + verr) * dinv, dinv, -1, 0.0])
+        for t in (t1, t2):
+            lin, ang, rel, dinv = row(t, np.cross(r, t))
+            fric.append([lin, ang, -rel * dinv, dinv, ci, mu])
+        if torsional:
+            for axis, coef in ((n, spin), (t1, roll), (t2, roll)):
+                if coef > 0:
+                    lin, ang, rel, dinv = row(np.zeros(3), axis)
+                    tors.append([lin, ang, -rel * dinv, dinv, ci, coef])
+    rows = normals + fric + tors
+    lam = np.zeros(len(rows))
+    dv, dw = np.zeros(3), np.zeros(3)
+    for _ in range(iters):
+        for k, (lin, ang, rhs, dinv, ni, coef) in enumerate(rows):
+            lo, hi = (0.0, 1e10) if ni < 0 else (-coef * lam[ni], coef * lam[ni])
+            dl = rhs - (lin @ dv + ang @ dw) * dinv
+            new = min(max(lam[k] + dl, lo), hi)
+            dl = new - lam[k]
+            lam[k] = new
+            dv += lin / mass * dl
+            dw += Iinv @ ang * dl
+    return vs + dv, ws + dw, lam[len(normals) + len(fric):]
+
+
+def test_torsional_friction_rows_match_an_independent_numpy_solver():
+    """Known answer for the rolling / spinning friction rows (tomato.urdf:6-7: 1e-3 each, table lateral friction 1.0 ->
+    combined 1e-3): the tomato can lying on its side, rolling along the table, is stepped once by the oracle and by an
+    independent numpy projected Gauss-Seidel over the oracle's own contact points.  Velocities must agree to 1e-8 (of 5.5 rad/s); the
+    torsional impulses must be active (leaving the rows out changes the result by far more than the tolerance), and a
+    rolling can must come to rest within a second."""
+    o = Oracle(3, 32, 32)
+    st = o.state.copy()
+    st[22 + 13: 22 + 26] = [-0.1, -0.3, 0.2794 + 0.0362 + 0.0005, np.sin(np.pi / 4), 0, 0, np.cos(np.pi / 4), 0, 0, 0, 0, 0, 0]   # axis along world y
+    o.state = st
+    for _ in range(80):
+        o.step(None)
+    st = o.state.copy()
+    assert abs(st[22 + 13 + 2] - (0.2794 + 0.0362)) < 2e-3            # lying on its side on the table
+    st[22 + 13 + 7: 22 + 13 + 13] = [0.2, 0.0, 0.0, 0.0, 0.2 / 0.0362, 0.0]      # rolling without slipping along +x
+    o.state = st
+    before = st[22 + 13: 22 + 26].copy()
+    o.step(None)
+    c = o.contacts()
+    sel = c[c[:, 0] == 17]
+    assert len(sel) >= 2 and (sel[:, 1] < 0).all()
+    cont = [np.concatenate([r[3:6], r[6:9], [r[9]], [r[11]]]) for r in sel]
+    v, w, lt = _numpy_step_free_body(before, cont, 3.0, (5.2528e-4, 5.2528e-4, 2.6219e-4), (0.01 * 0.01, 1e-3, 1e-3))
+    after = o.state[22 + 13: 22 + 26]
+    assert np.abs(after[7:10] - v).max() < 1e-8 and np.abs(after[10:13] - w).max() < 1e-8
+    assert np.abs(lt).max() > 1e-6                                     # the torsional rows carry impulse here
+    v0, w0, _ = _numpy_step_free_body(before, cont, 3.0, (5.2528e-4, 5.2528e-4, 2.6219e-4), (0.01 * 0.01, 1e-3, 1e-3), torsional=False)
+    assert np.abs(w0 - w).max() > 1e-4
+    for _ in range(200):
+        o.step(None)
+    assert np.abs(o.state[22 + 13 + 7: 22 + 26]).max() < 5e-3          # stopped rolling
