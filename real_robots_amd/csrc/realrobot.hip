@@ -102,9 +102,7 @@ enum {
     S_OIINV = S_OR + 27,         // 3*9
     S_OVS = S_OIINV + 27,        // 9
     S_OWS = S_OVS + 9,           // 9
-    S_MOT = S_OWS + 9,                       // 11 x {rhs, dinv, lambda}
-    S_LIM = S_MOT + 33,                      // 22 x {rhs, lambda}
-    S_TOTAL = S_LIM + 44
+    S_TOTAL = S_OWS + 9
 };
 
 // state slots (floats per env), SoA [slot][N]
@@ -334,6 +332,10 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
     int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= N) return;
     float *state = D.state, *scratch = D.scratch;
+    if (PHASE == 1) {       // k_collide classifies the solver groups of this step: reset its bookkeeping (no extra launch)
+        if ((env & 3) == 0) D.hgflag[env >> 2] = 0;
+        if (env == 0) { D.hcount[0] = 0; D.hcount[1] = 0; }
+    }
     if (PHASE == 2) { if (D.errflags[env]) return; }    // frozen, or command rejected by phase 1
     else {
         if (D.errflags[env] & 1u) return;   // frozen env
@@ -3411,8 +3413,6 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     } else {
         TIMED(0, launch_prep_serial(e, Dp));
     }
-    HIPCHK(hipMemsetAsync(e->D.hgflag, 0, (size_t)((N + 3) / 4) * sizeof(int), e->stream));     // k_collide classifies the solver groups
-    HIPCHK(hipMemsetAsync(e->D.hcount, 0, 4 * sizeof(int), e->stream));      // [0] heavy groups, [1] work counter of k_raster_list
     TIMED(1, launch_collide(e));
     if (dyn_forked) hipStreamWaitEvent(e->stream, e->ev_dyn, 0);
     const int ngroups = (N + SGRP - 1) / SGRP;
