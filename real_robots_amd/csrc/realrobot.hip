@@ -260,6 +260,22 @@ __device__ __forceinline__ m3 mul(const m3 &A, const m3 &B) {
         for (int j = 0; j < 3; j++) r.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
     return r;
 }
+// The narrow phase's inner loops use EXPLICIT fused multiply-adds in a fixed association, mirrored by fma()/fmaf() calls in
+// the oracle (verts_in_planes): v_fma_f32 and a C fmaf round identically, so the results stay bit-identical with half the
+// instructions of the unfused form.
+__device__ __forceinline__ v3 mulv_add_fma(const m3 &M, v3 v, v3 p) {       // M v + p
+    return mk(__builtin_fmaf(M.m[0], v.x, __builtin_fmaf(M.m[1], v.y, __builtin_fmaf(M.m[2], v.z, p.x))),
+              __builtin_fmaf(M.m[3], v.x, __builtin_fmaf(M.m[4], v.y, __builtin_fmaf(M.m[5], v.z, p.y))),
+              __builtin_fmaf(M.m[6], v.x, __builtin_fmaf(M.m[7], v.y, __builtin_fmaf(M.m[8], v.z, p.z))));
+}
+__device__ __forceinline__ v3 tmulv_fma(const m3 &M, v3 d) {               // M^T d
+    return mk(__builtin_fmaf(M.m[0], d.x, __builtin_fmaf(M.m[3], d.y, M.m[6] * d.z)),
+              __builtin_fmaf(M.m[1], d.x, __builtin_fmaf(M.m[4], d.y, M.m[7] * d.z)),
+              __builtin_fmaf(M.m[2], d.x, __builtin_fmaf(M.m[5], d.y, M.m[8] * d.z)));
+}
+__device__ __forceinline__ float plane_dist_fma(float4 pl, v3 x) {           // n . x - c
+    return __builtin_fmaf(pl.x, x.x, __builtin_fmaf(pl.y, x.y, __builtin_fmaf(pl.z, x.z, -pl.w)));
+}
 // sin and cos of x (|x| up to a few turns: joint angles) from explicit IEEE single operations only -- the same sequence
 // as det_sincosf in oracle/rr_oracle.c, hence bit-identical results on both sides (the vendor sincosf and glibc's differ
 // in the last bit).  Cody-Waite reduction by pi/2 in three parts, Cephes minimax polynomials on [-pi/4, pi/4]; < 2 ulp.
@@ -602,6 +618,7 @@ extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
 #define COLLIDE_THREADS 64
 #define NPREF 6          // leading planes of every shape used by the prefilter (tools/compile_model.py orders them)
 #define CAND_MAX 128     // candidates kept per pair (the oracle applies the same cap)
+#define CSHAPES 24       // collision shapes staged in LDS (rr_create checks the model: 22)
 #ifdef RR_RASTER_STATS
 #define CABL(bit) (P.ablate & (bit))      // development build: phase ablations (256 stage only, 512 no pairs, 1024 cull only)
 #else
@@ -662,14 +679,15 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
     float *scratch = D.scratch;
     if (D.errflags[env]) return;
     const ShapeData *S = D.shapes;
-    __shared__ float xf[MAXSHAPES][12];        // R (row-major 9), p (3) of every shape's owner
-    __shared__ float4 sph[MAXSHAPES];          // world bounding sphere
+    // 9.9 KB of LDS: sixteen workgroups (= all the envs a CU gets at 4096 envs) are resident at once
+    __shared__ float xf[CSHAPES][12];          // R (row-major 9), p (3) of every shape's owner
+    __shared__ float4 sph[CSHAPES];            // world bounding sphere
     __shared__ float4 planes[FMAXC];           // planes of "other" in the current direction
     __shared__ float surv[VMAXC][3];           // world position of the vertices that survive the prefilter, in vertex order
     __shared__ float4 cand_a[CAND_MAX];        // candidates of the pair: contact point, signed distance
-    __shared__ float4 cand_b[CAND_MAX];        //                         normal (B -> A)
+    __shared__ int cand_b[CAND_MAX];           //                         plane of "other" it is nearest to | direction << 8
     __shared__ int pair_ab[MAXPAIRS];          // shape a | shape b << 8 of every pair   } staged once: no global load of
-    __shared__ int shape_n[MAXSHAPES];         // vertex count | plane count << 8        } metadata inside the pair loop
+    __shared__ int shape_n[CSHAPES];           // vertex count | plane count << 8        } metadata inside the pair loop
     const int lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (int pr = lane; pr < P.npairs; pr += COLLIDE_THREADS) {
@@ -713,15 +731,30 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 Xm.p = mk(xf[sm][9], xf[sm][10], xf[sm][11]);
                 Xo.p = mk(xf[so][9], xf[so][10], xf[so][11]);
                 const int nv = shape_n[sm] & 255, nf = shape_n[so] >> 8;
+                // every global load of this direction is issued here, before the first wait: the planes of "other" (lane =
+                // plane, three per lane) and the vertices of "mine" (lane = vertex, three passes) -- one round trip
+                float4 plr[FMAXC / 64];
+                float vxr[VMAXC / 64], vyr[VMAXC / 64], vzr[VMAXC / 64];
+#pragma unroll
+                for (int i = 0; i < FMAXC / 64; i++) plr[i] = *(const float4 *)S->planes[so][min(lane + 64 * i, FMAXC - 1)];
+#pragma unroll
+                for (int i = 0; i < VMAXC / 64; i++) {
+                    const float *vp = S->verts[sm][min(lane + 64 * i, VMAXC - 1)];
+                    vxr[i] = vp[0]; vyr[i] = vp[1]; vzr[i] = vp[2];
+                }
                 CSYNC();            // the previous direction's reads of planes / surv are done
                 bool sep = false;
                 {   // a. exact cull + b. plane staging (lane = plane)
                     const float4 cm = sph[sm];
                     const v3 cl = nc::tmulv(Xo.R, nc::sub(mk(cm.x, cm.y, cm.z), Xo.p));
-                    for (int f = lane; f < nf; f += 64) {
-                        const float4 pl = *(const float4 *)S->planes[so][f];
-                        planes[f] = pl;
-                        sep = sep || (pl.x * cl.x + pl.y * cl.y + pl.z * cl.z - pl.w > cm.w + P.margin);
+#pragma unroll
+                    for (int i = 0; i < FMAXC / 64; i++) {
+                        const int f = lane + 64 * i;
+                        if (f < nf) {
+                            const float4 pl = plr[i];
+                            planes[f] = pl;
+                            sep = sep || (pl.x * cl.x + pl.y * cl.y + pl.z * cl.z - pl.w > cm.w + P.margin);
+                        }
                     }
                 }
                 if (__ballot(sep)) continue;
@@ -729,20 +762,17 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 CSYNC();
                 const int npre = min(NPREF, nf);
                 int nsurv = 0;                  // wave-uniform
-                for (int v0 = 0; v0 < nv; v0 += 64) {
-                    const int v = v0 + lane;
+#pragma unroll
+                for (int i = 0; i < VMAXC / 64; i++) {
+                    if (64 * i >= nv) break;
+                    const int v = 64 * i + lane;
                     bool keep = false;
                     v3 xw = mk(0, 0, 0);
                     if (v < nv) {
-                        const float *vp = S->verts[sm][v];
-                        xw = nc::add(nc::mulv(Xm.R, mk(vp[0], vp[1], vp[2])), Xm.p);
-                        const v3 xl = nc::tmulv(Xo.R, nc::sub(xw, Xo.p));
+                        xw = nc::mulv_add_fma(Xm.R, mk(vxr[i], vyr[i], vzr[i]), Xm.p);
+                        const v3 xl = nc::tmulv_fma(Xo.R, nc::sub(xw, Xo.p));
                         float best = -1e30f;
-                        for (int f = 0; f < npre; f++) {
-                            const float4 pl = planes[f];
-                            const float sd = pl.x * xl.x + pl.y * xl.y + pl.z * xl.z - pl.w;
-                            best = fmaxf(best, sd);
-                        }
+                        for (int f = 0; f < npre; f++) best = fmaxf(best, nc::plane_dist_fma(planes[f], xl));
                         keep = best < P.margin;
                     }
                     const unsigned long long km = __ballot(keep);
@@ -758,23 +788,22 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                     const int k = k0 + lane;
                     bool hit = false;
                     float cx = 0, cy = 0, cz = 0, cs = 0;
-                    v3 nw = mk(0, 0, 0);
+                    int bfk = 0;
                     if (k < nsurv) {
                         const v3 xw = mk(surv[k][0], surv[k][1], surv[k][2]);
-                        const v3 xl = nc::tmulv(Xo.R, nc::sub(xw, Xo.p));
+                        const v3 xl = nc::tmulv_fma(Xo.R, nc::sub(xw, Xo.p));
                         float best = -1e30f;
                         int bf = 0;
                         for (int f = 0; f < nf; f++) {
-                            const float4 pl = planes[f];
-                            const float sd = pl.x * xl.x + pl.y * xl.y + pl.z * xl.z - pl.w;
+                            const float sd = nc::plane_dist_fma(planes[f], xl);
                             if (sd > best) { best = sd; bf = f; }
                         }
                         if (best < P.margin) {
                             const float4 pl = planes[bf];
-                            nw = nc::mulv(Xo.R, mk(pl.x, pl.y, pl.z));
+                            const v3 nw = nc::mulv(Xo.R, mk(pl.x, pl.y, pl.z));
                             cx = xw.x - 0.5f * best * nw.x; cy = xw.y - 0.5f * best * nw.y; cz = xw.z - 0.5f * best * nw.z;
                             cs = best;
-                            if (dirflag) nw = nc::scale(nw, -1.0f);
+                            bfk = bf | (dirflag << 8);
                             hit = true;
                         }
                     }
@@ -782,7 +811,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                     const int pos = ncand + __popcll(hm & lt_mask);
                     if (hit && pos < CAND_MAX) {
                         cand_a[pos] = make_float4(cx, cy, cz, cs);
-                        cand_b[pos] = make_float4(nw.x, nw.y, nw.z, 0.0f);
+                        cand_b[pos] = bfk;
                     }
                     ncand = min(ncand + __popcll(hm), CAND_MAX);
                 }
@@ -834,7 +863,16 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
             }
             if (lane < k) {
                 const int ci = lane == 0 ? sel0 : (lane == 1 ? sel1 : (lane == 2 ? sel2 : sel3));
-                const float4 a = cand_a[ci], b = cand_b[ci];
+                const float4 a = cand_a[ci];
+                // the normal (B -> A) of a kept candidate: its plane of "other", rotated to the world, as in the candidate test
+                const int kb = cand_b[ci], so_ = (kb >> 8) ? sa : sb;
+                m3 Ro;
+#pragma unroll
+                for (int kk = 0; kk < 9; kk++) Ro.m[kk] = xf[so_][kk];
+                const float4 pl = *(const float4 *)S->planes[so_][kb & 255];
+                v3 nb = nc::mulv(Ro, mk(pl.x, pl.y, pl.z));
+                if (kb >> 8) nb = nc::scale(nb, -1.0f);
+                const float4 b = make_float4(nb.x, nb.y, nb.z, 0.0f);
                 const int4 pm = *(const int4 *)S->pair_meta[pair];
                 const int meta = (pm.x & 255) | ((pm.y & 255) << 8) | ((pm.z & 255) << 16);
                 float4 *rec = D.clist + ((size_t)env * MAXC + nct + lane) * 3;
@@ -3058,6 +3096,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     for (int r = 0; r < n_robot; r++) for (int i = 0; i < P.nobj; i++) { S.pair_a[np] = n_static + r; S.pair_b[np++] = s_obj0 + i; }
     P.npairs = np;
     e->n_shapes = ns;
+    if (ns > CSHAPES) { rr_destroy(e); return fail(RR_EMODEL, "rr_create: more collision shapes than k_collide stages in LDS"); }
     for (int k = 0; k < np; k++) {
         const int sa = S.pair_a[k], sb = S.pair_b[k];
         S.pair_meta[k][0] = S.otype[sa] == 0 ? -1 : (S.otype[sa] == 1 ? S.oidx[sa] : 16 + S.oidx[sa]);
