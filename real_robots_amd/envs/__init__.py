@@ -1,2 +1,2 @@
-from .env import REALRobotEnv, Goal, EnvCamera  # noqa: F401
+from .env import REALRobotEnv, Goal, EnvCamera, EyeCamera  # noqa: F401
 from .robot import Kuka  # noqa: F401

@@ -54,6 +54,81 @@ class EnvCamera:
         return self._be.host(nat.F_RGB)[0]
 
 
+class EyeCamera:
+    """The eye cameras of the reference (env.py:516-600): look-at from `eyePosition` to a target, up (0, 0, 1), fov 80,
+    320x240, near 0.1 / far 100.  `renderTarget(target)` returns (rgb [H, W, 3] u8, mask [H, W] i32, depth [H, W] f64) like
+    the reference does; the frame comes from the HIP rasteriser through a single-env backend that mirrors the simulation
+    state of the env the camera is attached to (the `bullet_client` argument of the reference is accepted and ignored)."""
+
+    def __init__(self, eyePosition, targetPosition, fov=80, width=320, height=240):
+        self.eyePosition, self.targetPosition = eyePosition, targetPosition
+        self.upVector = [0, 0, 1]
+        self.fov, self.render_width, self.render_height = fov, width, height
+        self._p, self._env, self._be, self._view_of = None, None, None, None
+        self.pitch_roll = False
+        self.pos = targetPosition
+
+    def _frame(self, view):
+        from ..kinematics import perspective
+        env = self._env
+        if env is None:
+            raise RuntimeError("EyeCamera is not attached to an environment (REALRobotEnv.set_eye)")
+        if self._be is None:
+            self._be = BatchedREALRobotEnv(1, objects=env._n_objects, width=self.render_width, height=self.render_height,
+                                           device=env._device)
+        key = np.asarray(view, dtype=np.float64).tobytes()
+        if key != self._view_of:
+            self._be.set_camera(view, perspective(self.fov, float(self.render_width) / self.render_height, 0.1, 100.0))
+            self._view_of = key
+        self._be.state = env._backend().state
+        self._be.render()
+        return self._be.host(nat.F_RGB)[0], self._be.host(nat.F_MASK)[0], self._be.host(nat.F_DEPTH)[0].astype(np.float64)
+
+    def render(self, *args, **kargs):
+        return self.renderPitchRoll(*args, **kargs) if self.pitch_roll else self.renderTarget(*args, **kargs)
+
+    def renderTarget(self, targetPosition, bullet_client=None):
+        from ..kinematics import look_at
+        self.targetPosition = targetPosition
+        return self._frame(look_at(self.eyePosition, targetPosition, self.upVector))
+
+    def renderPitchRoll(self, distance, roll, pitch, yaw, bullet_client=None):
+        from ..kinematics import view_from_yaw_pitch_roll
+        return self._frame(view_from_yaw_pitch_roll(self.pos, distance, yaw, pitch, roll))[0]
+
+
+class _BulletShim:
+    """`env._p`: the handful of pybullet client calls that callers of the reference use on the env (videomaker.py:84,124,
+    generate_goals.py:105), answered from the batched backend.  Anything else raises AttributeError -- there is no Bullet here."""
+
+    def __init__(self, env):
+        self._env = env
+
+    @staticmethod
+    def getQuaternionFromEuler(rpy):
+        from ..kinematics import quat_from_euler
+        return tuple(quat_from_euler(*rpy))
+
+    @staticmethod
+    def getEulerFromQuaternion(q):
+        x, y, z, w = q
+        return (float(np.arctan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y))),
+                float(np.arcsin(np.clip(2 * (w * y - z * x), -1, 1))),
+                float(np.arctan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))))
+
+    def getBasePositionAndOrientation(self, body_uid):
+        env = self._env
+        if body_uid >= 2:                                    # objects: unique ids 2.. in load order (SURVEY A.1.1)
+            pose = env._backend().host(nat.F_OBJ_POSE)[0, body_uid - 2].astype(np.float64)
+            return tuple(pose[:3]), tuple(pose[3:])
+        if body_uid == 1:
+            return (0.0, 0.0, 0.08), (0.0, 0.0, 0.0, 1.0)   # table (robot.py:20)
+        return tuple(env.robot.robot_position), (0.0, 0.0, 0.0, 1.0)
+
+    def stepSimulation(self):
+        self._env._backend().step(None)
+
+
 class REALRobotEnv:
     metadata = {'render.modes': ['human', 'rgb_array']}
     intrinsic_timesteps = int(15e6)      # env.py:32-34
@@ -95,6 +170,9 @@ class REALRobotEnv:
         self._cam_pos = [0, 0, .4]
         self.envCamera = EnvCamera(self._cam_dist, self._cam_yaw, self._cam_pitch, self._cam_roll, self._cam_pos,
                                    width=self._render_width, height=self._render_height)
+        self.eyes = {}
+        self.set_eye("eye")                              # env.py:95,136-141
+        self._p = _BulletShim(self)
         self.reward_func = DefaultRewardFunc
         H, W = self.robot.eye_height, self.robot.eye_width
         self.goal = Goal(retina=np.zeros((H, W, 3), np.uint8))
@@ -109,6 +187,26 @@ class REALRobotEnv:
             self.get_observation = self.get_observation_extended
             self.no_mask = np.zeros((H, W), np.int32)
             self.goal.mask = self.no_mask
+
+    def setCamera(self):
+        """(Re)creates the debug camera of render('rgb_array') from the `_cam_*` attributes (env.py:124-134)."""
+        self.envCamera = EnvCamera(self._cam_dist, self._cam_yaw, self._cam_pitch, self._cam_roll, self._cam_pos,
+                                   width=self._render_width, height=self._render_height)
+
+    def set_eye(self, name, eye_pos=[0.01, 0, 1.2], target_pos=[0, 0, 0]):
+        """Registers an eye camera under `name` (env.py:136-141); `self.eyes[name].render(target)` returns (rgb, mask, depth)."""
+        cam = EyeCamera(eye_pos, target_pos, width=self.robot.eye_width, height=self.robot.eye_height)
+        cam._env = self
+        cam._p = getattr(self, '_p', None)
+        self.eyes[name] = cam
+
+    def extrinsicFormula(self, p_goal, p, a_goal, a, w=1):
+        """Position / orientation score of the earlier challenge rounds (env.py:168-179): 0.25 at 5 cm and at 0.3 of
+        quaternion distance, mixed by w."""
+        pos_value = np.exp(np.log(0.25) / 0.05 * np.linalg.norm(np.asarray(p_goal) - np.asarray(p)))
+        orient_dist = min(np.linalg.norm(np.asarray(a_goal) - np.asarray(a)), np.linalg.norm(np.asarray(a_goal) + np.asarray(a)))
+        orient_value = np.exp(np.log(0.25) / 0.30 * orient_dist)
+        return w * pos_value + (1 - w) * orient_value
 
     # ------------------------------------------------------------------ backend
     def _backend(self):

@@ -35,6 +35,10 @@ def test_env_camera_view_matches_the_oracle_pixel_exact():
         assert set(np.unique(m).tolist()) >= {-1, 0, 1}            # background, robot and table are in the oblique view
         for _ in range(80):
             env.step({'joint_command': np.array([0.8, 0.6, 0, -1.0, 0, 0.5, 0, 0.3, 0.2]), 'render': False})
+    # the eye camera object of the reference API (env.py:516-567): same view as the observation's retina
+    obs, _, _, _ = env.step({'joint_command': np.array([0.8, 0.6, 0, -1.0, 0, 0.5, 0, 0.3, 0.2]), 'render': True})
+    rgb, mask, depth = env.eyes['eye'].render(env.robot.object_bodies['table'].get_position())
+    assert rgb.shape == (64, 64, 3) and (rgb == obs['retina']).mean() > 0.999 and (mask == obs['mask']).mean() > 0.999
     env.close()
 
 
@@ -232,3 +236,35 @@ def test_dlpack_and_vector_env_adapter():
     obs, rew, term, trunc, info = venv.step(act)               # truncated envs were reset at the start of this step
     assert (venv._be.host(nat.F_TIMESTEP) == 1).all() and not trunc.any()
     venv.close()
+
+
+def test_heavy_light_split_is_bitwise_equivalent(monkeypatch):
+    """rr_step solves and renders the solver groups with generic contact rows on the side stream, beside the others
+    (DESIGN.md 5.1).  That is scheduling only: with full-range commands (arms pressed on the table, grippers in the objects:
+    a few dozen heavy groups) 240 steps with a render every step must leave bit-identical states, contact forces and
+    images whether the split is on or off, and with per-env render flags."""
+    N, T = 512, 240
+    ids = np.arange(N)
+    flags = (np.arange(N) % 3 != 0).astype(np.uint8)
+
+    def run(no_split):
+        if no_split:
+            monkeypatch.setenv("RR_NO_SPLIT", "1")
+        env = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+        if no_split:
+            monkeypatch.delenv("RR_NO_SPLIT")
+        heavy = 0
+        for t in range(T):
+            env.step(synthetic_actions(ids, t, seed=77), render=(flags if t % 2 else True))
+            if t % 40 == 39:
+                heavy = max(heavy, sum(len(env.contacts(i)) > 12 for i in range(0, N, 8)))
+        out = (env.state, env.host(nat.F_RGB), env.host(nat.F_DEPTH), env.host(nat.F_MASK), env.host(nat.F_TOUCH), env.host(nat.F_ERRFLAGS))
+        env.close()
+        return out, heavy
+
+    a, heavy = run(False)
+    b, _ = run(True)
+    assert heavy >= 2                                   # the run did have envs with generic contacts
+    assert (a[5] == 0).all()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)

@@ -109,6 +109,14 @@ def test_env_spaces_and_constructor_contract():
     assert np.allclose(lim[[0, 1, 2, 6, 7]], [0.666 * np.pi, 0.666 * np.pi, 0.944 * np.pi, 0.972 * np.pi, np.pi / 2])
     assert (env2.intrinsic_timesteps, env2.extrinsic_timesteps, env2.extrinsic_trials) == (int(15e6), int(10e3), 50)
     assert env2.goal_idx == -1 and (env2.goal.retina == 0).all()
+    # minor API of the reference env: eye cameras, the debug camera factory, the earlier rounds' score formula, `_p`
+    from real_robots_amd.envs import EyeCamera
+    assert isinstance(env2.eyes['eye'], EyeCamera) and env2.eyes['eye'].eyePosition == [0.01, 0, 1.2]
+    env2.set_eye('side', eye_pos=[0.5, 0.5, 0.8], target_pos=[0, 0, 0.3])
+    assert set(env2.eyes) == {'eye', 'side'}
+    env2.setCamera()
+    assert abs(env2.extrinsicFormula(np.zeros(3), np.array([0.05, 0, 0]), np.array([0, 0, 0, 1.0]), np.array([0, 0, 0, 1.0])) - 0.25) < 1e-12
+    assert np.allclose(env2._p.getEulerFromQuaternion(env2._p.getQuaternionFromEuler([0.1, -0.2, 0.3])), [0.1, -0.2, 0.3])
     with pytest.raises(ValueError):
         rr.REALRobotEnv(action_type='teleport')
     with pytest.raises(AssertionError):
