@@ -95,7 +95,8 @@ def _fuzz_case(case, seed0, stats, bad):
                 continue
             fmax = float(cd[:, 10].max()) if len(cd) else 0.0
             dj = float(np.abs(st1[i][:22] - o.state[:22]).max())
-            do = float(np.abs((st1[i][22:22 + 13 * nobj] - o.state[22:22 + 13 * nobj]).reshape(nobj, 13)[:, :3]).max())
+            dobj = np.abs((st1[i][22:22 + 13 * nobj] - o.state[22:22 + 13 * nobj]).reshape(nobj, 13))
+            do, dv = float(dobj[:, :7].max()), float(dobj[:, 7:].max())      # pose; linear and angular velocity
             if fmax > CRUSH_FORCE:
                 stats['crush'] += 1
                 if not np.isfinite(st1[i]).all():
@@ -103,8 +104,10 @@ def _fuzz_case(case, seed0, stats, bad):
             else:
                 stats['dj'] = max(stats['dj'], dj)
                 stats['do'] = max(stats['do'], do)
-                if dj > 2e-3 or do > 1e-3:
-                    bad.append(tag + ('state', dj, do, fmax))
+                stats['dv'] = max(stats['dv'], dv)
+                # measured worst over the 300 cases: joints (q, qd) 8.5e-5, object pose 3e-8 - bounds are ~4x / ~30x that
+                if dj > 3e-4 or do > 1e-6 or dv > 2e-4:
+                    bad.append(tag + ('state', dj, do, dv, fmax))
             o.state = st1[i].astype(np.float64)
             r, d, m = o.render()
             diff = np.abs(r.astype(int) - rgb[i].astype(int)).max(-1)
@@ -121,14 +124,14 @@ def test_seeded_differential_run_contact_lists_bit_identical():
     """>= 300 seeded cases; zero disagreements in the contact lists (in particular no candidate that sits at the 2 cm margin
     on one side only), states within the one-step tolerances outside crush scenarios, image masks and depths exact, RGB within
     one grey level except at most two texel-boundary pixels per frame."""
-    stats = dict(checks=0, contacts=0, crush=0, dj=0.0, do=0.0)
+    stats = dict(checks=0, contacts=0, crush=0, dj=0.0, do=0.0, dv=0.0)
     bad = []
     n_cases = int(os.environ.get('RR_FUZZ_CASES', '300'))
     only = os.environ.get('RR_FUZZ_ONLY')
     for case in ([int(only)] if only else range(n_cases)):
         _fuzz_case(case, 2, stats, bad)
-    print("fuzz: %d cases, %d one-step checks, %d contacts compared, %d crush checks, worst joints %.2e objects %.2e; %d violations"
-          % (n_cases, stats['checks'], stats['contacts'], stats['crush'], stats['dj'], stats['do'], len(bad)))
+    print("fuzz: %d cases, %d one-step checks, %d contacts compared, %d crush checks, worst joints %.2e object pose %.2e object velocity %.2e; %d violations"
+          % (n_cases, stats['checks'], stats['contacts'], stats['crush'], stats['dj'], stats['do'], stats['dv'], len(bad)))
     for b in bad[:20]:
         print("   violation:", b)
     assert not bad, bad[:20]

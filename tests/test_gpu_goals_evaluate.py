@@ -79,3 +79,34 @@ def test_evaluate_batched_matches_single_env_scores(tmp_path):
     # env 0 walks the goals in the same order as the single env: trial 0 -> goal 0, trial 1 -> goal 1
     assert abs(scores_b['2D'][0] - scores_s['2D'][0]) < 1e-3 and abs(scores_b['2D'][6] - scores_s['2D'][1]) < 1e-3
     assert 0 < res_b['score_total'] <= 1
+
+
+def test_generated_goals_are_rest_states_of_the_oracle_and_render_the_same():
+    """SURVEY 8(f2) against the oracle, not only its own properties: every generated goal state (settled on the HIP
+    path) is a rest state of the CPU restatement too - placed there, the oracle's objects stay within 1 mm / 0.5 deg
+    over 60 zero-command steps - and the oracle's render of that state reproduces the goal's retina and mask."""
+    from oracle.oracle import Oracle
+    from real_robots_amd.generate_goals import generate_goals, OBJECT_NAMES
+    W, H, n_obj = 96, 72, 3
+    goals = generate_goals(n_2d_goals=2, n_25d_goals=2, n_3d_goals=2, n_obj=n_obj, seed=11, batch=64, width=W, height=H)
+    assert [g.challenge for g in goals] == ['2D'] * 2 + ['2.5D'] * 2 + ['3D'] * 2
+    o = Oracle(n_objects=n_obj, width=W, height=H, f32=True)
+    for g in goals:
+        for state, check_image in ((g.initial_state, False), (g.final_state, True)):
+            o.reset()
+            for _ in range(30):
+                o.step(None)
+            for i, name in enumerate(OBJECT_NAMES[:n_obj]):
+                o.set_object_pose(i, np.asarray(state[name], np.float64))
+            if check_image:
+                rgb, depth, mask = o.render()
+                assert (mask == g.mask).mean() > 0.995, (g.challenge, (mask == g.mask).mean())
+                close = (np.abs(rgb.astype(int) - g.retina.astype(int)).max(-1) <= 1)
+                assert close.mean() > 0.99, (g.challenge, close.mean())
+            for _ in range(60):
+                o.step(None)
+            s = o.state[22:].reshape(3, 13)          # per object: position, quaternion, velocities
+            for i, name in enumerate(OBJECT_NAMES[:n_obj]):
+                assert np.linalg.norm(s[i, :3] - state[name][:3]) < 1e-3, (g.challenge, name, s[i, :3], state[name][:3])
+                qdot = abs(np.dot(s[i, 3:7], state[name][3:7]))
+                assert qdot > np.cos(np.radians(0.25)), (g.challenge, name, qdot)      # rotated by < 0.5 deg
