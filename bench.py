@@ -206,6 +206,7 @@ def main():
     ap.add_argument('--presettle', type=int, default=150,
                     help='untimed steps before the warmup so that the timed region runs in steady state '
                          '(objects landed on the table, arms moving, contacts active)')
+    ap.add_argument('--image', default=None, help='WxH of the rendered observation (development A/B; the headline config is 128x128)')
     ap.add_argument('--no-render', action='store_true', help='dynamics-only variant (not the headline metric)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary workloads (profiling runs)')
@@ -214,6 +215,9 @@ def main():
     ap.add_argument('--gather', nargs='?', const='lowdim', default='none', choices=('none', 'lowdim', 'images'),
                     help='also all-gather observations every step (RCCL): joints/touch/object poses, or those + RGB + depth')
     args = ap.parse_args()
+    if args.image:
+        global W, H
+        W, H = (int(x) for x in args.image.lower().split('x'))
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

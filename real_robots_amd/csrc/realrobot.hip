@@ -2044,15 +2044,21 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 }
 
 // ---------------------------------------------------------------------------------------------- rasteriser
-// One workgroup per (env, tile). Tile = full-width strip of tile_h rows (<= 16384 pixels -> 128 KiB of LDS keys).
-#define RASTER_THREADS 1024
+// One workgroup per (env, tile). Tile = full-width strip of tile_h rows (<= TILE_PIX pixels, 8 bytes of LDS key each).
+#ifndef RASTER_THREADS
+#define RASTER_THREADS 512       // with TILE_PIX 4096: 47 KB of LDS -> three workgroups = six waves per SIMD (A/B below)
+#endif
 #define VIS_WAS_DYNAMIC (~0ull - 1)   // visibility key of a pixel that was dynamic in the previous frame and is not (yet) now
 #define FRAG_VACATED 0x3ffffu         // triangle field of a fragment-list entry for such a pixel: back to the static layer
+// A/B at 4096 envs, 128x128 (k_raster ms): 16384 px x 1024 threads (one workgroup per CU) 0.564; 8192 x 512 (two) 0.521;
+// 4096 x 512 (three) 0.449; 4096 x 256 0.629; 2048 x 256 0.546.  At 320x240: 0.460 / 0.432 / 0.442.
 #ifndef TILE_PIX
-#define TILE_PIX 16384
+#define TILE_PIX 4096
 #endif
 #define MAXWIN 1024      // 64-triangle windows per model (rr_create checks nt)
-#define CLIPQ 2048        // triangles crossing the near plane per (env, tile) that are clipped (a link cut by the plane has a few hundred)
+#ifndef CLIPQ
+#define CLIPQ 2048       // triangles crossing the near plane per (env, tile) that are clipped (a link cut by the plane has a few hundred)
+#endif
 #ifndef INLINE_PIX
 #define INLINE_PIX 2     // sample points of a small triangle walked by its own lane; the rest is redistributed over the wave
 #endif
@@ -2998,7 +3004,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     if (cfg->num_envs < 1) return fail(RR_EINVAL, "rr_create: num_envs < 1");
     if (cfg->n_objects < 1 || cfg->n_objects > NOBJ) return fail(RR_EINVAL, "rr_create: n_objects must be 1..3");
     if (cfg->width < 4 || cfg->height < 1 || cfg->width % 4 != 0 || cfg->width > TILE_PIX)
-        return fail(RR_EINVAL, "rr_create: width must be a multiple of 4 in [4,16384]");
+        return fail(RR_EINVAL, "rr_create: width must be a multiple of 4 in [4,4096]");
     Blob b;
     if (!b.init(model_blob, blob_bytes)) return fail(RR_EMODEL, "rr_create: bad model blob header");
     const int32_t *dims = b.i32("dims", 11);
