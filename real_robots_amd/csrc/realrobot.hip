@@ -615,14 +615,31 @@ extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
 //      the "first best wins" selections of the oracle's reduce4() are wave reductions with lowest-index tie-breaks.
 // The whole kernel is contraction-free (see "contraction-free twins"): results are bit-identical to the oracle's float
 // build.  No atomics, no work list: results do not depend on scheduling.
-#define COLLIDE_THREADS 64
+#define COLLIDE_WAVES COLLIDE_WAVES_   // waves per env: the close pairs are dealt out among them (the slowest env sets the kernel's duration)
+#define COLLIDE_THREADS (64 * COLLIDE_WAVES)
+#define CCHUNK 64         // close pairs whose results are held in LDS at a time (COLLIDE_THREADS / 4 record writers)
 #define NPREF 6          // leading planes of every shape used by the prefilter (tools/compile_model.py orders them)
 #define CAND_MAX 128     // candidates kept per pair (the oracle applies the same cap)
 #define CSHAPES 24       // collision shapes staged in LDS (rr_create checks the model: 22)
+#define COLLIDE_WAVES_ 4
 #ifdef RR_RASTER_STATS
 #define CABL(bit) (P.ablate & (bit))      // development build: phase ablations (256 stage only, 512 no pairs, 1024 cull only)
+// per-env phase cycles of k_collide (scratch/cprof.py): 0 stage, 1 sphere tests, 2 loads + cull, 3 prefilter, 4 all-plane pass,
+// 5 manifold reduction, 6 record write, 7 close pairs
+__device__ unsigned g_cprof[8192 * COLLIDE_WAVES_][8];
+extern "C" int rr_debug_collide_prof(unsigned *out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cprof), sizeof(unsigned) * 8 * COLLIDE_WAVES_ * (size_t)n) == hipSuccess ? 0 : -1;   // [n][waves][8]
+}
+#define CPROF_INIT unsigned cp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long cp_t0 = __builtin_readcyclecounter();
+#define CPROF(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); cp_[i] += (unsigned)(now_ - cp_t0); cp_t0 = now_; } while (0)
+#define CPROF_COUNT(i) cp_[i]++
+#define CPROF_END do { if (lane == 0 && env < 8192) for (int i_ = 0; i_ < 8; i_++) g_cprof[env * COLLIDE_WAVES_ + wv][i_] = cp_[i_]; } while (0)
 #else
 #define CABL(bit) false
+#define CPROF_INIT
+#define CPROF(i)
+#define CPROF_COUNT(i)
+#define CPROF_END
 #endif
 
 // wave-wide "first lane holding the maximum of v among lanes with ok" (returns -1 when no lane is ok or none exceeds
@@ -647,9 +664,22 @@ __device__ __forceinline__ float lane_f(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
-// the workgroup is a single wavefront: LDS traffic is ordered per wave, so a compiler-level fence replaces s_barrier
+// exclusive prefix sum over the 64 lanes of a wave (DPP row_shr scan inside each 16-lane row + the row totals)
+template <int SHR> __device__ __forceinline__ int dpp_shr0(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + SHR, 0xf, 0xf, true); }
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
+    int x = v;
+    x += dpp_shr0<1>(x); x += dpp_shr0<2>(x); x += dpp_shr0<4>(x); x += dpp_shr0<8>(x);
+    const int t0 = __builtin_amdgcn_readlane(x, 15), t1 = __builtin_amdgcn_readlane(x, 31), t2 = __builtin_amdgcn_readlane(x, 47),
+              t3 = __builtin_amdgcn_readlane(x, 63);
+    const int row = lane >> 4;
+    const int off = row == 0 ? 0 : (row == 1 ? t0 : (row == 2 ? t0 + t1 : t0 + t1 + t2));
+    total = t0 + t1 + t2 + t3;
+    return x + off - v;
+}
+
+// the candidate / plane / survivor arrays are private to a wave: LDS traffic is ordered per wave, so a compiler-level fence replaces s_barrier
 #define CSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-static_assert(COLLIDE_THREADS == 64, "k_collide synchronises with wave-level fences");
+static_assert(CCHUNK * 4 == COLLIDE_THREADS && CCHUNK <= 64 && MAXPAIRS < 256, "one record writer per (slot, r); pair ids in bytes");
 static_assert(VMAXC % 64 == 0 && FMAXC % 64 == 0 && VMAXC < 256 && FMAXC < 256, "vertex / plane passes of 64, counts packed in bytes");
 // (the whole kernel is contraction-free and uses the nc:: helpers: see "contraction-free twins" above)
 #pragma clang fp contract(off)
@@ -679,47 +709,80 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
     float *scratch = D.scratch;
     if (D.errflags[env]) return;
     const ShapeData *S = D.shapes;
-    // 9.9 KB of LDS: sixteen workgroups (= all the envs a CU gets at 4096 envs) are resident at once
+    // 38.9 KB of LDS: four workgroups = sixteen waves per CU
     __shared__ float xf[CSHAPES][12];          // R (row-major 9), p (3) of every shape's owner
     __shared__ float4 sph[CSHAPES];            // world bounding sphere
-    __shared__ float4 planes[FMAXC];           // planes of "other" in the current direction
-    __shared__ float surv[VMAXC][3];           // world position of the vertices that survive the prefilter, in vertex order
-    __shared__ float4 cand_a[CAND_MAX];        // candidates of the pair: contact point, signed distance
-    __shared__ int cand_b[CAND_MAX];           //                         plane of "other" it is nearest to | direction << 8
     __shared__ int pair_ab[MAXPAIRS];          // shape a | shape b << 8 of every pair   } staged once: no global load of
     __shared__ int shape_n[CSHAPES];           // vertex count | plane count << 8        } metadata inside the pair loop
-    const int lane = threadIdx.x;
+    __shared__ unsigned char close_pair[MAXPAIRS];   // the pairs that pass the sphere test, in pair order
+    __shared__ int n_close, next_item, nct_sh;
+    __shared__ float4 res_a[CCHUNK][4];        // per close pair of the chunk: the kept candidates (contact point, signed distance)
+    __shared__ int res_b[CCHUNK][4];           //                              plane of "other" | direction << 8
+    __shared__ int res_k[CCHUNK];              //                              their number; after the scan: offset in the env's list | kept << 8
+    // per wave:
+    __shared__ float4 planes_w[COLLIDE_WAVES][FMAXC];      // planes of "other" in the current direction
+    __shared__ float surv_w[COLLIDE_WAVES][VMAXC][3];      // world position of the vertices that survive the prefilter, in vertex order
+    __shared__ float4 cand_a_w[COLLIDE_WAVES][CAND_MAX];   // candidates of the pair: contact point, signed distance
+    __shared__ int cand_b_w[COLLIDE_WAVES][CAND_MAX];      //                         plane of "other" it is nearest to | direction << 8
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float4 *planes = planes_w[wv];
+    float (*surv)[3] = surv_w[wv];
+    float4 *cand_a = cand_a_w[wv];
+    int *cand_b = cand_b_w[wv];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (int pr = lane; pr < P.npairs; pr += COLLIDE_THREADS) {
+    CPROF_INIT
+    for (int pr = tid; pr < P.npairs; pr += COLLIDE_THREADS) {
         const int ba = S->pair_meta[pr][0], bb = S->pair_meta[pr][1];
         const int cls = (((ba >= 0 && ba < 16) || (bb >= 0 && bb < 16)) ? 1 : 0) | ((ba >= 16 && bb >= 16) ? 2 : 0);
         pair_ab[pr] = S->pair_a[pr] | (S->pair_b[pr] << 8) | (cls << 16);      // + robot involved (bit 16), object-object (bit 17)
     }
-    if (lane < ns) {
-        shape_n[lane] = S->nv[lane] | (S->nf[lane] << 8);
-        const Xf X = load_xf(S, lane, state, scratch, N, env);
+    if (tid < ns) {
+        shape_n[tid] = S->nv[tid] | (S->nf[tid] << 8);
+        const Xf X = load_xf(S, tid, state, scratch, N, env);
 #pragma unroll
-        for (int k = 0; k < 9; k++) xf[lane][k] = X.R.m[k];
-        xf[lane][9] = X.p.x; xf[lane][10] = X.p.y; xf[lane][11] = X.p.z;
-        const v3 c = nc::add(nc::mulv(X.R, mk(S->sphere[lane][0], S->sphere[lane][1], S->sphere[lane][2])), X.p);
-        sph[lane] = make_float4(c.x, c.y, c.z, S->sphere[lane][3]);
+        for (int k = 0; k < 9; k++) xf[tid][k] = X.R.m[k];
+        xf[tid][9] = X.p.x; xf[tid][10] = X.p.y; xf[tid][11] = X.p.z;
+        const v3 c = nc::add(nc::mulv(X.R, mk(S->sphere[tid][0], S->sphere[tid][1], S->sphere[tid][2])), X.p);
+        sph[tid] = make_float4(c.x, c.y, c.z, S->sphere[tid][3]);
     }
-    CSYNC();
+    __syncthreads();
+    CPROF(0);
     if (CABL(256)) return;
-    int nct = 0;                                // contacts of this env so far (wave-uniform)
-    bool heavy = false;                         // some contact is not an object-vs-static one the object lanes take (wave-uniform)
-    unsigned oscnt = 0;                         // object-vs-static contacts per object, 4 bits each
-    for (int p0 = 0; p0 < P.npairs; p0 += 64) {
-        const int pr = p0 + lane;
-        bool close = false;
-        if (pr < P.npairs) {
-            const float4 a = sph[pair_ab[pr] & 255], b = sph[(pair_ab[pr] >> 8) & 255];
-            const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, rr = a.w + b.w + P.margin;
-            close = !(dx * dx + dy * dy + dz * dz > rr * rr);
+    // ---- the pairs whose bounding spheres come within the margin, in pair order (wave 0)
+    if (wv == 0) {
+        int nc_ = 0;
+        for (int p0 = 0; p0 < P.npairs; p0 += 64) {
+            const int pr = p0 + lane;
+            bool close = false;
+            if (pr < P.npairs) {
+                const float4 a = sph[pair_ab[pr] & 255], b = sph[(pair_ab[pr] >> 8) & 255];
+                const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, rr = a.w + b.w + P.margin;
+                close = !(dx * dx + dy * dy + dz * dz > rr * rr);
+            }
+            const unsigned long long cm_ = CABL(512) ? 0ull : __ballot(close);
+            if (close && !CABL(512)) close_pair[nc_ + __popcll(cm_ & lt_mask)] = (unsigned char)pr;
+            nc_ += __popcll(cm_);
         }
-        unsigned long long todo = CABL(512) ? 0ull : __ballot(close);
-        for (; todo && nct < MAXC; todo &= todo - 1) {
-            const int pair = p0 + __ffsll((long long)todo) - 1;
+        if (lane == 0) { n_close = nc_; next_item = 0; }
+    }
+    __syncthreads();
+    CPROF(1);
+    const int ncl = n_close;
+    int nct = 0;                                // contacts of this env so far        }
+    bool heavy = false;                         // some contact is not an object-vs-static one the object lanes take    } tracked by wave 0
+    int oscnt0 = 0, oscnt1 = 0, oscnt2 = 0;     // object-vs-static contacts per object }
+    for (int base = 0; base < ncl && nct < MAXC; base += CCHUNK) {
+        const int nchunk = min(CCHUNK, ncl - base);
+        // ---- every wave takes the next unprocessed close pair of the chunk (the result goes to the pair's slot: the
+        // outcome does not depend on which wave took it)
+        for (;;) {
+            int item = 0;
+            if (lane == 0) item = atomicAdd(&next_item, 1);
+            item = __builtin_amdgcn_readfirstlane(item);
+            if (item >= base + nchunk) break;
+            CPROF_COUNT(7);
+            const int slot = item - base;
+            const int pair = close_pair[item];
             const int sa = pair_ab[pair] & 255, sb = (pair_ab[pair] >> 8) & 255;
             int ncand = 0;                      // wave-uniform
             for (int dirflag = 0; dirflag < 2; dirflag++) {
@@ -757,6 +820,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                         }
                     }
                 }
+                CPROF(2);
                 if (__ballot(sep)) continue;
                 if (CABL(1024)) continue;
                 CSYNC();
@@ -782,6 +846,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                     }
                     nsurv += __popcll(km);
                 }
+                CPROF(3);
                 if (nsurv == 0) continue;
                 CSYNC();
                 for (int k0 = 0; k0 < nsurv; k0 += 64) {
@@ -815,15 +880,15 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                     }
                     ncand = min(ncand + __popcll(hm), CAND_MAX);
                 }
+                CPROF(4);
             }
-            if (ncand == 0) continue;
             CSYNC();
-            if (CABL(2048)) continue;
             // manifold reduction, same rule as the oracle's reduce4(): deepest first, then maximal spread, preferring the
             // candidates within TIER_TOL (1 mm) of the deepest penetration at every pick; ties go to the first candidate
             int sel0 = -1, sel1 = -1, sel2 = -1, sel3 = -1, k = 0;
+            if (CABL(2048)) ncand = 0;
             if (ncand <= 4) {
-                sel0 = 0; sel1 = ncand > 1 ? 1 : -1; sel2 = ncand > 2 ? 2 : -1; sel3 = ncand > 3 ? 3 : -1;
+                sel0 = ncand > 0 ? 0 : -1; sel1 = ncand > 1 ? 1 : -1; sel2 = ncand > 2 ? 2 : -1; sel3 = ncand > 3 ? 3 : -1;
                 k = ncand;
             } else {
                 CAND_ARGMAX(sel0, -3.0e38f, true, -ca.w)                       // smallest s, first one
@@ -854,18 +919,48 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
 #undef V3_
                 k = sel3 >= 0 ? 4 : 3;
             }
-            k = min(k, MAXC - nct);             // the env's list holds MAXC contacts (the oracle stops there too)
-            {   // the solver's object lanes take up to four object-vs-static contacts per object; anything else is a generic row
-                const int cls = (pair_ab[pair] >> 16) & 3;
-                const int ob = sa - (ns - NOBJ);                        // object index of shape a for the object-vs-static pairs
-                if (cls != 0 || ob < 0) heavy = heavy || k > 0;
-                else { oscnt += (unsigned)k << (4 * ob); heavy = heavy || ((oscnt >> (4 * ob)) & 15u) > 4u; }
-            }
             if (lane < k) {
                 const int ci = lane == 0 ? sel0 : (lane == 1 ? sel1 : (lane == 2 ? sel2 : sel3));
-                const float4 a = cand_a[ci];
+                res_a[slot][lane] = cand_a[ci];
+                res_b[slot][lane] = cand_b[ci];
+            }
+            if (lane == 0) res_k[slot] = k;
+            CSYNC();            // the candidate list is reused by the next pair
+            CPROF(5);
+        }
+        __syncthreads();
+        // ---- the chunk's contacts go to the env's list in pair order, up to MAXC (the oracle stops there too): wave 0
+        // numbers them and classifies the env's solver group, then thread (slot, r) writes the slot's r-th record
+        if (wv == 0) {
+            const bool in_ = lane < nchunk;
+            const int kj = in_ ? res_k[lane] : 0;
+            int total;
+            const int off = min(nct + wave_excl_scan(kj, lane, total), MAXC);
+            const int kk = min(kj, MAXC - off);
+            if (in_) res_k[lane] = off | (kk << 8);
+            // the solver's object lanes take up to four object-vs-static contacts per object; anything else is a generic row
+            const int pab = pair_ab[close_pair[base + (in_ ? lane : 0)]];
+            const int cls = (pab >> 16) & 3;
+            const int ob = (pab & 255) - (ns - NOBJ);                   // object index of shape a for the object-vs-static pairs
+            const bool os = cls == 0 && ob >= 0;
+            heavy = heavy || __ballot(kk > 0 && !os) != 0ull;
+            int t0_, t1_, t2_;
+            wave_excl_scan(os && ob == 0 ? kk : 0, lane, t0_);
+            wave_excl_scan(os && ob == 1 ? kk : 0, lane, t1_);
+            wave_excl_scan(os && ob == 2 ? kk : 0, lane, t2_);
+            oscnt0 += t0_; oscnt1 += t1_; oscnt2 += t2_;
+            nct = min(nct + total, MAXC);
+        }
+        __syncthreads();
+        {
+            const int slot = tid >> 2, r = tid & 3;
+            const int ok_ = slot < nchunk ? res_k[slot] : 0;
+            if (r < (ok_ >> 8)) {
+                const int pair = close_pair[base + slot];
+                const int sa = pair_ab[pair] & 255, sb = (pair_ab[pair] >> 8) & 255;
+                const float4 a = res_a[slot][r];
                 // the normal (B -> A) of a kept candidate: its plane of "other", rotated to the world, as in the candidate test
-                const int kb = cand_b[ci], so_ = (kb >> 8) ? sa : sb;
+                const int kb = res_b[slot][r], so_ = (kb >> 8) ? sa : sb;
                 m3 Ro;
 #pragma unroll
                 for (int kk = 0; kk < 9; kk++) Ro.m[kk] = xf[so_][kk];
@@ -875,16 +970,22 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 const float4 b = make_float4(nb.x, nb.y, nb.z, 0.0f);
                 const int4 pm = *(const int4 *)S->pair_meta[pair];
                 const int meta = (pm.x & 255) | ((pm.y & 255) << 8) | ((pm.z & 255) << 16);
-                float4 *rec = D.clist + ((size_t)env * MAXC + nct + lane) * 3;
+                float4 *rec = D.clist + ((size_t)env * MAXC + (ok_ & 255) + r) * 3;
                 rec[0] = make_float4(a.x, a.y, a.z, b.x);
                 rec[1] = make_float4(b.y, b.z, a.w, __int_as_float(meta));
                 rec[2] = *(const float4 *)S->pair_mat[pair];
             }
-            nct += k;
-            CSYNC();            // the candidate list is reused by the next pair
+        }
+        CPROF(6);
+        if (base + CCHUNK < ncl) {  // (more than CCHUNK close pairs: rare) the result slots are reused; every wave needs the count
+            if (tid == 0) { nct_sh = nct; next_item = base + CCHUNK; }
+            __syncthreads();
+            nct = nct_sh;
         }
     }
-    if (lane == 0) {
+    CPROF_END;
+    if (tid == 0) {
+        heavy = heavy || oscnt0 > 4 || oscnt1 > 4 || oscnt2 > 4;
         D.ccount[env] = nct;
         if (heavy && atomicOr(&D.hgflag[env >> 2], 1) == 0) D.hlist[atomicAdd(D.hcount, 1)] = env >> 2;
     }
@@ -2125,19 +2226,6 @@ __device__ __forceinline__ void clip_edge(const float *a, const float *b, float 
     o[1] = a[1] + t * (b[1] - a[1]);
     o[2] = a[2] + t * (b[2] - a[2]);
     o[3] = NEAR_W;
-}
-
-// exclusive prefix sum over the 64 lanes of a wave (DPP row_shr scan inside each 16-lane row + the row totals)
-template <int SHR> __device__ __forceinline__ int dpp_shr0(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + SHR, 0xf, 0xf, true); }
-__device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
-    int x = v;
-    x += dpp_shr0<1>(x); x += dpp_shr0<2>(x); x += dpp_shr0<4>(x); x += dpp_shr0<8>(x);
-    const int t0 = __builtin_amdgcn_readlane(x, 15), t1 = __builtin_amdgcn_readlane(x, 31), t2 = __builtin_amdgcn_readlane(x, 47),
-              t3 = __builtin_amdgcn_readlane(x, 63);
-    const int row = lane >> 4;
-    const int off = row == 0 ? 0 : (row == 1 ? t0 : (row == 2 ? t0 + t1 : t0 + t1 + t2));
-    total = t0 + t1 + t2 + t3;
-    return x + off - v;
 }
 
 __device__ __forceinline__ bool bary(const STri &s, float px, float py, float *b) {
