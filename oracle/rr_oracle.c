@@ -1157,18 +1157,19 @@ typedef struct { float sx[3], sy[3], sz[3], w[3]; int ok; } stri_t;
 static void clip_coords(const float *MVP, const float *tp, float c[3][4]) {
     for (int k = 0; k < 3; k++) {
         const float *v = tp + 3 * k;
-        c[k][0] = MVP[0] * v[0] + MVP[1] * v[1] + MVP[2] * v[2] + MVP[3];
-        c[k][1] = MVP[4] * v[0] + MVP[5] * v[1] + MVP[6] * v[2] + MVP[7];
-        c[k][2] = MVP[8] * v[0] + MVP[9] * v[1] + MVP[10] * v[2] + MVP[11];
-        c[k][3] = MVP[12] * v[0] + MVP[13] * v[1] + MVP[14] * v[2] + MVP[15];
+        c[k][0] = fmaf(MVP[0], v[0], fmaf(MVP[1], v[1], fmaf(MVP[2], v[2], MVP[3])));
+        c[k][1] = fmaf(MVP[4], v[0], fmaf(MVP[5], v[1], fmaf(MVP[6], v[2], MVP[7])));
+        c[k][2] = fmaf(MVP[8], v[0], fmaf(MVP[9], v[1], fmaf(MVP[10], v[2], MVP[11])));
+        c[k][3] = fmaf(MVP[12], v[0], fmaf(MVP[13], v[1], fmaf(MVP[14], v[2], MVP[15])));
     }
 }
 /* perspective division + viewport of one clip-space vertex (TinyRenderer viewport(): integer sample points in a
  * (x+1)*W/2 window) */
 static void to_screen(const float *c, int W, int H, float *sx, float *sy, float *sz, float *w) {
     float iw = 1.0f / c[3];
-    *sx = (c[0] * iw + 1.0f) * (0.5f * (float)W);
-    *sy = (c[1] * iw + 1.0f) * (0.5f * (float)H);
+    const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+    *sx = fmaf(c[0] * iw, hw, hw);          /* (x / w + 1) * W / 2 */
+    *sy = fmaf(c[1] * iw, hh, hh);
     *sz = c[2] * iw;
     *w = c[3];
 }
@@ -1195,9 +1196,9 @@ static int clip_near(float c[3][4], float out[4][4]) {
         if (in_i != in_j) {
             const float *a = in_i ? c[i] : c[j], *b = in_i ? c[j] : c[i];
             float t = (NEAR_W - a[3]) / (b[3] - a[3]);
-            out[n][0] = a[0] + t * (b[0] - a[0]);
-            out[n][1] = a[1] + t * (b[1] - a[1]);
-            out[n][2] = a[2] + t * (b[2] - a[2]);
+            out[n][0] = fmaf(t, b[0] - a[0], a[0]);
+            out[n][1] = fmaf(t, b[1] - a[1], a[1]);
+            out[n][2] = fmaf(t, b[2] - a[2], a[2]);
             out[n][3] = NEAR_W;
             n++;
         }
@@ -1207,11 +1208,13 @@ static int clip_near(float c[3][4], float out[4][4]) {
 
 static inline int bary(const stri_t *s, float px, float py, float *b) {
     float x0 = s->sx[0], y0 = s->sy[0], x1 = s->sx[1], y1 = s->sy[1], x2 = s->sx[2], y2 = s->sy[2];
-    float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+    /* every product-difference is one multiplication and one fused multiply-add (a C fmaf and the GPU's v_fma_f32 round
+     * identically, so the HIP path reproduces these bits with half the instructions of the unfused form) */
+    float area = fmaf(x1 - x0, y2 - y0, -((x2 - x0) * (y1 - y0)));
     if (fabsf(area) < 1e-12f) return 0;
     float ia = 1.0f / area;
-    b[0] = ((x1 - px) * (y2 - py) - (x2 - px) * (y1 - py)) * ia;
-    b[1] = ((x2 - px) * (y0 - py) - (x0 - px) * (y2 - py)) * ia;
+    b[0] = fmaf(x1 - px, y2 - py, -((x2 - px) * (y1 - py))) * ia;
+    b[1] = fmaf(x2 - px, y0 - py, -((x0 - px) * (y2 - py))) * ia;
     b[2] = 1.0f - b[0] - b[1];
     return b[0] >= 0 && b[1] >= 0 && b[2] >= 0;
 }
@@ -1263,8 +1266,8 @@ void rro_render(rr_oracle *o, uint8_t *rgb, float *depth, int32_t *mask) {
                 for (int px = x0; px <= x1; px++) {
                     float b[3];
                     if (!bary(&s, (float)px, (float)py, b)) continue;
-                    float z = b[0] * s.sz[0] + b[1] * s.sz[1] + b[2] * s.sz[2];
-                    float d = 0.5f * z + 0.5f;
+                    float z = fmaf(b[0], s.sz[0], fmaf(b[1], s.sz[1], b[2] * s.sz[2]));
+                    float d = fmaf(0.5f, z, 0.5f);
                     if (!(d >= 0.0f && d <= 1.0f)) continue;
                     uint32_t db;
                     memcpy(&db, &d, 4);

@@ -2167,22 +2167,25 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 
 struct STri { float sx[3], sy[3], sz[3], w[3]; };
 
-// Coverage decisions are discontinuous: projection, barycentrics and depth are evaluated without FMA contraction so
-// that they round exactly like the oracle's (gcc -ffp-contract=off) -- geometry a few cm from the near plane projects to
-// huge screen coordinates where one rounding flips whole pixel bands.
+// Coverage decisions are discontinuous: projection, barycentrics and depth must round exactly like the oracle's --
+// geometry a few cm from the near plane projects to huge screen coordinates where one rounding flips whole pixel bands.
+// So nothing here is left to the compiler's contraction: the fused operations are written out (a C fmaf in the oracle and
+// v_fma_f32 round identically), everything else is compiled contraction-free.
+#define FMA3(a0, x0, a1, x1, a2, x2, c) __builtin_fmaf((a0), (x0), __builtin_fmaf((a1), (x1), __builtin_fmaf((a2), (x2), (c))))   // a0 x0 + (a1 x1 + (a2 x2 + c))
+#define PDIFF(a, b, c, d) __builtin_fmaf((a), (b), -((c) * (d)))                                                                  // a b - c d: one product, one fused step
 __device__ __forceinline__ bool project_tri(const float *mvp, const float *tp /*9 floats*/, int W, int H, STri &s) {
 #pragma clang fp contract(off)
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float vx = tp[3 * k], vy = tp[3 * k + 1], vz = tp[3 * k + 2];
-        float cx = mvp[0] * vx + mvp[1] * vy + mvp[2] * vz + mvp[3];
-        float cy = mvp[4] * vx + mvp[5] * vy + mvp[6] * vz + mvp[7];
-        float cz = mvp[8] * vx + mvp[9] * vy + mvp[10] * vz + mvp[11];
-        float cw = mvp[12] * vx + mvp[13] * vy + mvp[14] * vz + mvp[15];
+        float cx = FMA3(mvp[0], vx, mvp[1], vy, mvp[2], vz, mvp[3]);
+        float cy = FMA3(mvp[4], vx, mvp[5], vy, mvp[6], vz, mvp[7]);
+        float cz = FMA3(mvp[8], vx, mvp[9], vy, mvp[10], vz, mvp[11]);
+        float cw = FMA3(mvp[12], vx, mvp[13], vy, mvp[14], vz, mvp[15]);
         if (cw < 0.1f) return false;
         float iw = 1.0f / cw;
-        s.sx[k] = (cx * iw + 1.0f) * (0.5f * (float)W);
-        s.sy[k] = (cy * iw + 1.0f) * (0.5f * (float)H);
+        s.sx[k] = __builtin_fmaf(cx * iw, 0.5f * (float)W, 0.5f * (float)W);
+        s.sy[k] = __builtin_fmaf(cy * iw, 0.5f * (float)H, 0.5f * (float)H);
         s.sz[k] = cz * iw;
         s.w[k] = iw;             // reciprocal clip w (deferred shading)
     }
@@ -2192,13 +2195,13 @@ __device__ __forceinline__ bool project_tri(const float *mvp, const float *tp /*
 // One vertex of project_tri (identical arithmetic); a vertex nearer than the near plane yields sx = NaN.
 __device__ __forceinline__ void project_vertex(const float *mvp, float vx, float vy, float vz, int W, int H, float &sx, float &sy, float &sz) {
 #pragma clang fp contract(off)
-    const float cx = mvp[0] * vx + mvp[1] * vy + mvp[2] * vz + mvp[3];
-    const float cy = mvp[4] * vx + mvp[5] * vy + mvp[6] * vz + mvp[7];
-    const float cz = mvp[8] * vx + mvp[9] * vy + mvp[10] * vz + mvp[11];
-    const float cw = mvp[12] * vx + mvp[13] * vy + mvp[14] * vz + mvp[15];
+    const float cx = FMA3(mvp[0], vx, mvp[1], vy, mvp[2], vz, mvp[3]);
+    const float cy = FMA3(mvp[4], vx, mvp[5], vy, mvp[6], vz, mvp[7]);
+    const float cz = FMA3(mvp[8], vx, mvp[9], vy, mvp[10], vz, mvp[11]);
+    const float cw = FMA3(mvp[12], vx, mvp[13], vy, mvp[14], vz, mvp[15]);
     const float iw = 1.0f / cw;
-    sx = (cw < 0.1f) ? __int_as_float(0x7fc00000) : (cx * iw + 1.0f) * (0.5f * (float)W);
-    sy = (cy * iw + 1.0f) * (0.5f * (float)H);
+    sx = (cw < 0.1f) ? __int_as_float(0x7fc00000) : __builtin_fmaf(cx * iw, 0.5f * (float)W, 0.5f * (float)W);
+    sy = __builtin_fmaf(cy * iw, 0.5f * (float)H, 0.5f * (float)H);
     sz = cz * iw;
 }
 // Near-plane clipping (oracle clip_near / to_screen, identical arithmetic): clip coordinates of one vertex, the screen
@@ -2207,35 +2210,35 @@ __device__ __forceinline__ void project_vertex(const float *mvp, float vx, float
 #define NEAR_W 0.1f
 __device__ __forceinline__ void clip_vertex(const float *mvp, float vx, float vy, float vz, float *c) {
 #pragma clang fp contract(off)
-    c[0] = mvp[0] * vx + mvp[1] * vy + mvp[2] * vz + mvp[3];
-    c[1] = mvp[4] * vx + mvp[5] * vy + mvp[6] * vz + mvp[7];
-    c[2] = mvp[8] * vx + mvp[9] * vy + mvp[10] * vz + mvp[11];
-    c[3] = mvp[12] * vx + mvp[13] * vy + mvp[14] * vz + mvp[15];
+    c[0] = FMA3(mvp[0], vx, mvp[1], vy, mvp[2], vz, mvp[3]);
+    c[1] = FMA3(mvp[4], vx, mvp[5], vy, mvp[6], vz, mvp[7]);
+    c[2] = FMA3(mvp[8], vx, mvp[9], vy, mvp[10], vz, mvp[11]);
+    c[3] = FMA3(mvp[12], vx, mvp[13], vy, mvp[14], vz, mvp[15]);
 }
 __device__ __forceinline__ void clip_to_screen(const float *c, int W, int H, float &sx, float &sy, float &sz) {
 #pragma clang fp contract(off)
     const float iw = 1.0f / c[3];
-    sx = (c[0] * iw + 1.0f) * (0.5f * (float)W);
-    sy = (c[1] * iw + 1.0f) * (0.5f * (float)H);
+    sx = __builtin_fmaf(c[0] * iw, 0.5f * (float)W, 0.5f * (float)W);
+    sy = __builtin_fmaf(c[1] * iw, 0.5f * (float)H, 0.5f * (float)H);
     sz = c[2] * iw;
 }
 __device__ __forceinline__ void clip_edge(const float *a, const float *b, float *o) {
 #pragma clang fp contract(off)
     const float t = (NEAR_W - a[3]) / (b[3] - a[3]);
-    o[0] = a[0] + t * (b[0] - a[0]);
-    o[1] = a[1] + t * (b[1] - a[1]);
-    o[2] = a[2] + t * (b[2] - a[2]);
+    o[0] = __builtin_fmaf(t, b[0] - a[0], a[0]);
+    o[1] = __builtin_fmaf(t, b[1] - a[1], a[1]);
+    o[2] = __builtin_fmaf(t, b[2] - a[2], a[2]);
     o[3] = NEAR_W;
 }
 
 __device__ __forceinline__ bool bary(const STri &s, float px, float py, float *b) {
 #pragma clang fp contract(off)
     float x0 = s.sx[0], y0 = s.sy[0], x1 = s.sx[1], y1 = s.sy[1], x2 = s.sx[2], y2 = s.sy[2];
-    float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+    float area = PDIFF(x1 - x0, y2 - y0, x2 - x0, y1 - y0);
     if (fabsf(area) < 1e-12f) return false;
     float ia = 1.0f / area;
-    b[0] = ((x1 - px) * (y2 - py) - (x2 - px) * (y1 - py)) * ia;
-    b[1] = ((x2 - px) * (y0 - py) - (x0 - px) * (y2 - py)) * ia;
+    b[0] = PDIFF(x1 - px, y2 - py, x2 - px, y1 - py) * ia;
+    b[1] = PDIFF(x2 - px, y0 - py, x0 - px, y2 - py) * ia;
     b[2] = 1.0f - b[0] - b[1];
     return b[0] >= 0 && b[1] >= 0 && b[2] >= 0;
 }
@@ -2247,8 +2250,8 @@ __device__ __forceinline__ void raster_pixel(const STri &s, int t, int px, int p
     if (row < row0 || row >= row0 + rows) return;
     float b[3];
     if (!bary(s, (float)px, (float)py, b)) return;
-    float z = b[0] * s.sz[0] + b[1] * s.sz[1] + b[2] * s.sz[2];
-    float d = 0.5f * z + 0.5f;
+    float z = __builtin_fmaf(b[0], s.sz[0], __builtin_fmaf(b[1], s.sz[1], b[2] * s.sz[2]));
+    float d = __builtin_fmaf(0.5f, z, 0.5f);
     if (!(d >= 0.0f && d <= 1.0f)) return;
     unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
     atomicMin(&vis[(row - row0) * W + px], key);
@@ -2259,7 +2262,7 @@ __device__ __forceinline__ void raster_pixel(const STri &s, int t, int px, int p
 struct TriEdge { float ia; bool ok; };
 __device__ __forceinline__ TriEdge tri_edge(const STri &s) {
 #pragma clang fp contract(off)
-    float area = (s.sx[1] - s.sx[0]) * (s.sy[2] - s.sy[0]) - (s.sx[2] - s.sx[0]) * (s.sy[1] - s.sy[0]);
+    float area = PDIFF(s.sx[1] - s.sx[0], s.sy[2] - s.sy[0], s.sx[2] - s.sx[0], s.sy[1] - s.sy[0]);
     TriEdge e;
     e.ok = !(fabsf(area) < 1e-12f);
     e.ia = 1.0f / area;
@@ -2269,12 +2272,12 @@ __device__ __forceinline__ void raster_pixel_hoisted(const STri &s, float ia, in
                                                      unsigned long long *vis) {
 #pragma clang fp contract(off)
     const float fx = (float)px, fy = (float)py;
-    const float b0 = ((s.sx[1] - fx) * (s.sy[2] - fy) - (s.sx[2] - fx) * (s.sy[1] - fy)) * ia;
-    const float b1 = ((s.sx[2] - fx) * (s.sy[0] - fy) - (s.sx[0] - fx) * (s.sy[2] - fy)) * ia;
+    const float b0 = PDIFF(s.sx[1] - fx, s.sy[2] - fy, s.sx[2] - fx, s.sy[1] - fy) * ia;
+    const float b1 = PDIFF(s.sx[2] - fx, s.sy[0] - fy, s.sx[0] - fx, s.sy[2] - fy) * ia;
     const float b2 = 1.0f - b0 - b1;
     if (!(b0 >= 0 && b1 >= 0 && b2 >= 0)) return;
-    const float z = b0 * s.sz[0] + b1 * s.sz[1] + b2 * s.sz[2];
-    const float d = 0.5f * z + 0.5f;
+    const float z = __builtin_fmaf(b0, s.sz[0], __builtin_fmaf(b1, s.sz[1], b2 * s.sz[2]));
+    const float d = __builtin_fmaf(0.5f, z, 0.5f);
     if (!(d >= 0.0f && d <= 1.0f)) return;
     const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
     atomicMin(&vis[(H - 1 - py - row0) * W + px], key);
@@ -2290,8 +2293,8 @@ __device__ __forceinline__ bool block_may_overlap(const STri &s, float ia, int p
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const float fx = (float)((c & 1) ? px1 : px0), fy = (float)((c & 2) ? py1 : py0);
-        const float b0 = ((s.sx[1] - fx) * (s.sy[2] - fy) - (s.sx[2] - fx) * (s.sy[1] - fy)) * ia;
-        const float b1 = ((s.sx[2] - fx) * (s.sy[0] - fy) - (s.sx[0] - fx) * (s.sy[2] - fy)) * ia;
+        const float b0 = PDIFF(s.sx[1] - fx, s.sy[2] - fy, s.sx[2] - fx, s.sy[1] - fy) * ia;
+        const float b1 = PDIFF(s.sx[2] - fx, s.sy[0] - fy, s.sx[0] - fx, s.sy[2] - fy) * ia;
         const float b2 = 1.0f - b0 - b1;
         m0 = fmaxf(m0, b0); m1 = fmaxf(m1, b1); m2 = fmaxf(m2, b2);
     }
@@ -2520,7 +2523,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             float ymin = fminf(s.sy[0], fminf(s.sy[1], s.sy[2])), ymax = fmaxf(s.sy[0], fmaxf(s.sy[1], s.sy[2]));
             live = !(xmax < 0 || ymax < ty0 || xmin > (float)(W - 1) || ymin > ty1);
             // back faces of closed, consistently wound meshes can never win the depth test (opt-in, RR_CULL)
-            if (live && RM.in_cull[inst] && (s.sx[1] - s.sx[0]) * (s.sy[2] - s.sy[0]) - (s.sx[2] - s.sx[0]) * (s.sy[1] - s.sy[0]) <= 0.0f) live = false;
+            if (live && RM.in_cull[inst] && PDIFF(s.sx[1] - s.sx[0], s.sy[2] - s.sy[0], s.sx[2] - s.sx[0], s.sy[1] - s.sy[0]) <= 0.0f) live = false;
             if (live) {
                 x0 = (int)ceilf(fmaxf(xmin, 0.0f)); x1 = (int)floorf(fminf(xmax, (float)(W - 1)));
                 y0 = (int)ceilf(fmaxf(ymin, ty0)); y1 = (int)floorf(fminf(ymax, ty1));
