@@ -121,6 +121,7 @@ struct DevPtrs {
     int *hgflag;       // [ceil(N/4)] != 0: this solver group (four consecutive envs) holds an env with generic contacts -- "heavy"
     int *hlist;        // [ceil(N/4)] the heavy groups of this step (in arrival order: placement only, never a result)
     int *hcount;       // [1] their number
+    int *hcount_host;  // device address of the pinned host word that receives the previous step's number (or nullptr)
     int *timestep;     // [N]
     unsigned *errflags;// [N]
     float *obj_home;   // [NOBJ*7][N] per-env pose an object is put back to by reset / the out-of-bounds rule (robot.py:19-24, mutable there)
@@ -350,7 +351,11 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
     float *state = D.state, *scratch = D.scratch;
     if (PHASE == 1) {       // k_collide classifies the solver groups of this step: reset its bookkeeping (no extra launch)
         if ((env & 3) == 0) D.hgflag[env >> 2] = 0;
-        if (env == 0) { D.hcount[0] = 0; D.hcount[1] = 0; }
+        if (env == 0) {
+            // (the count of the step before goes to pinned host memory on the way: a posted write, nobody waits for it)
+            if (D.hcount_host) *D.hcount_host = D.hcount[0];
+            D.hcount[0] = 0; D.hcount[1] = 0;
+        }
     }
     if (PHASE == 2) { if (D.errflags[env]) return; }    // frozen, or command rejected by phase 1
     else {
@@ -2976,7 +2981,7 @@ struct rr_env {
     std::vector<void *> allocs;
     bool timing;
     bool full_copy, sep_restore;   // RR_FULL_COPY / RR_SEPARATE_RESTORE at create: the two earlier image-update schemes (tests, A/B)
-    int *h_hcount;                 // pinned host copy of D.hcount[0], refreshed asynchronously every step
+    int *h_hcount;                 // pinned host copy of D.hcount[0] (device-mapped: written by k_prep_a of the following step)
     bool split_heavy;              // heavy solver groups + their render on the side stream (RR_NO_SPLIT=1 turns it off: A/B, tests)
     bool images_valid;       // every env's image holds its previous frame (static layer + the pixels of its fragment list)
     hipEvent_t ev[2 * RR_NUM_KERNELS];
@@ -3119,7 +3124,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->sep_restore = getenv("RR_SEPARATE_RESTORE") != nullptr;
     e->split_heavy = getenv("RR_NO_SPLIT") == nullptr;
     e->h_hcount = nullptr;
-    if (hipHostMalloc((void **)&e->h_hcount, sizeof(int), hipHostMallocDefault) == hipSuccess) *e->h_hcount = 0; else e->h_hcount = nullptr;
+    if (hipHostMalloc((void **)&e->h_hcount, sizeof(int), hipHostMallocMapped) == hipSuccess) *e->h_hcount = 0; else e->h_hcount = nullptr;
     e->plan = nullptr; e->plan_step = nullptr; e->ik_in = nullptr; e->ik_out = nullptr; e->ik_err = nullptr;
     e->cfg = *cfg;
     e->stream = (hipStream_t)stream;
@@ -3243,6 +3248,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     ALLOC(D.hgflag, (size_t)(N + 3) / 4);
     ALLOC(D.hlist, (size_t)(N + 3) / 4);
     ALLOC(D.hcount, (size_t)4);
+    e->D.hcount_host = nullptr;
+    if (e->h_hcount && hipHostGetDevicePointer((void **)&e->D.hcount_host, e->h_hcount, 0) != hipSuccess) e->D.hcount_host = nullptr;
     ALLOC(D.timestep, (size_t)N);
     ALLOC(D.errflags, (size_t)N);
     ALLOC(D.obj_home, (size_t)NOBJ * 7 * N);
@@ -3553,9 +3560,8 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     if (dyn_forked) hipStreamWaitEvent(e->stream, e->ev_dyn, 0);
     const int ngroups = (N + SGRP - 1) / SGRP;
     const size_t lds64 = (size_t)SGRP * LF_TOTAL * sizeof(float);
-    // (the number of heavy groups of a recent step, copied to pinned host memory without waiting for it: when most groups are
+    // (the number of heavy groups of a recent step, written to pinned host memory by k_prep_a without anybody waiting for it: when most groups are
     // heavy -- macro actions, every gripper pushing -- there is nothing to gain from the split)
-    if (e->h_hcount) HIPCHK(hipMemcpyAsync(e->h_hcount, e->D.hcount, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     const bool mostly_heavy = e->h_hcount && *(volatile int *)e->h_hcount * 4 > ngroups;
     if (dyn_forked && render_mode && e->split_heavy && !mostly_heavy) {
         // The few solver groups with generic contact rows take several times as long as the others (the kernel lasts as long

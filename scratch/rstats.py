@@ -8,14 +8,15 @@ from real_robots_amd import _native as nat
 from real_robots_amd.batched import BatchedREALRobotEnv
 from real_robots_amd.distributed import synthetic_actions
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+SC = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 env = BatchedREALRobotEnv(N, objects=3, width=128, height=128)
 lib = nat.load_library()
 ids = list(range(N))
 for t in range(160):
-    env.step(synthetic_actions(ids, (t // 20) * 20) * 0.5, render=False)
+    env.step(synthetic_actions(ids, (t // 20) * 20, hold_prob=0.05) * SC, render=False)
 out = (ctypes.c_ulonglong * 16)()
 lib.rr_debug_raster_stats(out, 1)
-env.step(synthetic_actions(ids, 160) * 0.5, render=True); env.sync() if hasattr(env, 'sync') else None
+env.step(synthetic_actions(ids, 160, hold_prob=0.05) * SC, render=True); env.sync() if hasattr(env, 'sync') else None
 torch.cuda.synchronize()
 lib.rr_debug_raster_stats(out, 0)
 v = np.array(list(out), dtype=np.float64) / N
