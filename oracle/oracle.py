@@ -28,7 +28,7 @@ class Params(C.Structure):
     _fields_ = [('dt', C.c_double), ('gravity', C.c_double), ('solver_iters', C.c_int), ('erp', C.c_double),
                 ('margin', C.c_double), ('motor_kp', C.c_double), ('motor_kd', C.c_double),
                 ('motor_max_force', C.c_double), ('lin_damping', C.c_double), ('ang_damping', C.c_double),
-                ('rest_threshold', C.c_double), ('use_urdf_inertia', C.c_int)]
+                ('rest_threshold', C.c_double), ('use_urdf_inertia', C.c_int), ('edge_contacts', C.c_int)]
 
 
 def build(force=False):

@@ -76,6 +76,7 @@ static const uint8_t *blob_u8(const void *blob, const char *name) {
 
 /* ------------------------------------------------------------------------------------------- model */
 #define MAXSHAPES 32
+#define EMAXC 48         /* long sharp hull edges per shape (tools/compile_model.py EMAX) */
 #define VMAXC 192
 #define FMAXC 192
 #define MAXINST 32
@@ -92,6 +93,8 @@ typedef struct {
     int sh_nv[MAXSHAPES], sh_nf[MAXSHAPES];
     real sh_verts[MAXSHAPES][VMAXC][3], sh_planes[MAXSHAPES][FMAXC][4], sh_sphere[MAXSHAPES][4];
     real sh_fric[MAXSHAPES], sh_rest[MAXSHAPES], sh_roll[MAXSHAPES], sh_spin[MAXSHAPES];
+    int sh_ne[MAXSHAPES];
+    real sh_edges[MAXSHAPES][EMAXC][12];     /* long sharp hull edges: p0, p1 - p0, the two facet normals (owner frame) */
     int touch_links[4];
     int link_body[MAXLINKS];
     real link_pos[MAXLINKS][3], link_rot[MAXLINKS][9];
@@ -230,7 +233,7 @@ static void inertia_world(real *Iw, const real *R, const real *I6) {
 
 /* ------------------------------------------------------------------------------------------- create */
 void rro_default_params(rro_params *p) {
-    p->dt = 0.005; p->gravity = 9.81; p->solver_iters = 50; p->erp = 0.2; p->margin = 0.02;
+    p->dt = 0.005; p->gravity = 9.81; p->solver_iters = 50; p->erp = 0.2; p->margin = 0.02; p->edge_contacts = 1;
     p->motor_kp = 0.1; p->motor_kd = 1.0; p->motor_max_force = 100000.0;
     p->lin_damping = 0.04; p->ang_damping = 0.04; p->rest_threshold = 0.2; p->use_urdf_inertia = 0;
 }
@@ -279,6 +282,8 @@ rr_oracle *rro_create(const void *blob_in, size_t nbytes, int n_objects, int wid
     for (int s = 0; s < m->ns; s++) { m->sh_fric[s] = sm[2 * s]; m->sh_rest[s] = sm[2 * s + 1]; }
     const float *sr = blob_f32(blob, "shape_roll");
     for (int s = 0; s < m->ns; s++) { m->sh_roll[s] = sr[2 * s]; m->sh_spin[s] = sr[2 * s + 1]; }
+    memcpy(m->sh_ne, blob_i32(blob, "shape_ne"), sizeof(int) * m->ns);
+    cpy_f(&m->sh_edges[0][0][0], blob_f32(blob, "shape_edges"), m->ns * EMAXC * 12);
     memcpy(m->touch_links, blob_i32(blob, "touch_links"), sizeof(int) * 4);
     memcpy(m->link_body, blob_i32(blob, "link_body"), sizeof(int) * m->nl);
     cpy_f(&m->link_pos[0][0], blob_f32(blob, "link_pos"), m->nl * 3);
@@ -529,6 +534,71 @@ static int verts_in_planes(const rr_oracle *o, int sa, const xform_t *Xa, int sb
     return n;
 }
 
+/* Edge-edge candidates.  The vertex tests above cannot see two edges that cross away from any vertex (a cube edge lying
+ * across a shelf edge: GJK/EPA in Bullet reports the closest points of the two edges).  For every pair of long sharp hull
+ * edges (tools/compile_model.py: >= 1.5 cm, dihedral angle >= 15 degrees, the 48 longest of a shape) whose lines' closest
+ * points lie strictly inside both segments: the common normal n = +-(d1 x d2)/|d1 x d2| is a contact normal iff it is a
+ * face of the Minkowski difference, i.e. the direction u from A towards B lies in the fan between the two facet normals
+ * of A's edge and -u in the fan of B's edge.  With the closest points inside both segments such a pair is the closest
+ * feature pair of the two convex shapes when they are apart (signed distance along the normal B -> A in [0, margin)); for
+ * overlapping shapes it is one separating-axis candidate among others, accepted only while shallow (> -EDGE_DEPTH): the
+ * true minimum translation is then no deeper than that. */
+#define EDGE_DEPTH ((real)0.005)
+#define EDGE_SLOP ((real)0.0005)
+static int edge_edge(const rr_oracle *o, int sa, const xform_t *Xa, int sb, const xform_t *Xb, cand_t *out, int n) {
+    const model_t *m = &o->m;
+    real margin = (real)o->p.margin;
+    /* overlapping shapes: an edge axis is only the contact normal if it is not deeper than the face axes -- the deepest
+     * vertex candidate measures those (a gripper pad pressed on a cube face overlaps it by a fraction of a millimetre; the
+     * pad's edges cross the cube's edges with much larger overlaps along their common normals, which are no contacts) */
+    real smin = 0;
+    for (int i = 0; i < n; i++) if (out[i].s < smin) smin = out[i].s;
+    const real lo = o->p.edge_contacts == 2 ? (real)-1 : smin - EDGE_SLOP;      /* (2: diagnostic, no such guard) */
+    for (int i = 0; i < m->sh_ne[sa]; i++) {
+        const real *ea = m->sh_edges[sa][i];
+        real P0[3], D1[3], a1[3], a2[3];
+        m3_mulv(P0, Xa->R, ea); v3_add(P0, P0, Xa->p);
+        m3_mulv(D1, Xa->R, ea + 3); m3_mulv(a1, Xa->R, ea + 6); m3_mulv(a2, Xa->R, ea + 9);
+        for (int j = 0; j < m->sh_ne[sb]; j++) {
+            const real *eb = m->sh_edges[sb][j];
+            real Q0[3], D2[3], b1[3], b2[3];
+            m3_mulv(Q0, Xb->R, eb); v3_add(Q0, Q0, Xb->p);
+            m3_mulv(D2, Xb->R, eb + 3); m3_mulv(b1, Xb->R, eb + 6); m3_mulv(b2, Xb->R, eb + 9);
+            real r[3];
+            v3_sub(r, P0, Q0);
+            real a = v3_dot(D1, D1), e = v3_dot(D2, D2), b = v3_dot(D1, D2), c = v3_dot(D1, r), f = v3_dot(D2, r);
+            real ae = a * e, den = ae - b * b;
+            if (!(den > (real)1e-4 * ae)) continue;           /* (nearly) parallel: left to the end points */
+            real s = (b * f - c * e) / den, t = (a * f - b * c) / den;
+            if (!(s > 0 && s < 1 && t > 0 && t < 1)) continue;
+            real p[3], q[3], nv[3], u[3], w[3], ma[3], mb[3], c1[3], c2[3], pq[3];
+            for (int k = 0; k < 3; k++) { p[k] = P0[k] + s * D1[k]; q[k] = Q0[k] + t * D2[k]; }
+            v3_cross(nv, D1, D2);
+            real il = (real)1 / RSQRT(v3_dot(nv, nv));
+            v3_add(ma, a1, a2);
+            real sg = v3_dot(nv, ma) > 0 ? il : -il;           /* u: unit, from A towards B */
+            v3_scale(u, nv, sg);
+            v3_cross(c1, a1, u); v3_cross(c2, u, a2);
+            if (!(v3_dot(c1, c2) >= 0)) continue;
+            v3_scale(w, u, (real)-1);
+            v3_add(mb, b1, b2);
+            if (!(v3_dot(w, mb) > 0)) continue;
+            v3_cross(c1, b1, w); v3_cross(c2, w, b2);
+            if (!(v3_dot(c1, c2) >= 0)) continue;
+            v3_sub(pq, p, q);
+            real dist = v3_dot(w, pq);
+            if (!(dist < margin && dist > -EDGE_DEPTH && dist > lo)) continue;
+            if (n < CAND_MAX) {
+                cand_t *cd = &out[n++];
+                for (int k = 0; k < 3; k++) cd->x[k] = q[k] + (real)0.5 * pq[k];
+                v3_copy(cd->n, w);
+                cd->s = dist;
+            }
+        }
+    }
+    return n;
+}
+
 /* Manifold reduction to <= 4 points: deepest point first, then the three points that spread the manifold most
  * (farthest from the first, farthest from that line, farthest on the other side of it). "Deepest" is taken with a
  * tolerance (TIE_TOL, see below). Candidates within
@@ -604,6 +674,7 @@ static void collide_pair(rr_oracle *o, int sa, int sb, const xform_t *X) {
     int n = 0;
     n = verts_in_planes(o, sa, Xa, sb, Xb, (real)1, cand, n);   /* A's vertices in B: normal B->A */
     n = verts_in_planes(o, sb, Xb, sa, Xa, (real)-1, cand, n);  /* B's vertices in A: normal A->B, flipped */
+    if (o->p.edge_contacts) n = edge_edge(o, sa, Xa, sb, Xb, cand, n);
     if (n == 0) return;
     int sel[4];
     int k = reduce4(cand, n, sel);

@@ -47,6 +47,7 @@ typedef struct rro_params {
     double ang_damping;     /* 0.04 */
     double rest_threshold;  /* 0.2              m_restitutionVelocityThreshold */
     int use_urdf_inertia;   /* 0: Bullet AABB inertia for robot links (default); 1: URDF <inertia> */
+    int edge_contacts;      /* 1                edge-edge candidates for pairs without a vertex candidate (0: vertex tests only) */
 } rro_params;
 
 typedef struct rr_oracle rr_oracle;

@@ -39,6 +39,7 @@
 #define MAXSHAPES 32
 #define VMAXC 192        // caps of collision vertices / planes per shape (tools/compile_model.py stops earlier at 0.3 mm)
 #define FMAXC 192
+#define EMAXC 48         // long sharp hull edges per shape (tools/compile_model.py EMAX)
 #define MAXINST 32
 #define MAXPAIRS 96
 #define NSTATE 61
@@ -64,7 +65,7 @@ struct BodyParams {   // passed by value as kernel argument -> scalar loads, uni
 };
 
 struct SimParams {
-    int N, nobj, iters, npairs, ablate, small_area, os_cap;   // os_cap: object-vs-static contacts per env with rows in LDS (<= OS_CAP)
+    int N, nobj, iters, npairs, ablate, small_area, os_cap, edge_contacts;   // os_cap: object-vs-static contacts per env with rows in LDS (<= OS_CAP)
     float dt, gravity, erp, margin, kp, kd, max_impulse, lin_damp, ang_damp, rest_thresh;
 };
 
@@ -74,6 +75,8 @@ struct ShapeData {    // global memory, read uniformly
     float planes[MAXSHAPES][FMAXC][4];
     float sphere[MAXSHAPES][4];
     float fric[MAXSHAPES], rest[MAXSHAPES], roll[MAXSHAPES], spin[MAXSHAPES];
+    int ne[MAXSHAPES];
+    float edges[MAXSHAPES][EMAXC][12];    // long sharp hull edges: p0, p1 - p0, the two facet normals (owner frame)
     int pair_a[MAXPAIRS], pair_b[MAXPAIRS];
     int pair_meta[MAXPAIRS][4];      // {bodyA, bodyB, link of shape a, 0}: body = -1 static, 0..15 robot body, 16+i object i
     float pair_mat[MAXPAIRS][4];     // {friction, restitution} products of the two shapes, combined {rolling, spinning} friction
@@ -688,6 +691,47 @@ static_assert(CCHUNK * 4 == COLLIDE_THREADS && CCHUNK <= 64 && MAXPAIRS < 256, "
 static_assert(VMAXC % 64 == 0 && FMAXC % 64 == 0 && VMAXC < 256 && FMAXC < 256, "vertex / plane passes of 64, counts packed in bytes");
 // (the whole kernel is contraction-free and uses the nc:: helpers: see "contraction-free twins" above)
 #pragma clang fp contract(off)
+// An edge of a shape in the world frame, and the edge-edge candidate test -- the oracle's edge_edge(), operation for operation.
+struct EdgeW { v3 p0, d, n1, n2; };
+__device__ __forceinline__ EdgeW edge_world(const float *e, const float *x /* R (9), p (3) */) {
+    m3 R;
+#pragma unroll
+    for (int k = 0; k < 9; k++) R.m[k] = x[k];
+    EdgeW E;
+    E.p0 = nc::add(nc::mulv(R, mk(e[0], e[1], e[2])), mk(x[9], x[10], x[11]));
+    E.d = nc::mulv(R, mk(e[3], e[4], e[5]));
+    E.n1 = nc::mulv(R, mk(e[6], e[7], e[8]));
+    E.n2 = nc::mulv(R, mk(e[9], e[10], e[11]));
+    return E;
+}
+// true: the closest points of the two edge lines lie strictly inside both segments, the common normal is a face of the
+// Minkowski difference and the signed distance along it is inside (-EDGE_DEPTH, margin); cnd = (contact point, distance),
+// nrm = the normal B -> A
+__device__ __forceinline__ bool edge_pair(const EdgeW &A, const EdgeW &B, float margin, float lo, float4 &cnd, v3 &nrm) {
+    const v3 r = nc::sub(A.p0, B.p0);
+    const float a = nc::dot(A.d, A.d), e = nc::dot(B.d, B.d), b = nc::dot(A.d, B.d), c = nc::dot(A.d, r), f = nc::dot(B.d, r);
+    const float ae = a * e, den = ae - b * b;
+    nrm = mk(0, 0, 0); cnd = make_float4(0, 0, 0, 0);
+    if (!(den > 1e-4f * ae)) return false;
+    const float s = (b * f - c * e) / den, t = (a * f - b * c) / den;
+    if (!(s > 0 && s < 1 && t > 0 && t < 1)) return false;
+    const v3 p = nc::add(A.p0, nc::scale(A.d, s)), q = nc::add(B.p0, nc::scale(B.d, t));
+    const v3 nv = nc::cross(A.d, B.d);
+    const float il = 1.0f / sqrtf(nc::dot(nv, nv));
+    const float sg = nc::dot(nv, nc::add(A.n1, A.n2)) > 0 ? il : -il;
+    const v3 u = nc::scale(nv, sg);
+    if (!(nc::dot(nc::cross(A.n1, u), nc::cross(u, A.n2)) >= 0)) return false;
+    const v3 w = nc::scale(u, -1.0f);
+    if (!(nc::dot(w, nc::add(B.n1, B.n2)) > 0)) return false;
+    if (!(nc::dot(nc::cross(B.n1, w), nc::cross(w, B.n2)) >= 0)) return false;
+    const v3 pq = nc::sub(p, q);
+    const float dist = nc::dot(w, pq);
+    if (!(dist < margin && dist > -0.005f && dist > lo)) return false;      // (oracle EDGE_DEPTH; lo: not deeper than the face axes)
+    const v3 x = nc::add(q, nc::scale(pq, 0.5f));
+    cnd = make_float4(x.x, x.y, x.z, dist);
+    nrm = w;
+    return true;
+}
 // index of the first maximum of val(i) over the candidates i < n with ok(i), or -1 when there is none above `floor_`;
 // candidates are visited 64 at a time, a later chunk only replaces the winner when it is strictly greater
 #define CAND_ARGMAX(RESULT, FLOOR, OKEXPR, VALEXPR)                                                   \
@@ -718,7 +762,8 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
     __shared__ float xf[CSHAPES][12];          // R (row-major 9), p (3) of every shape's owner
     __shared__ float4 sph[CSHAPES];            // world bounding sphere
     __shared__ int pair_ab[MAXPAIRS];          // shape a | shape b << 8 of every pair   } staged once: no global load of
-    __shared__ int shape_n[CSHAPES];           // vertex count | plane count << 8        } metadata inside the pair loop
+    __shared__ int shape_n[CSHAPES];           // vertex count | plane count << 8 | edge count << 16   } metadata inside the pair loop
+    __shared__ unsigned char edge_id[COLLIDE_WAVES][2][EMAXC];   // per wave: the original indices of the staged edges
     __shared__ unsigned char close_pair[MAXPAIRS];   // the pairs that pass the sphere test, in pair order
     __shared__ int n_close, next_item, nct_sh;
     __shared__ float4 res_a[CCHUNK][4];        // per close pair of the chunk: the kept candidates (contact point, signed distance)
@@ -742,7 +787,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
         pair_ab[pr] = S->pair_a[pr] | (S->pair_b[pr] << 8) | (cls << 16);      // + robot involved (bit 16), object-object (bit 17)
     }
     if (tid < ns) {
-        shape_n[tid] = S->nv[tid] | (S->nf[tid] << 8);
+        shape_n[tid] = S->nv[tid] | (S->nf[tid] << 8) | (S->ne[tid] << 16);
         const Xf X = load_xf(S, tid, state, scratch, N, env);
 #pragma unroll
         for (int k = 0; k < 9; k++) xf[tid][k] = X.R.m[k];
@@ -790,6 +835,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
             const int pair = close_pair[item];
             const int sa = pair_ab[pair] & 255, sb = (pair_ab[pair] >> 8) & 255;
             int ncand = 0;                      // wave-uniform
+            bool apart = false;                 // the exact cull of a direction found the shapes more than the margin apart
             for (int dirflag = 0; dirflag < 2; dirflag++) {
                 // "mine" = the shape whose vertices are tested, "other" = the shape whose planes they are tested against
                 const int sm = dirflag ? sb : sa, so = dirflag ? sa : sb;
@@ -798,7 +844,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 for (int kk = 0; kk < 9; kk++) { Xm.R.m[kk] = xf[sm][kk]; Xo.R.m[kk] = xf[so][kk]; }
                 Xm.p = mk(xf[sm][9], xf[sm][10], xf[sm][11]);
                 Xo.p = mk(xf[so][9], xf[so][10], xf[so][11]);
-                const int nv = shape_n[sm] & 255, nf = shape_n[so] >> 8;
+                const int nv = shape_n[sm] & 255, nf = (shape_n[so] >> 8) & 255;
                 // every global load of this direction is issued here, before the first wait: the planes of "other" (lane =
                 // plane, three per lane) and the vertices of "mine" (lane = vertex, three passes) -- one round trip
                 float4 plr[FMAXC / 64];
@@ -826,7 +872,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                     }
                 }
                 CPROF(2);
-                if (__ballot(sep)) continue;
+                if (__ballot(sep)) { apart = true; continue; }
                 if (CABL(1024)) continue;
                 CSYNC();
                 const int npre = min(NPREF, nf);
@@ -888,6 +934,70 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 CPROF(4);
             }
             CSYNC();
+            // ---- edge-edge candidates (oracle edge_edge()): two edges crossing away from any vertex.  Lane = edge: the long sharp edges of both shapes go to the world frame, those that come
+            // within the margin of the other shape's bounding sphere are staged in LDS (planes: A's, surv: B's; in index
+            // order); then lane = edge pair, in the oracle's (i, j) order.
+            const int ne_a = shape_n[sa] >> 16, ne_b = shape_n[sb] >> 16;
+            if (!apart && ne_a > 0 && ne_b > 0 && P.edge_contacts && !CABL(1024)) {
+                int nst[2];
+#pragma unroll
+                for (int side = 0; side < 2; side++) {
+                    const int sm = side ? sb : sa, so = side ? sa : sb, ne = side ? ne_b : ne_a;
+                    bool keep = false;
+                    EdgeW E;
+                    if (lane < ne) {
+                        E = edge_world(S->edges[sm][lane], xf[sm]);
+                        // conservative: a contact needs a point of this edge within radius + margin of the other sphere's centre
+                        const float4 co = sph[so];
+                        const v3 r0 = nc::sub(mk(co.x, co.y, co.z), E.p0);
+                        const float dd = nc::dot(E.d, E.d);
+                        float tt = nc::dot(r0, E.d) / dd;
+                        tt = fminf(fmaxf(tt, 0.0f), 1.0f);
+                        const v3 rr = nc::sub(r0, nc::scale(E.d, tt));
+                        const float lim = co.w + P.margin;
+                        keep = nc::dot(rr, rr) <= lim * lim * 1.01f + 1e-6f;
+                    }
+                    const unsigned long long km = __ballot(keep);
+                    if (keep) {
+                        const int pos = __popcll(km & lt_mask);
+                        float4 *dst = side ? (float4 *)&surv[0][0] + 3 * pos : planes + 3 * pos;
+                        dst[0] = make_float4(E.p0.x, E.p0.y, E.p0.z, E.d.x);
+                        dst[1] = make_float4(E.d.y, E.d.z, E.n1.x, E.n1.y);
+                        dst[2] = make_float4(E.n1.z, E.n2.x, E.n2.y, E.n2.z);
+                        edge_id[wv][side][pos] = (unsigned char)lane;
+                    }
+                    nst[side] = __popcll(km);
+                }
+                CSYNC();
+                // overlapping shapes: an edge axis deeper than the deepest vertex candidate (the face axes) is no contact
+                float smin = 0.0f;
+                for (int c0_ = 0; c0_ < ncand; c0_ += 64) smin = fminf(smin, -wave_max(c0_ + lane < ncand ? -cand_a[c0_ + lane].w : -3.0e38f));
+                const float lo = smin - 0.0005f;                 // (oracle EDGE_SLOP)
+                const int na = nst[0], nb = nst[1], npairs_e = na * nb;
+                const float inb = 1.0f / (float)nb;
+                for (int k0 = 0; k0 < npairs_e; k0 += 64) {
+                    const int kk = k0 + lane;
+                    bool hit = false;
+                    float4 cnd = make_float4(0, 0, 0, 0);
+                    int ids = 0;
+                    if (kk < npairs_e) {
+                        const int i = (int)(((float)kk + 0.5f) * inb), j = kk - i * nb;      // exact for these small integers
+                        const float4 *pa = planes + 3 * i, *pb = (const float4 *)&surv[0][0] + 3 * j;
+                        const float4 a0 = pa[0], a1_ = pa[1], a2_ = pa[2], b0 = pb[0], b1_ = pb[1], b2_ = pb[2];
+                        EdgeW A, B;
+                        A.p0 = mk(a0.x, a0.y, a0.z); A.d = mk(a0.w, a1_.x, a1_.y); A.n1 = mk(a1_.z, a1_.w, a2_.x); A.n2 = mk(a2_.y, a2_.z, a2_.w);
+                        B.p0 = mk(b0.x, b0.y, b0.z); B.d = mk(b0.w, b1_.x, b1_.y); B.n1 = mk(b1_.z, b1_.w, b2_.x); B.n2 = mk(b2_.y, b2_.z, b2_.w);
+                        v3 nrm;
+                        hit = edge_pair(A, B, P.margin, lo, cnd, nrm);
+                        ids = edge_id[wv][0][i] | (edge_id[wv][1][j] << 8) | (1 << 16);
+                    }
+                    const unsigned long long hm = __ballot(hit);
+                    const int pos = ncand + __popcll(hm & lt_mask);
+                    if (hit && pos < CAND_MAX) { cand_a[pos] = cnd; cand_b[pos] = ids; }
+                    ncand = min(ncand + __popcll(hm), CAND_MAX);
+                }
+                CSYNC();
+            }
             // manifold reduction, same rule as the oracle's reduce4(): deepest first, then maximal spread, preferring the
             // candidates within TIER_TOL (1 mm) of the deepest penetration at every pick; ties go to the first candidate
             int sel0 = -1, sel1 = -1, sel2 = -1, sel3 = -1, k = 0;
@@ -965,13 +1075,20 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 const int sa = pair_ab[pair] & 255, sb = (pair_ab[pair] >> 8) & 255;
                 const float4 a = res_a[slot][r];
                 // the normal (B -> A) of a kept candidate: its plane of "other", rotated to the world, as in the candidate test
-                const int kb = res_b[slot][r], so_ = (kb >> 8) ? sa : sb;
-                m3 Ro;
+                const int kb = res_b[slot][r];
+                v3 nb;
+                if (kb >> 16) {       // edge-edge candidate: the common normal of edge (kb & 255) of a and edge (kb >> 8 & 255) of b, as in the test
+                    float4 dummy;
+                    edge_pair(edge_world(S->edges[sa][kb & 255], xf[sa]), edge_world(S->edges[sb][(kb >> 8) & 255], xf[sb]), P.margin, -1.0f, dummy, nb);
+                } else {
+                    const int so_ = (kb >> 8) ? sa : sb;
+                    m3 Ro;
 #pragma unroll
-                for (int kk = 0; kk < 9; kk++) Ro.m[kk] = xf[so_][kk];
-                const float4 pl = *(const float4 *)S->planes[so_][kb & 255];
-                v3 nb = nc::mulv(Ro, mk(pl.x, pl.y, pl.z));
-                if (kb >> 8) nb = nc::scale(nb, -1.0f);
+                    for (int kk = 0; kk < 9; kk++) Ro.m[kk] = xf[so_][kk];
+                    const float4 pl = *(const float4 *)S->planes[so_][kb & 255];
+                    nb = nc::mulv(Ro, mk(pl.x, pl.y, pl.z));
+                    if (kb >> 8) nb = nc::scale(nb, -1.0f);
+                }
                 const float4 b = make_float4(nb.x, nb.y, nb.z, 0.0f);
                 const int4 pm = *(const int4 *)S->pair_meta[pair];
                 const int meta = (pm.x & 255) | ((pm.y & 255) << 8) | ((pm.z & 255) << 16);
@@ -3171,6 +3288,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     P.ablate = getenv("RR_ABLATE") ? atoi(getenv("RR_ABLATE")) : 0;
     P.small_area = getenv("RR_SMALL_AREA") ? atoi(getenv("RR_SMALL_AREA")) : SMALL_AREA;
     // RR_SOLVER_POOL (tests): LDS floats for object-vs-static rows, 60 per contact; contacts beyond it take the generic (slot layout) path
+    P.edge_contacts = getenv("RR_NO_EDGE_CONTACTS") ? 0 : 1;       // (diagnostics: vertex candidates only)
     P.os_cap = getenv("RR_SOLVER_POOL") ? std::max(0, std::min(atoi(getenv("RR_SOLVER_POOL")) / 60, (int)OS_CAP)) : OS_CAP;
     P.lin_damp = 0.04f; P.ang_damp = 0.04f; P.rest_thresh = 0.2f;
     e->epb = cfg->envs_per_block > 0 ? cfg->envs_per_block : 64;
@@ -3191,6 +3309,9 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     for (int s = 0; s < ns; s++) { S.fric[s] = f[2 * s]; S.rest[s] = f[2 * s + 1]; }
     NEED(f = b.f32("shape_roll", ns * 2));       // URDF <rolling_friction>, <spinning_friction> (cube.urdf:6-7, kuka_gripper.urdf:292-296 ...)
     for (int s = 0; s < ns; s++) { S.roll[s] = f[2 * s]; S.spin[s] = f[2 * s + 1]; }
+    NEED(ip = b.i32("shape_ne", ns)); memcpy(S.ne, ip, ns * 4);
+    NEED(f = b.f32("shape_edges", ns * EMAXC * 12)); memcpy(S.edges, f, (size_t)ns * EMAXC * 12 * 4);
+    for (int s = 0; s < ns; s++) if (S.ne[s] < 0 || S.ne[s] > EMAXC) { rr_destroy(e); return fail(RR_EMODEL, "rr_create: bad shape_ne"); }
     int np = 0, s_obj0 = n_static + n_robot;
     for (int i = 0; i < P.nobj; i++) for (int s = 0; s < n_static; s++) { S.pair_a[np] = s_obj0 + i; S.pair_b[np++] = s; }
     for (int i = 0; i < P.nobj; i++) for (int j = i + 1; j < P.nobj; j++) { S.pair_a[np] = s_obj0 + i; S.pair_b[np++] = s_obj0 + j; }

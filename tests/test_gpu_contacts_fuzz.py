@@ -207,3 +207,37 @@ def test_touch_sensors_and_normal_forces_match_the_oracle():
                 _check_forces(env, o, int(i), st0, plans[i][t], ('push', t, int(i)), stats)
     assert stats['forces'] - before['forces'] > 200, stats
     env.close()
+
+
+def test_edge_edge_contacts_match_the_oracle():
+    """Crossing edges (a tilted cube edge over the shelf's front edge, tests/test_oracle_pins.py) at several gaps, small overlaps
+    and tilts: the device's contact lists -- vertex candidates followed by the edge-edge candidate -- are those of the float
+    oracle bit for bit, and so is the list without the edge pass (RR_NO_EDGE_CONTACTS)."""
+    from tests.test_oracle_pins import _edge_crossing_pose
+    cases = [(0.002, -40.0), (0.0005, -55.0), (-0.001, -40.0), (0.012, -30.0), (-0.0003, -50.0), (0.019, -45.0)]
+    N = len(cases)
+    for edges in (1, 0):
+        if not edges:
+            os.environ['RR_NO_EDGE_CONTACTS'] = '1'
+        try:
+            env = BatchedREALRobotEnv(N, objects=1, width=64, height=64)
+        finally:
+            os.environ.pop('RR_NO_EDGE_CONTACTS', None)
+        o = Oracle(1, 64, 64, f32=True, edge_contacts=edges)
+        env.reset()
+        for i, (gap, tilt) in enumerate(cases):
+            env.set_object_pose(i, 0, _edge_crossing_pose(gap, tilt)[0].astype(np.float32))
+        st0 = env.state
+        env.step(None, render=False)
+        n_edge = 0
+        for i, (gap, tilt) in enumerate(cases):
+            o.state = st0[i].astype(np.float64)
+            o.step(None)
+            cd, co = env.contacts(i), o.contacts()
+            assert _lists_identical(cd, co), (edges, i, cd, co)
+            # an edge-edge contact: its normal is the common normal of the two edges (neither a shelf nor a cube facet normal)
+            n_exp = _edge_crossing_pose(gap, tilt)[1]
+            n_edge += int(any(np.abs(c[6:9] - n_exp).max() < 1e-3 and abs(c[9] - gap) < 3e-4 for c in cd))
+        # (an edge pair that overlaps by more than 0.5 mm beyond the deepest vertex candidate is no contact: the -1 mm case)
+        assert n_edge == (N - 1 if edges else 0), (edges, n_edge)
+        env.close()

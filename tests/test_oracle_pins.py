@@ -511,3 +511,53 @@ def test_torsional_friction_rows_match_an_independent_numpy_solver():
     for _ in range(200):
         o.step(None)
     assert np.abs(o.state[22 + 13 + 7: 22 + 26]).max() < 2e-2          # stopped rolling (it started at 5.5 rad/s; the 12-gon keeps a residual rocking)
+
+
+def _edge_crossing_pose(gap=0.002, tilt_deg=-40.0):
+    """Cube pose that puts one of its long edges across the shelf's front top edge (x = 0.079, z = 0.381, along y; shape
+    `table_upper`), tilted so that both end points of the cube edge are outside the shelf's margin zone: returns (pose7,
+    expected normal shelf -> cube, expected contact point)."""
+    from real_robots_amd.kinematics import quat_from_euler
+    from real_robots_amd.model import load_model
+    m = load_model()
+    cube = int(m['dims'][2]) - 3                                                    # the objects are the last three shapes
+    E = m['shape_edges'][cube][:m['shape_ne'][cube]].astype(np.float64)             # the cube's long edges (owner frame)
+    k = [i for i in range(len(E)) if abs(E[i, 3]) > 0.05 and E[i, 7] < 0 and E[i, 8] < 0 and E[i, 10] < 0 and E[i, 11] < 0][0]
+    q = np.array(quat_from_euler(np.radians(45.0), np.radians(tilt_deg), 0.0))     # roll 45: that edge is the lowest one; then tilt
+    x, y, z, w = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    mid = R @ (E[k, :3] + 0.5 * E[k, 3:6])
+    d1 = R @ E[k, 3:6]
+    n = np.cross(d1, [0.0, 1.0, 0.0]); n /= np.linalg.norm(n)
+    if n[2] < 0:
+        n = -n
+    on_shelf_edge = np.array([0.079, 0.02, 0.381])
+    pos = on_shelf_edge + gap * n - mid
+    return np.concatenate([pos, q]), n, on_shelf_edge + 0.5 * gap * n
+
+
+def test_edge_edge_contact_known_answer():
+    """Two edges crossing away from any vertex: a tilted cube edge 2 mm above the shelf's front edge.
+    The vertex tests only see speculative candidates more than a centimetre away, and the edges pass through each other; the
+    edge pass adds the contact at the crossing point, along the common normal of the two edges, and it stops the cube."""
+    pose, n_exp, x_exp = _edge_crossing_pose()
+    res = {}
+    for edges in (0, 1):
+        o = Oracle(1, 32, 32, edge_contacts=edges)
+        o.reset()
+        o.set_object_pose(0, pose)
+        s = o.state
+        s[22 + 7:22 + 10] = -1.0 * n_exp          # approaching along the normal at 1 m/s
+        o.state = s
+        o.step(None)
+        res[edges] = (o.contacts(), o.state[22 + 7:22 + 10] @ n_exp)
+    c0, c1 = res[0][0], res[1][0]
+    assert (c0[:, 9] > 0.01).all() and res[0][1] < -0.95          # vertex tests alone: nothing within a centimetre, not slowed down
+    assert len(c1) == len(c0) + 1 and (c1[:len(c0)] == c0).all()  # the vertex candidates are unchanged, the edge contact comes after them
+    e = c1[-1]
+    assert e[0] == 16 and e[1] == -1
+    # (the shelf's vertices are float32 in the model blob and the expected numbers use the rounded 0.079 / 0.381)
+    assert np.abs(e[6:9] - n_exp).max() < 1e-3 and abs(e[9] - 0.002) < 2e-4 and np.abs(e[3:6] - x_exp).max() < 5e-4
+    assert res[1][1] > -0.45          # speculative contact: the approach speed is cut to distance / dt = 0.4 m/s

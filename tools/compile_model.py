@@ -184,6 +184,59 @@ def plane_deviation(hv, eq, chosen):
     return max(float(viol.max()), 0.0), int(fi)
 
 
+# Long edges of a shape's full hull: the vertex-in-polytope candidates of the narrow phase cannot see two edges that cross away
+# from any vertex (a cube edge lying across a shelf edge); edges shorter than EDGE_MIN are covered by their end points.
+EMAX = 48           # long edges kept per shape (the longest first)
+EDGE_MIN = 0.015    # m
+EDGE_COS = 0.9659   # only sharp edges (dihedral angle >= 15 degrees): on a rounded surface the end points of an edge are close to it
+
+
+def hull_edges(pts, min_len, cos_tol=0.9995):
+    """Long geometric edges of the convex hull of pts: [(p0, p1, n1, n2)] -- segments between two facets whose normals differ,
+    collinear pieces with the same pair of facets merged."""
+    hull = ConvexHull(pts)
+    eq, simp, nb = hull.equations, hull.simplices, hull.neighbors
+    # facet id per simplex: union of coplanar neighbours
+    parent = list(range(len(simp)))
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]; a = parent[a]
+        return a
+    for i in range(len(simp)):
+        for j in nb[i]:
+            if j > i and eq[i, :3] @ eq[j, :3] > cos_tol and abs(eq[i, 3] - eq[j, 3]) < 1e-4 * max(1.0, abs(eq[i, 3])) + 2e-4:
+                parent[find(i)] = find(j)
+    fac = np.array([find(i) for i in range(len(simp))])
+    # facet normal = area-weighted mean
+    fn = {}
+    for f in np.unique(fac):
+        idx = np.where(fac == f)[0]
+        n = np.zeros(3)
+        for i in idx:
+            a, b, c = pts[simp[i]]
+            n += 0.5 * np.linalg.norm(np.cross(b - a, c - a)) * eq[i, :3]
+        fn[f] = n / np.linalg.norm(n)
+    segs = {}
+    for i in range(len(simp)):
+        for j in nb[i]:
+            if j > i and fac[i] != fac[j]:
+                common = list(set(simp[i]) & set(simp[j]))
+                if len(common) == 2:
+                    key = (min(fac[i], fac[j]), max(fac[i], fac[j]))
+                    segs.setdefault(key, []).append(common)
+    out = []
+    for (f1, f2), lst in segs.items():
+        # merge: all segments between the same two facets are collinear (intersection line of two planes)
+        P = pts[np.unique(np.array(lst).ravel())]
+        d = np.cross(fn[f1], fn[f2]); d /= np.linalg.norm(d)
+        t = P @ d
+        # chain may have gaps in principle (not for convex facets): take the extent
+        p0, p1 = P[np.argmin(t)], P[np.argmax(t)]
+        if np.linalg.norm(p1 - p0) >= min_len and fn[f1] @ fn[f2] <= EDGE_COS:
+            out.append((p0, p1, fn[f1], fn[f2]))
+    return out
+
+
 def simplify_hull(pts):
     """pts [V,3] (already in the owner's frame). Returns verts[<=VMAX,3], planes[<=FMAX,4] (n, c: n.x<=c inside),
     (vertex deviation, plane deviation) in metres."""
@@ -563,13 +616,14 @@ def main(out_path):
 
     def add_shape(name, owner_type, owner_idx, lid, pts_owner_frame, L, body_uid):
         verts, planes, dev = simplify_hull(pts_owner_frame)
+        edges = sorted(hull_edges(pts_owner_frame, EDGE_MIN), key=lambda e: -np.linalg.norm(e[1] - e[0]))[:EMAX]
         c = 0.5 * (pts_owner_frame.min(0) + pts_owner_frame.max(0))
         r = float(np.max(np.linalg.norm(pts_owner_frame - c, axis=1)))
         shapes.append(dict(name=name, otype=owner_type, oidx=owner_idx, link=lid, verts=verts, planes=planes,
                            center=c, radius=r, friction=L.friction, restitution=L.restitution, uid=body_uid, dev=dev,
-                           rolling=L.rolling, spinning=L.spinning))
-        print('shape %-12s owner(%d,%2d) link %2d  V=%3d F=%3d  deviation from the full hull: vertices %.2f mm, planes %.2f mm  r=%.3f' %
-              (name, owner_type, owner_idx, lid, len(verts), len(planes), dev[0] * 1e3, dev[1] * 1e3, r))
+                           rolling=L.rolling, spinning=L.spinning, edges=edges))
+        print('shape %-12s owner(%d,%2d) link %2d  V=%3d F=%3d E=%2d  deviation from the full hull: vertices %.2f mm, planes %.2f mm  r=%.3f' %
+              (name, owner_type, owner_idx, lid, len(verts), len(planes), len(edges), dev[0] * 1e3, dev[1] * 1e3, r))
 
     # statics first: table, shelf, robot base link_0
     for ln in ('table_base', 'table_upper'):
@@ -599,6 +653,8 @@ def main(out_path):
     sh_mat = np.zeros((NS, 2))
     sh_roll = np.zeros((NS, 2))                 # rolling, spinning friction coefficients (URDF <contact>)
     sh_dev = np.zeros((NS, 2))                  # deviation of the reduced vertex / plane set from the full hull (m)
+    sh_ne = np.zeros(NS, np.int32)
+    sh_edges = np.zeros((NS, EMAX, 12))         # long hull edges: p0 (3), p1 - p0 (3), the two facet normals (3 + 3), owner frame
     for s, S in enumerate(shapes):
         sh_owner[s] = [S['otype'], S['oidx'], S['link'], S['uid']]
         nv, nf = len(S['verts']), len(S['planes'])
@@ -611,6 +667,9 @@ def main(out_path):
         sh_mat[s] = [S['friction'], S['restitution']]
         sh_roll[s] = [S['rolling'], S['spinning']]
         sh_dev[s] = S['dev']
+        sh_ne[s] = len(S['edges'])
+        for k, (p0, p1, n1, n2) in enumerate(S['edges']):
+            sh_edges[s, k] = np.concatenate([p0, p1 - p0, n1, n2])
 
     # touch sensor links: skin_00, skin_01, skin_10, skin_11  (robot.py:156)
     touch_links = np.array([link_id[n] for n in ('skin_00', 'skin_01', 'skin_10', 'skin_11')], np.int32)
@@ -818,6 +877,8 @@ def main(out_path):
     B.add('shape_mat', sh_mat, F)
     B.add('shape_roll', sh_roll, F)
     B.add('shape_dev', sh_dev, F)
+    B.add('shape_ne', sh_ne, I32)
+    B.add('shape_edges', sh_edges, F)
     B.add('touch_links', touch_links, I32)
     B.add('link_body', link_body, I32)
     B.add('link_pos', link_pos, F)
