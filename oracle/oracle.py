@@ -28,7 +28,8 @@ class Params(C.Structure):
     _fields_ = [('dt', C.c_double), ('gravity', C.c_double), ('solver_iters', C.c_int), ('erp', C.c_double),
                 ('margin', C.c_double), ('motor_kp', C.c_double), ('motor_kd', C.c_double),
                 ('motor_max_force', C.c_double), ('lin_damping', C.c_double), ('ang_damping', C.c_double),
-                ('rest_threshold', C.c_double), ('use_urdf_inertia', C.c_int), ('edge_contacts', C.c_int)]
+                ('rest_threshold', C.c_double), ('use_urdf_inertia', C.c_int), ('edge_contacts', C.c_int),
+                ('warmstart', C.c_double)]
 
 
 def build(force=False):
@@ -61,6 +62,7 @@ def _lib(f32=False):
         L.rro_link_pose.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rro_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.rro_set_object_pose.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rro_set_contact_cache.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.rro_mass_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rro_set_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rro_default_params.argtypes = [C.POINTER(Params)]
@@ -144,6 +146,11 @@ class Oracle:
         out = np.empty((48, 12))
         n = self.L.rro_contacts(self.h, out.ctypes.data, 48)
         return out[:n]
+
+    def set_contact_cache(self, records):
+        """Contact history for the warm start (records as returned by contacts()); call after setting the state."""
+        r = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 12)
+        self.L.rro_set_contact_cache(self.h, r.ctypes.data, len(r))
 
     def set_object_pose(self, obj, pose7):
         p = np.ascontiguousarray(pose7, dtype=np.float64)

@@ -112,7 +112,8 @@ typedef struct {
     int linkA;          /* robot link id of the robot-side shape (or -1) */
     real x[3], n[3], dist, mu, rest;
     real roll, spin;    /* combined rolling / spinning friction coefficients */
-    real lambda_n;
+    real lambda_n;      /* normal impulse the solver found */
+    real lambda0;       /* warm start: warmstart factor x the normal impulse of the matched contact of the previous step */
 } contact_t;
 
 struct rr_oracle {
@@ -233,7 +234,7 @@ static void inertia_world(real *Iw, const real *R, const real *I6) {
 
 /* ------------------------------------------------------------------------------------------- create */
 void rro_default_params(rro_params *p) {
-    p->dt = 0.005; p->gravity = 9.81; p->solver_iters = 50; p->erp = 0.2; p->margin = 0.02; p->edge_contacts = 1;
+    p->dt = 0.005; p->gravity = 9.81; p->solver_iters = 50; p->erp = 0.2; p->margin = 0.02; p->edge_contacts = 1; p->warmstart = 0.85;
     p->motor_kp = 0.1; p->motor_kd = 1.0; p->motor_max_force = 100000.0;
     p->lin_damping = 0.04; p->ang_damping = 0.04; p->rest_threshold = 0.2; p->use_urdf_inertia = 0;
 }
@@ -696,6 +697,47 @@ static void collide_pair(rr_oracle *o, int sa, int sb, const xform_t *X) {
         if (c->roll > 10) c->roll = 10;
         if (c->spin > 10) c->spin = 10;
         c->lambda_n = 0;
+        c->lambda0 = 0;
+    }
+}
+
+/* Warm starting (btPersistentManifold + SOLVER_USE_WARMSTARTING, m_warmstartingFactor 0.85).  Bullet keeps
+ * up to four points per collision-object pair alive from step to step, matches a new point to the cached one nearest to it
+ * within the contact breaking threshold (getCacheEntry) and starts the solver from 0.85 x its normal impulse
+ * (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint: friction and torsional rows start from zero).  Contacts
+ * are regenerated from scratch here, so the cache is the previous step's contact list: a new contact inherits from the
+ * previous contact of the same bodies (bodyA, bodyB, linkA) nearest to it in world space within the margin, provided no
+ * other new contact of those bodies is nearer to that previous contact (mutual nearest neighbours: one heir per cached
+ * point, independent of the order of evaluation). */
+#define WARM_DIST2 ((real)0.0004)      /* (0.02 m)^2 */
+static void warm_start_match(rr_oracle *o, const contact_t *prev, int nprev) {
+    const real factor = (real)o->p.warmstart;
+    const int n = o->ncontacts;
+    for (int i = 0; i < n; i++) o->contacts[i].lambda0 = 0;
+    if (!(factor > 0)) return;
+    for (int i = 0; i < n; i++) {
+        contact_t *c = &o->contacts[i];
+        int bj = -1;
+        real bd = WARM_DIST2;
+        for (int j = 0; j < nprev; j++) {
+            const contact_t *pc = &prev[j];
+            if (pc->bodyA != c->bodyA || pc->bodyB != c->bodyB || pc->linkA != c->linkA) continue;
+            real d[3];
+            v3_sub(d, c->x, pc->x);
+            real d2 = v3_dot(d, d);
+            if (d2 < bd) { bd = d2; bj = j; }
+        }
+        if (bj < 0) continue;
+        int heir = 1;
+        for (int k = 0; k < n && heir; k++) {
+            const contact_t *ck = &o->contacts[k];
+            if (k == i || ck->bodyA != c->bodyA || ck->bodyB != c->bodyB || ck->linkA != c->linkA) continue;
+            real d[3];
+            v3_sub(d, ck->x, prev[bj].x);
+            real d2 = v3_dot(d, d);
+            if (d2 < bd || (d2 == bd && k < i)) heir = 0;
+        }
+        if (heir) c->lambda0 = factor * prev[bj].lambda_n;
     }
 }
 
@@ -951,6 +993,16 @@ static void solve_and_integrate(rr_oracle *o) {
     /* projected Gauss-Seidel on velocity deltas */
     real dq[NB], dv[NOBJ][3], dw[NOBJ][3];
     memset(dq, 0, sizeof dq); memset(dv, 0, sizeof dv); memset(dw, 0, sizeof dw);
+    for (int c = 0; c < o->ncontacts; c++) {     /* warm start: the normal rows start from the inherited impulses, already applied */
+        row_t *r = &rows[first_normal + c];
+        real l0 = o->contacts[c].lambda0;
+        if (!(l0 > 0)) continue;
+        r->lambda = l0;
+        int robot = (r->bodyA >= 0 && r->bodyA < 16) || (r->bodyB >= 0 && r->bodyB < 16);
+        if (robot) for (int i = 0; i < NB; i++) dq[i] += r->MJa[i] * l0;
+        if (r->bodyA >= 16) { int ob = r->bodyA - 16; v3_madd(dv[ob], r->mla, l0); v3_madd(dw[ob], r->maa, l0); }
+        if (r->bodyB >= 16) { int ob = r->bodyB - 16; v3_madd(dv[ob], r->mlb, l0); v3_madd(dw[ob], r->mab, l0); }
+    }
     for (int it = 0; it < P->solver_iters; it++) {
         for (int k = 0; k < nr; k++) {
             row_t *r = &rows[k];
@@ -1054,7 +1106,13 @@ int rro_step(rr_oracle *o, const double *action9) {
     o->tgt[8] = -a[8]; o->tgt[10] = -a[8];
     /* scene.global_step() env.py:340 */
     forward_kinematics(o);
-    collide(o);
+    {
+        static contact_t prev[MAXC];
+        const int nprev = o->ncontacts;
+        memcpy(prev, o->contacts, sizeof(contact_t) * (size_t)nprev);
+        collide(o);
+        warm_start_match(o, prev, nprev);
+    }
     solve_and_integrate(o);
     /* touch sensors robot.py:152-163: max normal force over contacts of each skin link, |distance| < 0.1 */
     for (int k = 0; k < 4; k++) o->touch[k] = 0;
@@ -1094,6 +1152,25 @@ void rro_set_state(rr_oracle *o, const double *s) {
         for (int j = 0; j < 3; j++) o->ovel[i][j] = (real)s[k++];
         for (int j = 0; j < 3; j++) o->oang[i][j] = (real)s[k++];
     }
+    o->ncontacts = 0;        /* a state set from outside has no contact history: the next step starts cold */
+}
+/* The contact cache of the warm start = the contact list of the previous step, in rro_contacts() layout
+ * {bodyA, bodyB, linkA, x (3), n (3), dist, normal force, mu}: lets a differential test continue from another
+ * simulator's state *and* history. */
+void rro_set_contact_cache(rr_oracle *o, const double *rec, int n) {
+    if (n > MAXC) n = MAXC;
+    if (n < 0) n = 0;
+    for (int c = 0; c < n; c++) {
+        const double *r = rec + 12 * c;
+        contact_t *ct = &o->contacts[c];
+        memset(ct, 0, sizeof *ct);
+        ct->bodyA = (int)r[0]; ct->bodyB = (int)r[1]; ct->linkA = (int)r[2];
+        for (int k = 0; k < 3; k++) { ct->x[k] = (real)r[3 + k]; ct->n[k] = (real)r[6 + k]; }
+        ct->dist = (real)r[9];
+        ct->lambda_n = (real)r[10] * (real)o->p.dt;
+        ct->mu = (real)r[11];
+    }
+    o->ncontacts = n;
 }
 void rro_get_obs(const rr_oracle *o, double *joints9, double *touch4, double *objpos) {
     real j9[9];

@@ -47,7 +47,8 @@ typedef struct rro_params {
     double ang_damping;     /* 0.04 */
     double rest_threshold;  /* 0.2              m_restitutionVelocityThreshold */
     int use_urdf_inertia;   /* 0: Bullet AABB inertia for robot links (default); 1: URDF <inertia> */
-    int edge_contacts;      /* 1                edge-edge candidates for pairs without a vertex candidate (0: vertex tests only) */
+    int edge_contacts;      /* 1                edge-edge candidates (0: vertex tests only) */
+    double warmstart;       /* 0.85             Bullet m_warmstartingFactor on the matched normal impulses (0: cold start every step) */
 } rro_params;
 
 typedef struct rr_oracle rr_oracle;
@@ -65,7 +66,9 @@ void rro_render(rr_oracle *o, uint8_t *rgb, float *depth, int32_t *mask);
 /* camera override for the following renders (row-major 4x4 OpenGL view / projection; EnvCamera env.py:470-513) */
 void rro_set_camera(rr_oracle *o, const float *view16, const float *proj16);
 void rro_get_state(const rr_oracle *o, double *state61);
-void rro_set_state(rr_oracle *o, const double *state61);
+void rro_set_state(rr_oracle *o, const double *state61);      /* also forgets the contact history (cold start) */
+/* contact history for the warm start, in rro_contacts() layout (call after rro_set_state) */
+void rro_set_contact_cache(rr_oracle *o, const double *rec12, int n);
 void rro_get_obs(const rr_oracle *o, double *joints9, double *touch4, double *objpos /*[nobj*3]*/);
 int rro_timestep(const rr_oracle *o);
 /* world pose (xyz + xyzw quaternion) of the COM frame of robot link `link` (0..16, URDF depth-first) */

@@ -65,7 +65,8 @@ struct BodyParams {   // passed by value as kernel argument -> scalar loads, uni
 };
 
 struct SimParams {
-    int N, nobj, iters, npairs, ablate, small_area, os_cap, edge_contacts;   // os_cap: object-vs-static contacts per env with rows in LDS (<= OS_CAP)
+    int N, nobj, iters, npairs, ablate, small_area, os_cap, edge_contacts;
+    float warmstart;   // Bullet's m_warmstartingFactor (0.85); 0: cold start every step   // os_cap: object-vs-static contacts per env with rows in LDS (<= OS_CAP)
     float dt, gravity, erp, margin, kp, kd, max_impulse, lin_damp, ang_damp, rest_thresh;
 };
 
@@ -120,6 +121,8 @@ struct DevPtrs {
                        // spinning}; meta = bodyA | bodyB << 8 | linkA << 16 (bytes; -1 static, 0..15 robot body, 16+i object i).
                        // Written by the env's k_collide wavefront, read by its k_solve group in one round trip.
     int *ccount;       // [N] number of contacts in clist
+    float4 *clist_prev; // the list of the step before (the two buffers change roles every step): contact history of the warm start
+    float *cwarm;      // [N][MAXC] initial normal impulse of every contact of clist (k_collide: 0.85 x the matched previous one)
     float *cforce;     // [N][MAXC] normal force of every contact of the last step (rr_get_contacts, touch sensors)
     int *hgflag;       // [ceil(N/4)] != 0: this solver group (four consecutive envs) holds an env with generic contacts -- "heavy"
     int *hlist;        // [ceil(N/4)] the heavy groups of this step (in arrival order: placement only, never a result)
@@ -687,7 +690,7 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
 
 // the candidate / plane / survivor arrays are private to a wave: LDS traffic is ordered per wave, so a compiler-level fence replaces s_barrier
 #define CSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-static_assert(CCHUNK * 4 == COLLIDE_THREADS && CCHUNK <= 64 && MAXPAIRS < 256, "one record writer per (slot, r); pair ids in bytes");
+static_assert(CCHUNK * 4 == COLLIDE_THREADS && CCHUNK <= 64 && MAXPAIRS < 128 && EMAXC <= 64 && MAXC <= 64, "one record writer per (slot, r); pair ids in 7 bits, edge ids in 6, the contact history staged by one wave");
 static_assert(VMAXC % 64 == 0 && FMAXC % 64 == 0 && VMAXC < 256 && FMAXC < 256, "vertex / plane passes of 64, counts packed in bytes");
 // (the whole kernel is contraction-free and uses the nc:: helpers: see "contraction-free twins" above)
 #pragma clang fp contract(off)
@@ -751,7 +754,7 @@ __device__ __forceinline__ bool edge_pair(const EdgeW &A, const EdgeW &B, float 
         }                                                                                             \
         RESULT = besti_;                                                                              \
     }
-__global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtrs D, int ns) {
+__global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, DevPtrs D, int ns) {
     const int N = P.N;
     const int env = blockIdx.x;
     const float *state = D.state;
@@ -763,28 +766,50 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
     __shared__ float4 sph[CSHAPES];            // world bounding sphere
     __shared__ int pair_ab[MAXPAIRS];          // shape a | shape b << 8 of every pair   } staged once: no global load of
     __shared__ int shape_n[CSHAPES];           // vertex count | plane count << 8 | edge count << 16   } metadata inside the pair loop
+    __shared__ int pair_key[MAXPAIRS];         // bodyA | bodyB << 8 | link of shape a << 16 (the meta word of the pair's contacts)
     __shared__ unsigned char edge_id[COLLIDE_WAVES][2][EMAXC];   // per wave: the original indices of the staged edges
     __shared__ unsigned char close_pair[MAXPAIRS];   // the pairs that pass the sphere test, in pair order
     __shared__ int n_close, next_item, nct_sh;
     __shared__ float4 res_a[CCHUNK][4];        // per close pair of the chunk: the kept candidates (contact point, signed distance)
     __shared__ int res_b[CCHUNK][4];           //                              plane of "other" | direction << 8
     __shared__ int res_k[CCHUNK];              //                              their number; after the scan: offset in the env's list | kept << 8
+    __shared__ int res_key[CCHUNK];            //                              bodyA | bodyB << 8 | linkA << 16 of the pair
     // per wave:
     __shared__ float4 planes_w[COLLIDE_WAVES][FMAXC];      // planes of "other" in the current direction
     __shared__ float surv_w[COLLIDE_WAVES][VMAXC][3];      // world position of the vertices that survive the prefilter, in vertex order
     __shared__ float4 cand_a_w[COLLIDE_WAVES][CAND_MAX];   // candidates of the pair: contact point, signed distance
-    __shared__ int cand_b_w[COLLIDE_WAVES][CAND_MAX];      //                         plane of "other" it is nearest to | direction << 8
+    __shared__ unsigned short cand_b_w[COLLIDE_WAVES][CAND_MAX];   //                 plane of "other" it is nearest to | direction << 8; edge candidates: edge of a | edge of b << 6 | 1 << 15
+    __shared__ float4 pv[MAXC];                // contact history (warm start): {x, y, z, normal force} of the previous step's contacts,
+    __shared__ int pv_key[MAXC];               //   their bodyA | bodyB << 8 | linkA << 16 | pair << 24,
+    __shared__ unsigned char run_s[MAXPAIRS], run_e[MAXPAIRS];   //   and per pair its run [start, end) of that list
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float4 *planes = planes_w[wv];
     float (*surv)[3] = surv_w[wv];
     float4 *cand_a = cand_a_w[wv];
-    int *cand_b = cand_b_w[wv];
+    unsigned short *cand_b = cand_b_w[wv];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     CPROF_INIT
+    const int nprev = P.warmstart > 0.0f ? min(D.ccount[env], MAXC) : 0;      // contacts of the step before (this kernel replaces the count at its end)
     for (int pr = tid; pr < P.npairs; pr += COLLIDE_THREADS) {
         const int ba = S->pair_meta[pr][0], bb = S->pair_meta[pr][1];
         const int cls = (((ba >= 0 && ba < 16) || (bb >= 0 && bb < 16)) ? 1 : 0) | ((ba >= 16 && bb >= 16) ? 2 : 0);
-        pair_ab[pr] = S->pair_a[pr] | (S->pair_b[pr] << 8) | (cls << 16);      // + robot involved (bit 16), object-object (bit 17)
+        pair_key[pr] = (ba & 255) | ((bb & 255) << 8) | ((S->pair_meta[pr][2] & 255) << 16);
+        pair_ab[pr] = S->pair_a[pr] | (S->pair_b[pr] << 8) | (cls << 16) | (bb < 0 ? 1 << 18 : 0);      // + robot involved (bit 16), object-object (bit 17), b static (bit 18)
+    }
+    if (wv == 1) {       // the contact history comes in with the same round trip as the shape transforms (it has left the L2 since k_solve read it)
+        for (int q = lane; q < MAXPAIRS; q += 64) { run_s[q] = 0; run_e[q] = 0; }
+        if (lane < nprev) {
+            const float4 *pr_ = D.clist_prev + ((size_t)env * MAXC + lane) * 3;
+            const float4 p0 = pr_[0], p1 = pr_[1];
+            pv[lane] = make_float4(p0.x, p0.y, p0.z, D.cforce[(size_t)env * MAXC + lane]);
+            pv_key[lane] = __float_as_int(p1.w);
+        }
+        CSYNC();
+        if (lane < nprev) {       // the list is in pair order: the contacts of a pair form one run
+            const int pj = pv_key[lane] >> 24;
+            if (lane == 0 || (pv_key[lane - 1] >> 24) != pj) run_s[pj] = (unsigned char)lane;
+            if (lane + 1 >= nprev || (pv_key[lane + 1] >> 24) != pj) run_e[pj] = (unsigned char)(lane + 1);
+        }
     }
     if (tid < ns) {
         shape_n[tid] = S->nv[tid] | (S->nf[tid] << 8) | (S->ne[tid] << 16);
@@ -821,8 +846,15 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
     int nct = 0;                                // contacts of this env so far        }
     bool heavy = false;                         // some contact is not an object-vs-static one the object lanes take    } tracked by wave 0
     int oscnt0 = 0, oscnt1 = 0, oscnt2 = 0;     // object-vs-static contacts per object }
-    for (int base = 0; base < ncl && nct < MAXC; base += CCHUNK) {
-        const int nchunk = min(CCHUNK, ncl - base);
+    int nchunk = 0;
+    for (int base = 0; base < ncl && nct < MAXC; base += nchunk) {
+        nchunk = min(CCHUNK, ncl - base);
+        // (more than CCHUNK close pairs: rare) the pairs of one moving shape with the statics share their bodies -- the warm
+        // start below looks at all contacts of the same bodies, so a chunk never ends inside such a run (<= 3 pairs)
+        while (base + nchunk < ncl) {
+            const int pa_ = pair_ab[close_pair[base + nchunk - 1]], pb_ = pair_ab[close_pair[base + nchunk]];
+            if ((pa_ & 255) == (pb_ & 255) && (pa_ & pb_ & (1 << 18))) nchunk--; else break;
+        }
         // ---- every wave takes the next unprocessed close pair of the chunk (the result goes to the pair's slot: the
         // outcome does not depend on which wave took it)
         for (;;) {
@@ -927,7 +959,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                     const int pos = ncand + __popcll(hm & lt_mask);
                     if (hit && pos < CAND_MAX) {
                         cand_a[pos] = make_float4(cx, cy, cz, cs);
-                        cand_b[pos] = bfk;
+                        cand_b[pos] = (unsigned short)bfk;
                     }
                     ncand = min(ncand + __popcll(hm), CAND_MAX);
                 }
@@ -989,11 +1021,11 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                         B.p0 = mk(b0.x, b0.y, b0.z); B.d = mk(b0.w, b1_.x, b1_.y); B.n1 = mk(b1_.z, b1_.w, b2_.x); B.n2 = mk(b2_.y, b2_.z, b2_.w);
                         v3 nrm;
                         hit = edge_pair(A, B, P.margin, lo, cnd, nrm);
-                        ids = edge_id[wv][0][i] | (edge_id[wv][1][j] << 8) | (1 << 16);
+                        ids = edge_id[wv][0][i] | (edge_id[wv][1][j] << 6) | (1 << 15);
                     }
                     const unsigned long long hm = __ballot(hit);
                     const int pos = ncand + __popcll(hm & lt_mask);
-                    if (hit && pos < CAND_MAX) { cand_a[pos] = cnd; cand_b[pos] = ids; }
+                    if (hit && pos < CAND_MAX) { cand_a[pos] = cnd; cand_b[pos] = (unsigned short)ids; }
                     ncand = min(ncand + __popcll(hm), CAND_MAX);
                 }
                 CSYNC();
@@ -1052,7 +1084,10 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
             int total;
             const int off = min(nct + wave_excl_scan(kj, lane, total), MAXC);
             const int kk = min(kj, MAXC - off);
-            if (in_) res_k[lane] = off | (kk << 8);
+            if (in_) {
+                res_k[lane] = off | (kk << 8);
+                res_key[lane] = pair_key[close_pair[base + lane]];
+            }
             // the solver's object lanes take up to four object-vs-static contacts per object; anything else is a generic row
             const int pab = pair_ab[close_pair[base + (in_ ? lane : 0)]];
             const int cls = (pab >> 16) & 3;
@@ -1077,9 +1112,9 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                 // the normal (B -> A) of a kept candidate: its plane of "other", rotated to the world, as in the candidate test
                 const int kb = res_b[slot][r];
                 v3 nb;
-                if (kb >> 16) {       // edge-edge candidate: the common normal of edge (kb & 255) of a and edge (kb >> 8 & 255) of b, as in the test
+                if (kb >> 15) {       // edge-edge candidate: the common normal of edge (kb & 63) of a and edge (kb >> 6 & 63) of b, as in the test
                     float4 dummy;
-                    edge_pair(edge_world(S->edges[sa][kb & 255], xf[sa]), edge_world(S->edges[sb][(kb >> 8) & 255], xf[sb]), P.margin, -1.0f, dummy, nb);
+                    edge_pair(edge_world(S->edges[sa][kb & 63], xf[sa]), edge_world(S->edges[sb][(kb >> 6) & 63], xf[sb]), P.margin, -1.0f, dummy, nb);
                 } else {
                     const int so_ = (kb >> 8) ? sa : sb;
                     m3 Ro;
@@ -1090,17 +1125,77 @@ __global__ void __launch_bounds__(COLLIDE_THREADS) k_collide(SimParams P, DevPtr
                     if (kb >> 8) nb = nc::scale(nb, -1.0f);
                 }
                 const float4 b = make_float4(nb.x, nb.y, nb.z, 0.0f);
-                const int4 pm = *(const int4 *)S->pair_meta[pair];
-                const int meta = (pm.x & 255) | ((pm.y & 255) << 8) | ((pm.z & 255) << 16);
+                const int meta = pair_key[pair];
                 float4 *rec = D.clist + ((size_t)env * MAXC + (ok_ & 255) + r) * 3;
                 rec[0] = make_float4(a.x, a.y, a.z, b.x);
-                rec[1] = make_float4(b.y, b.z, a.w, __int_as_float(meta));
+                rec[1] = make_float4(b.y, b.z, a.w, __int_as_float(meta | (pair << 24)));      // (bits 24..30: the pair, for the next step's matching)
                 rec[2] = *(const float4 *)S->pair_mat[pair];
+                // warm start (oracle warm_start_match()): the previous contact of the same bodies nearest to this one within the
+                // margin, unless another new contact of those bodies is nearer to it (or as near and earlier in the list).
+                // Pairs with the same bodies -- a moving shape against the statics -- are at most three consecutive ones, so
+                // their contacts form one range of the previous list and one range of slots; all LDS reads of a stage are
+                // issued together (a chain of dependent LDS round trips at the kernel's tail costs more than the arithmetic).
+                float lam0 = 0.0f;
+                {
+                    const v3 x = mk(a.x, a.y, a.z);
+                    const int key = meta, me = (ok_ & 255) + r;
+                    int J0 = MAXC, J1 = 0;
+                    {
+                        int kq[5], rs[5], re[5];
+#pragma unroll
+                        for (int u = 0; u < 5; u++) {
+                            const int q = min(max(pair - 2 + u, 0), P.npairs - 1);
+                            kq[u] = pair_key[q]; rs[u] = run_s[q]; re[u] = run_e[q];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 5; u++) if (kq[u] == key && re[u] > rs[u]) { J0 = min(J0, rs[u]); J1 = max(J1, re[u]); }
+                    }
+                    int bj = -1;
+                    float bd = 0.0004f;
+                    for (int j0_ = J0; j0_ < J1; j0_ += 4) {
+                        float4 pj[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) pj[u] = pv[min(j0_ + u, MAXC - 1)];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const v3 d = nc::sub(x, mk(pj[u].x, pj[u].y, pj[u].z));
+                            const float d2 = nc::dot(d, d);
+                            if (j0_ + u < J1 && d2 < bd) { bd = d2; bj = j0_ + u; }
+                        }
+                    }
+                    if (bj >= 0) {
+                        const float4 pb = pv[bj];
+                        int k2[5], o2[5];
+#pragma unroll
+                        for (int u = 0; u < 5; u++) {
+                            const int s2 = min(max(slot - 2 + u, 0), nchunk - 1);
+                            k2[u] = res_key[s2]; o2[u] = res_k[s2];
+                        }
+                        bool heir = true;
+#pragma unroll
+                        for (int u = 0; u < 5; u++) {
+                            const int s2 = slot - 2 + u;
+                            if (s2 < 0 || s2 >= nchunk || k2[u] != key) continue;       // (wave-divergent, but the body's reads are issued together)
+                            float4 a2[4];
+#pragma unroll
+                            for (int r2 = 0; r2 < 4; r2++) a2[r2] = res_a[s2][r2];
+#pragma unroll
+                            for (int r2 = 0; r2 < 4; r2++) {
+                                const int other = (o2[u] & 255) + r2;
+                                const v3 d = nc::sub(mk(a2[r2].x, a2[r2].y, a2[r2].z), mk(pb.x, pb.y, pb.z));
+                                const float d2 = nc::dot(d, d);
+                                if (r2 < (o2[u] >> 8) && other != me && (d2 < bd || (d2 == bd && other < me))) heir = false;
+                            }
+                        }
+                        if (heir) lam0 = P.warmstart * (pb.w * P.dt);
+                    }
+                }
+                D.cwarm[(size_t)env * MAXC + (ok_ & 255) + r] = lam0;
             }
         }
         CPROF(6);
-        if (base + CCHUNK < ncl) {  // (more than CCHUNK close pairs: rare) the result slots are reused; every wave needs the count
-            if (tid == 0) { nct_sh = nct; next_item = base + CCHUNK; }
+        if (base + nchunk < ncl) {  // (more than CCHUNK close pairs: rare) the result slots are reused; every wave needs the count
+            if (tid == 0) { nct_sh = nct; next_item = base + nchunk; }
             __syncthreads();
             nct = nct_sh;
         }
@@ -1311,11 +1406,15 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
     // of the stage-in -- lane l holds float4 #(l + 16 i) of the 144; records beyond the count are never looked at
     const int nct = dead ? 0 : min(D.ccount[env], MAXC);
     float4 crec[9];
+    float cw0, cw1, cw2;              // warm-start impulses of contacts l, 16 + l, 32 + l
     {
         const float4 *cl = D.clist + (size_t)env * MAXC * 3;
 #pragma unroll
         for (int i = 0; i < 9; i++) crec[i] = cl[16 * i + l];
+        const float *cwp = D.cwarm + (size_t)env * MAXC;
+        cw0 = l < nct ? cwp[l] : 0.0f; cw1 = 16 + l < nct ? cwp[16 + l] : 0.0f; cw2 = 32 + l < nct ? cwp[32 + l] : 0.0f;
     }
+    float wsA = 0.0f, wsB = 0.0f;     // slot-layout velocity change of the warm-start impulses of the generic normal rows
     // lanes 11..13 fetch "their" object's pose / inverse inertia / unconstrained velocities and publish them in LDS: the row
     // builder reads the data of a contact's objects from there (20 floats per object: position, 1/mass, I^-1, v*, w*)
     ObjData myobj;
@@ -1384,6 +1483,8 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
             const int cm = __float_as_int(rb_.w);
             const int bodyA = (signed char)(cm & 255), bodyB = (signed char)((cm >> 8) & 255), linkA = (signed char)((cm >> 16) & 255);
             const float mu = rc.x, rest = rc.y, roll = rc.z, spin = rc.w;
+            // warm start: this contact's initial normal impulse is held by lane ci of the group
+            const float lam0 = lane_gather(bt == 0 ? cw0 : (bt == 1 ? cw1 : cw2), (threadIdx.x & 48) + ci);
             const bool ospair = bodyA >= 16 && bodyB < 0;
             ObjData oA, oB;
 #pragma unroll
@@ -1438,7 +1539,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                     float4 *bp4 = (float4 *)&LD(L_OSL + (3 * slot + l) * 12);
                     bp4[0] = make_float4(dir.x, dir.y, dir.z, ang.x);
                     bp4[1] = make_float4(ang.y, ang.z, mang.x, mang.y);
-                    bp4[2] = make_float4(mang.z, rhs, dinv, 0.0f);
+                    bp4[2] = make_float4(mang.z, rhs, dinv, l == 0 ? lam0 : 0.0f);      // (.w of the normal row: warm-start impulse)
                     float4 *tp4 = (float4 *)&LD(L_OST + (3 * slot + l) * 8);
                     tp4[0] = make_float4(tm.x, tm.y, tm.z, trhs);
                     tp4[1] = make_float4(tdinv, 0.0f, 0.0f, 0.0f);
@@ -1476,6 +1577,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                 const float diag = group_sum(ja * mja + jb * mjb);
                 const float rel = group_sum(ja * ua + jb * ub);
                 if (present) D.grows[((size_t)env * GROWS + r0 + kr) * 16 + l] = make_float4(ja, mja, jb, mjb);
+                if (kr == 0) { wsA = fmaf(mja, lam0, wsA); wsB = fmaf(mjb, lam0, wsB); }
                 float rhsn;
                 if (kr == 0) {
                     float r = 0;
@@ -1487,7 +1589,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                 } else rhsn = -rel;
                 if (l == 0) {
                     const float dinv = (present && diag > 0) ? 1.0f / diag : 0.0f;
-                    *(float4 *)&LD(L_GSC + 4 * (r0 + kr)) = make_float4(rhsn * dinv, dinv, kr == 0 ? 0.0f : (kr < 3 ? mu : (kr == 3 ? spin : roll)), 0.0f);
+                    *(float4 *)&LD(L_GSC + 4 * (r0 + kr)) = make_float4(rhsn * dinv, dinv, kr == 0 ? 0.0f : (kr < 3 ? mu : (kr == 3 ? spin : roll)), kr == 0 ? lam0 : 0.0f);
                 }
             }
             ng++;
@@ -1524,7 +1626,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
     for (int js = 0; js < 2 * NB; js++) if (LD(L_LIM + 2 * js) > -1e29f) limmask |= 1u << js;    // 22 independent LDS reads
     // ---- PGS.  Lane state: dq (slot A: lanes 0..10 joints, lanes 11..15 object 2 during generic sweeps), vb (slot B), and
     // (dv, dw) of object lane-11 on lanes 11..13
-    float dq = 0, vb = 0;
+    float dq = wsA, vb = wsB;          // (warm start: the inherited impulses of the generic normal rows are already applied)
     v3 dv = mk(0, 0, 0), dw = mk(0, 0, 0);
     const float inv_mass = lo_ >= 0 ? 1.0f / B.obj_mass[lo_ >= 0 ? lo_ : 0] : 0.0f;
     const float max_imp = P.max_impulse;
@@ -1648,6 +1750,16 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
     if (gobj_w & 1u) { OP(0, 0, dv.x, vb, 0) OP(0, 1, dv.y, vb, 1) OP(0, 2, dv.z, vb, 2) OP(0, 3, dw.x, vb, 3) OP(0, 4, dw.y, vb, 4) OP(0, 5, dw.z, vb, 5) } \
     if (gobj_w & 2u) { OP(1, 0, dv.x, vb, 6) OP(1, 1, dv.y, vb, 7) OP(1, 2, dv.z, vb, 8) OP(1, 3, dw.x, vb, 9) OP(1, 4, dw.y, vb, 10) OP(1, 5, dw.z, vb, 11) } \
     if (gobj_w & 4u) { OP(2, 0, dv.x, dq, 11) OP(2, 1, dv.y, dq, 12) OP(2, 2, dv.z, dq, 13) OP(2, 3, dw.x, dq, 14) OP(2, 4, dw.y, dq, 15) OP(2, 5, dw.z, vb, 12) }
+    // warm start: the object components of the generic rows' initial velocity change go from the slots to the object lanes,
+    // then the register rows add theirs (b2.w of a normal row = its inherited impulse; absent rows are all-zero)
+    if (ng_max > 0) { OBJ_SLOTS(FROM_SLOT) }
+#pragma unroll
+    for (int i = 0; i < KOS; i++) {
+        const float l0_ = os_n2[i].w, sm_ = l0_ * inv_mass;
+        os_ln[i] = l0_;
+        dv.x += os_n0[i].x * sm_; dv.y += os_n0[i].y * sm_; dv.z += os_n0[i].z * sm_;
+        dw.x += os_n1[i].z * l0_; dw.y += os_n1[i].w * l0_; dw.z += os_n2[i].x * l0_;
+    }
     int nF = 0, nT = 0;                                   // entries of this env's lateral / torsional row lists
     for (int it = 0; it < P.iters; it++) {
         // compiler barrier: the row data in LDS / global memory is loop invariant, but hoisting hundreds of such loads out
@@ -2749,7 +2861,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             const float Y = fmaxf(fabsf(bs.sy[0]), fmaxf(fabsf(bs.sy[1]), fabsf(bs.sy[2]))) + (float)H;
             const float delta2 = 2.0f * (8.0e-6f * X * Y * fabsf(bia) + 1.0e-6f);
             const float inbx = 1.0f / (float)nbx;
-            if (lane == 0) { RSTAT(10, 1); RSTAT(11, nblk); }
+            if (lane == 0) { RSTAT(10, 1); }
             for (int c0 = 0; c0 < nblk; c0 += 64) {
                 const int bi = c0 + lane;
                 bool keep = false;
@@ -2848,7 +2960,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             const float Y = fmaxf(fabsf(bs.sy[0]), fmaxf(fabsf(bs.sy[1]), fabsf(bs.sy[2]))) + (float)H;
             const float delta2 = 2.0f * (8.0e-6f * X * Y * fabsf(bia) + 1.0e-6f);
             const float inbx = 1.0f / (float)nbx;
-            if (lane == 0) { RSTAT(10, 1); RSTAT(11, nblk); }
+            if (lane == 0) { RSTAT(10, 1); }
             for (int c0 = 0; c0 < nblk; c0 += 64) {
                 const int bi = c0 + lane;
                 bool keep = false;
@@ -2886,6 +2998,17 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     // (the comparison with the static layer's key is left to k_shade: a dependent global read at the tail of this
     // LDS-limited workgroup is exposed latency, in the high-occupancy shading kernel it is not)
     uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
+#ifdef RR_RASTER_STATS
+    __shared__ unsigned win_bits[MAXWIN / 32];      // clusters that own a pixel of the tile at the end
+    for (int i = tid; i < MAXWIN / 32; i += RASTER_THREADS) win_bits[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < npix; i += RASTER_THREADS) {
+        const unsigned long long key = vis[i];
+        if (key != ~0ull && key != VIS_WAS_DYNAMIC) { const unsigned w_ = ((unsigned)(key & 0xffffffffu) - (unsigned)t_begin) >> 6; atomicOr(&win_bits[w_ >> 5], 1u << (w_ & 31)); }
+    }
+    __syncthreads();
+    if (tid < MAXWIN / 32) RSTAT(11, __popc(win_bits[tid]));      // (slot 11 reused: clusters with at least one winning pixel)
+#endif
     for (int i = tid; i < npix; i += RASTER_THREADS) {
         const unsigned long long key = vis[i];
         const unsigned tri = key == VIS_WAS_DYNAMIC ? FRAG_VACATED : (unsigned)(key & 0xffffffffu);
@@ -3288,6 +3411,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     P.ablate = getenv("RR_ABLATE") ? atoi(getenv("RR_ABLATE")) : 0;
     P.small_area = getenv("RR_SMALL_AREA") ? atoi(getenv("RR_SMALL_AREA")) : SMALL_AREA;
     // RR_SOLVER_POOL (tests): LDS floats for object-vs-static rows, 60 per contact; contacts beyond it take the generic (slot layout) path
+    P.warmstart = getenv("RR_NO_WARMSTART") ? 0.0f : 0.85f;       // (diagnostics: cold start every step)
     P.edge_contacts = getenv("RR_NO_EDGE_CONTACTS") ? 0 : 1;       // (diagnostics: vertex candidates only)
     P.os_cap = getenv("RR_SOLVER_POOL") ? std::max(0, std::min(atoi(getenv("RR_SOLVER_POOL")) / 60, (int)OS_CAP)) : OS_CAP;
     P.lin_damp = 0.04f; P.ang_damp = 0.04f; P.rest_thresh = 0.2f;
@@ -3365,6 +3489,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     ALLOC(D.scratch, (size_t)S_TOTAL * N);
     ALLOC(D.clist, (size_t)N * MAXC * 3);
     ALLOC(D.ccount, (size_t)N);
+    ALLOC(D.clist_prev, (size_t)N * MAXC * 3);
+    ALLOC(D.cwarm, (size_t)N * MAXC);
     ALLOC(D.cforce, (size_t)N * MAXC);
     ALLOC(D.hgflag, (size_t)(N + 3) / 4);
     ALLOC(D.hlist, (size_t)(N + 3) / 4);
@@ -3627,6 +3753,7 @@ static void launch_prep_serial(rr_env *e, const DevPtrs &Dp) {
 }
 
 static void launch_collide(rr_env *e) {
+    std::swap(e->D.clist, e->D.clist_prev);      // the list of the step before becomes the contact history of this one
     hipLaunchKernelGGL(k_collide, dim3(e->P.N), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D, e->n_shapes);
 }
 

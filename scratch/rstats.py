@@ -20,5 +20,5 @@ env.step(synthetic_actions(ids, 160, hold_prob=0.05) * SC, render=True); env.syn
 torch.cuda.synchronize()
 lib.rr_debug_raster_stats(out, 0)
 v = np.array(list(out), dtype=np.float64) / N
-names = ['windows', 'windows after cluster cull', 'live tris', 'big tris', 'sum small area', 'sum window-max small area', 'windows with live', 'windows with small', 'sum big area', 'hier blocks rasterised', 'hier tris', 'hier blocks total', 'pixlist', 'blocks', 'wave cycles idle at loop-end barrier (sum over 16 waves)', 'wave cycles in the window loop (sum over 16 waves)']
+names = ['windows', 'windows after cluster cull', 'live tris', 'big tris', 'sum small area', 'sum window-max small area', 'windows with live', 'windows with small', 'sum big area', 'hier blocks rasterised', 'hier tris', 'clusters that own a pixel at the end', 'pixlist', 'blocks', 'wave cycles idle at loop-end barrier (sum over 16 waves)', 'wave cycles in the window loop (sum over 16 waves)']
 for n, x in zip(names, v): print(f'{n:32s} {x:10.1f} per env')

@@ -75,6 +75,7 @@ def _fuzz_case(case, seed0, stats, bad):
             ncs = np.array([len(env.contacts(i)) for i in range(N)])
             sel = sorted(set(list(np.argsort(-ncs)[:2]) + [int(rng.integers(0, N))]))
             flags[sel] = 1
+            cache = {int(i): env.contacts(int(i)) for i in sel}      # contact history (warm start) of the envs that are checked
         env.step(cmd, render=flags if N > 1 else bool(flags[0]))
         if not chk:
             continue
@@ -82,6 +83,7 @@ def _fuzz_case(case, seed0, stats, bad):
         rgb, dep, msk = env.host(nat.F_RGB), env.host(nat.F_DEPTH), env.host(nat.F_MASK)
         for i in sel:
             o.state = st0[i].astype(np.float64)
+            o.set_contact_cache(cache[int(i)])
             o.step(cmd[i].astype(np.float64))
             cd, co = env.contacts(i), o.contacts()
             stats['checks'] += 1
@@ -151,16 +153,17 @@ def _grasp_script():
     return np.array(cmds, np.float32)
 
 
-def _check_forces(env, o, i, st0, cmd, where, stats):
+def _check_forces(env, o, i, st0, cache, cmd, where, stats):
     """One step of env i from the device state st0: contact list identical, normal forces and the four touch sensors
     (max normal force per skin link, robot.py:152-163) within 0.1 % (+ 0.02 N) of the float oracle."""
     o.state = st0[i].astype(np.float64)
+    o.set_contact_cache(cache)                  # the device's contact list before the step: the history of the warm start
     o.step(cmd.astype(np.float64))
     cd, co = env.contacts(i), o.contacts()
     assert _lists_identical(cd, co), where
     if len(cd):
         f_dev, f_orc = cd[:, 10].astype(np.float64), co[:, 10]
-        if f_orc.max() > CRUSH_FORCE:
+        if f_orc.max() > 3 * CRUSH_FORCE:       # (the warm-started squeeze of the gripper reaches 2.8 kN on a skin)
             return
         assert np.abs(f_dev - f_orc).max() <= 1e-3 * f_orc.max() + 0.02, (where, float(np.abs(f_dev - f_orc).max()), float(f_orc.max()))
         stats['forces'] += int((f_orc > 1.0).sum())
@@ -182,10 +185,10 @@ def test_touch_sensors_and_normal_forces_match_the_oracle():
     for t, c in enumerate(cmds):
         chk = t >= 262 and t % 2 == 0
         if chk:
-            st0 = env.state
+            st0, cache = env.state, env.contacts(0)
         env.step(np.tile(c, (4, 1)))
         if chk:
-            _check_forces(env, o, 0, st0, c, ('grasp', t), stats)
+            _check_forces(env, o, 0, st0, cache, c, ('grasp', t), stats)
     assert stats['touch'] >= 20, stats                # the distal skins pressed on the cube in the steps that were checked
     env.close()
     N = 34
@@ -201,10 +204,11 @@ def test_touch_sensors_and_normal_forces_match_the_oracle():
             ncs = np.array([len(env.contacts(i)) for i in range(N)])
             sel = np.argsort(-ncs)[:4]
             st0 = env.state
+            cache = {int(i): env.contacts(int(i)) for i in sel}
         env.step_plan(render=False)
         if chk:
             for i in sel:
-                _check_forces(env, o, int(i), st0, plans[i][t], ('push', t, int(i)), stats)
+                _check_forces(env, o, int(i), st0, cache[int(i)], plans[i][t], ('push', t, int(i)), stats)
     assert stats['forces'] - before['forces'] > 200, stats
     env.close()
 

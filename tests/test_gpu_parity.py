@@ -394,8 +394,9 @@ def test_pushing_gripper_one_step_parity():
         env.step_plan(render=False)
         if check:
             st1 = env.state
-            for i in sel:
+            for k_, i in enumerate(sel):
                 o.state = st0[i].astype(np.float64)
+                o.set_contact_cache(cont0[k_])          # contact history of the warm start
                 o.step(plans[i][t].astype(np.float64))
                 c = env.contacts(i)
                 rob = int((((c[:, 0] >= 0) & (c[:, 0] < 16)) | ((c[:, 1] >= 0) & (c[:, 1] < 16))).sum()) if len(c) else 0
