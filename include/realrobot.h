@@ -121,7 +121,10 @@ int rr_get_buffer(rr_env *env, int32_t field, void **dev_ptr, size_t *bytes);
  * previous frame of that env, so a caller that scribbles into them would see its marks survive. */
 /* Synchronising copy of a whole field to host memory. */
 int rr_copy_to_host(rr_env *env, int32_t field, void *dst, size_t bytes);
-/* Overwrites the full simulation state from host memory (f32 [N, 61]); checkpoint restore / parity tests. */
+/* Overwrites the full simulation state from host memory (f32 [N, 61]); checkpoint restore / parity tests.  The contact
+ * history of the warm start (the previous step's contact list, see rr_get_contacts) is not part of the 61 floats: the
+ * step after rr_set_state / rr_reset starts cold, as after pybullet's resetSimulation / restoreState without a saved
+ * manifold cache. */
 int rr_set_state(rr_env *env, const float *state_host);
 int rr_sync(rr_env *env);
 
@@ -129,7 +132,9 @@ int rr_sync(rr_env *env);
  * every robot link, f32 [N, 17, 7] (URDF depth-first link order, see data/realrobot_model_links.txt). */
 int rr_link_poses(rr_env *env, float *out_host);
 /* Replaces Kuka.get_contacts (robot.py:131-150) for one env: up to max_contacts rows of 12 floats
- * {bodyA, bodyB, linkA, x,y,z, nx,ny,nz, distance, normal_force, mu}; *count receives the number written. */
+ * {bodyA, bodyB, linkA, x,y,z, nx,ny,nz, distance, normal_force, mu}; *count receives the number written.  This list --
+ * the contacts of the last step with the normal forces the solver found -- is also the contact history the next step's
+ * warm start matches its contacts against (Bullet: persistent manifolds, m_warmstartingFactor 0.85). */
 int rr_get_contacts(rr_env *env, int32_t env_index, float *out_host, int32_t max_contacts, int32_t *count);
 
 /* Batched damped-least-squares inverse kinematics for link 7 (gripper `base`), seeded with each env's current joints.
