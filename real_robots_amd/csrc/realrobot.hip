@@ -124,9 +124,9 @@ struct DevPtrs {
     float4 *clist_prev; // the list of the step before (the two buffers change roles every step): contact history of the warm start
     float *cwarm;      // [N][MAXC] initial normal impulse of every contact of clist (k_collide: 0.85 x the matched previous one)
     float *cforce;     // [N][MAXC] normal force of every contact of the last step (rr_get_contacts, touch sensors)
-    int *hgflag;       // [ceil(N/4)] != 0: this solver group (four consecutive envs) holds an env with generic contacts -- "heavy"
-    int *hlist;        // [ceil(N/4)] the heavy groups of this step (in arrival order: placement only, never a result)
-    int *hcount;       // [1] their number
+    int *hgflag;       // [N] != 0: this env has generic contact rows this step -- "heavy"
+    int *hlist;        // [N] the heavy envs of this step (in arrival order: placement only, never a result)
+    int *hcount;       // [0] their number, [1] work counter of k_raster_list
     int *hcount_host;  // device address of the pinned host word that receives the previous step's number (or nullptr)
     int *timestep;     // [N]
     unsigned *errflags;// [N]
@@ -154,12 +154,12 @@ struct DevPtrs {
     unsigned *frag_count;   // [N*ntiles]
 };
 
-// Which envs a launch handles: 0 all; 1 the envs of light solver groups; 2 the envs of heavy ones (rr_step runs the few
-// heavy groups -- an arm pressed on the table, a gripper pushing objects: dozens of generic contact rows -- and their
-// render on the side stream, beside the render of the others).
+// Which envs a launch handles: 0 all; 1 the light envs; 2 the heavy ones (rr_step runs the few heavy envs -- an arm
+// pressed on the table, a gripper pushing objects: dozens of generic contact rows -- and their render on the side stream,
+// beside the render of the others).
 __device__ __forceinline__ bool env_selected(const int *hgflag, int env, int sel) {
     if (sel == 0) return true;
-    const bool heavy = hgflag[env >> 2] != 0;
+    const bool heavy = hgflag[env] != 0;
     return sel == 1 ? !heavy : heavy;
 }
 
@@ -356,7 +356,7 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
     if (env >= N) return;
     float *state = D.state, *scratch = D.scratch;
     if (PHASE == 1) {       // k_collide classifies the solver groups of this step: reset its bookkeeping (no extra launch)
-        if ((env & 3) == 0) D.hgflag[env >> 2] = 0;
+        D.hgflag[env] = 0;
         if (env == 0) {
             // (the count of the step before goes to pinned host memory on the way: a posted write, nobody waits for it)
             if (D.hcount_host) *D.hcount_host = D.hcount[0];
@@ -1204,7 +1204,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, Dev
     if (tid == 0) {
         heavy = heavy || oscnt0 > 4 || oscnt1 > 4 || oscnt2 > 4;
         D.ccount[env] = nct;
-        if (heavy && atomicOr(&D.hgflag[env >> 2], 1) == 0) D.hlist[atomicAdd(D.hcount, 1)] = env >> 2;
+        if (heavy) { D.hgflag[env] = 1; D.hlist[atomicAdd(D.hcount, 1)] = env; }
     }
 }
 #undef CAND_ARGMAX
@@ -1371,21 +1371,22 @@ __device__ __forceinline__ float4 sel4(bool has, float4 v) {
     return make_float4(has ? v.x : 0.0f, has ? v.y : 0.0f, has ? v.z : 0.0f, has ? v.w : 0.0f);
 }
 
-// sel 0: workgroup b handles the solver group b (envs 4 b .. 4 b + 3); 1: the same, but heavy groups are left out; 2: wave w of
-// the launch handles the w-th heavy group of D.hlist (256-thread workgroups: four heavy groups fill a CU's LDS and leave
-// the other CUs to the render of the light envs).
+// sel 0: wave b handles the envs 4 b .. 4 b + 3; 1: the same, but heavy envs are left out (their 16 lanes run along as no-ops);
+// 2: wave w of the launch handles the heavy envs 4 w .. 4 w + 3 of D.hlist -- packed four to a wave whichever groups they
+// come from (256-thread workgroups: sixteen heavy envs fill a CU's LDS and leave the other CUs to the render of the light
+// envs).  No result depends on which envs share a wave: only trip counts and the choice between equivalent code paths do.
 __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtrs D, int sel) {
     const int N = P.N;
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
-    int unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // solver group = the four envs of this wave
-    bool skip = false;
-    if (sel == 2) { skip = unit >= *D.hcount; unit = skip ? 0 : D.hlist[unit]; }
-    else if (sel == 1) skip = 4 * unit < N && D.hgflag[unit] != 0;
-    if (skip) return;                                                 // (wave-uniform; the kernel has no workgroup barrier)
-    const int env_raw = 4 * unit + (grp & 3);
+    const int unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // the wave's index in the launch
+    int env_raw = 4 * unit + (grp & 3);
+    bool mine = true;                                                 // this 16-lane group has an env to solve in this launch
+    if (sel == 2) { mine = env_raw < *D.hcount; env_raw = mine ? D.hlist[env_raw] : N; }
+    else if (sel == 1) mine = env_raw < N && D.hgflag[env_raw] == 0;
+    if (__ballot(mine) == 0ull) return;                               // (wave-uniform; the kernel has no workgroup barrier)
     const int env = env_raw < N ? env_raw : N - 1;                    // groups without an env run along as no-ops
     float *state = D.state, *scratch = D.scratch;
-    const bool dead = env_raw >= N || D.errflags[env] != 0;
+    const bool dead = !mine || env_raw >= N || D.errflags[env] != 0;
     const ShapeData *S = D.shapes;
     const int fix = grp * LF_TOTAL;
     const int L_MINV = fix + LF_MINV, L_MOT = fix + LF_MOT, L_LIM = fix + LF_LIM, L_META = fix + LF_META, L_MU = fix + LF_MU,
@@ -3029,11 +3030,11 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     raster_tile(P, *RMp, D, n_inst_used, pass, env, tile, restore);
 }
 
-// The envs of the heavy solver groups (D.hlist, D.hcount -- known on the device only): a fixed number of workgroups walk the
+// The heavy envs (D.hlist, D.hcount -- known on the device only): a fixed number of workgroups walk the
 // list, so that no LDS-filling workgroup is launched just to find that its env is not on it.
 __global__ void __launch_bounds__(RASTER_THREADS) k_raster_list(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int restore) {
     const RenderModel &RM = *RMp;
-    const int nitems = D.hcount[0] * 4 * RM.ntiles;
+    const int nitems = D.hcount[0] * RM.ntiles;
     __shared__ int s_item;
     for (;;) {
         if (threadIdx.x == 0) s_item = atomicAdd(&D.hcount[1], 1);      // dynamic assignment: tiles differ a lot in cost
@@ -3041,7 +3042,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster_list(SimParams P, con
         const int it = s_item;
         if (it >= nitems) break;
         const int tile = it % RM.ntiles, ge = it / RM.ntiles;
-        const int env = 4 * D.hlist[ge >> 2] + (ge & 3);
+        const int env = D.hlist[ge];
         if (env < P.N && !(D.render_flags && !D.render_flags[env])) raster_tile(P, RM, D, n_inst_used, 0, env, tile, restore);
         __syncthreads();        // the LDS of the tile is reused
     }
@@ -3221,6 +3222,7 @@ struct rr_env {
     std::vector<void *> allocs;
     bool timing;
     bool full_copy, sep_restore;   // RR_FULL_COPY / RR_SEPARATE_RESTORE at create: the two earlier image-update schemes (tests, A/B)
+    int split_max_pct;             // the heavy / light split is used while at most this share of the solver groups is heavy (RR_SPLIT_MAX_PCT)
     int *h_hcount;                 // pinned host copy of D.hcount[0] (device-mapped: written by k_prep_a of the following step)
     bool split_heavy;              // heavy solver groups + their render on the side stream (RR_NO_SPLIT=1 turns it off: A/B, tests)
     bool images_valid;       // every env's image holds its previous frame (static layer + the pixels of its fragment list)
@@ -3364,6 +3366,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->sep_restore = getenv("RR_SEPARATE_RESTORE") != nullptr;
     e->split_heavy = getenv("RR_NO_SPLIT") == nullptr;
     e->h_hcount = nullptr;
+    e->split_max_pct = getenv("RR_SPLIT_MAX_PCT") ? atoi(getenv("RR_SPLIT_MAX_PCT")) : 25;
     if (hipHostMalloc((void **)&e->h_hcount, sizeof(int), hipHostMallocMapped) == hipSuccess) *e->h_hcount = 0; else e->h_hcount = nullptr;
     e->plan = nullptr; e->plan_step = nullptr; e->ik_in = nullptr; e->ik_out = nullptr; e->ik_err = nullptr;
     e->cfg = *cfg;
@@ -3492,8 +3495,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     ALLOC(D.clist_prev, (size_t)N * MAXC * 3);
     ALLOC(D.cwarm, (size_t)N * MAXC);
     ALLOC(D.cforce, (size_t)N * MAXC);
-    ALLOC(D.hgflag, (size_t)(N + 3) / 4);
-    ALLOC(D.hlist, (size_t)(N + 3) / 4);
+    ALLOC(D.hgflag, (size_t)N);
+    ALLOC(D.hlist, (size_t)N);
     ALLOC(D.hcount, (size_t)4);
     e->D.hcount_host = nullptr;
     if (e->h_hcount && hipHostGetDevicePointer((void **)&e->D.hcount_host, e->h_hcount, 0) != hipSuccess) e->D.hcount_host = nullptr;
@@ -3810,7 +3813,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     const size_t lds64 = (size_t)SGRP * LF_TOTAL * sizeof(float);
     // (the number of heavy groups of a recent step, written to pinned host memory by k_prep_a without anybody waiting for it: when most groups are
     // heavy -- macro actions, every gripper pushing -- there is nothing to gain from the split)
-    const bool mostly_heavy = e->h_hcount && *(volatile int *)e->h_hcount * 4 > ngroups;
+    const bool mostly_heavy = e->h_hcount && (long long)*(volatile int *)e->h_hcount * 100 > (long long)N * e->split_max_pct;
     if (dyn_forked && render_mode && e->split_heavy && !mostly_heavy) {
         // The few solver groups with generic contact rows take several times as long as the others (the kernel lasts as long
         // as its longest Gauss-Seidel chain).  They are solved and rendered on the side stream -- four groups per 256-thread
