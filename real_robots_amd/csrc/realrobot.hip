@@ -65,7 +65,7 @@ struct BodyParams {   // passed by value as kernel argument -> scalar loads, uni
 };
 
 struct SimParams {
-    int N, nobj, iters, npairs, ablate, small_area, os_cap, edge_contacts;
+    int N, nobj, iters, npairs, ablate, small_area, os_cap, edge_contacts, heavy_min;
     float warmstart;   // Bullet's m_warmstartingFactor (0.85); 0: cold start every step   // os_cap: object-vs-static contacts per env with rows in LDS (<= OS_CAP)
     float dt, gravity, erp, margin, kp, kd, max_impulse, lin_damp, ang_damp, rest_thresh;
 };
@@ -844,7 +844,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, Dev
     CPROF(1);
     const int ncl = n_close;
     int nct = 0;                                // contacts of this env so far        }
-    bool heavy = false;                         // some contact is not an object-vs-static one the object lanes take    } tracked by wave 0
+    int ngen = 0;                               // contacts that are not object-vs-static ones the object lanes take: generic rows    } tracked by wave 0
     int oscnt0 = 0, oscnt1 = 0, oscnt2 = 0;     // object-vs-static contacts per object }
     int nchunk = 0;
     for (int base = 0; base < ncl && nct < MAXC; base += nchunk) {
@@ -1093,7 +1093,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, Dev
             const int cls = (pab >> 16) & 3;
             const int ob = (pab & 255) - (ns - NOBJ);                   // object index of shape a for the object-vs-static pairs
             const bool os = cls == 0 && ob >= 0;
-            heavy = heavy || __ballot(kk > 0 && !os) != 0ull;
+            { int tg_; wave_excl_scan(os ? 0 : kk, lane, tg_); ngen += tg_; }
             int t0_, t1_, t2_;
             wave_excl_scan(os && ob == 0 ? kk : 0, lane, t0_);
             wave_excl_scan(os && ob == 1 ? kk : 0, lane, t1_);
@@ -1202,7 +1202,10 @@ __global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, Dev
     }
     CPROF_END;
     if (tid == 0) {
-        heavy = heavy || oscnt0 > 4 || oscnt1 > 4 || oscnt2 > 4;
+        // "heavy": more generic contacts than P.heavy_min (an env with a few generic rows lengthens its wave's chain by a
+        // quarter, an arm pressed on the table fourfold -- only the latter are worth the side stream when many envs have some)
+        ngen += max(oscnt0 - 4, 0) + max(oscnt1 - 4, 0) + max(oscnt2 - 4, 0);
+        const bool heavy = ngen > P.heavy_min;
         D.ccount[env] = nct;
         if (heavy) { D.hgflag[env] = 1; D.hlist[atomicAdd(D.hcount, 1)] = env; }
     }
@@ -3030,6 +3033,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const Re
     raster_tile(P, *RMp, D, n_inst_used, pass, env, tile, restore);
 }
 
+#define RASTER_LIST_WGS 768      // three per CU, as many as fit (a long list of heavy envs must not be rendered at a third of the occupancy)
 // The heavy envs (D.hlist, D.hcount -- known on the device only): a fixed number of workgroups walk the
 // list, so that no LDS-filling workgroup is launched just to find that its env is not on it.
 __global__ void __launch_bounds__(RASTER_THREADS) k_raster_list(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int restore) {
@@ -3366,7 +3370,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->sep_restore = getenv("RR_SEPARATE_RESTORE") != nullptr;
     e->split_heavy = getenv("RR_NO_SPLIT") == nullptr;
     e->h_hcount = nullptr;
-    e->split_max_pct = getenv("RR_SPLIT_MAX_PCT") ? atoi(getenv("RR_SPLIT_MAX_PCT")) : 25;
+    e->split_max_pct = getenv("RR_SPLIT_MAX_PCT") ? atoi(getenv("RR_SPLIT_MAX_PCT")) : 60;
     if (hipHostMalloc((void **)&e->h_hcount, sizeof(int), hipHostMallocMapped) == hipSuccess) *e->h_hcount = 0; else e->h_hcount = nullptr;
     e->plan = nullptr; e->plan_step = nullptr; e->ik_in = nullptr; e->ik_out = nullptr; e->ik_err = nullptr;
     e->cfg = *cfg;
@@ -3414,6 +3418,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     P.ablate = getenv("RR_ABLATE") ? atoi(getenv("RR_ABLATE")) : 0;
     P.small_area = getenv("RR_SMALL_AREA") ? atoi(getenv("RR_SMALL_AREA")) : SMALL_AREA;
     // RR_SOLVER_POOL (tests): LDS floats for object-vs-static rows, 60 per contact; contacts beyond it take the generic (slot layout) path
+    P.heavy_min = getenv("RR_HEAVY_MIN") ? atoi(getenv("RR_HEAVY_MIN")) : 0;
     P.warmstart = getenv("RR_NO_WARMSTART") ? 0.0f : 0.85f;       // (diagnostics: cold start every step)
     P.edge_contacts = getenv("RR_NO_EDGE_CONTACTS") ? 0 : 1;       // (diagnostics: vertex candidates only)
     P.os_cap = getenv("RR_SOLVER_POOL") ? std::max(0, std::min(atoi(getenv("RR_SOLVER_POOL")) / 60, (int)OS_CAP)) : OS_CAP;
@@ -3735,7 +3740,7 @@ static void launch_render(rr_env *e, const DevPtrs &D, int restore, int sel, hip
         TIMED(6, hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel));
     } else {
         hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, st, e->B, e->P, e->RM_dev, D, sel);
-        if (sel == 2) hipLaunchKernelGGL(k_raster_list, dim3(std::min(N * e->RM.ntiles, 256)), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, restore);
+        if (sel == 2) hipLaunchKernelGGL(k_raster_list, dim3(std::min(N * e->RM.ntiles, RASTER_LIST_WGS)), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, restore);
         else hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, 0, 0, restore, sel);
         hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel);
     }
