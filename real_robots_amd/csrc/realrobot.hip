@@ -1745,8 +1745,12 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
     // completed (workgroup scope: the CU's vector L1 is write-through and shared by the workgroup -- no cache maintenance;
     // an agent-scope fence would write back the XCD's L2)
     if (ng_max > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    const int grow_base = env * GROWS * 16;               // float4 index of row 0 of this env (fits an int: N <= 2^31 / 4608)
-    const int zrow = P.N * GROWS * 16;                    // an all-zero row behind the last env's rows
+    // byte offsets into D.grows (32 bits: rr_create checks N; a uniform base + a 32-bit lane offset is one address operand
+    // of the load instead of a 64-bit add per row)
+    const int grow_base = (int)((unsigned)env * (unsigned)(GROWS * 256));      // row 0 of this env
+    const int zrow = (int)((unsigned)P.N * (unsigned)(GROWS * 256));           // an all-zero row behind the last env's rows
+    const unsigned lane_off = (unsigned)l << 4;
+#define GROW_AT(IDX) (*(const float4 *)((const char *)D.grows + ((unsigned)(IDX) + lane_off)))
     // object lane (11 + O) -> slots, and back; comps 0..5 = dv.xyz, dw.xyz
 #define TO_SLOT(O, C, REG, SLOTREG, LANE) { const float t_ = row_bcast<NB + (O)>(REG); SLOTREG = (l == (LANE)) ? t_ : SLOTREG; }
 #define FROM_SLOT(O, C, REG, SLOTREG, LANE) { const float t_ = row_bcast<LANE>(SLOTREG); REG = (l == NB + (O)) ? t_ : REG; }
@@ -1802,14 +1806,14 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                                                       max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
             const unsigned short *lst = pass == 1 ? listF : listT;
 #define ENTRY(I) ((I) < cnt ? (pass == 0 ? 6 * (I) : (int)lst[(I) < cnt ? (I) : 0]) : 0xffff)        /* row id | k << 9 */
-#define ENTRY_IDX(E) ((E) == 0xffff ? zrow : grow_base + ((E) & 511) * 16)
+#define ENTRY_IDX(E) ((E) == 0xffff ? zrow : grow_base + ((E) & 511) * 256)
             int e_cur = ENTRY(l), e_nxt = ENTRY(16 + l);
             int idx_cur = ENTRY_IDX(e_cur), idx_nxt = ENTRY_IDX(e_nxt);
             float4 Q0, Q1, Q2, Q3, Q4, Q5, Q6, Q7;
             if (cmax > 0) {
-                Q0 = D.grows[row_bcast_i<0>(idx_cur) + l]; Q1 = D.grows[row_bcast_i<1>(idx_cur) + l]; Q2 = D.grows[row_bcast_i<2>(idx_cur) + l];
-                Q3 = D.grows[row_bcast_i<3>(idx_cur) + l]; Q4 = D.grows[row_bcast_i<4>(idx_cur) + l]; Q5 = D.grows[row_bcast_i<5>(idx_cur) + l];
-                Q6 = D.grows[row_bcast_i<6>(idx_cur) + l]; Q7 = D.grows[row_bcast_i<7>(idx_cur) + l];
+                Q0 = GROW_AT(row_bcast_i<0>(idx_cur)); Q1 = GROW_AT(row_bcast_i<1>(idx_cur)); Q2 = GROW_AT(row_bcast_i<2>(idx_cur));
+                Q3 = GROW_AT(row_bcast_i<3>(idx_cur)); Q4 = GROW_AT(row_bcast_i<4>(idx_cur)); Q5 = GROW_AT(row_bcast_i<5>(idx_cur));
+                Q6 = GROW_AT(row_bcast_i<6>(idx_cur)); Q7 = GROW_AT(row_bcast_i<7>(idx_cur));
             }
             // ---- object-vs-static rows of this pass (object lanes, side by side; all register resident)
             if (pass == 0) { OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3) }
@@ -1833,7 +1837,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
 #define GROW_STEP(S, Q, NEXTIDX)                                                                                       \
                 {                                                                                                      \
                     const float4 rw_ = Q;                                                                              \
-                    Q = D.grows[(NEXTIDX) + l];                                                                              \
+                    Q = GROW_AT(NEXTIDX);                                                                                    \
                     const float p_ = fmaf(rw_.z, vb, rw_.x * dq);                                                      \
                     const float jv_ = group_sum(p_);                                                                   \
                     const float s0_ = fmaf(-jv_, dinv, lam + rhs);                                                     \
@@ -3344,6 +3348,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     if (!cfg || !model_blob || !out) return fail(RR_EINVAL, "rr_create: null argument");
     if (cfg->abi_version != RR_ABI_VERSION) return fail(RR_EINVAL, "rr_create: abi_version mismatch");
     if (cfg->num_envs < 1) return fail(RR_EINVAL, "rr_create: num_envs < 1");
+    if ((unsigned long long)cfg->num_envs * GROWS * 256ull + 256ull >= (1ull << 32)) return fail(RR_EINVAL, "rr_create: more than 58253 envs per rr_env (32-bit byte offsets of the solver's row store)");
     if (cfg->n_objects < 1 || cfg->n_objects > NOBJ) return fail(RR_EINVAL, "rr_create: n_objects must be 1..3");
     if (cfg->width < 4 || cfg->height < 1 || cfg->width % 4 != 0 || cfg->width > TILE_PIX)
         return fail(RR_EINVAL, "rr_create: width must be a multiple of 4 in [4,4096]");
