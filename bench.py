@@ -38,6 +38,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 # VALU issue peak in wave64 instructions / s: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4
 RENDER_KERNELS = ('k_image_setup', 'k_raster', 'k_shade')                      # together they produce the observation image
+SIDE_STREAM_KERNELS = ('k_solve_heavy', 'render_heavy')                        # the heavy envs' share, beside the main stream
 
 
 def algo_bytes(n_obj, w, h):
@@ -123,7 +124,13 @@ def kernel_table(env, nat, n_local, n_obj, w, h, render, step_fn, nprof):
         algo['k_shade'] += 15 * frags
     kernels = {}
     for k, (ms, n) in timing.items():
-        if n:
+        if not n:
+            continue
+        if k in SIDE_STREAM_KERNELS:
+            # what an untimed step runs on the side stream for its few heavy envs: listed, not priced
+            # (their number is known on the device only) and never the roofline unit -- they are off the step's critical path
+            kernels[k] = {"avg_ms": round(ms / n, 4), "launches": n, "stream": "side (beside the main stream's solve + render)"}
+        else:
             kernels[k] = {"avg_ms": round(ms / n, 4), "launches": n,
                           "algorithmic_GBs": round(algo[k] * n_local / (ms / n * 1e-3) / 1e9, 2)}
     return kernels, algo, frags
@@ -310,13 +317,15 @@ def main():
     views_saved, views = views, None              # the timing pass measures the kernels, not the gather
     kernels, algo, frags = kernel_table(env, nat, n_local, n_obj, W, H, render, lambda t: one_step(base_t + t), nprof)
     views = views_saved
-    dom_kernel = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+    # the dominant kernel = the largest share of the step's critical path: the main stream's launches (the side stream's
+    # solve + render of the few heavy envs end before the main stream's render does, profiles/README.md)
+    dom_kernel = max((k for k in kernels if k not in SIDE_STREAM_KERNELS), key=lambda k: kernels[k]["avg_ms"])
     dom = dom_kernel
     if render:
         # the image is produced by two kernels (visibility; deferred shading incl. putting vacated pixels back to the
         # static layer): the stage as a whole is what SURVEY 8(d)'s image bytes belong to
         members = [k for k in RENDER_KERNELS if k in kernels]
-        rms = sum(kernels[k]["avg_ms"] for k in members)
+        rms = sum(kernels[k]["avg_ms"] for k in members) + (kernels['render_heavy']["avg_ms"] if 'render_heavy' in kernels else 0.0)
         kernels['render_stage'] = {"avg_ms": round(rms, 4), "launches": kernels['k_raster']["launches"], "members": members,
                                    "algorithmic_GBs": round(algo['_image'] * n_local / (rms * 1e-3) / 1e9, 2),
                                    "list_entries_per_env": round(frags, 1)}
@@ -357,9 +366,11 @@ def main():
                               "env-step the dominant kernels are VALU-issue / latency bound (roofline.valu; DESIGN.md 5)",
                 "valu": valu,
                 "kernels": kernels,
-                "timing_note": "per-kernel durations: HIP events on the library's stream, every kernel alone on the stream "
-                               "(no side-stream overlap), %d steps of the same workload right after the timed region; "
-                               "rocprofv3 --stats of the overlapped run is under profiles/" % nprof}
+                "timing_note": "per-kernel durations: HIP events on the library's stream, the launches of a step one after the "
+                               "other (no side-stream overlap), %d steps of the same workload right after the timed region; "
+                               "k_solve / k_render_setup / k_raster / k_shade = the main stream's launches (light envs), "
+                               "k_solve_heavy / render_heavy = the side stream's (heavy envs); render_stage = the image of every "
+                               "env = k_raster + k_shade + render_heavy; rocprofv3 --stats of the overlapped run is under profiles/" % nprof}
     env.close()
 
     secondary = None

@@ -16,10 +16,11 @@ LINK_NAMES = open(os.path.join(_HERE, 'data', 'realrobot_model_links.txt')).read
 
 RR_ABI_VERSION = 1
 (F_JOINTS, F_TOUCH, F_OBJ_POSE, F_RGB, F_DEPTH, F_MASK, F_TIMESTEP, F_ERRFLAGS, F_STATE, F_FRAG_COUNT) = range(10)
-NUM_KERNELS = 7
+NUM_KERNELS = 9
 # id 5 = image set-up outside the two render kernels: the full static copy of the first frame (and the earlier schemes
 # RR_FULL_COPY / RR_SEPARATE_RESTORE); it does not run in steady state
-KERNEL_NAMES = ('k_prep', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster', 'k_image_setup', 'k_shade')
+KERNEL_NAMES = ('k_prep', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster', 'k_image_setup', 'k_shade',
+                'k_solve_heavy', 'render_heavy')      # 7, 8: the heavy envs' solve / render (side stream in an untimed step)
 
 # every symbol include/realrobot.h declares (tests check the library exports all of them)
 SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_object_pose', 'rr_set_object_home', 'rr_step', 'rr_render',

@@ -3129,15 +3129,11 @@ __global__ void k_background(const RenderModel *RMp, DevPtrs D) {
 // staging of the instance constants outweighs the tail of long lists.
 #define SHADE_THREADS 256
 #define SHADE_SPLIT 8
-__global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags, int env0, int sel) {
-    const RenderModel &RM = *RMp;
-    __shared__ __attribute__((aligned(16))) float mvp[MAXINST][16];
-    __shared__ __attribute__((aligned(16))) float sinst[MAXINST][16];
-    const int env = blockIdx.x + env0, tile = blockIdx.y;
-    if (use_flags && D.render_flags && !D.render_flags[env]) return;
-    if (!env_selected(D.hgflag, env, sel)) return;
+// chunk z of nz of the fragment list of (env, tile); mvp / sinst: the workgroup's staging arrays
+__device__ __forceinline__ void shade_block(const RenderModel &RM, const DevPtrs &D, const ImageOut &out, int env, int tile, int z, int nz,
+                                            float (*mvp)[16], float (*sinst)[16]) {
     const unsigned n = D.frag_count[(size_t)env * RM.ntiles + tile];
-    if (blockIdx.z * SHADE_THREADS >= n) return;
+    if ((unsigned)z * SHADE_THREADS >= n) return;               // (workgroup-uniform)
     stage_instances(RM, D, env, threadIdx.x, SHADE_THREADS, mvp, sinst);
     __syncthreads();
     ShadeCtx ctx;
@@ -3146,7 +3142,7 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp,
     const int row0 = tile * RM.tile_h;
     const size_t base = (size_t)env * out.env_stride + (size_t)row0 * RM.W;
     const unsigned long long *sv = D.static_vis ? D.static_vis + (size_t)row0 * RM.W : nullptr;   // null while the static layer itself is built
-    for (unsigned i = blockIdx.z * SHADE_THREADS + threadIdx.x; i < n; i += gridDim.z * SHADE_THREADS) {
+    for (unsigned i = z * SHADE_THREADS + threadIdx.x; i < n; i += nz * SHADE_THREADS) {
         const uint2 f = lst[i];
         const int pi = (int)(f.y >> 18), t = (int)(f.y & 0x3ffffu);
         // a moving triangle only shows where it beats the static layer (depth, then triangle id; static ids are lower);
@@ -3169,7 +3165,14 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp,
         if (out.mask) out.mask[o] = m;
     }
 }
-
+__global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags, int env0, int sel) {
+    __shared__ __attribute__((aligned(16))) float mvp[MAXINST][16];
+    __shared__ __attribute__((aligned(16))) float sinst[MAXINST][16];
+    const int env = blockIdx.x + env0, tile = blockIdx.y;
+    if (use_flags && D.render_flags && !D.render_flags[env]) return;
+    if (!env_selected(D.hgflag, env, sel)) return;
+    shade_block(*RMp, D, out, env, tile, blockIdx.z, gridDim.z, mvp, sinst);
+}
 // ---------------------------------------------------------------------------------------------- host side
 struct BlobEntry {
     char name[32];
@@ -3747,6 +3750,7 @@ static void launch_render(rr_env *e, const DevPtrs &D, int restore, int sel, hip
         hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, st, e->B, e->P, e->RM_dev, D, sel);
         if (sel == 2) hipLaunchKernelGGL(k_raster_list, dim3(std::min(N * e->RM.ntiles, RASTER_LIST_WGS)), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, restore);
         else hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, 0, 0, restore, sel);
+        // (a list-walking shade kernel for the heavy envs was tried: faster for a handful of them, much slower for a thousand)
         hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel);
     }
 }
@@ -3824,7 +3828,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     // (the number of heavy groups of a recent step, written to pinned host memory by k_prep_a without anybody waiting for it: when most groups are
     // heavy -- macro actions, every gripper pushing -- there is nothing to gain from the split)
     const bool mostly_heavy = e->h_hcount && (long long)*(volatile int *)e->h_hcount * 100 > (long long)N * e->split_max_pct;
-    if (dyn_forked && render_mode && e->split_heavy && !mostly_heavy) {
+    if ((dyn_forked || e->timing) && e->aux && render_mode && e->split_heavy && !mostly_heavy) {
         // The few solver groups with generic contact rows take several times as long as the others (the kernel lasts as long
         // as its longest Gauss-Seidel chain).  They are solved and rendered on the side stream -- four groups per 256-thread
         // workgroup, so that they fill the LDS of a few CUs and leave the rest to the raster workgroups of the light envs --
@@ -3832,6 +3836,16 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         DevPtrs D = e->D;
         if (render_mode != 2) D.render_flags = nullptr;
         const int restore = ensure_images(e, D);
+        if (e->timing) {
+            // timing leg: the very same launches, one after the other on the main stream, each under its timer -- 2 / 3 / 4 / 6
+            // what the main stream runs in an untimed step (the light envs), 7 / 8 what the side stream runs beside it
+            TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1));
+            TIMED(7, hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->stream, e->B, e->P, e->D, 2));
+            launch_render(e, D, restore, 1, e->stream, true);
+            TIMED(8, launch_render(e, D, restore, 2, e->stream, false));
+            HIPCHK(hipGetLastError());
+            return RR_OK;
+        }
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
         hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->aux, e->B, e->P, e->D, 2);
