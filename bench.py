@@ -12,8 +12,10 @@ batch.  Joint commands: README-style resample-and-hold `action_space.sample()` o
 Weak scaling by default (every rank owns --envs-per-gpu envs; `--scaling strong` splits a fixed total over the ranks);
 no collective on the stepping path; `--gather lowdim|images` adds the optional policy-side observation all-gather
 (RCCL).  Rank 0 prints ONE JSON line.  Extra objects in that line:
-  roofline      per-kernel HIP-event durations (library stream) and, for the unit that dominates the step, ALGORITHMIC bytes
-                per launch / duration against the 8 TB/s HBM peak (`achieved` is that ratio, not a measured HBM rate; the
+  roofline      per-kernel HIP-event durations (library stream; the launches of a step one after the other: k_solve, k_raster
+                ... are what the main stream runs for the light envs, k_solve_heavy / render_heavy what the side stream runs
+                beside them for the few heavy ones) and, for the unit that dominates the step's critical path, ALGORITHMIC
+                bytes per launch / duration against the 8 TB/s HBM peak (`achieved` is that ratio, not a measured HBM rate; the
                 measured HBM bytes of the same configuration, when a committed PMC profile matches it, are `traffic`).
                 `roofline.valu` prices the dominant kernel against the VALU issue peak, which is what actually bounds it.
   secondary     (N=1 only) the same library on the other workloads a reader needs to judge the headline: half-range
