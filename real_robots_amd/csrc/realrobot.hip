@@ -3585,7 +3585,12 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         // fork / join events order two streams of the same device: no timing, no system-scope fence (the cache writeback
         // and invalidation a default event performs when it is recorded costs ~6 us on the stream that records it)
         const unsigned evf = getenv("RR_EVENT_FLAGS") ? (unsigned)strtoul(getenv("RR_EVENT_FLAGS"), nullptr, 0) : (hipEventDisableTiming | hipEventDisableSystemFence);
-        if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, evf) != hipSuccess ||
+        // the side stream carries the step's longest chain (the heavy envs' solve, then their render): with a higher
+        // priority its few workgroups are dispatched ahead of the main stream's render when both are ready (RR_AUX_PRIORITY=0: same)
+        int prio_lo = 0, prio_hi = 0;
+        hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        const int prio = getenv("RR_AUX_PRIORITY") && atoi(getenv("RR_AUX_PRIORITY")) == 0 ? prio_lo : prio_hi;
+        if (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, evf) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_join, evf) != hipSuccess || hipEventCreateWithFlags(&e->ev_dyn, evf) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
     }
     e->field_ptr[RR_F_JOINTS] = D.joints; e->field_bytes[RR_F_JOINTS] = (size_t)N * 9 * 4;
