@@ -2389,7 +2389,7 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 // ---------------------------------------------------------------------------------------------- rasteriser
 // One workgroup per (env, tile). Tile = full-width strip of tile_h rows (<= TILE_PIX pixels, 8 bytes of LDS key each).
 #ifndef RASTER_THREADS
-#define RASTER_THREADS 512       // with TILE_PIX 4096: 47 KB of LDS -> three workgroups = six waves per SIMD (A/B below)
+#define RASTER_THREADS 512       // with TILE_PIX 4096: 39.5 KB of LDS -> four workgroups = eight waves per SIMD (A/B below)
 #endif
 #define VIS_WAS_DYNAMIC (~0ull - 1)   // visibility key of a pixel that was dynamic in the previous frame and is not (yet) now
 #define FRAG_VACATED 0x3ffffu         // triangle field of a fragment-list entry for such a pixel: back to the static layer
@@ -2398,7 +2398,12 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 #ifndef TILE_PIX
 #define TILE_PIX 4096
 #endif
-#define MAXWIN 1024      // 64-triangle windows per model (rr_create checks nt)
+// LDS of a raster workgroup: 32 KB of keys + 1 KB window list + 1 KB running ends + 1.5 KB matrices + 4 KB clip queue = 39.5 KB:
+// four workgroups per CU = eight waves per SIMD, which also needs <= 64 VGPRs (A/B: three workgroups 0.434 ms, four 0.390 ms)
+#define MAXWIN 512       // 64-triangle windows per model (rr_create checks nt)
+#define RASTER_INST 24   // instances whose matrices a raster workgroup stages (rr_create checks the model)
+#define RASTER_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+static_assert(RASTER_INST <= MAXINST && MAXWIN <= 512, "clip queue entries: window position (9 bits) << 6 | lane");
 #ifndef CLIPQ
 #define CLIPQ 2048       // triangles crossing the near plane per (env, tile) that are clipped (a link cut by the plane has a few hundred)
 #endif
@@ -2652,11 +2657,11 @@ extern "C" int rr_debug_raster_stats(unsigned long long *out16, int reset) {
 struct ImageOut { unsigned char *rgb; float *depth; int *mask; size_t env_stride; /* pixels between envs */ };
 __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderModel &RM, const DevPtrs &D, int n_inst_used, int pass, int env, int tile, int restore) {
     __shared__ unsigned long long vis[TILE_PIX];
-    __shared__ __attribute__((aligned(16))) float mvp[MAXINST][16];
+    __shared__ __attribute__((aligned(16))) float mvp[RASTER_INST][16];
     __shared__ unsigned nlist, wcount, wnext;
     __shared__ unsigned short wlist[MAXWIN];
-    __shared__ int wends[RASTER_THREADS / 64][64];      // per wave: running ends of the lanes' left-over points
-    __shared__ int clipq[CLIPQ];                        // triangles that cross the near plane (rare), clipped after the window loop
+    __shared__ unsigned short wends[RASTER_THREADS / 64][64];      // per wave: running ends of the lanes' left-over points (<= 64 x SMALL_AREA)
+    __shared__ unsigned short clipq[CLIPQ];             // triangles that cross the near plane (rare), clipped after the window loop: position in wlist << 6 | lane
     __shared__ unsigned nclipq;
     const int W = RM.W, H = RM.H;
     const int row0 = tile * RM.tile_h;
@@ -2812,14 +2817,14 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             int total;
             const int pre = wave_excl_scan(rem, lane, total);
             if (total > 0) {
-                int *we = wends[tid >> 6];
-                we[lane] = pre + rem;                                // inclusive ends, non-decreasing over the lanes
+                unsigned short *we = wends[tid >> 6];
+                we[lane] = (unsigned short)(pre + rem);                                // inclusive ends, non-decreasing over the lanes
                 for (int w0 = 0; w0 < total; w0 += 64) {             // wave-uniform trip count: ds_bpermute needs the owner lanes active
                     const int w = w0 + lane;
                     const bool valid = w < total;
                     int src = 0;                                     // owner = number of lanes whose points end at or before w
 #pragma unroll
-                    for (int step = 32; step; step >>= 1) if (we[src + step - 1] <= w) src += step;
+                    for (int step = 32; step; step >>= 1) if ((int)we[src + step - 1] <= w) src += step;
                     src = valid ? src : 0;
                     STri bs;
 #pragma unroll
@@ -2890,13 +2895,13 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             }
         }
         // triangles that cross the near plane are rare: they are queued and clipped after the window loop
-        if (needs_clip && !ABL(16)) { const unsigned qi = atomicAdd(&nclipq, 1u); if (qi < CLIPQ) clipq[qi] = t; }
+        if (needs_clip && !ABL(16)) { const unsigned qi = atomicAdd(&nclipq, 1u); if (qi < CLIPQ) clipq[qi] = (unsigned short)((k << 6) | lane); }
     }
     // ---- triangles that cross the near plane (queued above): clipped against w = NEAR_W (Sutherland-Hodgman, the oracle's
     // clip_near()) into a triangle or a fan of two, which a whole wave rasterises under the original triangle id
     __syncthreads();
     for (unsigned qi = tid >> 6; qi < min(nclipq, (unsigned)CLIPQ); qi += RASTER_THREADS / 64) {
-        const int bt = clipq[qi];
+        const int bt = t_begin + ((int)wlist[clipq[qi] >> 6] << 6) + (clipq[qi] & 63);
         const int tb = bt & ~63;
         const int inst = D.tri_inst[tb];
         STri ta, tb2;
@@ -3030,17 +3035,18 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
 }
 
 // One workgroup per (env, tile); sel (env_selected): all envs, or only those of light solver groups.
-__global__ void __launch_bounds__(RASTER_THREADS) k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int pass, int env0, int restore, int sel) {
+__global__ void __launch_bounds__(RASTER_THREADS) RASTER_ATTR k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int pass, int env0, int restore, int sel) {
     const int env = blockIdx.x + env0, tile = blockIdx.y;
     if (pass == 0 && D.render_flags && !D.render_flags[env]) return;
     if (!env_selected(D.hgflag, env, sel)) return;
     raster_tile(P, *RMp, D, n_inst_used, pass, env, tile, restore);
 }
 
-#define RASTER_LIST_WGS 768      // three per CU, as many as fit (a long list of heavy envs must not be rendered at a third of the occupancy)
+#define RASTER_LIST_WGS 768      // three per CU: the item loop around the tile needs more than the 64 VGPRs of four (a long list of heavy
+                                 // envs must not be rendered at a fraction of the occupancy)
 // The heavy envs (D.hlist, D.hcount -- known on the device only): a fixed number of workgroups walk the
 // list, so that no LDS-filling workgroup is launched just to find that its env is not on it.
-__global__ void __launch_bounds__(RASTER_THREADS) k_raster_list(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int restore) {
+__global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) k_raster_list(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int restore) {
     const RenderModel &RM = *RMp;
     const int nitems = D.hcount[0] * RM.ntiles;
     __shared__ int s_item;
@@ -3360,7 +3366,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     const int32_t *dims = b.i32("dims", 11);
     if (!dims) return fail(RR_EMODEL, "rr_create: blob has no dims");
     int nb = dims[0], nl = dims[1], ns = dims[2], ni = dims[3], nt = dims[4], ntex = dims[5], n_static = dims[6], n_robot = dims[7];
-    if (nb != NB || ns > MAXSHAPES || dims[8] != VMAXC || dims[9] != FMAXC || ni > MAXINST || nl > NLINK_MAX || ntex > 16 ||
+    if (nb != NB || ns > MAXSHAPES || dims[8] != VMAXC || dims[9] != FMAXC || ni > MAXINST || ni > RASTER_INST || nl > NLINK_MAX || ntex > 16 ||
         n_static != 3 || n_robot != 16)
         return fail(RR_EMODEL, "rr_create: blob dims do not match this build");
     int ndev = 0;
