@@ -126,7 +126,9 @@ struct DevPtrs {
     float *cforce;     // [N][MAXC] normal force of every contact of the last step (rr_get_contacts, touch sensors)
     int *hgflag;       // [N] != 0: this env has generic contact rows this step -- "heavy"
     int *hlist;        // [N] the heavy envs of this step (in arrival order: placement only, never a result)
-    int *hcount;       // [0] their number, [1] work counter of k_raster_list
+    int *hcount;       // [0] their number, [1] work counter of k_raster_list, [2] [3] front / back fill of corder
+    int *corder;       // [N] the order in which k_collide's workgroups take the envs: last step's heavy envs first (the slowest env
+                       //     sets the kernel's tail; started last it would add its whole duration to the kernel)
     int *hcount_host;  // device address of the pinned host word that receives the previous step's number (or nullptr)
     int *timestep;     // [N]
     unsigned *errflags;// [N]
@@ -356,6 +358,10 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
     if (env >= N) return;
     float *state = D.state, *scratch = D.scratch;
     if (PHASE == 1) {       // k_collide classifies the solver groups of this step: reset its bookkeeping (no extra launch)
+        {   // launch order of this step's k_collide: the envs that were heavy a step ago go first (placement only, never a result)
+            const int slot = D.hgflag[env] ? atomicAdd(&D.hcount[2], 1) : N - 1 - atomicAdd(&D.hcount[3], 1);
+            D.corder[slot] = env;
+        }
         D.hgflag[env] = 0;
         if (env == 0) {
             // (the count of the step before goes to pinned host memory on the way: a posted write, nobody waits for it)
@@ -756,7 +762,8 @@ __device__ __forceinline__ bool edge_pair(const EdgeW &A, const EdgeW &B, float 
     }
 __global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, DevPtrs D, int ns) {
     const int N = P.N;
-    const int env = blockIdx.x;
+    const int env = D.corder[blockIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { D.hcount[2] = 0; D.hcount[3] = 0; }      // (k_prep_a of the next step fills corder again)
     const float *state = D.state;
     float *scratch = D.scratch;
     if (D.errflags[env]) return;
@@ -3517,6 +3524,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     ALLOC(D.hgflag, (size_t)N);
     ALLOC(D.hlist, (size_t)N);
     ALLOC(D.hcount, (size_t)4);
+    ALLOC(D.corder, (size_t)N);
+    { std::vector<int> id(N); for (int i = 0; i < N; i++) id[i] = i; hipMemcpy(D.corder, id.data(), (size_t)N * 4, hipMemcpyHostToDevice); }
     e->D.hcount_host = nullptr;
     if (e->h_hcount && hipHostGetDevicePointer((void **)&e->D.hcount_host, e->h_hcount, 0) != hipSuccess) e->D.hcount_host = nullptr;
     ALLOC(D.timestep, (size_t)N);
