@@ -126,7 +126,7 @@ struct DevPtrs {
     float *cforce;     // [N][MAXC] normal force of every contact of the last step (rr_get_contacts, touch sensors)
     int *hgflag;       // [N] != 0: this env has generic contact rows this step -- "heavy"
     int *hlist;        // [N] the heavy envs of this step (in arrival order: placement only, never a result)
-    int *hcount;       // [0] their number, [1] work counter of k_raster_list, [2] [3] front / back fill of corder
+    int *hcount;       // [0] their number, [1] work counter of k_raster_list / k_render_list, [2] [3] front / back fill of corder
     int *corder;       // [N] the order in which k_collide's workgroups take the envs: last step's heavy envs first (the slowest env
                        //     sets the kernel's tail; started last it would add its whole duration to the kernel)
     int *hcount_host;  // device address of the pinned host word that receives the previous step's number (or nullptr)
@@ -2065,13 +2065,9 @@ __global__ void k_set_object_poses(SimParams P, DevPtrs D, const float *poses, c
 // transforms of its body's ancestors only (same operations, in the same order, as fk_all() for that chain), an object
 // thread converts the object's quaternion; the 12 floats of an instance are stored as three 16-byte words, so a wave
 // writes a contiguous span.  (One thread per env needed 264 stores with a 1.5 KB stride between lanes.)
-__global__ void __launch_bounds__(64) k_render_setup(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D, int sel) {
-    const RenderModel &RM = *RMp;
+// instance i of env: FK of its owner's ancestor chain -> model-view-projection matrix and shading constants (D.inst_xf)
+__device__ __forceinline__ void instance_setup(const BodyParams &B, const SimParams &P, const RenderModel &RM, const DevPtrs &D, int env, int i) {
     const int N = P.N;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int env = gid >> 5, i = gid & (MAXINST - 1);
-    static_assert(MAXINST == 32, "thread -> (env, instance) mapping");
-    if (env >= N || i >= RM.ni || !env_selected(D.hgflag, env, sel)) return;
     const float *state = D.state;
     m3 R = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
     v3 p = mk(0, 0, 0);
@@ -2123,6 +2119,14 @@ __global__ void __launch_bounds__(64) k_render_setup(BodyParams B, SimParams P, 
     o[6] = make_float4(R.m[8], RM.in_color[i][0], RM.in_color[i][1], RM.in_color[i][2]);
     o[7] = make_float4(__int_as_float(tidx >= 0 ? RM.tex_off[tidx] : 0), __int_as_float(tidx >= 0 ? RM.tex_w[tidx] : 0),
                        __int_as_float(tidx >= 0 ? RM.tex_h[tidx] : 0), __int_as_float(RM.in_uid[i]));
+}
+__global__ void __launch_bounds__(64) k_render_setup(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D, int sel) {
+    const RenderModel &RM = *RMp;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = gid >> 5, i = gid & (MAXINST - 1);
+    static_assert(MAXINST == 32, "thread -> (env, instance) mapping");
+    if (env >= P.N || i >= RM.ni || !env_selected(D.hgflag, env, sel)) return;
+    instance_setup(B, P, RM, D, env, i);
 }
 
 // link poses (COM frame) for rr_link_poses
@@ -3143,11 +3147,12 @@ __global__ void k_background(const RenderModel *RMp, DevPtrs D) {
 #define SHADE_THREADS 256
 #define SHADE_SPLIT 8
 // chunk z of nz of the fragment list of (env, tile); mvp / sinst: the workgroup's staging arrays
+template <int NTHREADS>
 __device__ __forceinline__ void shade_block(const RenderModel &RM, const DevPtrs &D, const ImageOut &out, int env, int tile, int z, int nz,
                                             float (*mvp)[16], float (*sinst)[16]) {
     const unsigned n = D.frag_count[(size_t)env * RM.ntiles + tile];
-    if ((unsigned)z * SHADE_THREADS >= n) return;               // (workgroup-uniform)
-    stage_instances(RM, D, env, threadIdx.x, SHADE_THREADS, mvp, sinst);
+    if ((unsigned)z * NTHREADS >= n) return;                    // (workgroup-uniform)
+    stage_instances(RM, D, env, threadIdx.x, NTHREADS, mvp, sinst);
     __syncthreads();
     ShadeCtx ctx;
     ctx.D = &D; ctx.mvp = &mvp[0][0]; ctx.sinst = &sinst[0][0]; ctx.W = RM.W; ctx.H = RM.H;
@@ -3155,7 +3160,7 @@ __device__ __forceinline__ void shade_block(const RenderModel &RM, const DevPtrs
     const int row0 = tile * RM.tile_h;
     const size_t base = (size_t)env * out.env_stride + (size_t)row0 * RM.W;
     const unsigned long long *sv = D.static_vis ? D.static_vis + (size_t)row0 * RM.W : nullptr;   // null while the static layer itself is built
-    for (unsigned i = z * SHADE_THREADS + threadIdx.x; i < n; i += nz * SHADE_THREADS) {
+    for (unsigned i = z * NTHREADS + threadIdx.x; i < n; i += nz * NTHREADS) {
         const uint2 f = lst[i];
         const int pi = (int)(f.y >> 18), t = (int)(f.y & 0x3ffffu);
         // a moving triangle only shows where it beats the static layer (depth, then triangle id; static ids are lower);
@@ -3184,8 +3189,40 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp,
     const int env = blockIdx.x + env0, tile = blockIdx.y;
     if (use_flags && D.render_flags && !D.render_flags[env]) return;
     if (!env_selected(D.hgflag, env, sel)) return;
-    shade_block(*RMp, D, out, env, tile, blockIdx.z, gridDim.z, mvp, sinst);
+    shade_block<SHADE_THREADS>(*RMp, D, out, env, tile, blockIdx.z, gridDim.z, mvp, sinst);
 }
+// The render of the heavy envs (D.hlist, D.hcount -- known on the device only), which follows their solve on the side stream
+// and is the tail of the step's longest chain: ONE launch instead of three.  A fixed number of workgroups walk the list of
+// (env, tile) items (dynamic assignment: tiles differ a lot in cost; no LDS-filling workgroup is launched just to find that
+// its env is not on the list); for each item: the env's instance matrices (22 threads; the four tiles of an env write the
+// same values), the visibility pass of the tile, the shading of its fragment list.
+#define RENDER_LIST_WGS 768      // three per CU (the item loop and the shading need more than the 64 VGPRs of four)
+__global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8)))
+k_render_list(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D, ImageOut out, int n_inst_used, int restore) {
+    const RenderModel &RM = *RMp;
+    __shared__ __attribute__((aligned(16))) float smvp[MAXINST][16];
+    __shared__ __attribute__((aligned(16))) float sinst[MAXINST][16];
+    const int nitems = D.hcount[0] * RM.ntiles;
+    __shared__ int s_item;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&D.hcount[1], 1);
+        __syncthreads();
+        const int it = s_item;
+        if (it >= nitems) break;
+        const int tile = it % RM.ntiles, env = D.hlist[it / RM.ntiles];
+        if (env < P.N && !(D.render_flags && !D.render_flags[env])) {
+            if ((int)threadIdx.x < RM.ni) instance_setup(B, P, RM, D, env, threadIdx.x);
+            __threadfence_block();
+            __syncthreads();
+            raster_tile(P, RM, D, n_inst_used, 0, env, tile, restore);
+            __threadfence_block();      // the fragment list and its count, written by this workgroup, are read back below
+            __syncthreads();
+            shade_block<RASTER_THREADS>(RM, D, out, env, tile, 0, 1, smvp, sinst);
+        }
+        __syncthreads();        // the LDS of the tile and the staging arrays are reused
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 struct BlobEntry {
     char name[32];
@@ -3767,10 +3804,16 @@ static void launch_render(rr_env *e, const DevPtrs &D, int restore, int sel, hip
         TIMED(4, hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, 0, 0, restore, sel));
         TIMED(6, hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel));
     } else {
+        // the heavy envs, a few (lagged host copy of their number: at most one item per workgroup): one list-walking launch for
+        // set-up, visibility and shading -- the tail of the step's longest chain; many: the three kernels (the fused one runs
+        // at three workgroups per CU with spills, which a long list pays for)
+        if (sel == 2 && e->h_hcount && (long long)*(volatile int *)e->h_hcount * e->RM.ntiles <= RENDER_LIST_WGS) {
+            hipLaunchKernelGGL(k_render_list, dim3(std::min(N * e->RM.ntiles, RENDER_LIST_WGS)), dim3(RASTER_THREADS), 0, st, e->B, e->P, e->RM_dev, D, io, e->n_inst_used, restore);
+            return;
+        }
         hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, st, e->B, e->P, e->RM_dev, D, sel);
         if (sel == 2) hipLaunchKernelGGL(k_raster_list, dim3(std::min(N * e->RM.ntiles, RASTER_LIST_WGS)), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, restore);
         else hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, 0, 0, restore, sel);
-        // (a list-walking shade kernel for the heavy envs was tried: faster for a handful of them, much slower for a thousand)
         hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel);
     }
 }
