@@ -65,7 +65,7 @@ struct BodyParams {   // passed by value as kernel argument -> scalar loads, uni
 };
 
 struct SimParams {
-    int N, nobj, iters, npairs, ablate, small_area, os_cap, edge_contacts, heavy_min;
+    int N, nobj, iters, npairs, ablate, small_area, os_cap, edge_contacts, heavy_min, heavy2_min;
     float warmstart;   // Bullet's m_warmstartingFactor (0.85); 0: cold start every step   // os_cap: object-vs-static contacts per env with rows in LDS (<= OS_CAP)
     float dt, gravity, erp, margin, kp, kd, max_impulse, lin_damp, ang_damp, rest_thresh;
 };
@@ -124,7 +124,9 @@ struct DevPtrs {
     float4 *clist_prev; // the list of the step before (the two buffers change roles every step): contact history of the warm start
     float *cwarm;      // [N][MAXC] initial normal impulse of every contact of clist (k_collide: 0.85 x the matched previous one)
     float *cforce;     // [N][MAXC] normal force of every contact of the last step (rr_get_contacts, touch sensors)
-    int *hgflag;       // [N] != 0: this env has generic contact rows this step -- "heavy"
+    int *hgflag;       // [N] 0: light; 1: this env has generic contact rows this step -- "heavy"; 2: more than P.heavy2_min of them -- "very heavy"
+    int *hlist2;       // [N] the very heavy envs of this step (a handful: an arm crushed onto the table at the contact cap)
+    int *hcount2;      // [0] their number, [1] work counter of their render
     int *hlist;        // [N] the heavy envs of this step (in arrival order: placement only, never a result)
     int *hcount;       // [0] their number, [1] work counter of k_raster_list / k_render_list, [2] [3] front / back fill of corder
     int *corder;       // [N] the order in which k_collide's workgroups take the envs: last step's heavy envs first (the slowest env
@@ -156,13 +158,14 @@ struct DevPtrs {
     unsigned *frag_count;   // [N*ntiles]
 };
 
-// Which envs a launch handles: 0 all; 1 the light envs; 2 the heavy ones (rr_step runs the few heavy envs -- an arm
-// pressed on the table, a gripper pushing objects: dozens of generic contact rows -- and their render on the side stream,
-// beside the render of the others).
+// Which envs a launch handles: 0 all; 1 the light envs; 2 the heavy ones; 3 the very heavy ones (rr_step runs the few heavy
+// envs -- an arm pressed on the table, a gripper pushing objects: dozens of generic contact rows -- and their render on the
+// side stream, beside the render of the others; the handful at the contact cap, whose solve takes half as long again, on
+// a side stream of their own, so that the render of the other heavy envs does not wait for them).
 __device__ __forceinline__ bool env_selected(const int *hgflag, int env, int sel) {
     if (sel == 0) return true;
-    const bool heavy = hgflag[env] != 0;
-    return sel == 1 ? !heavy : heavy;
+    const int cls = hgflag[env];
+    return sel == 1 ? cls == 0 : (sel == 2 ? cls == 1 : cls == 2);
 }
 
 // Kinematic tree of the 11 moving bodies (lbr_iiwa_link_1..7 [+gripper base], finger_00, finger_01, finger_10,
@@ -366,7 +369,7 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
         if (env == 0) {
             // (the count of the step before goes to pinned host memory on the way: a posted write, nobody waits for it)
             if (D.hcount_host) *D.hcount_host = D.hcount[0];
-            D.hcount[0] = 0; D.hcount[1] = 0;
+            D.hcount[0] = 0; D.hcount[1] = 0; D.hcount2[0] = 0; D.hcount2[1] = 0;
         }
     }
     if (PHASE == 2) { if (D.errflags[env]) return; }    // frozen, or command rejected by phase 1
@@ -1214,7 +1217,8 @@ __global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, Dev
         ngen += max(oscnt0 - 4, 0) + max(oscnt1 - 4, 0) + max(oscnt2 - 4, 0);
         const bool heavy = ngen > P.heavy_min;
         D.ccount[env] = nct;
-        if (heavy) { D.hgflag[env] = 1; D.hlist[atomicAdd(D.hcount, 1)] = env; }
+        if (heavy && ngen > P.heavy2_min) { D.hgflag[env] = 2; D.hlist2[atomicAdd(D.hcount2, 1)] = env; }
+        else if (heavy) { D.hgflag[env] = 1; D.hlist[atomicAdd(D.hcount, 1)] = env; }
     }
 }
 #undef CAND_ARGMAX
@@ -1392,6 +1396,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
     int env_raw = 4 * unit + (grp & 3);
     bool mine = true;                                                 // this 16-lane group has an env to solve in this launch
     if (sel == 2) { mine = env_raw < *D.hcount; env_raw = mine ? D.hlist[env_raw] : N; }
+    else if (sel == 3) { mine = env_raw < *D.hcount2; env_raw = mine ? D.hlist2[env_raw] : N; }
     else if (sel == 1) mine = env_raw < N && D.hgflag[env_raw] == 0;
     if (__ballot(mine) == 0ull) return;                               // (wave-uniform; the kernel has no workgroup barrier)
     const int env = env_raw < N ? env_raw : N - 1;                    // groups without an env run along as no-ops
@@ -3057,17 +3062,19 @@ __global__ void __launch_bounds__(RASTER_THREADS) RASTER_ATTR k_raster(SimParams
                                  // envs must not be rendered at a fraction of the occupancy)
 // The heavy envs (D.hlist, D.hcount -- known on the device only): a fixed number of workgroups walk the
 // list, so that no LDS-filling workgroup is launched just to find that its env is not on it.
-__global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) k_raster_list(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int restore) {
+__global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) k_raster_list(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int restore, int which) {
     const RenderModel &RM = *RMp;
-    const int nitems = D.hcount[0] * RM.ntiles;
+    int *hcount = which ? D.hcount2 : D.hcount;
+    const int *hlist = which ? D.hlist2 : D.hlist;
+    const int nitems = hcount[0] * RM.ntiles;
     __shared__ int s_item;
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(&D.hcount[1], 1);      // dynamic assignment: tiles differ a lot in cost
+        if (threadIdx.x == 0) s_item = atomicAdd(&hcount[1], 1);      // dynamic assignment: tiles differ a lot in cost
         __syncthreads();
         const int it = s_item;
         if (it >= nitems) break;
         const int tile = it % RM.ntiles, ge = it / RM.ntiles;
-        const int env = D.hlist[ge];
+        const int env = hlist[ge];
         if (env < P.N && !(D.render_flags && !D.render_flags[env])) raster_tile(P, RM, D, n_inst_used, 0, env, tile, restore);
         __syncthreads();        // the LDS of the tile is reused
     }
@@ -3198,18 +3205,20 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp,
 // same values), the visibility pass of the tile, the shading of its fragment list.
 #define RENDER_LIST_WGS 768      // three per CU (the item loop and the shading need more than the 64 VGPRs of four)
 __global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8)))
-k_render_list(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D, ImageOut out, int n_inst_used, int restore) {
+k_render_list(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D, ImageOut out, int n_inst_used, int restore, int which) {
     const RenderModel &RM = *RMp;
+    int *hcount = which ? D.hcount2 : D.hcount;
+    const int *hlist = which ? D.hlist2 : D.hlist;
     __shared__ __attribute__((aligned(16))) float smvp[MAXINST][16];
     __shared__ __attribute__((aligned(16))) float sinst[MAXINST][16];
-    const int nitems = D.hcount[0] * RM.ntiles;
+    const int nitems = hcount[0] * RM.ntiles;
     __shared__ int s_item;
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(&D.hcount[1], 1);
+        if (threadIdx.x == 0) s_item = atomicAdd(&hcount[1], 1);
         __syncthreads();
         const int it = s_item;
         if (it >= nitems) break;
-        const int tile = it % RM.ntiles, env = D.hlist[it / RM.ntiles];
+        const int tile = it % RM.ntiles, env = hlist[it / RM.ntiles];
         if (env < P.N && !(D.render_flags && !D.render_flags[env])) {
             if ((int)threadIdx.x < RM.ni) instance_setup(B, P, RM, D, env, threadIdx.x);
             __threadfence_block();
@@ -3289,7 +3298,8 @@ struct rr_env {
     bool images_valid;       // every env's image holds its previous frame (static layer + the pixels of its fragment list)
     hipEvent_t ev[2 * RR_NUM_KERNELS];
     hipStream_t aux;         // side stream: the HBM-bound static-layer copy runs beside the VALU-bound physics / visibility kernels
-    hipEvent_t ev_fork, ev_join, ev_dyn;
+    hipEvent_t ev_fork, ev_join, ev_dyn, ev_join2;
+    hipStream_t aux2;              // the very heavy envs' solve + render (RR_HEAVY2_MIN)
     int n_shapes;
     float t_ms[RR_NUM_KERNELS];
     int t_n[RR_NUM_KERNELS];
@@ -3361,6 +3371,8 @@ int rr_destroy(rr_env *e) {
     for (void *p : e->allocs) hipFree(p);
     for (int i = 0; i < 2 * RR_NUM_KERNELS; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
     if (e->aux) { hipStreamSynchronize(e->aux); hipStreamDestroy(e->aux); }
+    if (e->aux2) { hipStreamSynchronize(e->aux2); hipStreamDestroy(e->aux2); }
+    if (e->ev_join2) hipEventDestroy(e->ev_join2);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
     if (e->ev_dyn) hipEventDestroy(e->ev_dyn);
@@ -3477,6 +3489,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     P.small_area = getenv("RR_SMALL_AREA") ? atoi(getenv("RR_SMALL_AREA")) : SMALL_AREA;
     // RR_SOLVER_POOL (tests): LDS floats for object-vs-static rows, 60 per contact; contacts beyond it take the generic (slot layout) path
     P.heavy_min = getenv("RR_HEAVY_MIN") ? atoi(getenv("RR_HEAVY_MIN")) : 0;
+    P.heavy2_min = getenv("RR_HEAVY2_MIN") ? atoi(getenv("RR_HEAVY2_MIN")) : 16;      // generic contacts above which an env is "very heavy" (1000: never; A/B 6..30: 13-16 best)
     P.warmstart = getenv("RR_NO_WARMSTART") ? 0.0f : 0.85f;       // (diagnostics: cold start every step)
     P.edge_contacts = getenv("RR_NO_EDGE_CONTACTS") ? 0 : 1;       // (diagnostics: vertex candidates only)
     P.os_cap = getenv("RR_SOLVER_POOL") ? std::max(0, std::min(atoi(getenv("RR_SOLVER_POOL")) / 60, (int)OS_CAP)) : OS_CAP;
@@ -3561,6 +3574,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     ALLOC(D.hgflag, (size_t)N);
     ALLOC(D.hlist, (size_t)N);
     ALLOC(D.hcount, (size_t)4);
+    ALLOC(D.hlist2, (size_t)N);
+    ALLOC(D.hcount2, (size_t)4);
     ALLOC(D.corder, (size_t)N);
     { std::vector<int> id(N); for (int i = 0; i < N; i++) id[i] = i; hipMemcpy(D.corder, id.data(), (size_t)N * 4, hipMemcpyHostToDevice); }
     e->D.hcount_host = nullptr;
@@ -3643,7 +3658,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         const int prio = getenv("RR_AUX_PRIORITY") && atoi(getenv("RR_AUX_PRIORITY")) == 0 ? prio_lo : prio_hi;
         if (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, evf) != hipSuccess ||
-            hipEventCreateWithFlags(&e->ev_join, evf) != hipSuccess || hipEventCreateWithFlags(&e->ev_dyn, evf) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
+            hipEventCreateWithFlags(&e->ev_join, evf) != hipSuccess || hipEventCreateWithFlags(&e->ev_dyn, evf) != hipSuccess ||
+            hipStreamCreateWithPriority(&e->aux2, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&e->ev_join2, evf) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
     }
     e->field_ptr[RR_F_JOINTS] = D.joints; e->field_bytes[RR_F_JOINTS] = (size_t)N * 9 * 4;
     e->field_ptr[RR_F_TOUCH] = D.touch; e->field_bytes[RR_F_TOUCH] = (size_t)N * 4 * 4;
@@ -3807,12 +3823,12 @@ static void launch_render(rr_env *e, const DevPtrs &D, int restore, int sel, hip
         // the heavy envs, a few (lagged host copy of their number: at most one item per workgroup): one list-walking launch for
         // set-up, visibility and shading -- the tail of the step's longest chain; many: the three kernels (the fused one runs
         // at three workgroups per CU with spills, which a long list pays for)
-        if (sel == 2 && e->h_hcount && (long long)*(volatile int *)e->h_hcount * e->RM.ntiles <= RENDER_LIST_WGS) {
-            hipLaunchKernelGGL(k_render_list, dim3(std::min(N * e->RM.ntiles, RENDER_LIST_WGS)), dim3(RASTER_THREADS), 0, st, e->B, e->P, e->RM_dev, D, io, e->n_inst_used, restore);
+        if (sel == 3 || (sel == 2 && e->h_hcount && (long long)*(volatile int *)e->h_hcount * e->RM.ntiles <= RENDER_LIST_WGS)) {
+            hipLaunchKernelGGL(k_render_list, dim3(std::min(N * e->RM.ntiles, sel == 3 ? 256 : RENDER_LIST_WGS)), dim3(RASTER_THREADS), 0, st, e->B, e->P, e->RM_dev, D, io, e->n_inst_used, restore, sel == 3 ? 1 : 0);
             return;
         }
         hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, st, e->B, e->P, e->RM_dev, D, sel);
-        if (sel == 2) hipLaunchKernelGGL(k_raster_list, dim3(std::min(N * e->RM.ntiles, RASTER_LIST_WGS)), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, restore);
+        if (sel == 2) hipLaunchKernelGGL(k_raster_list, dim3(std::min(N * e->RM.ntiles, RASTER_LIST_WGS)), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, restore, 0);
         else hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, 0, 0, restore, sel);
         hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel);
     }
@@ -3903,13 +3919,18 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
             // timing leg: the very same launches, one after the other on the main stream, each under its timer -- 2 / 3 / 4 / 6
             // what the main stream runs in an untimed step (the light envs), 7 / 8 what the side stream runs beside it
             TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1));
-            TIMED(7, hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->stream, e->B, e->P, e->D, 2));
+            TIMED(7, { hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->stream, e->B, e->P, e->D, 2);
+                       hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->stream, e->B, e->P, e->D, 3); });
             launch_render(e, D, restore, 1, e->stream, true);
-            TIMED(8, launch_render(e, D, restore, 2, e->stream, false));
+            TIMED(8, { launch_render(e, D, restore, 2, e->stream, false); launch_render(e, D, restore, 3, e->stream, false); });
             HIPCHK(hipGetLastError());
             return RR_OK;
         }
         hipEventRecord(e->ev_fork, e->stream);
+        hipStreamWaitEvent(e->aux2, e->ev_fork, 0);      // the longest chain first
+        hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->aux2, e->B, e->P, e->D, 3);
+        launch_render(e, D, restore, 3, e->aux2, false);
+        hipEventRecord(e->ev_join2, e->aux2);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
         hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->aux, e->B, e->P, e->D, 2);
         launch_render(e, D, restore, 2, e->aux, false);
@@ -3917,6 +3938,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1);
         launch_render(e, D, restore, 1, e->stream, false);
         hipStreamWaitEvent(e->stream, e->ev_join, 0);
+        hipStreamWaitEvent(e->stream, e->ev_join2, 0);
         HIPCHK(hipGetLastError());
         return RR_OK;
     }

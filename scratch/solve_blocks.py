@@ -17,7 +17,8 @@ if macro:
     env.plan_macro(np.random.default_rng(0).uniform([-0.25, -0.5], [0.05, 0.5], size=(N, 2, 2)))
     for t in range(420): env.step_plan()
 else:
-    for t in range(200): env.step(synthetic_actions(ids, (t // 20) * 20) * scale)
+    T = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+    for t in range(T): env.step(synthetic_actions(ids, (t // 20) * 20, hold_prob=0.05) * scale, render=False)
 torch.cuda.synchronize()
 nb = N // 4
 buf = (ctypes.c_uint * (8 * nb))()
