@@ -3203,8 +3203,8 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp,
 // (env, tile) items (dynamic assignment: tiles differ a lot in cost; no LDS-filling workgroup is launched just to find that
 // its env is not on the list); for each item: the env's instance matrices (22 threads; the four tiles of an env write the
 // same values), the visibility pass of the tile, the shading of its fragment list.
-#define RENDER_LIST_WGS 768      // three per CU (the item loop and the shading need more than the 64 VGPRs of four)
-__global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8)))
+#define RENDER_LIST_WGS 768      // (two resident per CU: set-up, visibility and shading in one body need 128 VGPRs -- capped at 80 it spilled)
+__global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 k_render_list(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D, ImageOut out, int n_inst_used, int restore, int which) {
     const RenderModel &RM = *RMp;
     int *hcount = which ? D.hcount2 : D.hcount;

@@ -18,13 +18,15 @@ import csv, glob, os, json, collections
 R=os.environ['GRAFT_REPO_ROOT']; O=R+'/gpurun_out/round'; TAG=os.environ['TAG']
 cfg={"envs": 4096, "objects": 3, "width": 128, "height": 128, "render": True, "command_scale": 1.0, "solver_iters": 50}
 def means(d):
+    """mean per dispatch and, for kernels launched more than once per step, the number of dispatches per step"""
     f=glob.glob(O+'/%s/*counter_collection.csv'%d)
     acc=collections.defaultdict(list)
     if not f: print('no counter csv in', d); return {}
     for row in csv.DictReader(open(f[0])):
         acc[(row['Kernel_Name'].split('(')[0], row['Counter_Name'])].append(float(row['Counter_Value']))
+    steps=max([len(v) for (k,c),v in acc.items() if k=='k_prep_a'] or [1])
     out={}
-    for (k,c),v in acc.items(): out.setdefault(k,{})[c]={'mean': sum(v)/len(v), 'n': len(v)}
+    for (k,c),v in acc.items(): out.setdefault(k,{})[c]={'mean': sum(v)/len(v), 'n': len(v), 'per_step': sum(v)/steps}
     return out
 fe, wr, sq = means('pmc_fetch'), means('pmc_write'), means('sq')
 json.dump({'fetch': fe, 'write': wr}, open(O+'/%s_pmc_summary.json'%TAG,'w'), indent=1)
@@ -32,12 +34,13 @@ json.dump(sq, open(O+'/%s_sq_counters.json'%TAG,'w'), indent=1)
 # HBM bytes per launch: (2*FETCH_SIZE + WRITE_SIZE) KB (MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts half of wide coalesced reads)
 tr={}
 for k in set(fe)|set(wr):
-    f=fe.get(k,{}).get('FETCH_SIZE',{}).get('mean',0.0); w=wr.get(k,{}).get('WRITE_SIZE',{}).get('mean',0.0)
+    # bytes per STEP (a kernel launched for the light and again for the heavy envs counts with all its launches)
+    f=fe.get(k,{}).get('FETCH_SIZE',{}).get('per_step',0.0); w=wr.get(k,{}).get('WRITE_SIZE',{}).get('per_step',0.0)
     tr[k]=round((2*f+w)*1024)
-tr['render_stage']=tr.get('k_raster',0)+tr.get('k_shade',0)
+tr['render_stage']=tr.get('k_raster',0)+tr.get('k_shade',0)+tr.get('k_render_list',0)+tr.get('k_raster_list',0)
 tr['k_prep']=tr.get('k_prep_a',0)+tr.get('k_prep_b',0)+tr.get('k_balance',0)
 tr['config']=cfg; tr['source']=TAG+'_pmc_summary.json'
-tr['_note']="HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), (2*FETCH_SIZE + WRITE_SIZE) * 1024; render_stage = k_raster + k_shade; only valid for `config`"
+tr['_note']="HBM bytes per step from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), (2*FETCH_SIZE + WRITE_SIZE) * 1024, all launches of a kernel in a step added up (the first untimed frames included in the mean); render_stage = k_raster + k_shade + the heavy envs' k_render_list / k_raster_list; only valid for `config`"
 json.dump(tr, open(O+'/traffic_latest.json','w'), indent=1)
 sv={'config': cfg, 'source': TAG+'_sq_counters.json', 'valu_wave_instr_per_launch': {k: round(v['SQ_INSTS_VALU']['mean']) for k,v in sq.items() if 'SQ_INSTS_VALU' in v}}
 json.dump(sv, open(O+'/sq_latest.json','w'), indent=1)
