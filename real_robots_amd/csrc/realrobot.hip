@@ -1583,6 +1583,9 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                 const int ka = tors ? kr - 3 : kr;
                 const v3 d = ka == 0 ? n : (ka == 1 ? t1 : t2);
                 const bool present = !tors || (kr == 3 ? spin > 0 : roll > 0);
+                // a torsional row without a coefficient (robot link against table / shelf: most contacts of a crushed arm) is
+                // never swept: only its (zero) scalars are read, when the sweep lists are built
+                if (__ballot(present) == 0ull) { if (l == 0) *(float4 *)&LD(L_GSC + 4 * (r0 + kr)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f); continue; }
                 const float ja = dot(d, tors ? gc.gtA : gc.gA), jb = dot(d, tors ? gc.gtB : gc.gB);
                 const float mjb = dot(d, tors ? gc.htB : gc.hB);
                 float mja = 0;
