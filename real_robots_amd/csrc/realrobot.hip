@@ -1796,6 +1796,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
             OST_STEP(0) OST_STEP(1) OST_STEP(2) OST_STEP(3)
             continue;
         }
+        SPROF(4);
         SWEEP_MOTORS
         LIMIT_STEP(0) LIMIT_STEP(1)
 #pragma unroll 1
@@ -1813,6 +1814,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
             if (l == 0) LD(L_LIM + 2 * js + 1) = sum;
             if (l < NB) dq += LD(L_MINV + l * NB + j) * (sg * dl);
         }
+        SPROF(7);
 #pragma unroll 1
         for (int pass = 0; pass < 3; pass++) {    // all normals, then all lateral frictions, then all torsional frictions
             // ---- the generic sweep of this pass: its first rows are requested before the object lanes' own work
@@ -1834,9 +1836,11 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
             if (pass == 0) { OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3) }
             else if (pass == 1) { OSF_STEP(0) OSF_STEP(1) OSF_STEP(2) OSF_STEP(3) }
             else { OST_STEP(0) OST_STEP(1) OST_STEP(2) OST_STEP(3) }
+            SPROF(8);
             if (cmax == 0) continue;
             // ---- generic rows of this pass, blocks of 16 rows: lane k of the group holds the scalars of the block's row k
             OBJ_SLOTS(TO_SLOT)
+            SPROF(9);
             for (int i0 = 0; i0 < cmax; i0 += 16) {
                 const int e = e_cur;
                 const bool valid = e != 0xffff;
@@ -1880,6 +1884,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
             }
 #undef ENTRY
 #undef ENTRY_IDX
+            SPROF(10);
             OBJ_SLOTS(FROM_SLOT)
             if (pass == 0) {
                 // ---- the lateral and torsional rows that can move something: contacts with a normal impulse, or with a
@@ -1889,10 +1894,13 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                     const int j = j0 + l;
                     bool act = false, hs = false, hr = false;
                     if (j < ng) {
+                        // (all eight LDS reads issued together: with `||` they would form a chain of dependent round trips)
                         const int r = L_GSC + 24 * j;
-                        act = LD(r + 3) > 0.0f || LD(r + 7) != 0.0f || LD(r + 11) != 0.0f || LD(r + 15) != 0.0f || LD(r + 19) != 0.0f || LD(r + 23) != 0.0f;
-                        hs = act && LD(r + 14) > 0.0f;          // coefficient of the spinning row
-                        hr = act && LD(r + 18) > 0.0f;          // ... of the rolling rows
+                        const float l0 = LD(r + 3), l1 = LD(r + 7), l2 = LD(r + 11), l3 = LD(r + 15), l4 = LD(r + 19), l5 = LD(r + 23);
+                        const float cs_ = LD(r + 14), cr_ = LD(r + 18);      // coefficients of the spinning / rolling rows
+                        act = (l0 > 0.0f) | (l1 != 0.0f) | (l2 != 0.0f) | (l3 != 0.0f) | (l4 != 0.0f) | (l5 != 0.0f);
+                        hs = act & (cs_ > 0.0f);
+                        hr = act & (cr_ > 0.0f);
                     }
                     const unsigned lt = (1u << l) - 1u;
                     const unsigned ma = (unsigned)(__ballot(act) >> (16 * (grp & 3))) & 0xffffu, ms = (unsigned)(__ballot(hs) >> (16 * (grp & 3))) & 0xffffu,
@@ -1907,6 +1915,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                     nF += 2 * __popc(ma); nT += __popc(ms) + 2 * __popc(mr);
                 }
             }
+            SPROF(11);
         }
     }
     SPROF(4);

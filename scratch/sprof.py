@@ -11,19 +11,21 @@ SCALE = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
 env = BatchedREALRobotEnv(N, objects=3, width=128, height=128)
 lib = nat.load_library()
 ids = list(range(N))
-for t in range(160):
-    env.step(synthetic_actions(ids, (t // 20) * 20) * SCALE, render=False)
+T0 = int(sys.argv[2]) if len(sys.argv) > 2 else 160
+for t in range(T0):
+    env.step(synthetic_actions(ids, (t // 20) * 20, hold_prob=0.05) * SCALE, render=False)
 out = (ctypes.c_ulonglong * 16)()
 torch.cuda.synchronize()
 lib.rr_debug_solver_prof(out, 1)
-K = 20
+K = 10
 for t in range(K):
-    env.step(synthetic_actions(ids, 160) * SCALE, render=False)
+    env.step(synthetic_actions(ids, (T0 // 20) * 20, hold_prob=0.05) * SCALE, render=False)
 torch.cuda.synchronize()
 lib.rr_debug_solver_prof(out, 0)
-v = np.array(list(out), dtype=np.float64) / (K * N / 4)
+DIV = K if (int(os.environ.get('RR_ABLATE', '0')) & 0x4000) else K * N / 4
+v = np.array(list(out), dtype=np.float64) / DIV
 names = ['stage Minv', 'pair loop: tail after the last stamp', 'motor+limit rows', 'limmask + register rows', 'PGS iterations', 'integrate', 'touch/forces',
-         'pair header: loads + object gathers', 'pair: wait + contact setup', 'object-lane contact rows', 'generic contact stage 1', 'generic contact rows', '-', '-', '-', '-']
+         'sweep: motors + limits', 'sweep: pass prologue + object-lane rows', 'sweep: to slots', 'sweep: generic row blocks', 'sweep: from slots + list build', '-', '-', '-', '-']
 tot = v[:12].sum()
 for n, x in zip(names, v): print(f'{n:28s} {x:10.0f} ticks  {100 * x / tot:5.1f} %')
 print('total', tot, 'ticks (shader clock cycles)')
