@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 1
+#define RR_ABI_VERSION 2   /* 2: RR_NUM_KERNELS 9 (rr_get_timing arrays), rr_set_object_poses, rr_step_plan_masked */
 
 enum {
     RR_OK = 0,

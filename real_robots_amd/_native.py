@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('RR_LIB', os.path.join(_HERE, 'csrc', 'librealrobot_hi
 BLOB_GZ = os.path.join(_HERE, 'data', 'realrobot_model.bin.gz')
 LINK_NAMES = open(os.path.join(_HERE, 'data', 'realrobot_model_links.txt')).read().split()
 
-RR_ABI_VERSION = 1
+RR_ABI_VERSION = 2
 (F_JOINTS, F_TOUCH, F_OBJ_POSE, F_RGB, F_DEPTH, F_MASK, F_TIMESTEP, F_ERRFLAGS, F_STATE, F_FRAG_COUNT) = range(10)
 NUM_KERNELS = 9
 # id 5 = image set-up outside the two render kernels: the full static copy of the first frame (and the earlier schemes
