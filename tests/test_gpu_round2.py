@@ -241,20 +241,20 @@ def test_dlpack_and_vector_env_adapter():
 
 
 def test_heavy_light_split_is_bitwise_equivalent(monkeypatch):
-    """rr_step solves and renders the solver groups with generic contact rows on the side stream, beside the others
-    (DESIGN.md 5.1).  That is scheduling only: with full-range commands (arms pressed on the table, grippers in the objects:
+    """rr_step solves and renders the envs with generic contact rows on side streams, beside the others (DESIGN.md 5.1:
+    light / heavy / very heavy).  That is scheduling only: with full-range commands (arms pressed on the table, grippers in the objects:
     a few dozen heavy groups) 240 steps with a render every step must leave bit-identical states, contact forces and
     images whether the split is on or off, and with per-env render flags."""
     N, T = 512, 240
     ids = np.arange(N)
     flags = (np.arange(N) % 3 != 0).astype(np.uint8)
 
-    def run(no_split):
-        if no_split:
-            monkeypatch.setenv("RR_NO_SPLIT", "1")
+    def run(**envvars):
+        for k, v in envvars.items():
+            monkeypatch.setenv(k, v)
         env = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
-        if no_split:
-            monkeypatch.delenv("RR_NO_SPLIT")
+        for k in envvars:
+            monkeypatch.delenv(k)
         heavy = 0
         for t in range(T):
             env.step(synthetic_actions(ids, t, seed=77), render=(flags if t % 2 else True))
@@ -264,9 +264,14 @@ def test_heavy_light_split_is_bitwise_equivalent(monkeypatch):
         env.close()
         return out, heavy
 
-    a, heavy = run(False)
-    b, _ = run(True)
+    a, heavy = run()
+    b, _ = run(RR_NO_SPLIT="1")
+    # the third class (very heavy envs on a stream of their own) with a threshold that puts most heavy envs into it, and
+    # the heavy envs' render by the three kernels instead of the fused list kernel
+    c, _ = run(RR_HEAVY2_MIN="2")
+    d, _ = run(RR_HEAVY2_MIN="1000")
     assert heavy >= 2                                   # the run did have envs with generic contacts
     assert (a[5] == 0).all()
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)
+    for other in (b, c, d):
+        for x, y in zip(a, other):
+            assert np.array_equal(x, y)
