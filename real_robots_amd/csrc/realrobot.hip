@@ -1577,38 +1577,56 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                 const v3 cj = cross(ak_l, x - pk_l) * jm, aj = ak_l * jm;
                 gc.gA = l < NB ? cj : gA; gc.gtA = l < NB ? aj : gtA; gc.hA = hA; gc.htA = htA;
             }
-#pragma unroll 1        // one copy of the row evaluation
-            for (int kr = 0; kr < 6; kr++) {
-                const bool tors = kr >= 3;
-                const int ka = tors ? kr - 3 : kr;
-                const v3 d = ka == 0 ? n : (ka == 1 ? t1 : t2);
-                const bool present = !tors || (kr == 3 ? spin > 0 : roll > 0);
-                // a torsional row without a coefficient (robot link against table / shelf: most contacts of a crushed arm) is
-                // never swept: only its (zero) scalars are read, when the sweep lists are built
-                if (__ballot(present) == 0ull) { if (l == 0) *(float4 *)&LD(L_GSC + 4 * (r0 + kr)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f); continue; }
-                const float ja = dot(d, tors ? gc.gtA : gc.gA), jb = dot(d, tors ? gc.gtB : gc.gB);
-                const float mjb = dot(d, tors ? gc.htB : gc.hB);
-                float mja = 0;
-#define MJA_STEP(J) mja += minv_l[J] * row_bcast<J>(ja);
+            // the three linear rows (n, t1, t2), then the three torsional rows about the same axes: the rows of a triple are
+            // independent, so their chains (the 11-step M^-1 product, the group sums) are evaluated side by side
+#pragma unroll 1
+            for (int tq = 0; tq < 2; tq++) {
+                const bool tors = tq == 1;
+                // torsional rows without a coefficient (robot link against table / shelf: most contacts of a crushed arm) are
+                // never swept: only their (zero) scalars are read, when the sweep lists are built
+                if (tors && __ballot(spin > 0 || roll > 0) == 0ull) {
+                    if (l == 0) {
+                        *(float4 *)&LD(L_GSC + 4 * (r0 + 3)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        *(float4 *)&LD(L_GSC + 4 * (r0 + 4)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        *(float4 *)&LD(L_GSC + 4 * (r0 + 5)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
+                    continue;
+                }
+                const v3 gA_ = tors ? gc.gtA : gc.gA, gB_ = tors ? gc.gtB : gc.gB, hA_ = tors ? gc.htA : gc.hA, hB_ = tors ? gc.htB : gc.hB;
+                float ja3[3], jb3[3], mja3[3], mjb3[3];
+#pragma unroll
+                for (int ka = 0; ka < 3; ka++) {
+                    const v3 d = ka == 0 ? n : (ka == 1 ? t1 : t2);
+                    ja3[ka] = dot(d, gA_); jb3[ka] = dot(d, gB_); mjb3[ka] = dot(d, hB_);
+                    mja3[ka] = 0.0f;
+                }
+#define MJA_STEP(J) { mja3[0] += minv_l[J] * row_bcast<J>(ja3[0]); mja3[1] += minv_l[J] * row_bcast<J>(ja3[1]); mja3[2] += minv_l[J] * row_bcast<J>(ja3[2]); }
                 MJA_STEP(0) MJA_STEP(1) MJA_STEP(2) MJA_STEP(3) MJA_STEP(4) MJA_STEP(5) MJA_STEP(6) MJA_STEP(7) MJA_STEP(8) MJA_STEP(9) MJA_STEP(10)
 #undef MJA_STEP
-                mja = l < NB ? mja : dot(d, tors ? gc.htA : gc.hA);
-                const float diag = group_sum(ja * mja + jb * mjb);
-                const float rel = group_sum(ja * ua + jb * ub);
-                if (present) D.grows[((size_t)env * GROWS + r0 + kr) * 16 + l] = make_float4(ja, mja, jb, mjb);
-                if (kr == 0) { wsA = fmaf(mja, lam0, wsA); wsB = fmaf(mjb, lam0, wsB); }
-                float rhsn;
-                if (kr == 0) {
-                    float r = 0;
-                    if (fabsf(rel) >= P.rest_thresh) { r = rest * -rel; if (r < 0) r = 0; }
-                    float verr = r - rel, perr = 0;
-                    if (dist > 0) verr -= dist * inv_dt;
-                    else perr = -dist * P.erp * inv_dt;
-                    rhsn = perr + verr;
-                } else rhsn = -rel;
-                if (l == 0) {
-                    const float dinv = (present && diag > 0) ? 1.0f / diag : 0.0f;
-                    *(float4 *)&LD(L_GSC + 4 * (r0 + kr)) = make_float4(rhsn * dinv, dinv, kr == 0 ? 0.0f : (kr < 3 ? mu : (kr == 3 ? spin : roll)), kr == 0 ? lam0 : 0.0f);
+#pragma unroll
+                for (int ka = 0; ka < 3; ka++) {
+                    const int kr = 3 * tq + ka;
+                    const v3 d = ka == 0 ? n : (ka == 1 ? t1 : t2);
+                    const bool present = !tors || (ka == 0 ? spin > 0 : roll > 0);
+                    const float ja = ja3[ka], jb = jb3[ka], mjb = mjb3[ka];
+                    const float mja = l < NB ? mja3[ka] : dot(d, hA_);
+                    const float diag = group_sum(ja * mja + jb * mjb);
+                    const float rel = group_sum(ja * ua + jb * ub);
+                    if (present) D.grows[((size_t)env * GROWS + r0 + kr) * 16 + l] = make_float4(ja, mja, jb, mjb);
+                    if (kr == 0) { wsA = fmaf(mja, lam0, wsA); wsB = fmaf(mjb, lam0, wsB); }
+                    float rhsn;
+                    if (kr == 0) {
+                        float r = 0;
+                        if (fabsf(rel) >= P.rest_thresh) { r = rest * -rel; if (r < 0) r = 0; }
+                        float verr = r - rel, perr = 0;
+                        if (dist > 0) verr -= dist * inv_dt;
+                        else perr = -dist * P.erp * inv_dt;
+                        rhsn = perr + verr;
+                    } else rhsn = -rel;
+                    if (l == 0) {
+                        const float dinv = (present && diag > 0) ? 1.0f / diag : 0.0f;
+                        *(float4 *)&LD(L_GSC + 4 * (r0 + kr)) = make_float4(rhsn * dinv, dinv, kr == 0 ? 0.0f : (kr < 3 ? mu : (kr == 3 ? spin : roll)), kr == 0 ? lam0 : 0.0f);
+                    }
                 }
             }
             ng++;
