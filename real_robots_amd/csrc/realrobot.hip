@@ -3851,8 +3851,8 @@ static void launch_render(rr_env *e, const DevPtrs &D, int restore, int sel, hip
         TIMED(6, hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel));
     } else {
         // the heavy envs, a few (lagged host copy of their number: at most one item per workgroup): one list-walking launch for
-        // set-up, visibility and shading -- the tail of the step's longest chain; many: the three kernels (the fused one runs
-        // at three workgroups per CU with spills, which a long list pays for)
+        // set-up, visibility and shading -- the tail of the step's longest chain; many: the three kernels (the fused one needs
+        // 128 VGPRs: two workgroups per CU, which a long list pays for)
         if (sel == 3 || (sel == 2 && e->h_hcount && (long long)*(volatile int *)e->h_hcount * e->RM.ntiles <= RENDER_LIST_WGS)) {
             hipLaunchKernelGGL(k_render_list, dim3(std::min(N * e->RM.ntiles, sel == 3 ? 256 : RENDER_LIST_WGS)), dim3(RASTER_THREADS), 0, st, e->B, e->P, e->RM_dev, D, io, e->n_inst_used, restore, sel == 3 ? 1 : 0);
             return;

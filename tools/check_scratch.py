@@ -5,8 +5,8 @@ import re
 import subprocess
 import sys
 
-HOT = ('k_prep_a', 'k_prep_b', 'k_collide', 'k_balance', 'k_solve', 'k_raster', 'k_shade', 'k_static_copy', 'k_restore', 'k_render_setup', 'k_ik',
-       'k_plan_macro')
+HOT = ('k_prep_a', 'k_prep_b', 'k_collide', 'k_solve', 'k_raster', 'k_render_list', 'k_shade', 'k_static_copy', 'k_restore', 'k_render_setup',
+       'k_ik', 'k_plan_macro')
 
 
 def main():
