@@ -107,8 +107,9 @@ def _fuzz_case(case, seed0, stats, bad):
                 stats['dj'] = max(stats['dj'], dj)
                 stats['do'] = max(stats['do'], do)
                 stats['dv'] = max(stats['dv'], dv)
-                # measured worst over the 300 cases: joints (q, qd) 8.5e-5, object pose 3e-8 - bounds are ~4x / ~30x that
-                if dj > 3e-4 or do > 1e-6 or dv > 2e-4:
+                # measured worst over 1200 cases (warm starting on): joints (q, qd) 1.6e-4, object pose 4.6e-7, object velocity
+                # 1.8e-4 -- the bounds are about twice that
+                if dj > 3e-4 or do > 1e-6 or dv > 4e-4:
                     bad.append(tag + ('state', dj, do, dv, fmax))
             o.state = st1[i].astype(np.float64)
             r, d, m = o.render()
