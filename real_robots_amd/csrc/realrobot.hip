@@ -2112,6 +2112,9 @@ __device__ __forceinline__ void instance_setup(const BodyParams &B, const SimPar
 #pragma unroll
         for (int b = 0; b < NB; b++) if (oi == b) anc = ANC[b];
         p = mk(B.robot_pos[0], B.robot_pos[1], B.robot_pos[2]);
+        float qj[NB];              // all joint angles requested up front: one round trip instead of one per ancestor
+#pragma unroll
+        for (int b = 0; b < NB; b++) qj[b] = STT(ST_Q + b);
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             if (!((anc >> b) & 1u)) continue;
@@ -2121,7 +2124,7 @@ __device__ __forceinline__ void instance_setup(const BodyParams &B, const SimPar
             const m3 Rj = nc::mul(R, jr);
             const v3 ax = mk(B.axis[b][0], B.axis[b][1], B.axis[b][2]);
             p = nc::add(p, nc::mulv(R, mk(B.jpos[b][0], B.jpos[b][1], B.jpos[b][2])));
-            R = nc::mul(Rj, nc::axis_angle(ax, STT(ST_Q + b)));
+            R = nc::mul(Rj, nc::axis_angle(ax, qj[b]));
         }
     } else if (ot == 2) {
         R = nc::quat_to_m3(STT(ST_OQUAT + 4 * oi), STT(ST_OQUAT + 4 * oi + 1), STT(ST_OQUAT + 4 * oi + 2), STT(ST_OQUAT + 4 * oi + 3));
