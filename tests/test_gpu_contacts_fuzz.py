@@ -246,3 +246,28 @@ def test_edge_edge_contacts_match_the_oracle():
         # (an edge pair that overlaps by more than 0.5 mm beyond the deepest vertex candidate is no contact: the -1 mm case)
         assert n_edge == (N - 1 if edges else 0), (edges, n_edge)
         env.close()
+
+
+def test_warm_start_follows_the_oracle_over_a_trajectory():
+    """Device and oracle run side by side from reset, each with its own contact history (no hand-over): two solver sweeps
+    per step only, so that the inherited impulses carry the resting objects -- without the warm start they sink by a
+    millimetre (tests/test_oracle_pins.py); matching decisions that differed between the two sides would show as a
+    different penetration or a different set of active contacts."""
+    env = BatchedREALRobotEnv(3, objects=3, width=64, height=64, solver_iters=2)
+    o = Oracle(3, 64, 64, f32=True, solver_iters=2)
+    env.reset()
+    o.reset()
+    for t in range(250):
+        env.step(None, render=False)
+        o.step(None)
+        if t % 50 == 49:
+            cd, co = env.contacts(1), o.contacts()
+            assert len(cd) == len(co) == 12, (t, len(cd), len(co))
+            assert np.abs(cd[:, 9] - co[:, 9]).max() < 2e-5, (t, np.abs(cd[:, 9] - co[:, 9]).max())          # penetrations
+            assert np.abs(cd[:, 10] - co[:, 10]).max() < 0.02 * co[:, 10].max() + 0.02, t                     # normal forces
+    d = env.state[1].astype(np.float64) - o.state
+    dp = np.abs(d[22:].reshape(3, 13)[:, :3])
+    assert dp[:, 2].max() < 2e-5 and dp[:, :2].max() < 3e-4          # heights; the slow lateral creep at two sweeps per step
+    c = env.contacts(0)
+    assert c[:, 9].min() > -5e-4            # (a cold start at two sweeps per step: below -6e-4)
+    env.close()
