@@ -3690,9 +3690,11 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         int prio_lo = 0, prio_hi = 0;
         hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         const int prio = getenv("RR_AUX_PRIORITY") && atoi(getenv("RR_AUX_PRIORITY")) == 0 ? prio_lo : prio_hi;
-        if (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, evf) != hipSuccess ||
+        // (a runtime without stream priorities: plain non-blocking streams)
+        auto side_stream = [&](hipStream_t *st) { return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio) == hipSuccess || hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess; };
+        if (!side_stream(&e->aux) || hipEventCreateWithFlags(&e->ev_fork, evf) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_join, evf) != hipSuccess || hipEventCreateWithFlags(&e->ev_dyn, evf) != hipSuccess ||
-            hipStreamCreateWithPriority(&e->aux2, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&e->ev_join2, evf) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
+            !side_stream(&e->aux2) || hipEventCreateWithFlags(&e->ev_join2, evf) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
     }
     e->field_ptr[RR_F_JOINTS] = D.joints; e->field_bytes[RR_F_JOINTS] = (size_t)N * 9 * 4;
     e->field_ptr[RR_F_TOUCH] = D.touch; e->field_bytes[RR_F_TOUCH] = (size_t)N * 4 * 4;
