@@ -3184,8 +3184,12 @@ __global__ void k_background(const RenderModel *RMp, DevPtrs D) {
 // SHADE_THREADS-entry chunks to SHADE_SPLIT workgroups (blocks whose first chunk lies beyond the list exit at once).
 // A/B (k_shade, ms): 64x16 0.175, 128x8 0.145, 256x8 0.131, 256x2 0.122, 512x2 0.119, 1024x1 0.120 -- the per-block
 // staging of the instance constants outweighs the tail of long lists.
+#ifndef SHADE_THREADS
 #define SHADE_THREADS 256
-#define SHADE_SPLIT 8
+#endif
+#ifndef SHADE_SPLIT
+#define SHADE_SPLIT 2       // with four tiles per env a list holds ~300 entries: 256 x 8 0.113 ms, x 4 0.101, x 2 0.098, 512 x 1 0.106, 128 x 3 0.100
+#endif
 // chunk z of nz of the fragment list of (env, tile); mvp / sinst: the workgroup's staging arrays
 template <int NTHREADS>
 __device__ __forceinline__ void shade_block(const RenderModel &RM, const DevPtrs &D, const ImageOut &out, int env, int tile, int z, int nz,
