@@ -4,19 +4,26 @@
 // wavefront whose lanes are consecutive envs reads/writes 256-byte contiguous lines.  A step is these kernels
 // (main stream unless noted; DESIGN.md 5 has the work-item maps and what bounds each of them):
 //   k_prep_a        1 thread / env : action protocol (env.py:314-321, 257-264; robot.py:188-201), forward kinematics,
-//                                    object terms (rotation, world inverse inertia, unconstrained velocities)
+//                                    object terms (rotation, world inverse inertia, unconstrained velocities); launch order
+//                                    of k_collide (last step's heavy envs first)
 //   k_prep_b        1 thread / env : joint-space mass matrix (composite rigid bodies), bias (RNEA), Cholesky, M^-1,
 //                                    unconstrained joint velocities -- side stream, beside k_collide
-//   k_collide       1 wavefront / env: bounding spheres -> pair list -> lane-per-vertex convex tests -> <=4 points/pair
-//   k_solve         16 lanes / env : row assembly (motors, joint limits, contact normal + 2 friction), PGS with the
-//                                    common rows in registers and the others streamed from a per-workgroup LDS row
-//                                    pool, semi-implicit Euler, touch sensors, observation pack (robot.py:152-163,203-211)
+//   k_collide       4 wavefronts / env: bounding spheres -> close pairs, dealt out among the waves -> lane-per-vertex convex
+//                                    tests + edge-edge pass -> <= 4 points / pair, listed in pair order; warm-start matching
+//                                    against the previous step's list; classifies the env (light / heavy / very heavy)
+//   k_solve         16 lanes / env : row assembly (motors, joint limits, contact normal + 2 friction + 3 torsional rows),
+//                                    PGS with the object-vs-static rows in registers and the generic rows in a slot layout
+//                                    streamed from global memory, semi-implicit Euler, touch sensors, observation pack
+//                                    (robot.py:152-163,203-211); three launches in a rendering step: light envs (main
+//                                    stream), heavy and very heavy envs (two side streams)
 //   k_render_setup  1 thread / (env, instance): FK of the ancestor chain -> model-view-projection + shading constants
 //   k_raster        1 workgroup / (env, tile): visibility only -- 64-bit atomic-min buffer (depth | triangle id) in LDS,
 //                                    meshlet clusters, fragment list out (winners + pixels vacated since the last frame)
 //   k_shade         deferred shading of the fragment lists; vacated / occluded pixels go back to the static layer
 //                                    (the images persist in HBM: k_static_copy, the full copy, only runs for the first
 //                                    frame; k_restore is the separate-pass variant kept for RR_SEPARATE_RESTORE)
+//   k_render_list / k_raster_list  the same three stages for the envs of a heavy list (side streams): one list-walking
+//                                    launch for a short list, list-walking visibility + the grid kernels for a long one
 // The arithmetic restates what the reference delegates to pybullet.stepSimulation / getCameraImage
 // (env.py:340, 536-567); the algorithm and its constants are specified in DESIGN.md and checked against
 // oracle/rr_oracle.c by tests/ (never linked here).
