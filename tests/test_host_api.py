@@ -246,3 +246,38 @@ def test_dlpack_capsule_lifecycle_without_a_gpu():
     del cap, m
     gc.collect()
     assert len(nat._dl_alive) == n0
+
+
+def test_bench_bookkeeping_and_committed_profiles():
+    """bench.py's accounting without a GPU: the algorithmic bytes of SURVEY 8(d) (state + command + low-dim observation,
+    128x128 RGB + depth), the rule that a committed PMC profile is only attached to a run of the configuration it was
+    collected on, and the committed `*_latest.json` files themselves (per-step bytes below the algorithmic image bytes: the
+    images persist in HBM and a frame rewrites only what changed)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = bench.algo_bytes(3, 128, 128)
+    assert a['_state'] == (22 + 39 + 11) * 8 + 36 + (9 + 4 + 21) * 4 == 748
+    assert a['_image'] == 128 * 128 * 7 + 22 * 12 * 4 == 115744
+    cfg = {"envs": 4096, "objects": 3, "width": 128, "height": 128, "render": True, "command_scale": 1.0, "solver_iters": 50}
+    prof, why = bench.load_profile('traffic_latest.json', cfg)
+    assert prof is not None and why is None and prof['config'] == cfg
+    other, why = bench.load_profile('traffic_latest.json', dict(cfg, envs=1024))
+    assert other is None and 'collected on' in why
+    assert bench.load_profile('no_such_file.json', cfg)[0] is None
+    # the committed figures: every kernel of the step is there, the render stage stays below a full image write
+    for k in ('k_prep_a', 'k_prep_b', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster', 'k_shade', 'render_stage'):
+        assert prof[k] > 0, k
+    assert prof['render_stage'] < a['_image'] * 4096 and prof['k_solve'] < 100e6
+    sq, _ = bench.load_profile('sq_latest.json', cfg)
+    assert sq['valu_wave_instr_per_launch']['k_raster'] > 1e8
+    assert os.path.exists(os.path.join(ROOT, 'profiles', prof['source'])) and os.path.exists(os.path.join(ROOT, 'profiles', sq['source']))
+    assert bench.SIDE_STREAM_KERNELS == ('k_solve_heavy', 'render_heavy') and set(bench.SIDE_STREAM_KERNELS) <= set(nat_names())
+
+
+def nat_names():
+    from real_robots_amd import _native as nat
+    assert len(nat.KERNEL_NAMES) == nat.NUM_KERNELS == 9
+    return nat.KERNEL_NAMES
