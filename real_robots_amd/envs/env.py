@@ -239,20 +239,22 @@ class REALRobotEnv:
         self.goals = list(np.load(self.goals_dataset_path, allow_pickle=True).items())[0][1]
 
     def set_goals_dataset_path(self, path):
-        assert os.path.exists(path), "Non existent path {}".format(path)
+        """env.py:147-149: the dataset must exist when it is named (AssertionError otherwise)."""
+        if not os.path.exists(path):
+            raise AssertionError("Non existent path {}".format(path))
         self.goals_dataset_path = path
 
     def set_goal(self):
+        """env.py:151-166: advance to the next goal of the dataset, put its objects at their initial poses and keep only the
+        positions of the final state (the score compares positions); returns the observation with the new goal image."""
         if self.goals is None:
             self.load_goals()
         self.goal_idx += 1
-        self.goal = self.goals[self.goal_idx]
-        for obj in self.goal.initial_state.keys():
-            position = self.goal.initial_state[obj][:3]
-            orientation = self.goal.initial_state[obj][3:]
-            self.robot.object_bodies[obj].reset_pose(position, orientation)
-        for obj in self.goal.final_state.keys():
-            self.goal.final_state[obj] = self.goal.final_state[obj][:3]
+        goal = self.goal = self.goals[self.goal_idx]
+        bodies = self.robot.object_bodies
+        for name, pose in goal.initial_state.items():
+            bodies[name].reset_pose(pose[:3], pose[3:])
+        goal.final_state = {name: pose[:3] for name, pose in goal.final_state.items()}
         return self.get_observation()
 
     def evaluateGoal(self):
