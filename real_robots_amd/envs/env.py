@@ -348,15 +348,10 @@ class REALRobotEnv:
         self._backend().step(a.reshape(1, 9), render=camera_on)
         observation = self.get_observation(camera_on, _rendered=True)
         reward = self.reward_func(observation)
-        done = False
         self.timestep += 1
-        if self.goal_idx < 0:
-            if self.timestep >= self.intrinsic_timesteps:
-                done = True
-        else:
-            if self.timestep >= self.extrinsic_timesteps:
-                done = True
-        return observation, reward, done, {}
+        # env.py:343-352: the episode ends with the phase it is in (intrinsic before the first set_goal, extrinsic after)
+        limit = self.intrinsic_timesteps if self.goal_idx < 0 else self.extrinsic_timesteps
+        return observation, reward, bool(self.timestep >= limit), {}
 
     def _q11(self):
         return self._backend().state[0, :11].astype(np.float64)
