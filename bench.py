@@ -18,9 +18,14 @@ no collective on the stepping path; `--gather lowdim|images` adds the optional p
                 bytes per launch / duration against the 8 TB/s HBM peak (`achieved` is that ratio, not a measured HBM rate; the
                 measured HBM bytes of the same configuration, when a committed PMC profile matches it, are `traffic`).
                 `roofline.valu` prices the dominant kernel against the VALU issue peak, which is what actually bounds it.
-  secondary     (N=1 only) the same library on the other workloads a reader needs to judge the headline: half-range
-                commands (round 1's headline), macro-action pushing (BASELINE config 5 shape), BASELINE config 2
-                (1024 envs, 1 object, no render)
+  timed_steps / heavy_envs   which steps of the workload the timed region covered and how many envs were heavy / very heavy
+                (solved and rendered on the side streams) at its start and end: full-range random commands
+                press more and more arms onto the table, so the rate depends on the window
+  secondary     (N=1 only) the same library on the other workloads a reader needs to judge the headline: the LATE window
+                (steps 2000-2200, SURVEY 8(d) config 3's horizon), half-range commands (round 1's headline), macro-action
+                pushing and a batched evaluate() (BASELINE config 5), BASELINE config 2 (1024 envs, 1 object, no render),
+                BASELINE config 1 (one env through real_robots.make(...).step, camera off / on, with the CPU oracle's
+                single-core rate beside it)
   cpu_baseline  PyBullet ("reference") when importable on this box, else the CPU oracle ("port"; oracle/ is the checker,
                 never the product), timed on the host cores on a bounded sample of the same workload
 """
@@ -48,6 +53,7 @@ def algo_bytes(n_obj, w, h):
     state = (22 + 13 * n_obj + 11) * 4 * 2 + 9 * 4 + (9 + 4 + 7 * n_obj) * 4          # state R/W + command + low-dim obs
     inst = 22 * 12 * 4
     return {'k_prep': state, 'k_collide': state, 'k_solve': state, 'k_render_setup': 11 * 4 + 13 * n_obj * 4 + inst,
+            'k_cmd': 9 * 4 + 9 * 4 + 11 * 4,   # command in, joint angles in, motor targets out
             'k_raster': inst,           # instance matrices in; + 8 B per listed fragment out (measured, added at run time)
             'k_image_setup': 0,         # steady state: does not run (first frame / earlier image-update schemes only)
             'k_shade': inst,            # + (8 B list entry in + 7 B pixel out) per list entry (measured, added at run time)
@@ -92,7 +98,24 @@ def cpu_baseline(seconds=10.0):
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(seconds, i) for i in range(cores)])
     rate = sum(n / t for n, t in res)
-    return {"value": round(rate, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+    # BASELINE config 1 (one env, REALRobot2020-R2J1, reference default 320x240 eye): the oracle's single-core rate, camera off / on
+    import numpy as np
+    c1 = {}
+    o = orc.Oracle(1, 320, 240)
+    rng = np.random.default_rng(0)
+    for cam in (False, True):
+        n, t0 = 0, time.perf_counter()
+        a = np.zeros(9)
+        while time.perf_counter() - t0 < 2.0:
+            if n % 20 == 0:
+                a = rng.uniform(-1.5, 1.5, 9)
+                a[7:] = np.abs(a[7:]) * 0.5
+            o.step(a)
+            if cam:
+                o.render()
+            n += 1
+        c1["camera_on" if cam else "camera_off"] = round(n / (time.perf_counter() - t0), 1)
+    return {"value": round(rate, 1), "unit": "env-steps/s", "cores": cores, "kind": "port", "config1_single_core": c1,
             "sample": "%d processes x 1 env x %.0f s each (%d env-steps in total), 3 objects, full-range commands, 128x128 "
                       "RGB+depth render every step (oracle/rr_oracle.c, float64 physics); PyBullet not importable on this box"
                       % (cores, seconds, sum(n for n, _ in res))}
@@ -138,6 +161,12 @@ def kernel_table(env, nat, n_local, n_obj, w, h, render, step_fn, nprof):
     return kernels, algo, frags
 
 
+def heavy_counts(env, nat):
+    """Envs the last step solved / rendered on the side streams (RR_F_ENV_CLASS: 1 heavy, 2 very heavy)."""
+    cls = env.host(nat.F_ENV_CLASS)
+    return {"heavy": int((cls == 1).sum()), "very_heavy": int((cls == 2).sum())}
+
+
 def load_profile(name, cfg):
     """A committed PMC-derived profile (profiles/<name>) applies to a run only when it was collected on the same
     configuration; returns (dict, None) or (None, reason)."""
@@ -164,18 +193,30 @@ def secondary_workloads(torch, np, nat, BatchedREALRobotEnv, device, steps):
         for t in range(presettle):
             step_fn(t)
         env.sync()
+        h0 = heavy_counts(env, nat)
         t0 = time.perf_counter()
         for t in range(presettle, presettle + steps_):
             step_fn(t)
         env.sync()
         el = time.perf_counter() - t0
+        h1 = heavy_counts(env, nat)
         ok = bool((env.host(nat.F_ERRFLAGS) == 0).all())
         kern, _, _ = kernel_table(env, nat, n_local, n_obj, w, h, render, lambda t: step_fn(presettle + steps_ + t), 10)
         out.append({"workload": label, "value": round(n_local * steps_ / el, 1), "unit": "env-steps/s",
-                    "ms_per_step": round(el / steps_ * 1e3, 4), "steps": steps_, "all_envs_finite": ok,
+                    "ms_per_step": round(el / steps_ * 1e3, 4), "steps": steps_, "timed_steps": [presettle, presettle + steps_],
+                    "heavy_envs": {"start": h0, "end": h1}, "all_envs_finite": ok,
                     "kernels_ms": {k: v["avg_ms"] for k, v in kern.items()}})
 
     ids = np.arange(ENVS_PER_GPU)
+    # (0) the headline workload in its LATE window: SURVEY 8(d) quotes config 3 over 2000 steps; by then a quarter of the arms
+    # press on the table (heavy / very heavy envs) and the rate is lower than in the default run's early window
+    env = BatchedREALRobotEnv(ENVS_PER_GPU, objects=3, width=W, height=H, device=device, want_mask=False)
+    cmds = make_commands(torch, np, ids, 2000 + 200 + 10, 1.0, dev)
+    timed(env, ENVS_PER_GPU, lambda t: env.step(device_ptr=cmds[t].data_ptr(), render=True), 2000, 200,
+          "config 3, LATE window: the headline workload (4096 envs, 3 objects, full-range commands, 128x128 render every step) "
+          "timed over steps 2000-2200", 3, W, H, True)
+    env.close()
+    del cmds
     # (1) round 1's headline: commands scaled by 0.5 (arms rarely reach the objects)
     env = BatchedREALRobotEnv(ENVS_PER_GPU, objects=3, width=W, height=H, device=device, want_mask=False)
     cmds = make_commands(torch, np, ids, 150 + steps + 10, 0.5, dev)
@@ -198,7 +239,78 @@ def secondary_workloads(torch, np, nat, BatchedREALRobotEnv, device, steps):
     timed(env, n2, lambda t: env.step(device_ptr=cmds2[t].data_ptr(), render=False), 150, 4 * steps,
           "config 2: REALRobot2020-R2J1, 1024 envs, 1 object, full-range joint commands, no render (dynamics-only)", 1, 64, 64, False)
     env.close()
+    # (4) BASELINE config 5 at size: batched evaluate() -- 4096 envs, macro actions, intrinsic phase + extrinsic trials with
+    # goals of a seeded synthetic dataset, a device-side batched policy, scores computed on the device
+    try:
+        from real_robots_amd.evaluate import bench_evaluate_batched
+        out.append(bench_evaluate_batched(ENVS_PER_GPU, device=device, width=W, height=H))
+    except Exception as ex:            # the headline must not depend on it
+        out.append({"workload": "config 5 end to end (evaluate_batched at 4096 envs)", "error": repr(ex)})
+    # (5) BASELINE config 1: ONE env through the drop-in facade (what an unchanged BasePolicy agent sees), camera off / on
+    import real_robots_amd as rr
+    e1 = rr.make('REALRobot2020-R2J1-v0', device=device)
+    e1.reset()
+    rng = np.random.default_rng(0)
+    res = {}
+    for cam, n_steps in ((False, 2000), (True, 300)):
+        a = np.zeros(9)
+        for t in range(20):
+            e1.step({'joint_command': a, 'render': cam})
+        t0 = time.perf_counter()
+        for t in range(n_steps):
+            if rng.random() < 0.05:                 # README policy: a new action_space sample now and then, held in between
+                a = e1.action_space['joint_command'].sample()
+            e1.step({'joint_command': a, 'render': cam})
+        res["camera_on" if cam else "camera_off"] = {"steps": n_steps, "value": round(n_steps / (time.perf_counter() - t0), 1),
+                                                      "unit": "env-steps/s"}
+    e1.close()
+    out.append({"workload": "config 1: REALRobot2020-R2J1-v0, ONE env through real_robots.make(...).step (gym facade: rr_step + "
+                            "observation read-back every step, 320x240 eye when the action asks for it)", **res,
+                "note": "single-env drop-in latency, host-bound (ctypes + D2H per step); the CPU oracle's single-core rate on the "
+                        "same shape is cpu_baseline.config1_single_core"})
     return out
+
+
+class _StubEnv:
+    """Plumbing test double (`--stub-env`, tests/test_distributed_gloo.py): the surface of BatchedREALRobotEnv that main() uses,
+    on CPU tensors, so that argument handling, sharding, the barrier / max-over-ranks timing and the JSON assembly run under
+    gloo without a GPU.  It simulates nothing; a line produced with it says so in `data` and carries no roofline."""
+
+    def __init__(self, torch, np, nat, n, n_obj, w, h):
+        self.torch, self.np, self.nat, self.N = torch, np, nat, n
+        self.buf = {nat.F_JOINTS: torch.zeros(n, 9), nat.F_TOUCH: torch.zeros(n, 4), nat.F_OBJ_POSE: torch.zeros(n, n_obj, 7),
+                    nat.F_RGB: torch.zeros(n, h, w, 3, dtype=torch.uint8), nat.F_DEPTH: torch.zeros(n, h, w)}
+        self.steps = 0
+
+    def step(self, device_ptr=None, render=False, cmd=None):
+        self.steps += 1
+        if cmd is not None:
+            self.buf[self.nat.F_JOINTS] += 1e-3 * cmd
+
+    def device_buffer(self, field):
+        return self.buf[field]
+
+    def host(self, field):
+        np = self.np
+        if field == self.nat.F_ERRFLAGS:
+            return np.zeros(self.N, np.uint32)
+        if field == self.nat.F_ENV_CLASS:
+            return np.zeros(self.N, np.int32)
+        if field == self.nat.F_FRAG_COUNT:
+            return np.zeros((self.N, 1), np.uint32)
+        return self.buf[field].numpy()
+
+    def set_timing(self, on):
+        pass
+
+    def get_timing(self):
+        return {k: (0.0, 0) for k in self.nat.KERNEL_NAMES}
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
 
 
 def main():
@@ -223,6 +335,8 @@ def main():
                     help='weak: --envs-per-gpu envs on every rank; strong: --envs-per-gpu envs in total, split over the ranks')
     ap.add_argument('--gather', nargs='?', const='lowdim', default='none', choices=('none', 'lowdim', 'images'),
                     help='also all-gather observations every step (RCCL): joints/touch/object poses, or those + RGB + depth')
+    ap.add_argument('--stub-env', action='store_true',
+                    help='plumbing test on CPU (gloo): a stub replaces the simulator; the printed line is marked as such')
     args = ap.parse_args()
     if args.image:
         global W, H
@@ -237,7 +351,7 @@ def main():
         args.gpus = world
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub_env:
         cpu = cpu_baseline()             # before this process touches the GPU
 
     import numpy as np
@@ -247,12 +361,18 @@ def main():
     from real_robots_amd.batched import BatchedREALRobotEnv
     from real_robots_amd.distributed import gather_images, gather_observations, shard_range
 
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = 'cuda:%d' % local_rank
+    stub = args.stub_env
+    if stub:
+        dev = 'cpu'
+        device_sync = lambda: None                                                     # noqa: E731
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        dev = 'cuda:%d' % local_rank
+        device_sync = torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')          # RCCL on ROCm
+        dist.init_process_group('gloo' if stub else 'nccl')          # "nccl" = RCCL on ROCm
 
     if args.scaling == 'strong':
         total = args.envs_per_gpu
@@ -264,13 +384,22 @@ def main():
         start, stop = shard_range(total, rank, world)
     ids = np.arange(start, stop)
     n_obj = args.objects
-    env = BatchedREALRobotEnv(n_local, objects=n_obj, width=W, height=H, device=local_rank,
-                              envs_per_block=args.envs_per_block, solver_iters=args.solver_iters,
-                              want_mask=False)     # R2 observations carry no mask (robot.py:99-112)
+    # An explicit stream for the library AND for torch's work of this process (the observation gather): the collectives are
+    # ordered after the step that produced their buffers because both sit on this one stream, not because both happen to use
+    # the legacy default stream.
+    stream = None
+    if stub:
+        env = _StubEnv(torch, np, nat, n_local, n_obj, W, H)
+    else:
+        stream = torch.cuda.Stream(device=dev)
+        env = BatchedREALRobotEnv(n_local, objects=n_obj, width=W, height=H, device=local_rank,
+                                  envs_per_block=args.envs_per_block, solver_iters=args.solver_iters,
+                                  want_mask=False, stream=stream.cuda_stream)     # R2 observations carry no mask (robot.py:99-112)
     render = not args.no_render
 
     n_total_steps = args.presettle + args.warmup + args.steps + 20
     cmd_of_step = make_commands(torch, np, ids, n_total_steps, args.command_scale, dev)
+    device_sync()                          # the commands were uploaded on torch's default stream
     views = None
     if args.gather != 'none':
         views = {'joints': torch.as_tensor(env.device_buffer(nat.F_JOINTS), device=dev),
@@ -283,35 +412,58 @@ def main():
 
     def one_step(t):
         nonlocal gathered_bytes
-        env.step(device_ptr=cmd_of_step[t].data_ptr(), render=render)
+        if stub:
+            env.step(render=render, cmd=cmd_of_step[t])
+        else:
+            env.step(device_ptr=cmd_of_step[t].data_ptr(), render=render)
         if views is not None and world > 1:
-            # the library's stream is torch's current stream here (stream=None -> the default stream), so the collective is
-            # ordered after the step that produced the buffers
+            # (torch's current stream is the library's stream: see `stream` above)
             low = gather_observations({k: views[k] for k in ('joints', 'touch', 'objpose')})
             gathered_bytes = sum(v.numel() * v.element_size() for v in low.values())
             if args.gather == 'images':
                 rgb, depth = gather_images(views['rgb'], views['depth'])
                 gathered_bytes += rgb.numel() + depth.numel() * 4
 
-    for t in range(args.presettle + args.warmup):
-        one_step(t)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(args.presettle + args.warmup, args.presettle + args.warmup + args.steps):
-        one_step(t)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    import contextlib
+    on_stream = (lambda: torch.cuda.stream(stream)) if stream is not None else contextlib.nullcontext
+    with on_stream():
+        for t in range(args.presettle + args.warmup):
+            one_step(t)
+        device_sync()
+        heavy_start = heavy_counts(env, nat)
+        if world > 1:
+            dist.barrier()
+        device_sync()
+        t0 = time.perf_counter()
+        for t in range(args.presettle + args.warmup, args.presettle + args.warmup + args.steps):
+            one_step(t)
+        device_sync()
+        if world > 1:
+            dist.barrier()
+        device_sync()
+        elapsed = time.perf_counter() - t0
+        heavy_end = heavy_counts(env, nat)
+        if world > 1:
+            tt = torch.tensor([elapsed], device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
     assert (env.host(nat.F_ERRFLAGS) == 0).all(), "an env reported a non-finite state"
+    timed_steps = [args.presettle + args.warmup, args.presettle + args.warmup + args.steps]
+    if stub:
+        if rank == 0:
+            print(json.dumps({"metric": "env-steps/sec (whole node), 4096 envs, R2J3 3-obj + 128x128 cam", "value": round(total * args.steps / elapsed, 1),
+                              "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+                              "vs_baseline": None, "dtype": "f32", "data": "STUB ENV -- plumbing test, nothing was simulated",
+                              "config": {"workload": "stub", "envs_total": total, "envs_per_gpu": n_local, "world": world,
+                                         "gather": args.gather, "gathered_bytes_per_step_per_rank": gathered_bytes,
+                                         "rank_env_ids": [int(start), int(stop)], "parallelism": "env-shard x%d" % world},
+                              "timed_steps": timed_steps, "roofline": None}))
+        if world > 1:
+            # every rank reports its shard for the test that launched it
+            print("RANK %d ids %d %d steps %d" % (rank, start, stop, env.steps), file=sys.stderr)
+            dist.destroy_process_group()
+        return
 
     # per-kernel device time (HIP events on the library's stream), separate pass right behind the timed region
     nprof = min(20, args.steps)
@@ -356,22 +508,35 @@ def main():
     else:
         valu = {"kernel": dom_kernel, "frac": None, "note": "null: " + (why_sq or "kernel not in the profile")}
     ach = kernels[dom]["algorithmic_GBs"]
-    roofline = {"bound": "hbm", "kernel": dom if dom != 'render_stage' else "+".join(kernels['render_stage']['members']),
+    # what the counters say bounds the dominant kernel: VALU issue when its issue fraction exceeds its HBM fraction (it does,
+    # tenfold); the HBM figures stay the contract's accounting (achieved / peak / frac)
+    traffic_lo = prof.get('lower_bound', {}).get(dom) if prof is not None else None
+    dom_ms = kernels[dom]["avg_ms"]
+    traffic_frac = round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if traffic else None
+    bound = "valu" if (valu.get("frac") or 0.0) > max(ach / HBM_PEAK_GBS, traffic_frac or 0.0) else "hbm"
+    roofline = {"bound": bound, "kernel": dom if dom != 'render_stage' else "+".join(kernels['render_stage']['members']),
                 "dominant_single_kernel": dom_kernel,
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
                 "achieved_is": "ALGORITHMIC bytes per launch / HIP-event duration (full images, although a frame rewrites only "
                                "the pixels that changed) -- the contract's accounting, not a measured HBM rate; `traffic` is the measured one",
-                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_lower_bound": traffic_lo, "achieved_traffic_frac": traffic_frac,
+                "traffic_note": "HBM bytes of the unit per step from PMC counters; `traffic` applies the guide's x2 FETCH_SIZE correction "
+                                "(calibrated for 16-B-per-lane coalesced reads only) to every read, `traffic_lower_bound` to none: "
+                                "the unit's reads are mostly scattered 8/16-byte records, so the truth lies between; "
+                                "achieved_traffic_frac = traffic / duration / 8 TB/s",
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(algo[dom] * n_local),
                 "whole_step_algorithmic_GBs": round((algo['_state'] + (W * H * 7 if render else 0)) * n_local * args.steps / elapsed / 1e9, 2),
-                "bound_note": "HBM is the contract's ceiling for this byte-moving path, but at 116 KB and ~0.3 M instructions per "
-                              "env-step the dominant kernels are VALU-issue / latency bound (roofline.valu; DESIGN.md 5)",
+                "bound_note": "`bound` comes from the counters: the dominant kernel's VALU issue fraction (roofline.valu) against its HBM "
+                              "fractions. achieved / peak / frac stay in the contract's HBM terms (algorithmic bytes): at 116 KB and "
+                              "~0.3 M instructions per env-step the path is instruction-issue / latency bound (DESIGN.md 5)",
                 "valu": valu,
                 "kernels": kernels,
                 "timing_note": "per-kernel durations: HIP events on the library's stream, the launches of a step one after the "
                                "other (no side-stream overlap), %d steps of the same workload right after the timed region; "
                                "k_solve / k_render_setup / k_raster / k_shade = the main stream's launches (light envs), "
-                               "k_solve_heavy / render_heavy = the side stream's (heavy envs); render_stage = the image of every "
+                               "k_solve_heavy / render_heavy = the side streams' (heavy envs); k_prep / k_collide = the look-ahead "
+                               "of the next step, which an untimed step runs under the render; render_stage = the image of every "
                                "env = k_raster + k_shade + render_heavy; rocprofv3 --stats of the overlapped run is under profiles/" % nprof}
     env.close()
 
@@ -391,6 +556,10 @@ def main():
             "value": round(total * args.steps / elapsed, 1), "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timed_steps": timed_steps, "heavy_envs": {"start": heavy_start, "end": heavy_end, "of": n_local,
+                                                       "note": "envs with generic contact rows at the start / end of the timed region "
+                                                               "(rank 0): solved and rendered on the side streams; their number grows "
+                                                               "with the step index, and the rate falls with it (secondary: late window)"},
             "config": {"workload": "REALRobot2020-R2J%d-v0, %d envs/GPU, %d object(s) + contact solver, %s joint commands "
                                    "(README resample-and-hold over the joint limits, robot.py:58-67), %s" %
                                    (n_obj, n_local, n_obj, cmd_txt,

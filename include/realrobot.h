@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 2   /* 2: RR_NUM_KERNELS 9 (rr_get_timing arrays), rr_set_object_poses, rr_step_plan_masked */
+#define RR_ABI_VERSION 3   /* 3: RR_NUM_KERNELS 10 (k_cmd), RR_F_CONTACT_COUNT, rr_checkpoint_* */
 
 enum {
     RR_OK = 0,
@@ -45,7 +45,9 @@ enum {
     RR_F_ERRFLAGS = 7,  /* u32 [N]           bit0: non-finite state detected (env auto-frozen) */
     RR_F_STATE = 8,     /* f32 [N, 61]       q[11] qd[11] 3x(pos3 quat4 lin3 ang3)  (checkpoint / parity) */
     RR_F_FRAG_COUNT = 9,/* u32 [N, tiles]    diagnostic: entries of k_shade's work list in the last render (pixels won by moving geometry + pixels vacated since the frame before) */
-    RR_F_COUNT = 10
+    RR_F_CONTACT_COUNT = 10, /* i32 [N]      contacts of the last solved step (rr_get_contacts returns them one env at a time) */
+    RR_F_ENV_CLASS = 11,     /* i32 [N]      diagnostic: 0 light, 1 heavy, 2 very heavy -- which launch solved / rendered the env in the last step */
+    RR_F_COUNT = 12
 };
 
 /* rr_config.flags */
@@ -111,7 +113,8 @@ int rr_render(rr_env *env);
 
 /* Replaces the camera of this env handle (row-major 4x4 OpenGL view and projection matrices, host). The default is the
  * reference's eye camera; the facade uses a second env handle with EnvCamera's matrices for render('rgb_array')
- * (computeViewMatrixFromYawPitchRoll / computeProjectionMatrixFOV, env.py:480-499). */
+ * (computeViewMatrixFromYawPitchRoll / computeProjectionMatrixFOV, env.py:480-499).  Both pointers NULL: back to the default
+ * eye camera (eye (0.01, 0, 1.2) -> table position, up (0, 0, 1), fov 80, near 0.1, far 100; env.py:136-141, 253-255, 548-551). */
 int rr_set_camera(rr_env *env, const float *view16, const float *proj16);
 
 /* Device pointer + size of an observation/state buffer (valid until rr_destroy). */
@@ -121,11 +124,20 @@ int rr_get_buffer(rr_env *env, int32_t field, void **dev_ptr, size_t *bytes);
  * previous frame of that env, so a caller that scribbles into them would see its marks survive. */
 /* Synchronising copy of a whole field to host memory. */
 int rr_copy_to_host(rr_env *env, int32_t field, void *dst, size_t bytes);
-/* Overwrites the full simulation state from host memory (f32 [N, 61]); checkpoint restore / parity tests.  The contact
- * history of the warm start (the previous step's contact list, see rr_get_contacts) is not part of the 61 floats: the
- * step after rr_set_state / rr_reset starts cold, as after pybullet's resetSimulation / restoreState without a saved
- * manifold cache. */
+/* Overwrites the simulation state from host memory (f32 [N, 61]); parity tests, goal set-up.  The contact history of the warm
+ * start (the previous step's contact list, see rr_get_contacts) is not part of the 61 floats: the step after rr_set_state /
+ * rr_reset starts cold, as after pybullet's resetSimulation.  To continue a run exactly, use rr_checkpoint_save / _restore.
+ * (rr_set_object_pose(s) keeps the history, like resetBasePositionAndOrientation keeps Bullet's manifolds: cached points of a
+ * teleported body are farther than the contact margin from its new contacts and match nothing.) */
 int rr_set_state(rr_env *env, const float *state_host);
+/* Checkpoint = everything a restore needs to continue BIT FOR BIT where the save left off: the state (with the motor targets),
+ * the contact history of the warm start (contact list + normal forces of the last solved step -- Bullet's persistent manifolds
+ * with their cached impulses, which pybullet.saveState / restoreState carry too), episode clocks, error flags, touch sensors and
+ * the per-env object home poses.  Opaque host blob of rr_checkpoint_bytes() bytes, valid for env handles of the same num_envs /
+ * n_objects.  (Macro plans in flight are host-side policy state and not part of it.)  save + restore + step == step, tested. */
+int rr_checkpoint_bytes(rr_env *env, size_t *bytes);
+int rr_checkpoint_save(rr_env *env, void *dst_host, size_t bytes);
+int rr_checkpoint_restore(rr_env *env, const void *src_host, size_t bytes);
 int rr_sync(rr_env *env);
 
 /* Replaces robot.parts[name].get_position()/get_pose() (env.py:230-232): world pose of the COM frame of
@@ -157,11 +169,14 @@ int rr_step_plan_masked(rr_env *env, const uint8_t *idle_mask_host, int32_t rend
 /* Per-kernel device timing with HIP events on the library's stream (bench.py roofline leg).
  * After rr_set_timing(env, 1), each rr_step/rr_render records events; rr_get_timing returns accumulated
  * milliseconds and launch counts per kernel since the last call and resets them.
- * kernel ids: 0 prep, 1 collide, 2 solve, 3 render_setup, 4 raster, 5 image set-up outside the two render kernels (the full static copy of the first frame; the separate restore pass with RR_SEPARATE_RESTORE), 6 shade.
+ * kernel ids: 0 prep (state part: forward kinematics, object terms, joint-space dynamics), 1 collide, 2 solve, 3 render_setup,
+ * 4 raster, 5 image set-up outside the two render kernels (the full static copy of the first frame; the separate restore pass
+ * with RR_SEPARATE_RESTORE), 6 shade, 9 cmd (command part: rate limit, clipping, motor targets).
  * When the step would run its heavy envs on the side stream, the timed step runs the same launches one
  * after the other: 2 / 3 / 4 / 6 then hold what the main stream runs (the light envs), 7 the solve and 8 the render
- * (set-up + raster + shade) of the heavy envs, which run beside them in an untimed step. */
-#define RR_NUM_KERNELS 9
+ * (set-up + raster + shade) of the heavy envs, which run beside them in an untimed step.  0 and 1 are the LOOK-AHEAD of the
+ * next step, which an untimed step runs under its render. */
+#define RR_NUM_KERNELS 10
 int rr_set_timing(rr_env *env, int32_t enable);
 int rr_get_timing(rr_env *env, float *ms_out /*[RR_NUM_KERNELS]*/, int32_t *launches_out /*[RR_NUM_KERNELS]*/);
 

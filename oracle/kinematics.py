@@ -1,12 +1,17 @@
-"""Host-side kinematics of the Kuka + gripper (numpy, float64): forward kinematics, geometric Jacobian and a damped
-least squares IK for link 7 (gripper `base`) -- the host restatement of what the reference asks pybullet for in
-step_cartesian / generate_plan (real_robots/envs/env.py:372-375, 422-427:
+"""CPU checker of the K8 row (numpy, float64): forward kinematics, geometric Jacobian, the damped-least-squares IK for
+link 7 (gripper `base`) and the 1000-step macro plan -- the host restatement of what the reference asks pybullet for in
+step_cartesian / generate_plan (real_robots/envs/env.py:372-375, 388-454, 422-427:
 calculateInverseKinematics(0, 7, pos, orn, maxNumIterations=1000, residualThreshold=0.001)).
-Only (re)planning uses it (<= ~15 solves per 1000 steps); the per-step path stays on the GPU.
+
+TEST INFRASTRUCTURE ONLY (like everything under oracle/): the product path plans and solves IK on the device
+(k_ik, k_plan_macro in real_robots_amd/csrc/realrobot.hip) and never imports this module.  "parity unpinned" w.r.t.
+PyBullet: pybullet's IK branch choice is an implementation detail of its solver; the selection rule below is the one the
+device implements and the reference's tracking known answers (tests/test_actions.py:147-152) are what pins both.
 """
 import numpy as np
 
-from .model import load_model
+from real_robots_amd.mathutil import quat_from_euler  # noqa: F401  (re-exported for the tests)
+from real_robots_amd.model import load_model          # reader of the compiled model DATA (no arithmetic)
 
 PARENT = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 6, 9]
 EE_LINK = 8          # URDF depth-first id of gripper `base` (pybullet link index 7), rigidly attached to body 6
@@ -19,13 +24,6 @@ def _axis_angle(a, ang):
     return np.array([[t * x * x + c, t * x * y - s * z, t * x * z + s * y],
                      [t * x * y + s * z, t * y * y + c, t * y * z - s * x],
                      [t * x * z - s * y, t * y * z + s * x, t * z * z + c]])
-
-
-def quat_from_euler(r, p, y):
-    """pybullet.getQuaternionFromEuler (xyzw, rotation = Rz(y) Ry(p) Rx(r))."""
-    cr, sr, cp, sp, cy, sy = np.cos(r / 2), np.sin(r / 2), np.cos(p / 2), np.sin(p / 2), np.cos(y / 2), np.sin(y / 2)
-    return np.array([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy,
-                     cr * cp * cy + sr * sp * sy])
 
 
 def quat_to_mat(q):
@@ -80,7 +78,9 @@ def ee_jacobian(q11):
 ELBOW_UP_SEED = np.array([0.0, 0.6, 0.0, -1.3, 0.0, 1.2, 0.0])
 
 
-def _dls(q, target_pos, Rt, max_iters, residual, damping):
+def _dls(q, target_pos, Rt, max_iters, residual, damping, prev=None):
+    """`prev` (a list): receives the iterate before the last update and its residual -- where a float32 solver whose residual
+    crosses the threshold one iteration earlier stops."""
     lam2 = damping * damping
     err = np.inf
     for _ in range(int(max_iters)):
@@ -92,6 +92,8 @@ def _dls(q, target_pos, Rt, max_iters, residual, damping):
         err = np.linalg.norm(e)
         if err < residual:
             break
+        if prev is not None:
+            prev[:] = [q.copy(), float(err)]
         dq = J.T @ np.linalg.solve(J @ J.T + lam2 * np.eye(6), e)
         n = np.abs(dq).max()
         if n > 0.5:
@@ -123,6 +125,25 @@ def inverse_kinematics(q11, target_pos, target_quat, max_iters=1000, residual=1e
         if best is None or key > best_key:
             best, best_key = q, key
     return best
+
+
+def ik_candidates(q11, target_pos, target_quat, prefer=None, max_iters=1000, residual=1e-3, damping=0.1):
+    """Every seed's DLS result [(q11, residual, key, q11 one update earlier, its residual)] in seed order (current joints,
+    elbow-up, previous way-point) -- lets a test tell a branch disagreement (another seed won on a near-tie of the keys) or a
+    stop one iteration apart (residual within rounding of the threshold) from an arithmetic disagreement."""
+    q0 = np.array(q11, dtype=np.float64)
+    Rt = quat_to_mat(np.asarray(target_quat, dtype=np.float64) / np.linalg.norm(target_quat))
+    seeds = [q0[:7], ELBOW_UP_SEED] + ([np.asarray(prefer, dtype=np.float64)[:7]] if prefer is not None else [])
+    out = []
+    for seed in seeds:
+        q = q0.copy()
+        q[:7] = seed
+        prev = []
+        q, err = _dls(q, target_pos, Rt, max_iters, residual, damping, prev)
+        _, p, _ = forward(q)
+        key = -float(np.abs(q[:7] - np.asarray(prefer)[:7]).max()) if prefer is not None else float(p[3][2])
+        out.append((q, float(err), key, prev[0] if prev else q, prev[1] if prev else float(err)))
+    return out
 
 
 def generate_plan(q_seed11, macro_action):
@@ -166,36 +187,3 @@ def generate_plan(q_seed11, macro_action):
     return np.vstack(parts)
 
 
-def look_at(eye, target, up):
-    """pybullet.computeViewMatrix (right-handed look-at), row-major 4x4."""
-    eye, target, up = (np.asarray(a, dtype=np.float64) for a in (eye, target, up))
-    f = target - eye
-    f /= np.linalg.norm(f)
-    s = np.cross(f, up)
-    s /= np.linalg.norm(s)
-    u = np.cross(s, f)
-    V = np.eye(4)
-    V[0, :3], V[1, :3], V[2, :3] = s, u, -f
-    V[:3, 3] = -V[:3, :3] @ eye
-    return V
-
-
-def view_from_yaw_pitch_roll(target, distance, yaw, pitch, roll):
-    """pybullet.computeViewMatrixFromYawPitchRoll(..., upAxisIndex=2): eye = Rz(yaw) Ry(roll) Rx(pitch) (0,-d,0) + target."""
-    y, p, r = np.radians([yaw, pitch, roll])
-    Rz = np.array([[np.cos(y), -np.sin(y), 0], [np.sin(y), np.cos(y), 0], [0, 0, 1]])
-    Ry = np.array([[np.cos(r), 0, np.sin(r)], [0, 1, 0], [-np.sin(r), 0, np.cos(r)]])
-    Rx = np.array([[1, 0, 0], [0, np.cos(p), -np.sin(p)], [0, np.sin(p), np.cos(p)]])
-    R = Rz @ Ry @ Rx
-    eye = R @ np.array([0.0, -distance, 0.0]) + np.asarray(target, dtype=np.float64)
-    return look_at(eye, target, R @ np.array([0.0, 0.0, 1.0]))
-
-
-def perspective(fov_deg, aspect, near, far):
-    """pybullet.computeProjectionMatrixFOV (OpenGL perspective), row-major 4x4."""
-    ys = 1.0 / np.tan(np.radians(fov_deg) / 2)
-    P = np.zeros((4, 4))
-    P[0, 0], P[1, 1] = ys / aspect, ys
-    P[2, 2], P[2, 3] = (near + far) / (near - far), 2 * near * far / (near - far)
-    P[3, 2] = -1
-    return P

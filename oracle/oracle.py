@@ -66,6 +66,8 @@ def _lib(f32=False):
         L.rro_mass_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rro_set_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rro_default_params.argtypes = [C.POINTER(Params)]
+        L.rro_solution_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.rro_solution_residual.restype = C.c_int
         _libs[f32] = L
     return _libs[f32]
 
@@ -151,6 +153,17 @@ class Oracle:
         """Contact history for the warm start (records as returned by contacts()); call after setting the state."""
         r = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 12)
         self.L.rro_set_contact_cache(self.h, r.ctypes.data, len(r))
+
+    def solution_residual(self, state_after, normal_forces, active_thresh=1.0):
+        """Solver-independent check of a candidate solution of the LAST step's contact problem: post-step state (61) and the
+        normal force of every contact -> dict(res_sum, res_max [N: what one more Gauss-Seidel update of a normal row would
+        change], f_sum, f_max, n_active, active [bit mask of contacts with force > active_thresh])."""
+        s = np.ascontiguousarray(state_after, dtype=np.float64)
+        f = np.ascontiguousarray(normal_forces, dtype=np.float64)
+        out, bits = np.zeros(5), np.zeros(1, np.uint64)
+        n = self.L.rro_solution_residual(self.h, s.ctypes.data, f.ctypes.data, len(f), float(active_thresh), out.ctypes.data, bits.ctypes.data)
+        assert n == len(f), "contact count differs from the oracle's last step"
+        return dict(res_sum=out[0], res_max=out[1], f_sum=out[2], f_max=out[3], n_active=int(out[4]), active=int(bits[0]))
 
     def set_object_pose(self, obj, pose7):
         p = np.ascontiguousarray(pose7, dtype=np.float64)

@@ -875,6 +875,12 @@ static real build_row_torsional(const rr_oracle *o, row_t *r, const contact_t *c
     return rel;
 }
 
+/* the contact problem of the last rro_step (any oracle instance): rows, where the normal rows start, the unconstrained
+ * velocities -- kept for rro_solution_residual() */
+static row_t g_rows[NROWS];
+static int g_nr, g_first_normal, g_ncontacts;
+static real g_qds[NB], g_ovs[NOBJ][3], g_ows[NOBJ][3];
+
 static void solve_and_integrate(rr_oracle *o) {
     const model_t *m = &o->m;
     const rro_params *P = &o->p;
@@ -906,8 +912,8 @@ static void solve_and_integrate(rr_oracle *o) {
         m3_mulv(al, oIinv[i], g);
         for (int k = 0; k < 3; k++) ows[i][k] = o->oang[i][k] + dt * (-al[k] - o->oang[i][k] * (ka + ka * wn));
     }
-    /* rows */
-    static row_t rows[NROWS];
+    /* rows (file scope: rro_solution_residual() looks at the last step's problem) */
+    row_t *rows = g_rows;
     int nr = 0;
     for (int j = 0; j < NB; j++) { /* btMultiBodyJointMotor position control */
         row_t *r = &rows[nr++];
@@ -1026,6 +1032,8 @@ static void solve_and_integrate(rr_oracle *o) {
         }
     }
     for (int c = 0; c < o->ncontacts; c++) o->contacts[c].lambda_n = rows[first_normal + c].lambda;
+    g_nr = nr; g_first_normal = first_normal; g_ncontacts = o->ncontacts;
+    memcpy(g_qds, qds, sizeof g_qds); memcpy(g_ovs, ovs, sizeof g_ovs); memcpy(g_ows, ows, sizeof g_ows);
     /* integrate (semi-implicit Euler) */
     for (int i = 0; i < NB; i++) {
         o->qd[i] = qds[i] + dq[i];
@@ -1210,6 +1218,47 @@ int rro_contacts(const rr_oracle *o, double *out, int maxc) {
         for (int k = 0; k < 3; k++) { r[3 + k] = ct->x[k]; r[6 + k] = ct->n[k]; }
         r[9] = ct->dist; r[10] = ct->lambda_n / o->p.dt; r[11] = ct->mu;
     }
+    return n;
+}
+
+/* Solver-independent check of a candidate solution of the LAST step's contact problem (differential tests): given the
+ * velocities after the step (state61 layout) and the normal force of every contact, the natural residual of the normal
+ * rows  r_c = | max(lambda_c + rhs_c - dinv_c J_c (v - v*), 0) - lambda_c |  -- zero for an exact solution of the
+ * complementarity problem, and what one more Gauss-Seidel update of the row would change -- plus the force sum and the
+ * active set.  out[0] sum r_c / dt (N), out[1] max r_c / dt, out[2] sum of normal forces (N), out[3] largest normal
+ * force, out[4] number of contacts with force > active_thresh; active_bits: bit c set for those. Returns the number of
+ * contacts of the last step (-1: n does not match). */
+int rro_solution_residual(const rr_oracle *o, const double *state_after61, const double *normal_force, int n,
+                          double active_thresh, double *out5, uint64_t *active_bits) {
+    if (n != g_ncontacts) return -1;
+    real dq[NB], dv[NOBJ][3], dw[NOBJ][3];
+    for (int i = 0; i < NB; i++) dq[i] = (real)state_after61[NB + i] - g_qds[i];
+    for (int i = 0; i < NOBJ; i++)
+        for (int k = 0; k < 3; k++) {
+            dv[i][k] = i < o->nobj ? (real)state_after61[2 * NB + 13 * i + 7 + k] - g_ovs[i][k] : 0;
+            dw[i][k] = i < o->nobj ? (real)state_after61[2 * NB + 13 * i + 10 + k] - g_ows[i][k] : 0;
+        }
+    double sum = 0, mx = 0, fsum = 0, fmax = 0;
+    int nact = 0;
+    uint64_t bits = 0;
+    const double dt = o->p.dt;
+    for (int c = 0; c < n; c++) {
+        const row_t *r = &g_rows[g_first_normal + c];
+        double jv = 0;
+        int robot = (r->bodyA >= 0 && r->bodyA < 16) || (r->bodyB >= 0 && r->bodyB < 16);
+        if (robot) for (int i = 0; i < NB; i++) jv += (double)r->Ja[i] * dq[i];
+        if (r->bodyA >= 16) { int ob = r->bodyA - 16; jv += v3_dot(r->la, dv[ob]) + v3_dot(r->aa, dw[ob]); }
+        if (r->bodyB >= 16) { int ob = r->bodyB - 16; jv += v3_dot(r->lb, dv[ob]) + v3_dot(r->ab, dw[ob]); }
+        const double lam = normal_force[c] * dt;
+        double nxt = lam + (double)r->rhs - jv * (double)r->dinv;
+        if (nxt < 0) nxt = 0;
+        const double res = fabs(nxt - lam) / dt;
+        sum += res; if (res > mx) mx = res;
+        fsum += normal_force[c]; if (normal_force[c] > fmax) fmax = normal_force[c];
+        if (normal_force[c] > active_thresh) { nact++; bits |= 1ull << c; }
+    }
+    out5[0] = sum; out5[1] = mx; out5[2] = fsum; out5[3] = fmax; out5[4] = nact;
+    if (active_bits) *active_bits = bits;
     return n;
 }
 

@@ -77,6 +77,11 @@ void rro_link_pose(const rr_oracle *o, int link, double *pose7);
  * returns count */
 int rro_contacts(const rr_oracle *o, double *out, int max_contacts);
 void rro_set_object_pose(rr_oracle *o, int obj, const double *pose7);
+/* solver-independent check of a candidate solution (post-step velocities in state61 layout + one normal force per
+ * contact) of the contact problem of the last rro_step: natural residual of the normal rows, force sum, active set.
+ * out5 = {sum residual (N), max residual (N), sum of normal forces, largest normal force, active contacts} */
+int rro_solution_residual(const rr_oracle *o, const double *state_after61, const double *normal_force, int n,
+                          double active_thresh, double *out5, uint64_t *active_bits);
 /* diagnostics */
 void rro_mass_matrix(rr_oracle *o, double *M121, double *bias11);
 

@@ -14,19 +14,22 @@ LIB_PATH = os.environ.get('RR_LIB', os.path.join(_HERE, 'csrc', 'librealrobot_hi
 BLOB_GZ = os.path.join(_HERE, 'data', 'realrobot_model.bin.gz')
 LINK_NAMES = open(os.path.join(_HERE, 'data', 'realrobot_model_links.txt')).read().split()
 
-RR_ABI_VERSION = 2
-(F_JOINTS, F_TOUCH, F_OBJ_POSE, F_RGB, F_DEPTH, F_MASK, F_TIMESTEP, F_ERRFLAGS, F_STATE, F_FRAG_COUNT) = range(10)
-NUM_KERNELS = 9
+RR_ABI_VERSION = 3
+(F_JOINTS, F_TOUCH, F_OBJ_POSE, F_RGB, F_DEPTH, F_MASK, F_TIMESTEP, F_ERRFLAGS, F_STATE, F_FRAG_COUNT, F_CONTACT_COUNT,
+ F_ENV_CLASS) = range(12)
+NUM_KERNELS = 10
 # id 5 = image set-up outside the two render kernels: the full static copy of the first frame (and the earlier schemes
 # RR_FULL_COPY / RR_SEPARATE_RESTORE); it does not run in steady state
 KERNEL_NAMES = ('k_prep', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster', 'k_image_setup', 'k_shade',
-                'k_solve_heavy', 'render_heavy')      # 7, 8: the heavy envs' solve / render (side stream in an untimed step)
+                'k_solve_heavy', 'render_heavy',      # 7, 8: the heavy envs' solve / render (side stream in an untimed step)
+                'k_cmd')                              # 9: command part of the step (k_prep / k_collide = the look-ahead of the next step)
 
 # every symbol include/realrobot.h declares (tests check the library exports all of them)
 SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_object_pose', 'rr_set_object_home', 'rr_step', 'rr_render',
            'rr_get_buffer', 'rr_copy_to_host', 'rr_set_state', 'rr_sync', 'rr_link_poses', 'rr_get_contacts',
            'rr_set_timing', 'rr_get_timing', 'rr_last_error', 'rr_abi_version', 'rr_ik', 'rr_plan_macro', 'rr_get_plan',
-           'rr_step_plan', 'rr_set_camera', 'rr_set_object_poses', 'rr_step_plan_masked')
+           'rr_step_plan', 'rr_set_camera', 'rr_set_object_poses', 'rr_step_plan_masked', 'rr_checkpoint_bytes',
+           'rr_checkpoint_save', 'rr_checkpoint_restore')
 
 
 class Config(C.Structure):
@@ -94,6 +97,9 @@ def load_library():
     L.rr_set_camera.argtypes = [vp, vp, vp]
     L.rr_set_object_poses.argtypes = [vp, vp, vp]
     L.rr_step_plan_masked.argtypes = [vp, vp, i32, vp]
+    L.rr_checkpoint_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.rr_checkpoint_save.argtypes = [vp, vp, C.c_size_t]
+    L.rr_checkpoint_restore.argtypes = [vp, vp, C.c_size_t]
     L.rr_last_error.restype = C.c_char_p
     L.rr_abi_version.restype = i32
     for name in SYMBOLS:

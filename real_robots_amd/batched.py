@@ -36,7 +36,8 @@ class BatchedREALRobotEnv:
             nat.F_RGB: ((self.N, self.H, self.W, 3), np.uint8), nat.F_DEPTH: ((self.N, self.H, self.W), np.float32),
             nat.F_MASK: ((self.N, self.H, self.W), np.int32), nat.F_TIMESTEP: ((self.N,), np.int32),
             nat.F_ERRFLAGS: ((self.N,), np.uint32), nat.F_STATE: ((self.N, 61), np.float32),
-            nat.F_FRAG_COUNT: ((self.N, 1), np.uint32)}
+            nat.F_FRAG_COUNT: ((self.N, 1), np.uint32), nat.F_CONTACT_COUNT: ((self.N,), np.int32),
+            nat.F_ENV_CLASS: ((self.N,), np.int32)}
         p_, n_ = C.c_void_p(), C.c_size_t()                  # the tile count is the library's choice: ask for it
         nat.check(self.L.rr_get_buffer(self.h, nat.F_FRAG_COUNT, C.byref(p_), C.byref(n_)))
         self._shapes[nat.F_FRAG_COUNT] = ((self.N, max(1, n_.value // (4 * self.N))), np.uint32)
@@ -110,6 +111,19 @@ class BatchedREALRobotEnv:
         s = np.ascontiguousarray(s, dtype=np.float32)
         assert s.shape == (self.N, 61)
         nat.check(self.L.rr_set_state(self.h, s.ctypes.data))
+
+    def checkpoint(self):
+        """Opaque snapshot (numpy uint8 array) of everything a later `restore` needs to continue bit for bit: state with motor
+        targets, contact history of the warm start, episode clocks, error flags, touch sensors, object home poses."""
+        n = C.c_size_t()
+        nat.check(self.L.rr_checkpoint_bytes(self.h, C.byref(n)))
+        buf = np.empty(n.value, np.uint8)
+        nat.check(self.L.rr_checkpoint_save(self.h, buf.ctypes.data, buf.nbytes))
+        return buf
+
+    def restore(self, ckpt):
+        buf = np.ascontiguousarray(ckpt, dtype=np.uint8)
+        nat.check(self.L.rr_checkpoint_restore(self.h, buf.ctypes.data, buf.nbytes))
 
     def set_object_pose(self, env, obj, pose7):
         p = np.ascontiguousarray(pose7, dtype=np.float32)
@@ -211,7 +225,10 @@ class BatchedREALRobotEnv:
         self._macro_step[~none] += 1
 
     def set_camera(self, view, proj):
-        """Row-major 4x4 OpenGL view / projection matrices replacing the eye camera of this batch."""
+        """Row-major 4x4 OpenGL view / projection matrices replacing the eye camera of this batch (None, None: the default eye)."""
+        if view is None and proj is None:
+            nat.check(self.L.rr_set_camera(self.h, None, None))
+            return
         v = np.ascontiguousarray(view, dtype=np.float32).reshape(16)
         p = np.ascontiguousarray(proj, dtype=np.float32).reshape(16)
         nat.check(self.L.rr_set_camera(self.h, v.ctypes.data, p.ctypes.data))

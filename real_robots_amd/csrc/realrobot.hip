@@ -113,7 +113,8 @@ enum {
     S_OIINV = S_OR + 27,         // 3*9
     S_OVS = S_OIINV + 27,        // 9
     S_OWS = S_OVS + 9,           // 9
-    S_TOTAL = S_OWS + 9
+    S_OP = S_OWS + 9,            // 9: object positions the collision pass uses (the home position when the out-of-bounds rule fires)
+    S_TOTAL = S_OP + 9
 };
 
 // state slots (floats per env), SoA [slot][N]
@@ -124,21 +125,22 @@ enum {
 struct DevPtrs {
     float *state;      // [ST_TOTAL][N]
     float *scratch;    // [S_TOTAL][N]
+    // Contact frame of the step being solved ("current") -- the list k_solve reads, the classes the three solve / render
+    // launches select by -- and the frame the collision pass of the NEXT step fills ("next").  The host swaps the two when a
+    // step starts (rr_step); the current list with the normal forces (cforce) is also the contact history of the warm start.
     float4 *clist;     // [N][MAXC][3]  the env's contacts in pair order {x, y, z, nx | ny, nz, distance, meta | mu, restitution, rolling,
                        // spinning}; meta = bodyA | bodyB << 8 | linkA << 16 (bytes; -1 static, 0..15 robot body, 16+i object i).
-                       // Written by the env's k_collide wavefront, read by its k_solve group in one round trip.
+                       // Written by the env's k_collide workgroup (as clist_next), read by its k_solve group in one round trip.
     int *ccount;       // [N] number of contacts in clist
-    float4 *clist_prev; // the list of the step before (the two buffers change roles every step): contact history of the warm start
     float *cwarm;      // [N][MAXC] initial normal impulse of every contact of clist (k_collide: 0.85 x the matched previous one)
-    float *cforce;     // [N][MAXC] normal force of every contact of the last step (rr_get_contacts, touch sensors)
     int *hgflag;       // [N] 0: light; 1: this env has generic contact rows this step -- "heavy"; 2: more than P.heavy2_min of them -- "very heavy"
     int *hlist2;       // [N] the very heavy envs of this step (a handful: an arm crushed onto the table at the contact cap)
     int *hcount2;      // [0] their number, [1] work counter of their render
     int *hlist;        // [N] the heavy envs of this step (in arrival order: placement only, never a result)
-    int *hcount;       // [0] their number, [1] work counter of k_raster_list / k_render_list, [2] [3] front / back fill of corder
-    int *corder;       // [N] the order in which k_collide's workgroups take the envs: last step's heavy envs first (the slowest env
-                       //     sets the kernel's tail; started last it would add its whole duration to the kernel)
-    int *hcount_host;  // device address of the pinned host word that receives the previous step's number (or nullptr)
+    int *hcount;       // [0] their number, [1] work counter of k_raster_list / k_render_list
+    float4 *clist_next; int *ccount_next; float *cwarm_next; int *hgflag_next, *hlist2_next, *hcount2_next, *hlist_next, *hcount_next;
+    float *cforce;     // [N][MAXC] normal force of every contact of the last solved step (rr_get_contacts, touch sensors, warm start)
+    int *hcount_host;  // device address of the pinned host word that receives the current number of heavy envs (or nullptr)
     int *timestep;     // [N]
     unsigned *errflags;// [N]
     float *obj_home;   // [NOBJ*7][N] per-env pose an object is put back to by reset / the out-of-bounds rule (robot.py:19-24, mutable there)
@@ -355,44 +357,41 @@ __device__ void fk_all(const BodyParams &bp_, const float *q, m3 *bR, v3 *bp, v3
     }
 }
 
-// ---------------------------------------------------------------------------------------------- k_prep
-// The preparation of a step runs as two kernels: PHASE 1 = action
-// protocol, forward kinematics, object terms -- all the collision kernel needs -- and PHASE 2 = joint-space dynamics
-// (mass matrix, bias forces, Cholesky, M^-1, unconstrained velocities), which only the solver needs and which therefore
-// runs on the side stream next to k_collide (both kernels are latency bound with few wavefronts in flight; when the
-// kernels are timed one by one the two halves run back to back and are reported together as "k_prep").
-template <int PHASE>
-__device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &P, const DevPtrs &D) {
+// ---------------------------------------------------------------------------------------------- k_cmd / k_prep
+// Which env a work item of a per-class launch handles: sel 0 all envs (idx = env); 1 the light envs (idx = env, others are
+// skipped); 2 / 3 entry idx of the heavy / very heavy list of the CURRENT contact frame.  -1: nothing to do.
+__device__ __forceinline__ int pick_env(const DevPtrs &D, int sel, int idx, int N) {
+    if (idx >= N) return -1;
+    if (sel == 0) return idx;
+    if (sel == 1) return D.hgflag[idx] == 0 ? idx : -1;
+    if (sel == 2) return idx < D.hcount[0] ? D.hlist[idx] : -1;
+    return idx < D.hcount2[0] ? D.hlist2[idx] : -1;
+}
+
+// The out-of-bounds rule of control_objects_limits (env.py:257-264) as a function of the object's position.
+__device__ __forceinline__ bool object_out_of_bounds(float x, float z, float table_z) { return z < table_z || (x > 0.11f && z < 0.29f); }
+
+// The command part of a step -- everything that needs the action: limitActionByJoint (env.py:314-321), the clipping and
+// gripper coupling of Kuka.apply_action (robot.py:188-201) -> 11 motor targets; a non-finite command flags the env
+// (robot.py:189 asserts).  It also APPLIES the out-of-bounds rule to the state (the state part of the preparation, which may
+// have run under the previous step's render, only derived the collision inputs from the re-posed object) and resets the
+// bookkeeping of the contact frame that this step's look-ahead collision pass will fill.
+__global__ void __launch_bounds__(64) k_cmd(BodyParams B, SimParams P, DevPtrs D) {
     const int N = P.N;
-    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= N) return;
-    float *state = D.state, *scratch = D.scratch;
-    if (PHASE == 1) {       // k_collide classifies the solver groups of this step: reset its bookkeeping (no extra launch)
-        {   // launch order of this step's k_collide: the envs that were heavy a step ago go first (placement only, never a result)
-            const int slot = D.hgflag[env] ? atomicAdd(&D.hcount[2], 1) : N - 1 - atomicAdd(&D.hcount[3], 1);
-            D.corder[slot] = env;
-        }
-        D.hgflag[env] = 0;
-        if (env == 0) {
-            // (the count of the step before goes to pinned host memory on the way: a posted write, nobody waits for it)
-            if (D.hcount_host) *D.hcount_host = D.hcount[0];
-            D.hcount[0] = 0; D.hcount[1] = 0; D.hcount2[0] = 0; D.hcount2[1] = 0;
-        }
+    float *state = D.state;
+    if (env == 0) {
+        // (the number of heavy envs of this step goes to pinned host memory on the way: a posted write, nobody waits for it)
+        if (D.hcount_host) *D.hcount_host = D.hcount[0];
+        D.hcount_next[0] = 0; D.hcount_next[1] = 0; D.hcount2_next[0] = 0; D.hcount2_next[1] = 0;
     }
-    if (PHASE == 2) { if (D.errflags[env]) return; }    // frozen, or command rejected by phase 1
-    else {
-        if (D.errflags[env] & 1u) return;   // frozen env
-        D.errflags[env] &= ~2u;
-    }
-    float q[NB], qd[NB];
-#pragma unroll
-    for (int i = 0; i < NB; i++) { q[i] = STT(ST_Q + i); qd[i] = STT(ST_QD + i); }
-    if (PHASE != 2) {
-    // ---- action protocol
+    if (D.errflags[env] & 1u) return;   // frozen env
+    unsigned ef = D.errflags[env] & ~2u;
     float a[9], cur[9];
 #pragma unroll
-    for (int i = 0; i < 7; i++) cur[i] = q[i];
-    cur[7] = q[7]; cur[8] = -q[8];                                   // robot.py:203-211
+    for (int i = 0; i < 7; i++) cur[i] = STT(ST_Q + i);
+    cur[7] = STT(ST_Q + 7); cur[8] = -STT(ST_Q + 8);                 // robot.py:203-211
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
@@ -403,10 +402,11 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
         d = fmaxf(d, -B.act_maxdiff[i]);
         a[i] = cur[i] + d;
     }
-    if (bad) { D.errflags[env] |= 2u; return; }                      // robot.py:189 (assert in the reference)
+    D.errflags[env] = bad ? (ef | 2u) : ef;
+    if (bad) return;                                                 // robot.py:189 (assert in the reference)
     for (int i = 0; i < P.nobj; i++) {                               // env.py:257-264
         float x = STT(ST_OPOS + 3 * i), z = STT(ST_OPOS + 3 * i + 2);
-        if (z < B.table_z || (x > 0.11f && z < 0.29f)) {
+        if (object_out_of_bounds(x, z, B.table_z)) {
             for (int k = 0; k < 3; k++) { STT(ST_OPOS + 3 * i + k) = D.obj_home[(size_t)(7 * i + k) * N + env]; STT(ST_OVEL + 3 * i + k) = 0; STT(ST_OANG + 3 * i + k) = 0; }
             for (int k = 0; k < 4; k++) STT(ST_OQUAT + 4 * i + k) = D.obj_home[(size_t)(7 * i + 3 + k) * N + env];
         }
@@ -420,8 +420,25 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
     tgt[7] = a[7]; tgt[9] = a[7]; tgt[8] = -a[8]; tgt[10] = -a[8];                        // robot.py:195-201
 #pragma unroll
     for (int i = 0; i < NB; i++) STT(ST_TGT + i) = tgt[i];
-    }
+}
 
+// The state part of the preparation -- everything of a step that does NOT need the action, i.e. a function of the state the
+// previous step left: PHASE 1 = forward kinematics and object terms (rotation, world inverse inertia, unconstrained
+// velocities; the out-of-bounds rule decides which object pose counts) -- all the collision kernel needs -- and PHASE 2 =
+// joint-space dynamics (mass matrix, bias forces, Cholesky, M^-1, unconstrained velocities), which only the solver needs.
+// Together with k_collide they form the LOOK-AHEAD of a step: rr_step launches them for step t+1 behind the solve of step t,
+// class by class (sel, pick_env), under the render of step t; only when the state was changed from outside in between
+// (reset, set_state, teleports) do they run in line at the start of the step.  (When the kernels are timed one by one the
+// two phases run back to back and are reported together as "k_prep".)
+template <int PHASE>
+__device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &P, const DevPtrs &D, int env) {
+    const int N = P.N;
+    const float *state = D.state;
+    float *scratch = D.scratch;
+    if (D.errflags[env] & 1u) return;   // frozen env
+    float q[NB], qd[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) { q[i] = STT(ST_Q + i); qd[i] = STT(ST_QD + i); }
     // ---- kinematics
     m3 bR[NB]; v3 bp[NB], bax[NB], bcom[NB]; m3 bI[NB];
     fk_all(B, q, bR, bp, bax);
@@ -549,14 +566,23 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
     for (int i = 0; i < NB; i++) SCR(S_QDS + i) = qd[i] + P.dt * qdd[i];
     }
     if (PHASE == 2) return;
-    // ---- objects: rotation, inverse inertia, unconstrained velocities
+    // ---- objects: rotation, inverse inertia, unconstrained velocities -- of the pose that counts: an object the out-of-bounds
+    // rule (env.py:257-264) sends home is taken at its home pose, at rest (k_cmd writes that pose into the state when the step starts)
     for (int i = 0; i < P.nobj; i++) {
-        m3 R = nc::quat_to_m3(STT(ST_OQUAT + 4 * i), STT(ST_OQUAT + 4 * i + 1), STT(ST_OQUAT + 4 * i + 2), STT(ST_OQUAT + 4 * i + 3));
+        float px = STT(ST_OPOS + 3 * i), py = STT(ST_OPOS + 3 * i + 1), pz = STT(ST_OPOS + 3 * i + 2);
+        float qx = STT(ST_OQUAT + 4 * i), qy = STT(ST_OQUAT + 4 * i + 1), qz = STT(ST_OQUAT + 4 * i + 2), qw = STT(ST_OQUAT + 4 * i + 3);
+        v3 v = mk(STT(ST_OVEL + 3 * i), STT(ST_OVEL + 3 * i + 1), STT(ST_OVEL + 3 * i + 2));
+        v3 om = mk(STT(ST_OANG + 3 * i), STT(ST_OANG + 3 * i + 1), STT(ST_OANG + 3 * i + 2));
+        if (object_out_of_bounds(px, pz, B.table_z)) {
+            px = D.obj_home[(size_t)(7 * i) * N + env]; py = D.obj_home[(size_t)(7 * i + 1) * N + env]; pz = D.obj_home[(size_t)(7 * i + 2) * N + env];
+            qx = D.obj_home[(size_t)(7 * i + 3) * N + env]; qy = D.obj_home[(size_t)(7 * i + 4) * N + env];
+            qz = D.obj_home[(size_t)(7 * i + 5) * N + env]; qw = D.obj_home[(size_t)(7 * i + 6) * N + env];
+            v = mk(0, 0, 0); om = mk(0, 0, 0);
+        }
+        m3 R = nc::quat_to_m3(qx, qy, qz, qw);
         float I6[6] = {B.obj_inertia[i][0], B.obj_inertia[i][1], B.obj_inertia[i][2], 0, 0, 0};
         float Ii6[6] = {1.0f / B.obj_inertia[i][0], 1.0f / B.obj_inertia[i][1], 1.0f / B.obj_inertia[i][2], 0, 0, 0};
         m3 Iw = inertia_world(R, I6), Iinv = inertia_world(R, Ii6);
-        v3 v = mk(STT(ST_OVEL + 3 * i), STT(ST_OVEL + 3 * i + 1), STT(ST_OVEL + 3 * i + 2));
-        v3 om = mk(STT(ST_OANG + 3 * i), STT(ST_OANG + 3 * i + 1), STT(ST_OANG + 3 * i + 2));
         float vn = sqrtf(dot(v, v)), wn = sqrtf(dot(om, om));
         v3 vs = v + (v * (-(P.lin_damp + P.lin_damp * vn))) * P.dt;
         vs.z -= P.dt * P.gravity;
@@ -565,10 +591,24 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
         for (int k = 0; k < 9; k++) { SCR(S_OR + 9 * i + k) = R.m[k]; SCR(S_OIINV + 9 * i + k) = Iinv.m[k]; }
         SCR(S_OVS + 3 * i) = vs.x; SCR(S_OVS + 3 * i + 1) = vs.y; SCR(S_OVS + 3 * i + 2) = vs.z;
         SCR(S_OWS + 3 * i) = ws.x; SCR(S_OWS + 3 * i + 1) = ws.y; SCR(S_OWS + 3 * i + 2) = ws.z;
+        SCR(S_OP + 3 * i) = px; SCR(S_OP + 3 * i + 1) = py; SCR(S_OP + 3 * i + 2) = pz;
     }
 }
-__global__ void __launch_bounds__(64) k_prep_a(BodyParams B, SimParams P, DevPtrs D) { prep_body<1>(B, P, D); }
-__global__ void __launch_bounds__(64) k_prep_b(BodyParams B, SimParams P, DevPtrs D) { prep_body<2>(B, P, D); }
+// One thread per env of the class `sel` (pick_env); the launches cover N work items whatever the class (a heavy list's length
+// is known on the device only; work items past its end exit at once).
+template <int PHASE>
+__device__ __forceinline__ void prep_class(const BodyParams &B, const SimParams &P, const DevPtrs &D, int sel) {
+    const int env = pick_env(D, sel, blockIdx.x * blockDim.x + threadIdx.x, P.N);
+    if (env < 0) return;
+    prep_body<PHASE>(B, P, D, env);
+}
+__global__ void __launch_bounds__(64) k_prep_a(BodyParams B, SimParams P, DevPtrs D, int sel, int zero_counts) {
+    if (zero_counts && blockIdx.x == 0 && threadIdx.x == 0) {       // in-line pass: the frame k_collide is about to fill holds stale counts
+        D.hcount_next[0] = 0; D.hcount_next[1] = 0; D.hcount2_next[0] = 0; D.hcount2_next[1] = 0;
+    }
+    prep_class<1>(B, P, D, sel);
+}
+__global__ void __launch_bounds__(64) k_prep_b(BodyParams B, SimParams P, DevPtrs D, int sel) { prep_class<2>(B, P, D, sel); }
 
 // ---------------------------------------------------------------------------------------------- k_collide
 struct Xf { m3 R; v3 p; };
@@ -586,7 +626,7 @@ __device__ __forceinline__ Xf load_xf(const ShapeData *S, int s, const float *st
     r[5] = SCR(rslot + 5); r[6] = SCR(rslot + 6); r[7] = SCR(rslot + 7); r[8] = SCR(rslot + 8);
     const int ob = ot == 2 ? oi : 0, bb = ot == 1 ? oi : 0;
     const float pbx = SCR(S_BP + 3 * bb), pby = SCR(S_BP + 3 * bb + 1), pbz = SCR(S_BP + 3 * bb + 2);
-    const float pox = STT(ST_OPOS + 3 * ob), poy = STT(ST_OPOS + 3 * ob + 1), poz = STT(ST_OPOS + 3 * ob + 2);
+    const float pox = SCR(S_OP + 3 * ob), poy = SCR(S_OP + 3 * ob + 1), poz = SCR(S_OP + 3 * ob + 2);      // (the pose that counts: prep_body<1>)
     const bool st = ot == 0, body = ot == 1;
     X.R.m[0] = st ? 1.0f : r[0]; X.R.m[1] = st ? 0.0f : r[1]; X.R.m[2] = st ? 0.0f : r[2];
     X.R.m[3] = st ? 0.0f : r[3]; X.R.m[4] = st ? 1.0f : r[4]; X.R.m[5] = st ? 0.0f : r[5];
@@ -770,13 +810,16 @@ __device__ __forceinline__ bool edge_pair(const EdgeW &A, const EdgeW &B, float 
         }                                                                                             \
         RESULT = besti_;                                                                              \
     }
-__global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, DevPtrs D, int ns) {
+// The collision pass of one env: reads the contact history (current frame: D.clist, D.ccount, D.cforce) and the collision
+// inputs prep_body<1> left in the scratch slab, fills the NEXT frame (D.clist_next, D.ccount_next, D.cwarm_next, class + lists).
+__device__ __forceinline__ void collide_env(const SimParams &P, const DevPtrs &D, int ns, int env) {
     const int N = P.N;
-    const int env = D.corder[blockIdx.x];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { D.hcount[2] = 0; D.hcount[3] = 0; }      // (k_prep_a of the next step fills corder again)
     const float *state = D.state;
     float *scratch = D.scratch;
-    if (D.errflags[env]) return;
+    if (D.errflags[env] & 1u) {         // frozen env: no contacts, light
+        if (threadIdx.x == 0) { D.ccount_next[env] = 0; D.hgflag_next[env] = 0; }
+        return;
+    }
     const ShapeData *S = D.shapes;
     // 38.9 KB of LDS: four workgroups = sixteen waves per CU
     __shared__ float xf[CSHAPES][12];          // R (row-major 9), p (3) of every shape's owner
@@ -806,7 +849,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, Dev
     unsigned short *cand_b = cand_b_w[wv];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     CPROF_INIT
-    const int nprev = P.warmstart > 0.0f ? min(D.ccount[env], MAXC) : 0;      // contacts of the step before (this kernel replaces the count at its end)
+    const int nprev = P.warmstart > 0.0f ? min(D.ccount[env], MAXC) : 0;      // contacts of the step before (the current frame; this pass fills the next one)
     for (int pr = tid; pr < P.npairs; pr += COLLIDE_THREADS) {
         const int ba = S->pair_meta[pr][0], bb = S->pair_meta[pr][1];
         const int cls = (((ba >= 0 && ba < 16) || (bb >= 0 && bb < 16)) ? 1 : 0) | ((ba >= 16 && bb >= 16) ? 2 : 0);
@@ -816,7 +859,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, Dev
     if (wv == 1) {       // the contact history comes in with the same round trip as the shape transforms (it has left the L2 since k_solve read it)
         for (int q = lane; q < MAXPAIRS; q += 64) { run_s[q] = 0; run_e[q] = 0; }
         if (lane < nprev) {
-            const float4 *pr_ = D.clist_prev + ((size_t)env * MAXC + lane) * 3;
+            const float4 *pr_ = D.clist + ((size_t)env * MAXC + lane) * 3;
             const float4 p0 = pr_[0], p1 = pr_[1];
             pv[lane] = make_float4(p0.x, p0.y, p0.z, D.cforce[(size_t)env * MAXC + lane]);
             pv_key[lane] = __float_as_int(p1.w);
@@ -1143,7 +1186,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, Dev
                 }
                 const float4 b = make_float4(nb.x, nb.y, nb.z, 0.0f);
                 const int meta = pair_key[pair];
-                float4 *rec = D.clist + ((size_t)env * MAXC + (ok_ & 255) + r) * 3;
+                float4 *rec = D.clist_next + ((size_t)env * MAXC + (ok_ & 255) + r) * 3;
                 rec[0] = make_float4(a.x, a.y, a.z, b.x);
                 rec[1] = make_float4(b.y, b.z, a.w, __int_as_float(meta | (pair << 24)));      // (bits 24..30: the pair, for the next step's matching)
                 rec[2] = *(const float4 *)S->pair_mat[pair];
@@ -1207,7 +1250,7 @@ __global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, Dev
                         if (heir) lam0 = P.warmstart * (pb.w * P.dt);
                     }
                 }
-                D.cwarm[(size_t)env * MAXC + (ok_ & 255) + r] = lam0;
+                D.cwarm_next[(size_t)env * MAXC + (ok_ & 255) + r] = lam0;
             }
         }
         CPROF(6);
@@ -1223,10 +1266,18 @@ __global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, Dev
         // quarter, an arm pressed on the table fourfold -- only the latter are worth the side stream when many envs have some)
         ngen += max(oscnt0 - 4, 0) + max(oscnt1 - 4, 0) + max(oscnt2 - 4, 0);
         const bool heavy = ngen > P.heavy_min;
-        D.ccount[env] = nct;
-        if (heavy && ngen > P.heavy2_min) { D.hgflag[env] = 2; D.hlist2[atomicAdd(D.hcount2, 1)] = env; }
-        else if (heavy) { D.hgflag[env] = 1; D.hlist[atomicAdd(D.hcount, 1)] = env; }
+        D.ccount_next[env] = nct;
+        if (heavy && ngen > P.heavy2_min) { D.hgflag_next[env] = 2; D.hlist2_next[atomicAdd(D.hcount2_next, 1)] = env; }
+        else if (heavy) { D.hgflag_next[env] = 1; D.hlist_next[atomicAdd(D.hcount_next, 1)] = env; }
+        else D.hgflag_next[env] = 0;
     }
+}
+// One workgroup per env of the class `sel` (pick_env): N workgroups whatever the class (a heavy list's length is known on the
+// device only; workgroups past its end, or whose env is not of the class, exit before touching anything).
+__global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, DevPtrs D, int ns, int sel) {
+    const int env = pick_env(D, sel, blockIdx.x, P.N);
+    if (env < 0) return;
+    collide_env(P, D, ns, env);
 }
 #undef CAND_ARGMAX
 #pragma clang fp contract(fast)
@@ -1409,6 +1460,9 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
     const int env = env_raw < N ? env_raw : N - 1;                    // groups without an env run along as no-ops
     float *state = D.state, *scratch = D.scratch;
     const bool dead = !mine || env_raw >= N || D.errflags[env] != 0;
+    // an env whose command was rejected (robot.py:189) does not step; the list the look-ahead made for this step is dropped with
+    // it, so that the normal forces of the last solved step (cforce) are never matched against a list they do not belong to
+    if (mine && env_raw < N && l == 0 && (D.errflags[env] & 2u)) D.ccount[env] = 0;
     const ShapeData *S = D.shapes;
     const int fix = grp * LF_TOTAL;
     const int L_MINV = fix + LF_MINV, L_MOT = fix + LF_MOT, L_LIM = fix + LF_LIM, L_META = fix + LF_META, L_MU = fix + LF_MU,
@@ -2210,7 +2264,7 @@ __global__ void __launch_bounds__(64) k_link_poses(BodyParams B, SimParams P, co
 // ---------------------------------------------------------------------------------------------- inverse kinematics (K8)
 // Batched damped-least-squares IK for link 7 (gripper `base`): the device restatement of what step_cartesian /
 // generate_plan ask pybullet for (env.py:372-375, 422-427: calculateInverseKinematics(0, 7, pos, orn,
-// maxNumIterations=1000, residualThreshold=0.001)); same algorithm as real_robots_amd/kinematics.py (the checker in
+// maxNumIterations=1000, residualThreshold=0.001)); same algorithm as oracle/kinematics.py (the numpy checker used by
 // tests): J^T (J J^T + 0.01 I)^-1 e steps clamped to 0.5 rad, wrapped to (-pi, pi], two or three seeds, branch choice
 // by (converged, continuity with the previous way-point | elbow height).
 struct IkModel {          // arm chain constants, passed by value
@@ -3344,7 +3398,16 @@ struct rr_env {
     hipStream_t aux;         // side stream: the HBM-bound static-layer copy runs beside the VALU-bound physics / visibility kernels
     hipEvent_t ev_fork, ev_join, ev_dyn, ev_join2;
     hipStream_t aux2;              // the very heavy envs' solve + render (RR_HEAVY2_MIN)
+    // Look-ahead: the state part of step t+1 (k_prep_a, k_prep_b, k_collide) runs behind the solve of step t,
+    // class by class, under the render of step t -- on the streams la (k_prep_a -> k_collide) and la2 (k_prep_b).
+    struct Frame { float4 *clist; int *ccount; float *cwarm; int *hgflag, *hlist, *hcount, *hlist2, *hcount2; } fr[2];
+    int cur;                       // fr[cur]: the frame of the last solved step (rr_get_contacts, contact history); fr[cur ^ 1]: the look-ahead's
+    bool la_valid;                 // fr[cur ^ 1] and the scratch slab hold the collision pass / dynamics of the next step for the present state
+    bool lookahead;                // RR_NO_LOOKAHEAD=1: never ahead, every step prepares itself in line (A/B, tests)
+    hipStream_t la, la2;
+    hipEvent_t ev_solved[3], ev_la, ev_la2;
     int n_shapes;
+    float table_pos[3];            // target of the default eye camera (env.py:253-255)
     float t_ms[RR_NUM_KERNELS];
     int t_n[RR_NUM_KERNELS];
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -3416,6 +3479,11 @@ int rr_destroy(rr_env *e) {
     for (int i = 0; i < 2 * RR_NUM_KERNELS; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
     if (e->aux) { hipStreamSynchronize(e->aux); hipStreamDestroy(e->aux); }
     if (e->aux2) { hipStreamSynchronize(e->aux2); hipStreamDestroy(e->aux2); }
+    if (e->la) { hipStreamSynchronize(e->la); hipStreamDestroy(e->la); }
+    if (e->la2) { hipStreamSynchronize(e->la2); hipStreamDestroy(e->la2); }
+    if (e->ev_la) hipEventDestroy(e->ev_la);
+    if (e->ev_la2) hipEventDestroy(e->ev_la2);
+    for (int i = 0; i < 3; i++) if (e->ev_solved[i]) hipEventDestroy(e->ev_solved[i]);
     if (e->ev_join2) hipEventDestroy(e->ev_join2);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
@@ -3424,6 +3492,21 @@ int rr_destroy(rr_env *e) {
     if (e->h_hcount) hipHostFree(e->h_hcount);
     delete e;
     return RR_OK;
+}
+
+// points the device view at the contact frames: current = fr[cur], next = fr[cur ^ 1]
+static void bind_frames(rr_env *e) {
+    const rr_env::Frame &C = e->fr[e->cur], &X = e->fr[e->cur ^ 1];
+    DevPtrs &D = e->D;
+    D.clist = C.clist; D.ccount = C.ccount; D.cwarm = C.cwarm; D.hgflag = C.hgflag; D.hlist = C.hlist; D.hcount = C.hcount; D.hlist2 = C.hlist2; D.hcount2 = C.hcount2;
+    D.clist_next = X.clist; D.ccount_next = X.ccount; D.cwarm_next = X.cwarm; D.hgflag_next = X.hgflag; D.hlist_next = X.hlist; D.hcount_next = X.hcount;
+    D.hlist2_next = X.hlist2; D.hcount2_next = X.hcount2;
+}
+
+// the contact count and the class of every env belong to the contact frame of the last solved step, which changes place every step
+static void refresh_frame_fields(rr_env *e) {
+    e->field_ptr[RR_F_CONTACT_COUNT] = e->D.ccount;
+    e->field_ptr[RR_F_ENV_CLASS] = e->D.hgflag;
 }
 
 static ImageOut env_images(const rr_env *e) {
@@ -3483,6 +3566,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->full_copy = getenv("RR_FULL_COPY") != nullptr;
     e->sep_restore = getenv("RR_SEPARATE_RESTORE") != nullptr;
     e->split_heavy = getenv("RR_NO_SPLIT") == nullptr;
+    e->lookahead = getenv("RR_NO_LOOKAHEAD") == nullptr;
+    e->la = nullptr; e->la2 = nullptr; e->ev_la = nullptr; e->ev_la2 = nullptr; memset(e->ev_solved, 0, sizeof e->ev_solved);
     e->h_hcount = nullptr;
     e->split_max_pct = getenv("RR_SPLIT_MAX_PCT") ? atoi(getenv("RR_SPLIT_MAX_PCT")) : 60;
     if (hipHostMalloc((void **)&e->h_hcount, sizeof(int), hipHostMallocMapped) == hipSuccess) *e->h_hcount = 0; else e->h_hcount = nullptr;
@@ -3578,6 +3663,15 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         S.pair_mat[k][3] = std::min(S.spin[sa] * S.fric[sb] + S.spin[sb] * S.fric[sa], 10.0f);
     }
 
+    // k_collide's warm-start matching looks for the previous contacts of the same bodies (bodyA, bodyB, linkA) among the
+    // pairs pair-2 .. pair+2 only: pairs with equal keys must form runs of at most three consecutive pairs (one collision shape
+    // per robot link against table / shelf, one per object against the three statics)
+    for (int k = 0; k < np; k++)
+        for (int j = 0; j < np; j++) {
+            const bool same = S.pair_meta[k][0] == S.pair_meta[j][0] && S.pair_meta[k][1] == S.pair_meta[j][1] && S.pair_meta[k][2] == S.pair_meta[j][2];
+            if (same && std::abs(k - j) > 2) { rr_destroy(e); return fail(RR_EMODEL, "rr_create: collision pairs of the same bodies are more than two apart in the pair table (warm-start matching window)"); }
+        }
+
     // render model
     RenderModel &RM = e->RM;
     RM.ni = ni; RM.nt = nt; RM.W = cfg->width; RM.H = cfg->height; RM.nl = nl;
@@ -3600,6 +3694,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         int n_static_inst = dims[10];
         RM.first_dynamic_tri = (n_static_inst < ni) ? ir[2 * n_static_inst] : nt;
     }
+    memcpy(e->table_pos, table_pos, sizeof e->table_pos);
     look_at_persp(RM.VP, table_pos, RM.W, RM.H);
     frustum_plane_norms(RM);
     e->n_inst_used = ni - (NOBJ - P.nobj);
@@ -3610,18 +3705,14 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
 #define ALLOC(ptr, count) if ((rc = dev_alloc(e, &(ptr), (count))) != RR_OK) { rr_destroy(e); return rc; }
     ALLOC(D.state, (size_t)ST_TOTAL * N);
     ALLOC(D.scratch, (size_t)S_TOTAL * N);
-    ALLOC(D.clist, (size_t)N * MAXC * 3);
-    ALLOC(D.ccount, (size_t)N);
-    ALLOC(D.clist_prev, (size_t)N * MAXC * 3);
-    ALLOC(D.cwarm, (size_t)N * MAXC);
+    for (int f = 0; f < 2; f++) {
+        rr_env::Frame &F = e->fr[f];
+        ALLOC(F.clist, (size_t)N * MAXC * 3); ALLOC(F.ccount, (size_t)N); ALLOC(F.cwarm, (size_t)N * MAXC);
+        ALLOC(F.hgflag, (size_t)N); ALLOC(F.hlist, (size_t)N); ALLOC(F.hcount, (size_t)4); ALLOC(F.hlist2, (size_t)N); ALLOC(F.hcount2, (size_t)4);
+    }
+    e->cur = 0; e->la_valid = false;
+    bind_frames(e);
     ALLOC(D.cforce, (size_t)N * MAXC);
-    ALLOC(D.hgflag, (size_t)N);
-    ALLOC(D.hlist, (size_t)N);
-    ALLOC(D.hcount, (size_t)4);
-    ALLOC(D.hlist2, (size_t)N);
-    ALLOC(D.hcount2, (size_t)4);
-    ALLOC(D.corder, (size_t)N);
-    { std::vector<int> id(N); for (int i = 0; i < N; i++) id[i] = i; hipMemcpy(D.corder, id.data(), (size_t)N * 4, hipMemcpyHostToDevice); }
     e->D.hcount_host = nullptr;
     if (e->h_hcount && hipHostGetDevicePointer((void **)&e->D.hcount_host, e->h_hcount, 0) != hipSuccess) e->D.hcount_host = nullptr;
     ALLOC(D.timestep, (size_t)N);
@@ -3706,6 +3797,12 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         if (!side_stream(&e->aux) || hipEventCreateWithFlags(&e->ev_fork, evf) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_join, evf) != hipSuccess || hipEventCreateWithFlags(&e->ev_dyn, evf) != hipSuccess ||
             !side_stream(&e->aux2) || hipEventCreateWithFlags(&e->ev_join2, evf) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
+        // the look-ahead streams: RR_LA_PRIORITY=1 gives them the side streams' priority (default: the main stream's)
+        const int la_prio = getenv("RR_LA_PRIORITY") && atoi(getenv("RR_LA_PRIORITY")) ? prio : prio_lo;
+        auto la_stream = [&](hipStream_t *st) { return hipStreamCreateWithPriority(st, hipStreamNonBlocking, la_prio) == hipSuccess || hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess; };
+        bool ok = la_stream(&e->la) && la_stream(&e->la2) && hipEventCreateWithFlags(&e->ev_la, evf) == hipSuccess && hipEventCreateWithFlags(&e->ev_la2, evf) == hipSuccess;
+        for (int i = 0; i < 3 && ok; i++) ok = hipEventCreateWithFlags(&e->ev_solved[i], evf) == hipSuccess;
+        if (!ok) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: look-ahead streams"); }
     }
     e->field_ptr[RR_F_JOINTS] = D.joints; e->field_bytes[RR_F_JOINTS] = (size_t)N * 9 * 4;
     e->field_ptr[RR_F_TOUCH] = D.touch; e->field_bytes[RR_F_TOUCH] = (size_t)N * 4 * 4;
@@ -3717,6 +3814,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->field_ptr[RR_F_ERRFLAGS] = D.errflags; e->field_bytes[RR_F_ERRFLAGS] = (size_t)N * 4;
     e->field_ptr[RR_F_STATE] = e->state_aos; e->field_bytes[RR_F_STATE] = (size_t)N * NSTATE * 4;
     e->field_bytes[RR_F_FRAG_COUNT] = (size_t)N * RM.ntiles * 4;     // pointer set once the list is allocated
+    e->field_bytes[RR_F_CONTACT_COUNT] = (size_t)N * 4; e->field_bytes[RR_F_ENV_CLASS] = (size_t)N * 4;
+    refresh_frame_fields(e);
     *out = e;
     for (int i = 0; i < NOBJ; i++) { const int rh = rr_set_object_home(e, -1, i, e->B.obj_pose0[i]); if (rh != RR_OK) { rr_destroy(e); *out = nullptr; return rh; } }
     int r = rr_reset(e, nullptr);
@@ -3734,9 +3833,13 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         e->field_ptr[RR_F_FRAG_COUNT] = e->D.frag_count;
         if ((r = build_static_layer(e)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
     }
-    // the 256-thread form of k_solve (heavy solver groups, four per workgroup) asks for 158 KiB of dynamic LDS
-    HIPCHK(hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * SGRP * LF_TOTAL * sizeof(float))));
-    HIPCHK(hipGetLastError());
+    // the 256-thread form of k_solve (heavy solver groups, four per workgroup) asks for 158 KiB of dynamic LDS: only the
+    // heavy / light split launches it, and a device that cannot grant it runs without the split (same results, one launch)
+    if (e->split_heavy && hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * SGRP * LF_TOTAL * sizeof(float))) != hipSuccess) {
+        (void)hipGetLastError();
+        e->split_heavy = false;
+    }
+    if (hipGetLastError() != hipSuccess) { rr_destroy(e); *out = nullptr; return fail(RR_EDEVICE, "rr_create: device error during set-up"); }
     return RR_OK;
 }
 
@@ -3758,6 +3861,7 @@ int rr_reset(rr_env *e, const uint8_t *mask_host) {
         HIPCHK(hipMemcpyAsync(e->mask_dev, mask_host, e->P.N, hipMemcpyHostToDevice, e->stream));
         m = e->mask_dev;
     }
+    e->la_valid = false;          // the state changes from outside: the next step prepares itself in line
     hipLaunchKernelGGL(k_reset, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->B, e->P, e->D, m);
     hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
     HIPCHK(hipGetLastError());
@@ -3770,6 +3874,7 @@ int rr_set_object_home(rr_env *e, int32_t env_index, int32_t obj, const float *p
     if (!e || !pose7) return fail(RR_EINVAL, "null argument");
     if (env_index >= e->P.N || obj < 0 || obj >= NOBJ) return fail(RR_EINVAL, "rr_set_object_home: index out of range");
     HIPCHK(hipSetDevice(e->cfg.device));
+    e->la_valid = false;          // the out-of-bounds rule of the look-ahead used the old home pose
     const size_t N = e->P.N;
     if (env_index >= 0) {
         for (int k = 0; k < 7; k++)
@@ -3790,6 +3895,7 @@ int rr_set_object_pose(rr_env *e, int32_t env_index, int32_t obj, const float *p
     if (!e || !pose7) return fail(RR_EINVAL, "null argument");
     if (env_index < 0 || env_index >= e->P.N || obj < 0 || obj >= e->P.nobj) return fail(RR_EINVAL, "rr_set_object_pose: index out of range");
     HIPCHK(hipSetDevice(e->cfg.device));
+    e->la_valid = false;
     const size_t N = e->P.N;
     float zero = 0.0f;
     for (int k = 0; k < 3; k++) {
@@ -3808,6 +3914,7 @@ int rr_set_object_pose(rr_env *e, int32_t env_index, int32_t obj, const float *p
 int rr_set_object_poses(rr_env *e, const float *poses_host, const uint8_t *env_mask_host) {
     if (!e || !poses_host) return fail(RR_EINVAL, "null argument");
     HIPCHK(hipSetDevice(e->cfg.device));
+    e->la_valid = false;
     const int N = e->P.N;
     static_assert(NSTATE >= NOBJ * 7, "the state staging buffer doubles as pose staging");
     HIPCHK(hipMemcpyAsync(e->state_aos, poses_host, (size_t)N * e->P.nobj * 28, hipMemcpyHostToDevice, e->stream));
@@ -3889,14 +3996,20 @@ static int do_render(rr_env *e, bool use_flags) {
     return RR_OK;
 }
 
-static void launch_prep_serial(rr_env *e, const DevPtrs &Dp) {
-    hipLaunchKernelGGL(k_prep_a, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp);
-    hipLaunchKernelGGL(k_prep_b, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp);
+// ---- look-ahead: the state part of the NEXT step (k_prep_a -> k_collide, k_prep_b beside them) ------------------------------
+// Per-class launches (sel: pick_env) cover N work items whatever the class.
+static void launch_prep_a(rr_env *e, int sel, int zero_counts, hipStream_t st) {
+    hipLaunchKernelGGL(k_prep_a, env_grid(e), dim3(e->epb), 0, st, e->B, e->P, e->D, sel, zero_counts);
 }
-
-static void launch_collide(rr_env *e) {
-    std::swap(e->D.clist, e->D.clist_prev);      // the list of the step before becomes the contact history of this one
-    hipLaunchKernelGGL(k_collide, dim3(e->P.N), dim3(COLLIDE_THREADS), 0, e->stream, e->P, e->D, e->n_shapes);
+static void launch_prep_b(rr_env *e, int sel, hipStream_t st) {
+    hipLaunchKernelGGL(k_prep_b, env_grid(e), dim3(e->epb), 0, st, e->B, e->P, e->D, sel);
+}
+static void launch_collide(rr_env *e, int sel, hipStream_t st) {
+    hipLaunchKernelGGL(k_collide, dim3(e->P.N), dim3(COLLIDE_THREADS), 0, st, e->P, e->D, e->n_shapes, sel);
+}
+static void launch_prep_serial(rr_env *e, int sel, int zero_counts) {
+    launch_prep_a(e, sel, zero_counts, e->stream);
+    launch_prep_b(e, sel, e->stream);
 }
 
 // Next slot of the pinned ring (allocated on first use: N * 37 bytes per slot = commands + render flags).
@@ -3926,36 +4039,43 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         memcpy(pin, joint_cmd, (size_t)N * 36);
         HIPCHK(hipMemcpyAsync(e->D.cmd, pin, (size_t)N * 36, hipMemcpyHostToDevice, e->stream));
     }
-    // a device-resident command buffer is read in place by k_prep (stream order protects it like a copy would)
-    DevPtrs Dp = e->D;
-    if (joint_cmd && cmd_on_device) Dp.cmd = const_cast<float *>(joint_cmd);
     if (host_flags) {
         memcpy(pin + (size_t)N * 36, render_flags_host, N);
         HIPCHK(hipMemcpyAsync(e->D.render_flags, pin + (size_t)N * 36, N, hipMemcpyHostToDevice, e->stream));
     }
     if (pin_idx >= 0) { HIPCHK(hipEventRecord(e->pin_ev[pin_idx], e->stream)); e->pin_used[pin_idx] = true; }
-    bool dyn_forked = false;
-    if (e->aux && !e->timing && !g_skip) {
-        // phase 1 on the main stream, phase 2 (dynamics, needed by k_solve only) on the side stream beside k_collide
-        hipLaunchKernelGGL(k_prep_a, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp);
-        hipEventRecord(e->ev_fork, e->stream);
-        hipStreamWaitEvent(e->aux, e->ev_fork, 0);
-        hipLaunchKernelGGL(k_prep_b, env_grid(e), dim3(e->epb), 0, e->aux, e->B, e->P, Dp);
-        hipEventRecord(e->ev_dyn, e->aux);
-        dyn_forked = true;
-    } else {
-        TIMED(0, launch_prep_serial(e, Dp));
+    const bool overlap = e->aux && !e->timing && !g_skip;      // side streams in use (timing leg / diagnostics: everything on the main stream)
+    // ---- the state part of this step, unless the previous step already computed it (look-ahead) for exactly this state
+    if (!e->la_valid) {
+        if (overlap) {
+            // phase 1 on the main stream, phase 2 (dynamics, needed by k_solve only) on the side stream beside k_collide
+            launch_prep_a(e, 0, 1, e->stream);
+            hipEventRecord(e->ev_fork, e->stream);
+            hipStreamWaitEvent(e->aux, e->ev_fork, 0);
+            launch_prep_b(e, 0, e->aux);
+            hipEventRecord(e->ev_dyn, e->aux);
+            launch_collide(e, 0, e->stream);
+            hipStreamWaitEvent(e->stream, e->ev_dyn, 0);
+        } else {
+            TIMED(0, launch_prep_serial(e, 0, 1));
+            TIMED(1, launch_collide(e, 0, e->stream));
+        }
     }
-    TIMED(1, launch_collide(e));
-    if (dyn_forked) hipStreamWaitEvent(e->stream, e->ev_dyn, 0);
+    e->cur ^= 1; e->la_valid = false;           // the frame the collision pass filled is the one this step solves
+    bind_frames(e);
+    DevPtrs Dp = e->D;
+    // a device-resident command buffer is read in place by k_cmd (stream order protects it like a copy would)
+    if (joint_cmd && cmd_on_device) Dp.cmd = const_cast<float *>(joint_cmd);
+    TIMED(9, hipLaunchKernelGGL(k_cmd, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp));
     const int ngroups = (N + SGRP - 1) / SGRP;
     const size_t lds64 = (size_t)SGRP * LF_TOTAL * sizeof(float);
-    // (the number of heavy groups of a recent step, written to pinned host memory by k_prep_a without anybody waiting for it: when most groups are
+    // (the number of heavy envs of a recent step, written to pinned host memory by k_cmd without anybody waiting for it: when most are
     // heavy -- macro actions, every gripper pushing -- there is nothing to gain from the split)
     const bool mostly_heavy = e->h_hcount && (long long)*(volatile int *)e->h_hcount * 100 > (long long)N * e->split_max_pct;
-    if ((dyn_forked || e->timing) && e->aux && render_mode && e->split_heavy && !mostly_heavy) {
-        // The few solver groups with generic contact rows take several times as long as the others (the kernel lasts as long
-        // as its longest Gauss-Seidel chain).  They are solved and rendered on the side stream -- four groups per 256-thread
+    const bool ahead = e->lookahead;            // this step ends with the state part of the next one
+    if (e->aux && !g_skip && render_mode && e->split_heavy && !mostly_heavy) {
+        // The few envs with generic contact rows take several times as long as the others (the kernel lasts as long
+        // as its longest Gauss-Seidel chain).  They are solved and rendered on the side streams -- four groups per 256-thread
         // workgroup, so that they fill the LDS of a few CUs and leave the rest to the raster workgroups of the light envs --
         // while the main stream solves and renders everybody else.
         DevPtrs D = e->D;
@@ -3963,26 +4083,50 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         const int restore = ensure_images(e, D);
         if (e->timing) {
             // timing leg: the very same launches, one after the other on the main stream, each under its timer -- 2 / 3 / 4 / 6
-            // what the main stream runs in an untimed step (the light envs), 7 / 8 what the side stream runs beside it
+            // what the main stream runs in an untimed step (the light envs), 7 / 8 what the side streams run beside it, 0 / 1 the
+            // look-ahead of the next step, which an untimed step runs under the render
             TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1));
             TIMED(7, { hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->stream, e->B, e->P, e->D, 2);
                        hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->stream, e->B, e->P, e->D, 3); });
             launch_render(e, D, restore, 1, e->stream, true);
             TIMED(8, { launch_render(e, D, restore, 2, e->stream, false); launch_render(e, D, restore, 3, e->stream, false); });
+            if (ahead) {
+                TIMED(0, { launch_prep_serial(e, 1, 0); launch_prep_serial(e, 2, 0); launch_prep_serial(e, 3, 0); });
+                TIMED(1, { launch_collide(e, 1, e->stream); launch_collide(e, 2, e->stream); launch_collide(e, 3, e->stream); });
+                e->la_valid = true;
+            }
             HIPCHK(hipGetLastError());
             return RR_OK;
         }
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux2, e->ev_fork, 0);      // the longest chain first
         hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->aux2, e->B, e->P, e->D, 3);
+        if (ahead) hipEventRecord(e->ev_solved[2], e->aux2);
         launch_render(e, D, restore, 3, e->aux2, false);
         hipEventRecord(e->ev_join2, e->aux2);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
         hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->aux, e->B, e->P, e->D, 2);
+        if (ahead) hipEventRecord(e->ev_solved[1], e->aux);
         launch_render(e, D, restore, 2, e->aux, false);
         hipEventRecord(e->ev_join, e->aux);
         hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1);
+        if (ahead) hipEventRecord(e->ev_solved[0], e->stream);
         launch_render(e, D, restore, 1, e->stream, false);
+        if (ahead) {
+            // look-ahead, class by class in the order the solves finish: k_prep_a -> k_collide on `la`, k_prep_b on `la2`
+            for (int c = 0; c < 3; c++) {
+                hipStreamWaitEvent(e->la, e->ev_solved[c], 0);
+                launch_prep_a(e, 1 + c, 0, e->la);
+                launch_collide(e, 1 + c, e->la);
+                hipStreamWaitEvent(e->la2, e->ev_solved[c], 0);
+                launch_prep_b(e, 1 + c, e->la2);
+            }
+            hipEventRecord(e->ev_la, e->la);
+            hipEventRecord(e->ev_la2, e->la2);
+            hipStreamWaitEvent(e->stream, e->ev_la, 0);
+            hipStreamWaitEvent(e->stream, e->ev_la2, 0);
+            e->la_valid = true;
+        }
         hipStreamWaitEvent(e->stream, e->ev_join, 0);
         hipStreamWaitEvent(e->stream, e->ev_join2, 0);
         HIPCHK(hipGetLastError());
@@ -3990,8 +4134,31 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     }
     TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 0));
     HIPCHK(hipGetLastError());
-    if (render_mode) return do_render(e, render_mode == 2);
-    return RR_OK;
+    if (ahead && overlap) {
+        // all envs in one class: the look-ahead runs beside the render (if any) of this step
+        hipEventRecord(e->ev_solved[0], e->stream);
+        hipStreamWaitEvent(e->la, e->ev_solved[0], 0);
+        launch_prep_a(e, 0, 0, e->la);
+        launch_collide(e, 0, e->la);
+        hipEventRecord(e->ev_la, e->la);
+        hipStreamWaitEvent(e->la2, e->ev_solved[0], 0);
+        launch_prep_b(e, 0, e->la2);
+        hipEventRecord(e->ev_la2, e->la2);
+        int rc = RR_OK;
+        if (render_mode) rc = do_render(e, render_mode == 2);
+        hipStreamWaitEvent(e->stream, e->ev_la, 0);
+        hipStreamWaitEvent(e->stream, e->ev_la2, 0);
+        e->la_valid = true;
+        return rc;
+    }
+    int rc = RR_OK;
+    if (render_mode) rc = do_render(e, render_mode == 2);
+    if (ahead) {
+        TIMED(0, launch_prep_serial(e, 0, 0));
+        TIMED(1, launch_collide(e, 0, e->stream));
+        e->la_valid = true;
+    }
+    return rc;
 }
 
 int rr_render(rr_env *e) {
@@ -4002,6 +4169,7 @@ int rr_render(rr_env *e) {
 
 int rr_get_buffer(rr_env *e, int32_t field, void **dev_ptr, size_t *bytes) {
     if (!e || field < 0 || field >= RR_F_COUNT) return fail(RR_EINVAL, "rr_get_buffer: bad field");
+    refresh_frame_fields(e);
     if (dev_ptr) *dev_ptr = e->field_ptr[field];
     if (bytes) *bytes = e->field_bytes[field];
     return RR_OK;
@@ -4009,6 +4177,7 @@ int rr_get_buffer(rr_env *e, int32_t field, void **dev_ptr, size_t *bytes) {
 
 int rr_copy_to_host(rr_env *e, int32_t field, void *dst, size_t bytes) {
     if (!e || !dst || field < 0 || field >= RR_F_COUNT) return fail(RR_EINVAL, "rr_copy_to_host: bad argument");
+    refresh_frame_fields(e);
     if (!e->field_ptr[field]) return fail(RR_EINVAL, "rr_copy_to_host: field not available (RR_FLAG_NO_MASK)");
     if (bytes != e->field_bytes[field]) return fail(RR_EINVAL, "rr_copy_to_host: size mismatch");
     HIPCHK(hipSetDevice(e->cfg.device));
@@ -4022,10 +4191,66 @@ int rr_copy_to_host(rr_env *e, int32_t field, void *dst, size_t bytes) {
 int rr_set_state(rr_env *e, const float *state_host) {
     if (!e || !state_host) return fail(RR_EINVAL, "null argument");
     HIPCHK(hipSetDevice(e->cfg.device));
+    e->la_valid = false;
     HIPCHK(hipMemcpyAsync(e->state_aos, state_host, e->field_bytes[RR_F_STATE], hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(k_state_io, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D, e->state_aos, 0);
     hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
     HIPCHK(hipStreamSynchronize(e->stream));
+    return RR_OK;
+}
+
+// ---- checkpoint: everything a later restore needs to continue bit for bit ----------------------------------------------------
+// {header, state slab [72][N] (incl. motor targets), contact count [N], contact list [N][48][3] float4, normal forces [N][48],
+//  timestep [N], errflags [N], touch [N][4], object home poses [21][N]}: the 61-float state of RR_F_STATE plus the contact
+// history of the warm start (Bullet: the persistent manifolds with their cached impulses) and the episode clocks.
+struct CkptHeader { char magic[8]; int32_t version, N, nobj, reserved; };
+static size_t ckpt_bytes(const rr_env *e) {
+    const size_t N = e->P.N;
+    return sizeof(CkptHeader) + 4 * (ST_TOTAL * N + N + N * MAXC * 12 + N * MAXC + N + N + N * 4 + NOBJ * 7 * N);
+}
+int rr_checkpoint_bytes(rr_env *e, size_t *bytes) {
+    if (!e || !bytes) return fail(RR_EINVAL, "null argument");
+    *bytes = ckpt_bytes(e);
+    return RR_OK;
+}
+static int ckpt_copy(rr_env *e, char *host, bool save) {
+    const size_t N = e->P.N;
+    struct Part { void *dev; size_t bytes; } parts[] = {
+        {e->D.state, 4 * ST_TOTAL * N}, {e->D.ccount, 4 * N}, {e->D.clist, 4 * N * MAXC * 12}, {e->D.cforce, 4 * N * MAXC},
+        {e->D.timestep, 4 * N}, {e->D.errflags, 4 * N}, {e->D.touch, 4 * N * 4}, {e->D.obj_home, 4 * NOBJ * 7 * N}};
+    char *h = host + sizeof(CkptHeader);
+    for (const Part &p : parts) {
+        if (save) HIPCHK(hipMemcpyAsync(h, p.dev, p.bytes, hipMemcpyDeviceToHost, e->stream));
+        else HIPCHK(hipMemcpyAsync(p.dev, h, p.bytes, hipMemcpyHostToDevice, e->stream));
+        h += p.bytes;
+    }
+    return RR_OK;
+}
+int rr_checkpoint_save(rr_env *e, void *dst_host, size_t bytes) {
+    if (!e || !dst_host) return fail(RR_EINVAL, "null argument");
+    if (bytes != ckpt_bytes(e)) return fail(RR_EINVAL, "rr_checkpoint_save: size mismatch (rr_checkpoint_bytes)");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    CkptHeader hd;
+    memcpy(hd.magic, "RRCKPT01", 8); hd.version = 1; hd.N = e->P.N; hd.nobj = e->P.nobj; hd.reserved = 0;
+    memcpy(dst_host, &hd, sizeof hd);
+    const int rc = ckpt_copy(e, (char *)dst_host, true);
+    if (rc != RR_OK) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return RR_OK;
+}
+int rr_checkpoint_restore(rr_env *e, const void *src_host, size_t bytes) {
+    if (!e || !src_host) return fail(RR_EINVAL, "null argument");
+    if (bytes != ckpt_bytes(e)) return fail(RR_EINVAL, "rr_checkpoint_restore: size mismatch (rr_checkpoint_bytes)");
+    CkptHeader hd;
+    memcpy(&hd, src_host, sizeof hd);
+    if (memcmp(hd.magic, "RRCKPT01", 8) != 0 || hd.version != 1 || hd.N != e->P.N || hd.nobj != e->P.nobj)
+        return fail(RR_EINVAL, "rr_checkpoint_restore: not a checkpoint of an env handle of this shape");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    e->la_valid = false;
+    const int rc = ckpt_copy(e, (char *)const_cast<void *>(src_host), false);
+    if (rc != RR_OK) return rc;
+    hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
+    HIPCHK(hipStreamSynchronize(e->stream));   // the source is host memory
     return RR_OK;
 }
 
@@ -4124,6 +4349,8 @@ int rr_get_plan(rr_env *e, int32_t env_index, float *plan_host) {
 int rr_step_plan_masked(rr_env *e, const uint8_t *idle_mask_host, int32_t render_mode, const uint8_t *render_flags_host) {
     if (!e) return fail(RR_EINVAL, "null env");
     if (!e->plan) return fail(RR_EINVAL, "rr_step_plan: call rr_plan_macro first");
+    // (checked here as well: k_plan_fetch advances the plan positions, which must not happen for a step rr_step then rejects)
+    if (render_mode < 0 || render_mode > 2 || (render_mode == 2 && !render_flags_host)) return fail(RR_EINVAL, "rr_step_plan: bad render_mode");
     HIPCHK(hipSetDevice(e->cfg.device));
     const unsigned char *idle = nullptr;
     if (idle_mask_host) { HIPCHK(hipMemcpyAsync(e->mask_dev, idle_mask_host, e->P.N, hipMemcpyHostToDevice, e->stream)); idle = e->mask_dev; }
@@ -4138,9 +4365,11 @@ int rr_step_plan(rr_env *e, int32_t render_mode, const uint8_t *render_flags_hos
 // Replaces the fixed eye camera by an arbitrary one (row-major 4x4 view and projection, OpenGL conventions) and rebuilds
 // the static layer. Used for the debug camera of render('rgb_array') (EnvCamera, env.py:470-513).
 int rr_set_camera(rr_env *e, const float *view16, const float *proj16) {
-    if (!e || !view16 || !proj16) return fail(RR_EINVAL, "null argument");
+    if (!e || (!view16) != (!proj16)) return fail(RR_EINVAL, "rr_set_camera: null argument (both matrices, or neither for the default eye)");
     HIPCHK(hipSetDevice(e->cfg.device));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (!view16) look_at_persp(e->RM.VP, e->table_pos, e->RM.W, e->RM.H);       // back to the reference's eye camera (env.py:136-141, 253-255)
+    else
     for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++) {
             float a = 0;

@@ -12,7 +12,7 @@ import numpy as np
 from .. import _native as nat
 from .. import spaces
 from ..batched import BatchedREALRobotEnv
-from ..kinematics import generate_plan, inverse_kinematics, quat_from_euler
+from ..mathutil import quat_from_euler
 from .robot import Kuka
 
 
@@ -43,7 +43,7 @@ class EnvCamera:
         self._be = None
 
     def render(self, env):
-        from ..kinematics import perspective, view_from_yaw_pitch_roll
+        from ..mathutil import perspective, view_from_yaw_pitch_roll
         if self._be is None:
             self._be = BatchedREALRobotEnv(1, objects=env._n_objects, width=self.render_width, height=self.render_height,
                                            device=env._device)
@@ -69,7 +69,7 @@ class EyeCamera:
         self.pos = targetPosition
 
     def _frame(self, view):
-        from ..kinematics import perspective
+        from ..mathutil import perspective
         env = self._env
         if env is None:
             raise RuntimeError("EyeCamera is not attached to an environment (REALRobotEnv.set_eye)")
@@ -88,12 +88,12 @@ class EyeCamera:
         return self.renderPitchRoll(*args, **kargs) if self.pitch_roll else self.renderTarget(*args, **kargs)
 
     def renderTarget(self, targetPosition, bullet_client=None):
-        from ..kinematics import look_at
+        from ..mathutil import look_at
         self.targetPosition = targetPosition
         return self._frame(look_at(self.eyePosition, targetPosition, self.upVector))
 
     def renderPitchRoll(self, distance, roll, pitch, yaw, bullet_client=None):
-        from ..kinematics import view_from_yaw_pitch_roll
+        from ..mathutil import view_from_yaw_pitch_roll
         return self._frame(view_from_yaw_pitch_roll(self.pos, distance, yaw, pitch, roll))[0]
 
 
@@ -106,7 +106,7 @@ class _BulletShim:
 
     @staticmethod
     def getQuaternionFromEuler(rpy):
-        from ..kinematics import quat_from_euler
+        from ..mathutil import quat_from_euler
         return tuple(quat_from_euler(*rpy))
 
     @staticmethod
@@ -171,8 +171,9 @@ class REALRobotEnv:
         self.envCamera = EnvCamera(self._cam_dist, self._cam_yaw, self._cam_pitch, self._cam_roll, self._cam_pos,
                                    width=self._render_width, height=self._render_height)
         self.eyes = {}
-        self.set_eye("eye")                              # env.py:95,136-141
         self._p = _BulletShim(self)
+        self.set_eye("eye")                              # env.py:95,136-141
+        self._eye_pushed = self._eye_key()               # the backend starts with this camera (rr_create)
         self.reward_func = DefaultRewardFunc
         H, W = self.robot.eye_height, self.robot.eye_width
         self.goal = Goal(retina=np.zeros((H, W, 3), np.uint8))
@@ -200,6 +201,26 @@ class REALRobotEnv:
         cam._p = getattr(self, '_p', None)
         self.eyes[name] = cam
 
+    def _eye_key(self):
+        cam = self.eyes["eye"]
+        return (tuple(float(x) for x in cam.eyePosition), tuple(float(x) for x in cam.upVector), float(cam.fov))
+
+    def _sync_eye_camera(self):
+        """get_retina is `self.eyes["eye"].render(table position)` in the reference (env.py:249-255): replacing that camera
+        (set_eye) or editing its eyePosition / upVector / fov changes the observation.  The retina comes from the main
+        backend, so an edited eye is pushed into it (rr_set_camera: look-at from the eye to the table position, env.py:536-551)
+        before the next frame."""
+        key = self._eye_key()
+        if key != self._eye_pushed:
+            from ..mathutil import look_at, perspective
+            cam = self.eyes["eye"]
+            if key == ((0.01, 0.0, 1.2), (0.0, 0.0, 1.0), 80.0):          # the reference's default eye: the library's own matrices
+                self._backend().set_camera(None, None)
+            else:
+                self._backend().set_camera(look_at(cam.eyePosition, [0.0, 0.0, 0.08], cam.upVector),         # table position, robot.py:20
+                                           perspective(cam.fov, float(self.robot.eye_width) / self.robot.eye_height, 0.1, 100.0))
+            self._eye_pushed = key
+
     def extrinsicFormula(self, p_goal, p, a_goal, a, w=1):
         """Position / orientation score of the earlier challenge rounds (env.py:168-179): 0.25 at 5 cm and at 0.3 of
         quaternion distance, mixed by w."""
@@ -220,7 +241,7 @@ class REALRobotEnv:
         """Kuka.object_poses is a plain dict that callers of the reference edit in place (tests/test_actions.py:95-98);
         reset and the out-of-bounds rule use it (robot.py:125-129, 165-185, env.py:257-264).  Edits are pushed to the
         device before the next reset / step."""
-        from ..kinematics import quat_from_euler
+        from ..mathutil import quat_from_euler
         cur = {k: tuple(float(x) for x in self.robot.object_poses[k]) for k in self.robot.used_objects[1:]}
         if cur != getattr(self, '_homes_synced', None):
             be = self._backend()
@@ -304,6 +325,7 @@ class REALRobotEnv:
 
     def get_retina(self):
         be = self._backend()
+        self._sync_eye_camera()
         be.render()
         return be.host(nat.F_RGB)[0], be.host(nat.F_MASK)[0], be.host(nat.F_DEPTH)[0].astype(np.float64)
 
@@ -345,6 +367,8 @@ class REALRobotEnv:
         assert np.isfinite(a).all()                     # robot.py:189
         assert len(a) == self.robot.num_joints          # robot.py:190
         self._sync_object_homes()
+        if camera_on:
+            self._sync_eye_camera()
         self._backend().step(a.reshape(1, 9), render=camera_on)
         observation = self.get_observation(camera_on, _rendered=True)
         reward = self.reward_func(observation)

@@ -4,7 +4,7 @@ import numpy as np
 
 from .. import _native as nat
 from .. import spaces
-from ..kinematics import quat_from_euler
+from ..mathutil import quat_from_euler
 
 
 class BodyHandle:

@@ -15,7 +15,7 @@ import numpy as np
 from . import _native as nat
 from .batched import BatchedREALRobotEnv, OBJECT_NAMES
 from .envs.env import Goal
-from .kinematics import quat_from_euler
+from .mathutil import quat_from_euler
 
 
 def _orient_diff(q1, q2):

@@ -5,7 +5,10 @@ The reference has no vectorised env (one env per process); this i
 When `gymnasium` is importable the class derives from `gymnasium.vector.VectorEnv`, otherwise it is a plain class with
 the same methods and attributes (`num_envs`, `single_action_space`, `single_observation_space`, `action_space`,
 `observation_space`).  Episodes end like the reference's (env.py:345-352): `truncated` once `timestep >=
-max_episode_steps`; truncated envs are reset at the start of the next step (gymnasium's next-step autoreset).
+max_episode_steps`.  Autoreset is gymnasium's SAME-STEP mode (`metadata["autoreset_mode"] = "same_step"`): a truncated env
+is reset inside the step() that truncated it, the returned observation is the first one of its next episode and the last
+observation of the finished episode is in `infos["final_obs"]` (low-dim entries; `infos["_final_obs"]` is the mask of the envs
+it applies to) -- every action acts on the episode its observation came from, no action is dropped.
 Observations are batched numpy arrays; with `device_obs=True` the image / low-dim entries are the library's device
 buffers instead (DLPack / __cuda_array_interface__, zero copy into torch on ROCm).
 """
@@ -22,6 +25,18 @@ except Exception:                       # pragma: no cover - gymnasium is not in
     _Base = object
 
 
+def _batch_dict_space(space, n):
+    """Dict of Boxes -> the same Dict with a leading axis of n (other entry types are kept as they are)."""
+    out = {}
+    for k, sp in space.spaces.items():
+        if hasattr(sp, 'low') and hasattr(sp, 'high'):
+            out[k] = spaces.Box(low=np.broadcast_to(sp.low, (n,) + tuple(sp.shape)).copy(),
+                                high=np.broadcast_to(sp.high, (n,) + tuple(sp.shape)).copy(), dtype=sp.dtype)
+        else:
+            out[k] = sp
+    return spaces.Dict(out)
+
+
 class REALRobotVectorEnv(_Base):
     def __init__(self, num_envs, objects=3, additional_obs=False, eye_width=320, eye_height=240, device=0,
                  max_episode_steps=int(15e6), render_every_step=True, device_obs=False):
@@ -29,14 +44,18 @@ class REALRobotVectorEnv(_Base):
         self._robot = Kuka(additional_obs, objects, eye_width, eye_height, env=None)
         self.single_action_space = spaces.Dict({"joint_command": self._robot.action_space, "render": spaces.MultiBinary(1)})
         self.single_observation_space = self._robot.observation_space
-        self.action_space = spaces.Box(low=np.tile(self._robot.min_joints, (self.num_envs, 1)),
-                                       high=np.tile(self._robot.max_joints, (self.num_envs, 1)), dtype=float)
-        self.observation_space = self.single_observation_space
+        # batched spaces = the single spaces with a leading env axis (gymnasium.vector.utils.batch_space)
+        self.action_space = spaces.Dict({
+            "joint_command": spaces.Box(low=np.tile(self._robot.min_joints, (self.num_envs, 1)),
+                                        high=np.tile(self._robot.max_joints, (self.num_envs, 1)), dtype=float),
+            "render": spaces.MultiBinary(1)})
+        self.observation_space = _batch_dict_space(self.single_observation_space, self.num_envs)
+        self.metadata = {"autoreset_mode": "same_step"}
         self.max_episode_steps = int(max_episode_steps)
         self.render_every_step, self.device_obs, self.additional_obs = bool(render_every_step), bool(device_obs), bool(additional_obs)
         self._be = BatchedREALRobotEnv(self.num_envs, objects=objects, width=eye_width, height=eye_height, device=device,
                                        want_mask=additional_obs)
-        self._pending_reset = np.zeros(self.num_envs, np.uint8)
+        self._steps = np.zeros(self.num_envs, np.int64)      # host-side episode clocks (no device read-back per step)
 
     # ------------------------------------------------------------------ observations
     def _obs(self, rendered):
@@ -53,7 +72,7 @@ class REALRobotVectorEnv(_Base):
 
     def reset(self, *, seed=None, options=None):
         self._be.reset()
-        self._pending_reset[:] = 0
+        self._steps[:] = 0
         if self.render_every_step:
             self._be.render()
         return self._obs(self.render_every_step), {}
@@ -64,15 +83,20 @@ class REALRobotVectorEnv(_Base):
         if isinstance(actions, dict):
             render = bool(np.any(actions.get("render", render)))
             actions = actions["joint_command"]
-        if self._pending_reset.any():
-            self._be.reset(self._pending_reset)
-            self._pending_reset[:] = 0
         self._be.step(np.asarray(actions, dtype=np.float32), render=render)
-        ts = self._be.host(nat.F_TIMESTEP)
-        truncated = ts >= self.max_episode_steps
-        self._pending_reset = truncated.astype(np.uint8)
+        self._steps += 1
+        truncated = self._steps >= self.max_episode_steps
         n = self.num_envs
-        return self._obs(render), np.zeros(n), np.zeros(n, bool), truncated, {}
+        infos = {}
+        if truncated.any():
+            # same-step autoreset: keep the finished episodes' last low-dim observation, reset those envs, re-render them
+            infos["final_obs"] = {"joint_positions": self._be.host(nat.F_JOINTS), "touch_sensors": self._be.host(nat.F_TOUCH)}
+            infos["_final_obs"] = truncated.copy()
+            self._be.reset(truncated.astype(np.uint8))
+            self._steps[truncated] = 0
+            if render:
+                self._be.render()
+        return self._obs(render), np.zeros(n), np.zeros(n, bool), truncated, infos
 
     def close(self, **kwargs):
         self._be.close()

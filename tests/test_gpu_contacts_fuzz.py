@@ -144,7 +144,7 @@ def test_seeded_differential_run_contact_lists_bit_identical():
 
 
 def _grasp_script():
-    from real_robots_amd.kinematics import inverse_kinematics, quat_from_euler
+    from oracle.kinematics import inverse_kinematics, quat_from_euler
     orient = quat_from_euler(0, 3.14, -1.57)
     q_hi = inverse_kinematics(np.zeros(11), [-0.1, 0.0, 0.55], orient)
     q_lo = inverse_kinematics(q_hi, [-0.1, 0.0, 0.47], orient)

@@ -1,5 +1,5 @@
-"""GPU tests (-m gpu) of the K8 row: batched DLS IK and device-side macro plans, checked against the host numpy
-restatement (real_robots_amd/kinematics.py) and the reference's tracking known answers."""
+"""GPU tests (-m gpu) of the K8 row: batched DLS IK and device-side macro plans, checked against the numpy checker
+(oracle/kinematics.py -- test infrastructure, float64, same algorithm) and the reference's tracking known answers."""
 import json
 import os
 
@@ -8,13 +8,19 @@ import pytest
 
 from real_robots_amd import _native as nat
 from real_robots_amd.batched import BatchedREALRobotEnv
-from real_robots_amd.kinematics import EE_LINK, generate_plan, inverse_kinematics, link_pose, quat_from_euler
+from oracle.kinematics import EE_LINK, generate_plan, ik_candidates, inverse_kinematics, link_pose, quat_from_euler
 
 pytestmark = pytest.mark.gpu
 ORIENT = quat_from_euler(0, 3.14, -1.57)
 
 
+IK_TOL = 1e-3       # rad: device (float32) vs checker (float64) on the same branch, both converged
+
+
 def test_batched_ik_reaches_cartesian_targets():
+    """Every converged device solution reaches its target to the residual pybullet is asked for (1e-3, env.py:372-375) and
+    equals the checker's solution for the SAME seed to IK_TOL = 1e-3 rad in all seven joints; the seed the device picked is
+    the one the checker picks (converged first, then elbow height) unless the two keys tie to 1e-4 m."""
     N = 64
     env = BatchedREALRobotEnv(N, objects=1, width=64, height=64)
     rng = np.random.default_rng(4)
@@ -22,14 +28,27 @@ def test_batched_ik_reaches_cartesian_targets():
     tg = np.concatenate([pos, np.tile(ORIENT, (N, 1))], 1)
     q, err = env.ik(tg)
     assert (err < 2e-3).mean() > 0.95
-    same = 0
+    n_same, worst = 0, 0.0
     for i in range(N):
         if err[i] < 2e-3:
             assert np.linalg.norm(link_pose(q[i].astype(np.float64), EE_LINK)[1] - pos[i]) < 3e-3
-        if i < 8:      # branch agreement with the host numpy IK (same seeds, same selection rule)
-            qh = inverse_kinematics(np.zeros(11), pos[i], ORIENT)
-            same += int(np.abs(qh[:7] - q[i][:7]).max() < 5e-2)
-    assert same >= 6
+        cands = ik_candidates(np.zeros(11), pos[i], ORIENT)
+        conv = [c for c in cands if c[1] < 1e-2]
+        if not conv or not err[i] < 1e-2:
+            assert not conv and not err[i] < 1e-2, (i, err[i], [c[1] for c in cands])     # both sides agree that nothing converged
+            continue
+        # the device's solution is one of the checker's candidates (final iterate; or the iterate before it when that one's
+        # residual is within float32 rounding of the threshold, where the two precisions stop one update apart)
+        d = [min(np.abs(c[0][:7] - q[i][:7]).max(), np.abs(c[3][:7] - q[i][:7]).max() if abs(c[4] - 1e-3) < 2e-5 else np.inf)
+             for c in conv]
+        k = int(np.argmin(d))
+        assert d[k] < IK_TOL, (i, d, err[i])
+        worst = max(worst, d[k])
+        best = max(conv, key=lambda c: c[2])
+        assert conv[k][2] > best[2] - 1e-4, (i, "device picked another branch", conv[k][2], best[2])
+        n_same += 1
+    assert n_same >= 0.9 * N
+    print("device IK vs checker, same branch: worst %.2e rad over %d targets" % (worst, n_same))
     assert np.all(q[:, 7:] == 0)          # fingers keep their current values (pybullet returns all movable dofs)
     env.close()
 
@@ -48,7 +67,7 @@ def test_device_macro_plan_matches_host_plan_and_tracks_reference_checkpoints():
     assert plan0.shape == (1000, 9)
     host = generate_plan(np.zeros(11), pairs[0])
     assert np.abs(plan0[:100] - host[:100]).max() < 1e-6                        # home2 segment
-    assert np.abs(plan0 - host).max() < 5e-2                                    # same IK branches along the path
+    assert np.abs(plan0 - host).max() < IK_TOL                                  # same IK branches along the path, same solutions
     base = nat.LINK_NAMES.index('base')
     home = np.array([-0.55, 0.0, 1.27])
     for t in range(1000):

@@ -47,7 +47,7 @@ def test_free_motion_and_resting_contact_parity():
 
 
 def _grasp_script(q_home):
-    from real_robots_amd.kinematics import inverse_kinematics, quat_from_euler
+    from oracle.kinematics import inverse_kinematics, quat_from_euler
     orient = quat_from_euler(0, 3.14, -1.57)
     q_hi = inverse_kinematics(q_home, [-0.1, 0.0, 0.55], orient)
     q_lo = inverse_kinematics(q_hi, [-0.1, 0.0, 0.47], orient)
@@ -314,7 +314,7 @@ def test_piled_objects_generic_and_overflow_rows_match_oracle(pool, monkeypatch)
         o.set_object_pose(k, p.astype(np.float64))
         for i in range(N):
             env.set_object_pose(i, k, p)
-    from real_robots_amd.kinematics import inverse_kinematics, quat_from_euler
+    from oracle.kinematics import inverse_kinematics, quat_from_euler
     q = inverse_kinematics(np.zeros(11), [-0.1, 0.0, 0.50], quat_from_euler(0, 3.14, -1.57))
     cmd = np.concatenate([q[:7], [0.3, 0.0]]).astype(np.float32)
     max_objobj = max_nc = 0
@@ -498,7 +498,7 @@ def test_incremental_image_update_equals_full_copy(mode, W, H, monkeypatch):
                 m = np.zeros(N, np.uint8); m[5] = 1
                 env.reset(m)
             if t == 120:                            # a new camera: new static layer, the next frame starts from a full copy
-                from real_robots_amd.kinematics import look_at, perspective
+                from real_robots_amd.mathutil import look_at, perspective
                 env.set_camera(look_at(np.array([0.3, 0.2, 1.1]), np.array([0.0, 0.0, 0.2]), np.array([0.0, 0.0, 1.0])),
                                perspective(70.0, W / H, 0.1, 100.0))
             env.step(act, render=flags[t])

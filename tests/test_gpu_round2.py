@@ -16,7 +16,7 @@ def test_env_camera_view_matches_the_oracle_pixel_exact():
     env.py:83-90,470-513) against an oracle render through the same view / projection matrices: mask identical, RGB
     within one grey level (but for at most two texel-boundary pixels), depth within 1e-6 -- for the reset pose and after 80 steps of arm motion."""
     import real_robots_amd as rr
-    from real_robots_amd.kinematics import perspective, view_from_yaw_pitch_roll
+    from real_robots_amd.mathutil import perspective, view_from_yaw_pitch_roll
     env = rr.make('REALRobot2020-R1J3-v0', eye_width=64, eye_height=64)
     env.reset()
     view = view_from_yaw_pitch_roll([0, 0, .4], 1.2, 30, -30, 0)
@@ -175,7 +175,7 @@ def test_near_plane_clipping_matches_the_oracle(W, H):
     discards fragments nearer than the near plane -- the same coverage) instead of being dropped.  Postures that put the
     gripper at z = 1.02 .. 1.12 under the camera, plus the sweep between them: mask and depth identical, RGB within one grey
     level; the frames must actually contain geometry cut by the plane (depth ~ 0)."""
-    from real_robots_amd.kinematics import inverse_kinematics, quat_from_euler
+    from oracle.kinematics import inverse_kinematics, quat_from_euler
     targets = [[0.0, 0.0, 1.02], [0.0, 0.05, 1.08], [-0.05, 0.0, 1.12], [0.02, -0.04, 1.10]]
     qs = [inverse_kinematics(np.zeros(11), t, quat_from_euler(0, 0, 0)) for t in targets]
     frames = []
@@ -233,10 +233,14 @@ def test_dlpack_and_vector_env_adapter():
         assert rew.shape == (6,) and not term.any() and trunc.all() == (t == 4)
     # zero copy: the tensors made before the steps see the new observations
     venv._be.sync()
-    assert np.allclose(j.cpu().numpy(), venv._be.host(nat.F_JOINTS)) and float(j[0, 1]) > 0.05
+    assert np.allclose(j.cpu().numpy(), venv._be.host(nat.F_JOINTS))
     assert (rgb.cpu().numpy() == venv._be.host(nat.F_RGB)).all()
-    obs, rew, term, trunc, info = venv.step(act)               # truncated envs were reset at the start of this step
-    assert (venv._be.host(nat.F_TIMESTEP) == 1).all() and not trunc.any()
+    # same-step autoreset: the step that truncated the episodes returned their final low-dim observation in infos and reset them
+    assert info["_final_obs"].all() and float(info["final_obs"]["joint_positions"][0, 1]) > 0.05
+    assert (venv._be.host(nat.F_TIMESTEP) == 0).all() and abs(float(j[0, 1])) < 1e-6
+    obs, rew, term, trunc, info = venv.step(act)
+    assert (venv._be.host(nat.F_TIMESTEP) == 1).all() and not trunc.any() and info == {}
+    assert venv.action_space["joint_command"].shape == (6, 9) and venv.observation_space["joint_positions"].shape[0] == 6
     venv.close()
 
 

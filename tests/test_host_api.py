@@ -177,7 +177,7 @@ def test_spaces_standins():
 
 
 def test_model_blob_and_ik():
-    from real_robots_amd.kinematics import EE_LINK, inverse_kinematics, link_pose, quat_from_euler
+    from oracle.kinematics import EE_LINK, inverse_kinematics, link_pose, quat_from_euler
     from real_robots_amd.model import load_model
     m = load_model()
     assert tuple(m['dims'][:4]) == (11, 17, 22, 22)
@@ -279,5 +279,30 @@ def test_bench_bookkeeping_and_committed_profiles():
 
 def nat_names():
     from real_robots_amd import _native as nat
-    assert len(nat.KERNEL_NAMES) == nat.NUM_KERNELS == 9
+    assert len(nat.KERNEL_NAMES) == nat.NUM_KERNELS == 10
     return nat.KERNEL_NAMES
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: no module of the product package may import it (statically), and importing the whole
+    product -- facade, evaluate, goal generator, vector adapter, CLI -- must not pull it in (dynamically).  The IK / plan
+    checker lives in oracle/kinematics.py; the product plans on the device."""
+    import ast
+    import glob
+    import subprocess
+    import sys
+    pkg = os.path.join(ROOT, 'real_robots_amd')
+    for path in glob.glob(os.path.join(pkg, '**', '*.py'), recursive=True):
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            mods = []
+            if isinstance(node, ast.Import):
+                mods = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom) and node.level == 0:
+                mods = [node.module or '']
+            assert not any(m == 'oracle' or m.startswith('oracle.') for m in mods), path
+    assert not os.path.exists(os.path.join(pkg, 'kinematics.py'))
+    code = ("import sys; import real_robots_amd, real_robots_amd.evaluate, real_robots_amd.generate_goals, real_robots_amd.vector, "
+            "real_robots_amd.cli, real_robots_amd.envs.env, real_robots; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'")
+    subprocess.check_call([sys.executable, '-c', code], cwd=ROOT)

@@ -148,7 +148,7 @@ def test_out_of_bounds_object_reset():
 def test_mass_matrix_against_independent_numpy_formula():
     """M = sum_b m_b Jv_b^T Jv_b + Jw_b^T I_b Jw_b from host kinematics (different formulation from the oracle's
     composite-rigid-body recursion)."""
-    from real_robots_amd.kinematics import forward, PARENT
+    from oracle.kinematics import forward, PARENT
     from real_robots_amd.model import load_model
     m = load_model()
     rng = np.random.default_rng(5)
@@ -201,7 +201,7 @@ def test_touch_sensor_fires_when_gripper_closes_on_cube():
     for _ in range(100):
         o.step(None)
     # bring the gripper above the cube, open, descend, close (joint-space script)
-    from real_robots_amd.kinematics import inverse_kinematics, quat_from_euler
+    from oracle.kinematics import inverse_kinematics, quat_from_euler
     orient = quat_from_euler(0, 3.14, -1.57)
     def goto(z, grip, n):
         q = inverse_kinematics(o.state[:11], [-0.1, 0.0, z], orient)
@@ -254,7 +254,7 @@ def test_reference_macro_plan_tracking():
     into the home2 segment (raw_xy[849]); like the reference (which only prints "Failed!") it is not asserted.
     Perimeter points whose z = 0.6 way-point is out of reach with the gripper pointing down ((0.05, +-0.5)) are
     excluded."""
-    from real_robots_amd.kinematics import generate_plan
+    from oracle.kinematics import generate_plan
     o = Oracle(1, 32, 32)
     home = np.array(GOLD['reference_known_answers']['home_base'])
     for p1, p2 in [((-0.25, -0.5), (0.05, 0.0)), ((0.05, 0.0), (-0.25, 0.5))]:
@@ -517,7 +517,7 @@ def _edge_crossing_pose(gap=0.002, tilt_deg=-40.0):
     """Cube pose that puts one of its long edges across the shelf's front top edge (x = 0.079, z = 0.381, along y; shape
     `table_upper`), tilted so that both end points of the cube edge are outside the shelf's margin zone: returns (pose7,
     expected normal shelf -> cube, expected contact point)."""
-    from real_robots_amd.kinematics import quat_from_euler
+    from oracle.kinematics import quat_from_euler
     from real_robots_amd.model import load_model
     m = load_model()
     cube = int(m['dims'][2]) - 3                                                    # the objects are the last three shapes

@@ -3,7 +3,7 @@
 # rocprofv3 kernel stats, PMC HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes, never combined with other trace
 # domains), SQ VALU counters.  Output: gpurun_out/round/ ; traffic_latest.json and sq_latest.json carry the run
 # configuration so that bench.py only attaches them to runs of that configuration.  Usage: tools/profile_round.sh [tag]
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; mkdir -p $O
 cd $R && python bench.py --steps 200 --warmup 20 > $O/${TAG}_bench.json 2> $O/bench.err; tail -c 600 $O/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
@@ -24,7 +24,7 @@ def means(d):
     if not f: print('no counter csv in', d); return {}
     for row in csv.DictReader(open(f[0])):
         acc[(row['Kernel_Name'].split('(')[0], row['Counter_Name'])].append(float(row['Counter_Value']))
-    steps=max([len(v) for (k,c),v in acc.items() if k=='k_prep_a'] or [1])
+    steps=max([len(v) for (k,c),v in acc.items() if k=='k_cmd'] or [1])
     out={}
     for (k,c),v in acc.items(): out.setdefault(k,{})[c]={'mean': sum(v)/len(v), 'n': len(v), 'per_step': sum(v)/steps}
     return out
@@ -32,19 +32,21 @@ fe, wr, sq = means('pmc_fetch'), means('pmc_write'), means('sq')
 json.dump({'fetch': fe, 'write': wr}, open(O+'/%s_pmc_summary.json'%TAG,'w'), indent=1)
 json.dump(sq, open(O+'/%s_sq_counters.json'%TAG,'w'), indent=1)
 # HBM bytes per launch: (2*FETCH_SIZE + WRITE_SIZE) KB (MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts half of wide coalesced reads)
-tr={}
+tr={}; lo={}
 for k in set(fe)|set(wr):
     # bytes per STEP (a kernel launched for the light and again for the heavy envs counts with all its launches)
     f=fe.get(k,{}).get('FETCH_SIZE',{}).get('per_step',0.0); w=wr.get(k,{}).get('WRITE_SIZE',{}).get('per_step',0.0)
-    tr[k]=round((2*f+w)*1024)
-tr['render_stage']=tr.get('k_raster',0)+tr.get('k_shade',0)+tr.get('k_render_list',0)+tr.get('k_raster_list',0)
-tr['k_prep']=tr.get('k_prep_a',0)+tr.get('k_prep_b',0)+tr.get('k_balance',0)
+    tr[k]=round((2*f+w)*1024); lo[k]=round((f+w)*1024)
+for d in (tr, lo):
+    d['render_stage']=d.get('k_raster',0)+d.get('k_shade',0)+d.get('k_render_list',0)+d.get('k_raster_list',0)+d.get('k_render_setup',0)
+    d['k_prep']=d.get('k_prep_a',0)+d.get('k_prep_b',0)+d.get('k_cmd',0)
+tr['lower_bound']=lo
 tr['config']=cfg; tr['source']=TAG+'_pmc_summary.json'
-tr['_note']="HBM bytes per step from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), (2*FETCH_SIZE + WRITE_SIZE) * 1024, all launches of a kernel in a step added up (the first untimed frames included in the mean); render_stage = k_raster + k_shade + the heavy envs' k_render_list / k_raster_list; only valid for `config`"
+tr['_note']="HBM bytes per step from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), all launches of a kernel in a step added up (the first untimed frames included in the mean). Top level: (2*FETCH_SIZE + WRITE_SIZE) * 1024 -- the guide's gfx950 correction, which is calibrated for 16-byte-per-lane coalesced streaming reads only (here: k_solve's contact records and row stream, k_static_copy); `lower_bound`: (FETCH_SIZE + WRITE_SIZE) * 1024, no correction -- for kernels whose reads are scattered 4/8/16-byte records (k_raster, k_shade, k_collide, k_prep_*) the truth lies between the two. render_stage = k_render_setup + k_raster + k_shade + the heavy envs' k_render_list / k_raster_list; only valid for `config`"
 json.dump(tr, open(O+'/traffic_latest.json','w'), indent=1)
 sv={'config': cfg, 'source': TAG+'_sq_counters.json', 'valu_wave_instr_per_launch': {k: round(v['SQ_INSTS_VALU']['mean']) for k,v in sq.items() if 'SQ_INSTS_VALU' in v}}
 json.dump(sv, open(O+'/sq_latest.json','w'), indent=1)
-for k in ('k_raster','k_shade','k_solve','k_collide','k_prep_a','k_prep_b','k_render_setup'):
+for k in ('k_raster','k_shade','k_solve','k_collide','k_prep_a','k_prep_b','k_cmd','k_render_setup','k_render_list'):
     r={c: x['mean'] for c,x in sq.get(k,{}).items()}
     if not r: continue
     wc=r.get('SQ_WAVE_CYCLES',0) or 1
