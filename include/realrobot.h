@@ -149,6 +149,11 @@ int rr_link_poses(rr_env *env, float *out_host);
  * warm start matches its contacts against (Bullet: persistent manifolds, m_warmstartingFactor 0.85). */
 int rr_get_contacts(rr_env *env, int32_t env_index, float *out_host, int32_t max_contacts, int32_t *count);
 
+/* Replaces REALRobotEnv.evaluateGoal (env.py:181-200) for all envs at once: score[i] = sum over the objects o of env i whose
+ * goal_mask byte is non-zero (NULL: every object) of exp(-(ln 4 / 0.10) * |goal_pos[i][o] - position[i][o]|), computed on the
+ * device from the state.  goal_pos: f32 [N, n_obj, 3] (host), goal_mask: u8 [N, n_obj] (host), score_out: f32 [N] (host). */
+int rr_evaluate_goals(rr_env *env, const float *goal_pos_host, const uint8_t *goal_mask_host, float *score_out_host);
+
 /* Batched damped-least-squares inverse kinematics for link 7 (gripper `base`), seeded with each env's current joints.
  * Replaces pybullet.calculateInverseKinematics(0, 7, pos, orn, maxNumIterations=1000, residualThreshold=0.001) in
  * step_cartesian (env.py:372-375).  targets: f32 [N, 7] (xyz + xyzw quaternion, host); q_out: f32 [N, 11] (all movable

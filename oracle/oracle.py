@@ -29,7 +29,7 @@ class Params(C.Structure):
                 ('margin', C.c_double), ('motor_kp', C.c_double), ('motor_kd', C.c_double),
                 ('motor_max_force', C.c_double), ('lin_damping', C.c_double), ('ang_damping', C.c_double),
                 ('rest_threshold', C.c_double), ('use_urdf_inertia', C.c_int), ('edge_contacts', C.c_int),
-                ('warmstart', C.c_double)]
+                ('warmstart', C.c_double), ('no_rate_limit', C.c_int)]
 
 
 def build(force=False):

@@ -226,7 +226,8 @@ def macro_plan(ref, point_1, point_2):
     """generate_plan (env.py:414-457) with this env's IK; 1000 x 9."""
     home, home2 = np.zeros(9), np.zeros(9)
     home2[5] = home2[6] = np.pi / 2
-    orn = ref.p.getQuaternionFromEuler([0, 3.14, -1.57])
+    from real_robots_amd.mathutil import quat_from_euler          # = pybullet.getQuaternionFromEuler
+    orn = quat_from_euler(0, 3.14, -1.57)
 
     def go(xyz):
         return ref.inverse_kinematics(xyz, orn)[:9]
@@ -259,12 +260,65 @@ def seeded_actions(seed, steps, scale=1.0):
     return np.stack([synthetic_actions([seed], t)[0].astype(np.float64) * scale for t in range(steps)])
 
 
-def record(out_path, width=128, height=128):
-    """Golden vectors from a live PyBullet: per stream the action sequence, the state after every step, contacts and
-    touch sensors at chosen steps and rendered frames; plus the way-point distances of the 36-pair macro script."""
-    ref = PyBulletRef(3, width, height)
+GOLDEN_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'pybullet_golden.npz')
+GOLDEN_STREAMS = (('free_0.4', 7, 300, 0.4), ('full_1.0', 11, 400, 1.0))     # name, env id of the seeded commands, steps, command scale
+MACRO_CHECK_STEPS = (199, 249, 749, 799, 849, 899, 999)
+
+
+class OracleBackend:
+    """The recorder's backend interface on top of oracle/rr_oracle.c + oracle/kinematics.py: lets the recorder / consumer pair
+    be exercised end to end without pybullet (tests/test_pybullet_golden.py) -- what it records is NOT a PyBullet vector."""
+
+    def __init__(self, n_objects=3, width=128, height=128):
+        from oracle.oracle import Oracle
+        self.o = Oracle(n_objects, width, height)
+        self.n_objects = n_objects
+
+    def reset(self):
+        self.o.reset()
+        self._prefer = None
+
+    def step(self, action9=None):
+        self.o.step(action9)
+
+    def state61(self):
+        return self.o.state
+
+    def touch_sensors(self):
+        return self.o.obs()[1]
+
+    def contacts(self):
+        return self.o.contacts()
+
+    def render(self):
+        return self.o.render()
+
+    def link_position(self, name):
+        return self.o.link_pose(name)[:3]
+
+    def inverse_kinematics(self, pos, orn):
+        from oracle.kinematics import inverse_kinematics
+        if not hasattr(self, '_prefer'):
+            self._prefer = None
+        q = inverse_kinematics(np.zeros(11), pos, orn, prefer=self._prefer)
+        self._prefer = q
+        return q[:9]
+
+    def engine_parameters(self):
+        return {'backend': 'oracle/rr_oracle.c (NOT pybullet)'}
+
+    def close(self):
+        pass
+
+
+def record(out_path=None, width=128, height=128, backend=None):
+    """Golden vectors from a live PyBullet (default out_path: tests/golden/pybullet_golden.npz, where the tests pick them up
+    automatically): per stream the action sequence, the state after every step, touch sensors, the contacts of the last step and
+    a rendered frame; plus the gripper-base positions at the check steps of the 36-pair macro script."""
+    out_path = out_path or GOLDEN_PATH
+    ref = backend if backend is not None else PyBulletRef(3, width, height)
     gold = {'engine_parameters': repr(ref.engine_parameters())}
-    for name, acts in (('free_0.4', seeded_actions(7, 300, 0.4)), ('full_1.0', seeded_actions(11, 400, 1.0))):
+    for name, acts in ((n_, seeded_actions(sd, st, sc)) for n_, sd, st, sc in GOLDEN_STREAMS):
         ref.reset()
         states, touch = [], []
         for a in acts:
@@ -283,13 +337,33 @@ def record(out_path, width=128, height=128):
         row = []
         for t, a in enumerate(plan):
             ref.step(a)
-            if t in (199, 249, 749, 799, 849, 899, 999):
+            if t in MACRO_CHECK_STEPS:
                 row.append(ref.link_position('base'))
         way.append(np.concatenate([p1, p2] + row))
     gold['macro_waypoints'] = np.array(way)
     np.savez_compressed(out_path, **gold)
     ref.close()
     return out_path
+
+
+def divergence(gold, make_stepper, streams=GOLDEN_STREAMS):
+    """Replays the recorded action streams through another simulator and returns, per stream, the largest deviation of joints
+    / object positions from the recorded states in windows of 50 steps.  `make_stepper()` -> object with reset(), step(a),
+    state61().  Used by tests/test_pybullet_golden.py for the oracle and for the HIP path."""
+    out = {}
+    for name, _, steps, _ in streams:
+        acts, states = gold[name + '/actions'], gold[name + '/states']
+        sim = make_stepper()
+        sim.reset()
+        rows = []
+        for t, a in enumerate(acts):
+            sim.step(a)
+            d = np.abs(np.asarray(sim.state61(), dtype=np.float64) - states[t])
+            rows.append((d[:11].max(), max(d[22 + 13 * k: 25 + 13 * k].max() for k in range(3))))
+        rows = np.array(rows)
+        out[name] = {'joints_rad': [float(rows[i:i + 50, 0].max()) for i in range(0, len(rows), 50)],
+                     'object_pos_m': [float(rows[i:i + 50, 1].max()) for i in range(0, len(rows), 50)]}
+    return out
 
 
 def compare():
@@ -353,9 +427,9 @@ def cpu_baseline(seconds=10.0, cores=1, n_objects=3, width=128, height=128):
 if __name__ == '__main__':
     if not available():
         sys.exit("pybullet is not importable on this machine; nothing to do")
-    if len(sys.argv) > 2 and sys.argv[1] == 'record':
-        print(record(sys.argv[2]))
+    if len(sys.argv) > 1 and sys.argv[1] == 'record':
+        print(record(sys.argv[2] if len(sys.argv) > 2 else None))
     elif len(sys.argv) > 1 and sys.argv[1] == 'compare':
         compare()
     else:
-        sys.exit("usage: python -m oracle.pybullet_ref record OUT.npz | compare")
+        sys.exit("usage: python -m oracle.pybullet_ref record [OUT.npz, default tests/golden/pybullet_golden.npz] | compare")

@@ -236,7 +236,7 @@ static void inertia_world(real *Iw, const real *R, const real *I6) {
 void rro_default_params(rro_params *p) {
     p->dt = 0.005; p->gravity = 9.81; p->solver_iters = 50; p->erp = 0.2; p->margin = 0.02; p->edge_contacts = 1; p->warmstart = 0.85;
     p->motor_kp = 0.1; p->motor_kd = 1.0; p->motor_max_force = 100000.0;
-    p->lin_damping = 0.04; p->ang_damping = 0.04; p->rest_threshold = 0.2; p->use_urdf_inertia = 0;
+    p->lin_damping = 0.04; p->ang_damping = 0.04; p->rest_threshold = 0.2; p->use_urdf_inertia = 0; p->no_rate_limit = 0;
 }
 
 static void cpy_f(real *dst, const float *src, int n) { for (int i = 0; i < n; i++) dst[i] = (real)src[i]; }
@@ -1082,7 +1082,7 @@ int rro_step(rr_oracle *o, const double *action9) {
     }
     /* limitActionByJoint env.py:314-321 */
     calc_state9(o, cur);
-    for (int i = 0; i < 9; i++) {
+    for (int i = 0; i < 9 && !o->p.no_rate_limit; i++) {
         real d = a[i] - cur[i];
         if (d > m->act_maxdiff[i]) d = m->act_maxdiff[i];
         if (d < -m->act_maxdiff[i]) d = -m->act_maxdiff[i];

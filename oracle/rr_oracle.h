@@ -49,6 +49,7 @@ typedef struct rro_params {
     int use_urdf_inertia;   /* 0: Bullet AABB inertia for robot links (default); 1: URDF <inertia> */
     int edge_contacts;      /* 1                edge-edge candidates (0: vertex tests only) */
     double warmstart;       /* 0.85             Bullet m_warmstartingFactor on the matched normal impulses (0: cold start every step) */
+    int no_rate_limit;      /* 0                diagnostics (tests/golden/make_macro_sensitivity.py): 1 skips limitActionByJoint (env.py:314-321) */
 } rro_params;
 
 typedef struct rr_oracle rr_oracle;

@@ -8,7 +8,7 @@ __version__ = '0.1.0'
 import os
 
 from .registry import register, make, registered_ids  # noqa: F401
-from .policy import BasePolicy  # noqa: F401
+from .policy import BasePolicy, BatchedPolicy  # noqa: F401
 from .batched import BatchedREALRobotEnv  # noqa: F401
 from .envs import REALRobotEnv  # noqa: F401
 from .evaluate import evaluate, evaluate_batched  # noqa: F401

@@ -29,7 +29,7 @@ SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_objec
            'rr_get_buffer', 'rr_copy_to_host', 'rr_set_state', 'rr_sync', 'rr_link_poses', 'rr_get_contacts',
            'rr_set_timing', 'rr_get_timing', 'rr_last_error', 'rr_abi_version', 'rr_ik', 'rr_plan_macro', 'rr_get_plan',
            'rr_step_plan', 'rr_set_camera', 'rr_set_object_poses', 'rr_step_plan_masked', 'rr_checkpoint_bytes',
-           'rr_checkpoint_save', 'rr_checkpoint_restore')
+           'rr_checkpoint_save', 'rr_checkpoint_restore', 'rr_evaluate_goals')
 
 
 class Config(C.Structure):
@@ -97,6 +97,7 @@ def load_library():
     L.rr_set_camera.argtypes = [vp, vp, vp]
     L.rr_set_object_poses.argtypes = [vp, vp, vp]
     L.rr_step_plan_masked.argtypes = [vp, vp, i32, vp]
+    L.rr_evaluate_goals.argtypes = [vp, vp, vp, vp]
     L.rr_checkpoint_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.rr_checkpoint_save.argtypes = [vp, vp, C.c_size_t]
     L.rr_checkpoint_restore.argtypes = [vp, vp, C.c_size_t]

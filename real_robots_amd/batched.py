@@ -148,6 +148,19 @@ class BatchedREALRobotEnv:
         assert p.shape == (7,)
         nat.check(self.L.rr_set_object_home(self.h, -1 if env is None else int(env), int(obj), p.ctypes.data))
 
+    def evaluate_goals(self, goal_pos, goal_mask=None):
+        """REALRobotEnv.evaluateGoal (env.py:181-200) for the whole batch, on the device: goal_pos [N, n_objects, 3], goal_mask
+        [N, n_objects] (None: every object counts) -> scores float32 [N]."""
+        g = np.ascontiguousarray(goal_pos, dtype=np.float32)
+        assert g.shape == (self.N, self.n_objects, 3)
+        m = None
+        if goal_mask is not None:
+            m = np.ascontiguousarray(goal_mask, dtype=np.uint8)
+            assert m.shape == (self.N, self.n_objects)
+        out = np.empty(self.N, np.float32)
+        nat.check(self.L.rr_evaluate_goals(self.h, g.ctypes.data, m.ctypes.data if m is not None else None, out.ctypes.data))
+        return out
+
     def link_poses(self):
         out = np.empty((self.N, len(nat.LINK_NAMES), 7), np.float32)
         nat.check(self.L.rr_link_poses(self.h, out.ctypes.data))

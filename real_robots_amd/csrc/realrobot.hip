@@ -2156,6 +2156,23 @@ __global__ void k_set_object_poses(SimParams P, DevPtrs D, const float *poses, c
     }
 }
 
+// REALRobotEnv.evaluateGoal (env.py:181-200) for every env: sum over the goal's objects of exp(-(ln 4 / 0.10) |p_goal - p|)
+__global__ void k_goal_score(SimParams P, DevPtrs D, const float *goal_pos /*[N][nobj][3]*/, const unsigned char *goal_mask /*[N][nobj] or nullptr*/, float *score) {
+    const int N = P.N;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    const float *state = D.state;
+    const float pos_const = 13.862943611198906f;        // -log(0.25) / 0.10: the score falls to 0.25 within 10 cm
+    float sc = 0.0f;
+    for (int i = 0; i < P.nobj; i++) {
+        if (goal_mask && !goal_mask[(size_t)env * P.nobj + i]) continue;
+        const float *g = goal_pos + ((size_t)env * P.nobj + i) * 3;
+        const float dx = g[0] - STT(ST_OPOS + 3 * i), dy = g[1] - STT(ST_OPOS + 3 * i + 1), dz = g[2] - STT(ST_OPOS + 3 * i + 2);
+        sc += expf(-pos_const * sqrtf(dx * dx + dy * dy + dz * dz));
+    }
+    score[env] = sc;
+}
+
 // ---------------------------------------------------------------------------------------------- render setup
 // Instance transforms for the rasteriser, one thread per (env, instance): a robot-link thread composes the joint
 // transforms of its body's ancestors only (same operations, in the same order, as fk_all() for that chain), an object
@@ -3387,6 +3404,7 @@ struct rr_env {
     float *link_out;         // [N][nl][7]
     IkModel IK;
     float *plan; int *plan_step; float *ik_in; float *ik_out; float *ik_err;   // lazily allocated (macro / cartesian adapters)
+    float *score_out; unsigned char *score_mask;                               // lazily allocated (rr_evaluate_goals)
     std::vector<void *> allocs;
     bool timing;
     bool full_copy, sep_restore;   // RR_FULL_COPY / RR_SEPARATE_RESTORE at create: the two earlier image-update schemes (tests, A/B)
@@ -3572,6 +3590,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->split_max_pct = getenv("RR_SPLIT_MAX_PCT") ? atoi(getenv("RR_SPLIT_MAX_PCT")) : 60;
     if (hipHostMalloc((void **)&e->h_hcount, sizeof(int), hipHostMallocMapped) == hipSuccess) *e->h_hcount = 0; else e->h_hcount = nullptr;
     e->plan = nullptr; e->plan_step = nullptr; e->ik_in = nullptr; e->ik_out = nullptr; e->ik_err = nullptr;
+    e->score_out = nullptr; e->score_mask = nullptr;
     e->cfg = *cfg;
     e->stream = (hipStream_t)stream;
     const int N = cfg->num_envs;
@@ -4290,6 +4309,22 @@ int rr_get_contacts(rr_env *e, int32_t env_index, float *out_host, int32_t max_c
         o[3] = r[0]; o[4] = r[1]; o[5] = r[2]; o[6] = r[3]; o[7] = r[4]; o[8] = r[5]; o[9] = r[6]; o[10] = force[c]; o[11] = r[8];
     }
     *count = nc;
+    return RR_OK;
+}
+
+int rr_evaluate_goals(rr_env *e, const float *goal_pos_host, const uint8_t *goal_mask_host, float *score_out_host) {
+    if (!e || !goal_pos_host || !score_out_host) return fail(RR_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t N = e->P.N, nobj = e->P.nobj;
+    int rc;
+    if (!e->score_out && ((rc = dev_alloc(e, &e->score_out, N)) != RR_OK || (rc = dev_alloc(e, &e->score_mask, N * NOBJ)) != RR_OK)) return rc;
+    static_assert(NSTATE >= NOBJ * 3, "the state staging buffer doubles as goal-position staging");
+    HIPCHK(hipMemcpyAsync(e->state_aos, goal_pos_host, N * nobj * 12, hipMemcpyHostToDevice, e->stream));
+    if (goal_mask_host) HIPCHK(hipMemcpyAsync(e->score_mask, goal_mask_host, N * nobj, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_goal_score, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D, e->state_aos, goal_mask_host ? e->score_mask : nullptr, e->score_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(score_out_host, e->score_out, N * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return RR_OK;
 }
 

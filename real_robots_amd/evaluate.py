@@ -7,7 +7,7 @@ evaluation-state dictionary keeps the reference schema (evaluate.py:100-121) and
 """
 import numpy as np
 
-from .policy import BasePolicy
+from .policy import BasePolicy, BatchedPolicy
 from .registry import make
 
 
@@ -174,6 +174,9 @@ def evaluate_batched(Controller, num_envs, environment='R1', action_type='macro_
     (evaluate.py:249-259, 282-324; env.py:181-200). Observations are assembled on the host per env; the retina is
     only rendered/fetched on the steps where `render_every` divides the step index (0: never) -- policies that need
     images every step should consume the device buffers of `BatchedREALRobotEnv` instead.
+    A `Controller` derived from `real_robots_amd.policy.BatchedPolicy` takes the batched path instead: ONE controller
+    object, one `step()` call per step for all envs, images stay on the device, the only per-step read-back is the
+    low-dimensional observation, goal scores are computed on the device (rr_evaluate_goals) -- BASELINE config 5 at 4096 envs.
     Returns (score_object, scores) aggregated over all envs and trials."""
     from . import _native as nat
     from .batched import BatchedREALRobotEnv, OBJECT_NAMES
@@ -184,6 +187,10 @@ def evaluate_batched(Controller, num_envs, environment='R1', action_type='macro_
         raise Exception("Action type cannot be macro_action in Round 2")
     if action_type not in ('joints', 'macro_action'):
         raise Exception("evaluate_batched supports 'joints' and 'macro_action'")
+    if isinstance(Controller, type) and issubclass(Controller, BatchedPolicy):
+        return _evaluate_batched_policy(Controller, num_envs, environment, action_type, n_objects, intrinsic_timesteps,
+                                        extrinsic_timesteps, extrinsic_trials, goals_dataset_path, eye_width, eye_height,
+                                        device, render_every)[:2]
     if not issubclass(Controller, BasePolicy):
         raise Exception("Supplied Controller is not a Sub-Class of real_robots.policy.BasePolicy")
     proto = REALRobotEnv(objects=n_objects, action_type=action_type, additional_obs=(environment == 'R1'),
@@ -274,3 +281,167 @@ def evaluate_batched(Controller, num_envs, environment='R1', action_type='macro_
         total += r
     score_object["score_total"] = np.mean(total) if total else float('nan')
     return score_object, scores
+
+
+def _score_object(scores):
+    total, score_object = [], {}
+    for key in ['2D', '2.5D', '3D']:
+        r = scores.get(key, [])
+        score_object["score_{}".format(key)] = np.mean(r) if r else 0
+        total += r
+    score_object["score_total"] = np.mean(total) if total else float('nan')
+    return score_object
+
+
+def _evaluate_batched_policy(Controller, num_envs, environment, action_type, n_objects, intrinsic_timesteps,
+                             extrinsic_timesteps, extrinsic_trials, goals_dataset_path, eye_width, eye_height, device,
+                             render_every, env=None):
+    """The batched-policy path of evaluate_batched (phases: evaluate.py:203-324 of the reference; goal set-up env.py:151-166;
+    scoring env.py:181-200).  Per step: one `Controller.step` call, one rr_step / rr_step_plan, one read-back of joints +
+    touch (+ object poses in R1).  Env i walks the goal list from goal i (cyclically), trial k takes goal (i + k) % len(goals).
+    Returns (score_object, scores, per_env_scores [trials][N], timing dict)."""
+    import time
+    from . import _native as nat
+    from .batched import BatchedREALRobotEnv, OBJECT_NAMES
+    from .envs.env import REALRobotEnv
+    proto = REALRobotEnv(objects=n_objects, action_type=action_type, additional_obs=(environment == 'R1'),
+                         eye_width=eye_width, eye_height=eye_height, device=device)
+    proto.set_goals_dataset_path(goals_dataset_path)
+    proto.load_goals()
+    goals = list(proto.goals)
+    names = OBJECT_NAMES[:n_objects]
+    N = int(num_envs)
+    own_env = env is None
+    if own_env:
+        env = BatchedREALRobotEnv(N, objects=n_objects, width=eye_width, height=eye_height, device=device,
+                                  want_mask=(environment == 'R1'))
+    ctrl = Controller(N, proto.action_space, proto.observation_space)
+    r1 = environment == 'R1'
+    dev_imgs = {"retina": env.device_buffer(nat.F_RGB), "depth": env.device_buffer(nat.F_DEPTH)}
+    if r1:
+        dev_imgs["mask"] = env.device_buffer(nat.F_MASK)
+    H, W = eye_height, eye_width
+    # per-goal arrays, gathered once: positions of the final state (NaN: object not named), which objects count, start poses
+    G = len(goals)
+    g_final = np.full((G, n_objects, 3), np.nan, np.float32)
+    g_mask = np.zeros((G, n_objects), np.uint8)
+    g_init = np.full((G, n_objects, 7), np.nan, np.float32)
+    for k, g in enumerate(goals):
+        for n_, pose in g.final_state.items():
+            if n_ in names:
+                g_final[k, names.index(n_)] = np.asarray(pose, np.float32)[:3]
+                g_mask[k, names.index(n_)] = 1
+        for n_, pose in g.initial_state.items():
+            if n_ in names:
+                g_init[k, names.index(n_)] = np.asarray(pose, np.float32)
+    challenges = [g.challenge for g in goals]
+    zero_goal = np.zeros((N, H, W, 3), np.uint8)
+    timing = {"env_steps": 0, "step_seconds": 0.0}
+
+    def observations(goal_idx, goal_img):
+        obs = {"joint_positions": env.host(nat.F_JOINTS), "touch_sensors": env.host(nat.F_TOUCH), "goal": goal_img}
+        obs.update(dev_imgs)
+        if r1:
+            obs["object_positions"] = env.host(nat.F_OBJ_POSE)
+            obs["goal_positions"] = g_final[goal_idx] if goal_idx is not None else None
+        return obs
+
+    def run_phase(n_steps, goal_idx, goal_img):
+        obs = observations(goal_idx, goal_img)
+        done = False
+        t0 = time.perf_counter()
+        for t in range(int(n_steps)):
+            act = ctrl.step(obs, 0, done)
+            rendered = bool(render_every) and (t % render_every == 0)
+            if isinstance(act, dict):
+                rendered = rendered or bool(np.any(act.get("render", False)))
+                act = act["macro_action" if action_type == 'macro_action' else "joint_command"]
+            if hasattr(act, 'detach'):                       # a torch tensor: the actions are tiny, bring them to the host
+                act = act.detach().cpu().numpy()
+            if action_type == 'macro_action':
+                env.step_macro(np.asarray(act, dtype=np.float64).reshape(N, 2, 2), render=rendered)
+            else:
+                env.step(np.asarray(act, dtype=np.float32).reshape(N, 9), render=rendered)
+            done = (t + 1) >= n_steps
+            obs = observations(goal_idx, goal_img)
+        env.sync()
+        timing["env_steps"] += N * int(n_steps)
+        timing["step_seconds"] += time.perf_counter() - t0
+        return obs
+
+    scores, per_env = {}, []
+    if intrinsic_timesteps and intrinsic_timesteps > 0:
+        env.reset()
+        ctrl.start_intrinsic_phase()
+        obs = run_phase(intrinsic_timesteps, None, zero_goal)
+        ctrl.end_intrinsic_phase(obs, 0, True)
+    ctrl.start_extrinsic_phase()
+    for trial in range(int(extrinsic_trials)):
+        env.reset()
+        gi = (np.arange(N) + trial) % G
+        start = env.host(nat.F_OBJ_POSE)                     # one upload for the whole batch (env.py:159-162 per env)
+        named = ~np.isnan(g_init[gi][:, :, 0])
+        start[named] = g_init[gi][named]
+        env.set_object_poses(start)
+        goal_img = np.stack([goals[k].retina for k in gi]) if N <= 256 else _goal_images(goals, gi, H, W)
+        ctrl.start_extrinsic_trial()
+        obs = run_phase(extrinsic_timesteps, gi, goal_img)
+        sc = env.evaluate_goals(np.nan_to_num(g_final[gi]), g_mask[gi]).astype(np.float64)      # on the device (env.py:181-200)
+        per_env.append(sc)
+        for i in range(N):
+            scores.setdefault(challenges[gi[i]], []).append(float(sc[i]))
+        ctrl.end_extrinsic_trial(obs, 0, True)
+    ctrl.end_extrinsic_phase()
+    if own_env:
+        env.close()
+    proto.close()
+    return _score_object(scores), scores, per_env, timing
+
+
+def _goal_images(goals, gi, H, W):
+    """[N, H, W, 3] goal retinas for a large batch without stacking N Python objects twice: one row per distinct goal, indexed."""
+    uniq, inv = np.unique(gi, return_inverse=True)
+    table = np.stack([goals[k].retina for k in uniq])
+    return table[inv]
+
+
+def bench_evaluate_batched(num_envs, device=0, width=128, height=128, intrinsic=200, trials=2, extrinsic=200, n_goals=512, seed=2020):
+    """bench.py's config-5 leg: a seeded synthetic goals dataset (generate_goals on the batched simulator, reference file format),
+    a BatchedPolicy that draws a new uniform macro action per env every 100 steps, evaluate_batched end to end.  Returns the
+    `secondary` entry (env-steps/s of the stepping loops incl. policy calls and observation read-back)."""
+    import os
+    import tempfile
+    import time
+    from .generate_goals import generate_goals, save_goals
+    from .registry import make  # noqa: F401
+
+    class RandomMacro(BatchedPolicy):
+        def __init__(self, n, a, o):
+            super().__init__(n, a, o)
+            self.rng = np.random.default_rng(seed)
+            self.t = 0
+            self.cur = None
+
+        def step(self, observations, reward, done):
+            if self.cur is None or self.t % 100 == 0:
+                self.cur = self.rng.uniform([-0.25, -0.5], [0.05, 0.5], size=(self.num_envs, 2, 2))      # macro_space, env.py:49-52
+            self.t += 1
+            return self.cur
+
+    t0 = time.perf_counter()
+    path = os.path.join(tempfile.gettempdir(), 'rr_goals_s%d_n%d_%dx%d.npy.npz' % (seed, n_goals, width, height))
+    if not os.path.exists(path):
+        n2, n25 = n_goals // 2, (3 * n_goals) // 10
+        goals = generate_goals(n_2d_goals=n2, n_25d_goals=n25, n_3d_goals=n_goals - n2 - n25, n_obj=3, seed=seed,
+                               batch=min(2048, max(64, n_goals)), width=width, height=height, device=device, max_rounds=80)
+        save_goals(path, goals)
+    t_goals = time.perf_counter() - t0
+    so, scores, per_env, timing = _evaluate_batched_policy(RandomMacro, num_envs, 'R1', 'macro_action', 3, intrinsic, extrinsic, trials,
+                                                          path, width, height, device, 0)
+    return {"workload": "config 5 end to end: real_robots.evaluate_batched, REALRobot2020-R1M3, %d envs, one BatchedPolicy (uniform macro "
+                        "actions, a new one every 100 steps), intrinsic phase %d steps + %d extrinsic trials x %d steps, %d seeded synthetic "
+                        "goals (generate_goals, %dx%d), device-side scores" % (num_envs, intrinsic, trials, extrinsic, n_goals, width, height),
+            "value": round(timing["env_steps"] / timing["step_seconds"], 1), "unit": "env-steps/s",
+            "ms_per_step": round(timing["step_seconds"] / (timing["env_steps"] / num_envs) * 1e3, 4),
+            "steps": timing["env_steps"] // num_envs, "goal_dataset_seconds": round(t_goals, 1),
+            "score_total": float(so["score_total"]), "scores_per_challenge": {k: round(float(np.mean(v)), 4) for k, v in scores.items()}}

@@ -99,9 +99,7 @@ class _Drawer:
                 start[e, o] = pose
         env.reset()
         settle(env)
-        for e in range(N):
-            for o in range(n):
-                env.set_object_pose(e, o, start[e, o])
+        env.set_object_poses(start.astype(np.float32))           # one upload for the whole batch
         actual, failed = settle(env)
         env.render()
         retina, mask = env.host(nat.F_RGB), env.host(nat.F_MASK)
