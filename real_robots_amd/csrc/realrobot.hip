@@ -72,7 +72,7 @@ struct BodyParams {   // passed by value as kernel argument -> scalar loads, uni
 };
 
 struct SimParams {
-    int N, nobj, iters, npairs, ablate, small_area, os_cap, edge_contacts, heavy_min, heavy2_min;
+    int N, nobj, iters, npairs, ablate, small_area, os_cap, edge_contacts, heavy_min, heavy2_min, coop_build;
     float warmstart;   // Bullet's m_warmstartingFactor (0.85); 0: cold start every step   // os_cap: object-vs-static contacts per env with rows in LDS (<= OS_CAP)
     float dt, gravity, erp, margin, kp, kd, max_impulse, lin_damp, ang_damp, rest_thresh;
 };
@@ -689,6 +689,7 @@ extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
 #define CAND_MAX 128     // candidates kept per pair (the oracle applies the same cap)
 #define CSHAPES 24       // collision shapes staged in LDS (rr_create checks the model: 22)
 #define COLLIDE_WAVES_ 4
+#define VH_MAX 256          // cap of the very heavy list (k_collide), = waves of the coop form of k_solve's launch for it
 #ifdef RR_RASTER_STATS
 #define CABL(bit) (P.ablate & (bit))      // development build: phase ablations (256 stage only, 512 no pairs, 1024 cull only)
 // per-env phase cycles of k_collide (scratch/cprof.py): 0 stage, 1 sphere tests, 2 loads + cull, 3 prefilter, 4 all-plane pass,
@@ -1267,9 +1268,16 @@ __device__ __forceinline__ void collide_env(const SimParams &P, const DevPtrs &D
         ngen += max(oscnt0 - 4, 0) + max(oscnt1 - 4, 0) + max(oscnt2 - 4, 0);
         const bool heavy = ngen > P.heavy_min;
         D.ccount_next[env] = nct;
-        if (heavy && ngen > P.heavy2_min) { D.hgflag_next[env] = 2; D.hlist2_next[atomicAdd(D.hcount2_next, 1)] = env; }
-        else if (heavy) { D.hgflag_next[env] = 1; D.hlist_next[atomicAdd(D.hcount_next, 1)] = env; }
-        else D.hgflag_next[env] = 0;
+        // (the very heavy list is capped at VH_MAX entries -- its solve is launched with one wave per entry; beyond that an env is
+        // just "heavy": classes are scheduling, never a result)
+        bool vh = heavy && ngen > P.heavy2_min;
+        if (vh) {
+            const int sl = atomicAdd(D.hcount2_next, 1);
+            if (sl < VH_MAX) { D.hgflag_next[env] = 2; D.hlist2_next[sl] = env; }
+            else { atomicSub(D.hcount2_next, 1); vh = false; }
+        }
+        if (heavy && !vh) { D.hgflag_next[env] = 1; D.hlist_next[atomicAdd(D.hcount_next, 1)] = env; }
+        else if (!heavy) D.hgflag_next[env] = 0;
     }
 }
 // One workgroup per env of the class `sel` (pick_env): N workgroups whatever the class (a heavy list's length is known on the
@@ -1451,7 +1459,12 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
     const int N = P.N;
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // the wave's index in the launch
-    int env_raw = 4 * unit + (grp & 3);
+    // coop (very heavy envs, sel 3): ONE env per wave -- its four 16-lane groups build the rows of four contacts at a time (the
+    // row build of an env at the contact cap is a fifth of its chain with 16 lanes); group 0 then sweeps, groups 1..3 run along
+    // as no-ops.  Same arithmetic per row whichever group builds it: results do not depend on the mode (tested bitwise).
+    const bool coop = sel == 3 && P.coop_build;
+    const int cg = coop ? (grp & 3) : 0;                              // this group's place among the builders of its env
+    int env_raw = coop ? unit : 4 * unit + (grp & 3);
     bool mine = true;                                                 // this 16-lane group has an env to solve in this launch
     if (sel == 2) { mine = env_raw < *D.hcount; env_raw = mine ? D.hlist[env_raw] : N; }
     else if (sel == 3) { mine = env_raw < *D.hcount2; env_raw = mine ? D.hlist2[env_raw] : N; }
@@ -1459,12 +1472,12 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
     if (__ballot(mine) == 0ull) return;                               // (wave-uniform; the kernel has no workgroup barrier)
     const int env = env_raw < N ? env_raw : N - 1;                    // groups without an env run along as no-ops
     float *state = D.state, *scratch = D.scratch;
-    const bool dead = !mine || env_raw >= N || D.errflags[env] != 0;
+    bool dead = !mine || env_raw >= N || D.errflags[env] != 0;
     // an env whose command was rejected (robot.py:189) does not step; the list the look-ahead made for this step is dropped with
     // it, so that the normal forces of the last solved step (cforce) are never matched against a list they do not belong to
     if (mine && env_raw < N && l == 0 && (D.errflags[env] & 2u)) D.ccount[env] = 0;
     const ShapeData *S = D.shapes;
-    const int fix = grp * LF_TOTAL;
+    const int fix = (coop ? (grp & ~3) : grp) * LF_TOTAL;            // (coop: the four groups share the LDS region of the wave's first group)
     const int L_MINV = fix + LF_MINV, L_MOT = fix + LF_MOT, L_LIM = fix + LF_LIM, L_META = fix + LF_META, L_MU = fix + LF_MU,
               L_SPIN = fix + LF_SPIN, L_ROLL = fix + LF_ROLL, L_OSL = fix + LF_OSL, L_OST = fix + LF_OST, L_GSC = fix + LF_GSC,
               L_OBJ = fix + LF_OBJ, L_CST = fix + LF_CST;
@@ -1553,7 +1566,10 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int ci = 0; ci < 16 && 16 * bt + ci < nct; ci++, nc++) {
+        // (coop: group cg takes contact ci0 + cg of every quadruple; otherwise one contact per trip)
+        for (int ci0 = 0; ci0 < 16 && 16 * bt + ci0 < nct; ci0 += coop ? 4 : 1) {
+            const int ci = min(ci0 + cg, 15);
+            const bool have = 16 * bt + ci0 + cg < nct;             // (coop: the last quadruple may be short -- the group runs along, stores nothing)
             const float4 ra = *(const float4 *)&LD(L_CST + 12 * ci), rb_ = *(const float4 *)&LD(L_CST + 12 * ci + 4), rc = *(const float4 *)&LD(L_CST + 12 * ci + 8);
             const v3 x = mk(ra.x, ra.y, ra.z), n = mk(ra.w, rb_.x, rb_.y);
             const float dist = rb_.z;
@@ -1577,23 +1593,38 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
             }
             // the first KOS object-vs-static contacts of an object are swept by the object's lane, any further ones take the
             // generic path (rows of different objects commute, and an object's own rows keep their order: its pairs with
-            // the statics precede every other pair)
+            // the statics precede every other pair).  The slots are handed out in list order: with four builders each group
+            // replays the decisions of the quadruple's contacts (codes exchanged with v_readlane) and keeps the one of its own.
             const int obA = bodyA >= 16 ? bodyA - 16 : 0;
-            const bool fast = ospair && ((fcnt >> (4 * obA)) & 15u) < KOS && n_os < P.os_cap;
-            const int slot = fast ? n_os : ng;
+            const int code = have ? (1 | (ospair ? 2 : 0) | (obA << 2)) : 0;
+            bool fast = false;
+            int slot = 0, mync = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (j > 0 && !coop) break;
+                const int cj = coop ? __builtin_amdgcn_readlane(code, 16 * j) : code;
+                if (!(cj & 1)) continue;
+                const int ob_j = (cj >> 2) & 3;
+                const bool fast_j = (cj & 2) && ((fcnt >> (4 * ob_j)) & 15u) < KOS && n_os < P.os_cap;
+                const int slot_j = fast_j ? n_os : ng;
+                if (j == cg) { fast = fast_j; slot = slot_j; mync = nc; }
+                if (fast_j) {
+                    n_os++;
+                    fcnt += 1u << (4 * ob_j);
+                    if (lo_ >= 0 && ob_j == lo_) own_os |= 1u << slot_j;
+                } else ng++;
+                nc++;
+            }
             const int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | ((fast ? 1 : 0) << 24) | (slot << 25) |
                              (fabsf(dist) < 0.1f ? (int)0x80000000u : 0);        // robot.py:136 contact_threshold
-            if (l == 0) {
-                *(int *)&LD(L_META + nc) = meta;
+            if (l == 0 && have) {
+                *(int *)&LD(L_META + mync) = meta;
                 if (fast) { LD(L_MU + slot) = mu; LD(L_SPIN + slot) = spin; LD(L_ROLL + slot) = roll; }      // (generic rows carry their coefficient)
             }
             v3 t1, t2;
             plane_space(n, t1, t2);
             if (fast) {
                 // the three linear rows (n, t1, t2) and the three torsional rows about the same axes are built by lanes 0, 1, 2
-                n_os++;
-                fcnt += 1u << (4 * obA);
-                if (lo_ >= 0 && bodyA == 16 + lo_) own_os |= 1u << slot;
                 const v3 dir = l == 0 ? n : (l == 1 ? t1 : t2);
                 const v3 ang = cross(x - oA.op, dir);
                 const v3 mang = mulv(oA.Iinv, ang);
@@ -1612,7 +1643,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                 const float tdiag = dot(dir, tm);
                 const float tdinv = (coef > 0 && tdiag > 0) ? 1.0f / tdiag : 0.0f;
                 const float trhs = -dot(dir, oA.ws) * tdinv;
-                if (l < 3) {
+                if (l < 3 && have) {
                     float4 *bp4 = (float4 *)&LD(L_OSL + (3 * slot + l) * 12);
                     bp4[0] = make_float4(dir.x, dir.y, dir.z, ang.x);
                     bp4[1] = make_float4(ang.y, ang.z, mang.x, mang.y);
@@ -1623,8 +1654,9 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                 }
                 continue;
             }
-            // generic contact j = ng: six rows in the slot layout
-            const int r0 = 6 * ng;
+            if (!have) continue;
+            // generic contact j = slot: six rows in the slot layout
+            const int r0 = 6 * slot;
             if (bodyA >= 16) gobj |= 1u << (bodyA - 16);
             if (bodyB >= 16) gobj |= 1u << (bodyB - 16);
             GrowCtx gc;
@@ -1674,7 +1706,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                     const float diag = group_sum(ja * mja + jb * mjb);
                     const float rel = group_sum(ja * ua + jb * ub);
                     if (present) D.grows[((size_t)env * GROWS + r0 + kr) * 16 + l] = make_float4(ja, mja, jb, mjb);
-                    if (kr == 0) { wsA = fmaf(mja, lam0, wsA); wsB = fmaf(mjb, lam0, wsB); }
+                    if (kr == 0 && !coop) { wsA = fmaf(mja, lam0, wsA); wsB = fmaf(mjb, lam0, wsB); }      // (coop: replayed in list order below)
                     float rhsn;
                     if (kr == 0) {
                         float r = 0;
@@ -1690,10 +1722,21 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                     }
                 }
             }
-            ng++;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // the staging area is rewritten by the next batch
         __builtin_amdgcn_wave_barrier();
+    }
+    if (coop) {
+        // the warm-start velocity change of the generic normal rows, in list order, from the stored rows: the very fma sequence
+        // a single builder runs in line (each of the four builders holds only its own contacts' share)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (int j = 0; j < ng; j++) {
+            const float4 rw = D.grows[((size_t)env * GROWS + 6 * j) * 16 + l];
+            const float l0 = LD(L_GSC + 24 * j + 3);
+            wsA = fmaf(rw.y, l0, wsA); wsB = fmaf(rw.w, l0, wsB);
+        }
+        // groups 1..3 have done their part: from here on they run along without rows of their own and store nothing
+        if (cg != 0) { ng = 0; own_os = 0; n_os = 0; wsA = 0.0f; wsB = 0.0f; dead = true; }
     }
     SPROF(1);
     // ---- motor + limit rows: lane j < 11 builds the rows of joint j
@@ -1722,6 +1765,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
     unsigned limmask = 0;
 #pragma unroll
     for (int js = 0; js < 2 * NB; js++) if (LD(L_LIM + 2 * js) > -1e29f) limmask |= 1u << js;    // 22 independent LDS reads
+    if (coop && cg != 0) limmask = 0;            // (the limit rows live in the LDS region group 0 sweeps)
     // ---- PGS.  Lane state: dq (slot A: lanes 0..10 joints, lanes 11..15 object 2 during generic sweeps), vb (slot B), and
     // (dv, dw) of object lane-11 on lanes 11..13
     float dq = wsA, vb = wsB;          // (warm start: the inherited impulses of the generic normal rows are already applied)
@@ -3639,6 +3683,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     P.heavy_min = getenv("RR_HEAVY_MIN") ? atoi(getenv("RR_HEAVY_MIN")) : 0;
     P.heavy2_min = getenv("RR_HEAVY2_MIN") ? atoi(getenv("RR_HEAVY2_MIN")) : 16;      // generic contacts above which an env is "very heavy" (1000: never; A/B 6..30: 13-16 best)
     P.warmstart = getenv("RR_NO_WARMSTART") ? 0.0f : 0.85f;       // (diagnostics: cold start every step)
+    P.coop_build = getenv("RR_NO_COOP") ? 0 : 1;                  // (A/B, tests: very heavy envs four to a wave like the heavy ones)
     P.edge_contacts = getenv("RR_NO_EDGE_CONTACTS") ? 0 : 1;       // (diagnostics: vertex candidates only)
     P.os_cap = getenv("RR_SOLVER_POOL") ? std::max(0, std::min(atoi(getenv("RR_SOLVER_POOL")) / 60, (int)OS_CAP)) : OS_CAP;
     P.lin_damp = 0.04f; P.ang_damp = 0.04f; P.rest_thresh = 0.2f;
@@ -4088,6 +4133,8 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     TIMED(9, hipLaunchKernelGGL(k_cmd, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp));
     const int ngroups = (N + SGRP - 1) / SGRP;
     const size_t lds64 = (size_t)SGRP * LF_TOTAL * sizeof(float);
+    // the very heavy envs: one wave per env (coop build, <= VH_MAX of them: k_collide) or four to a wave like the heavy ones
+    const int vh_blocks = e->P.coop_build ? std::min(VH_MAX / 4, (N + 3) / 4) : (ngroups + 3) / 4;
     // (the number of heavy envs of a recent step, written to pinned host memory by k_cmd without anybody waiting for it: when most are
     // heavy -- macro actions, every gripper pushing -- there is nothing to gain from the split)
     const bool mostly_heavy = e->h_hcount && (long long)*(volatile int *)e->h_hcount * 100 > (long long)N * e->split_max_pct;
@@ -4106,7 +4153,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
             // look-ahead of the next step, which an untimed step runs under the render
             TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1));
             TIMED(7, { hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->stream, e->B, e->P, e->D, 2);
-                       hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->stream, e->B, e->P, e->D, 3); });
+                       hipLaunchKernelGGL(k_solve, dim3(vh_blocks), dim3(256), 4 * lds64, e->stream, e->B, e->P, e->D, 3); });
             launch_render(e, D, restore, 1, e->stream, true);
             TIMED(8, { launch_render(e, D, restore, 2, e->stream, false); launch_render(e, D, restore, 3, e->stream, false); });
             if (ahead) {
@@ -4119,7 +4166,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         }
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux2, e->ev_fork, 0);      // the longest chain first
-        hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->aux2, e->B, e->P, e->D, 3);
+        hipLaunchKernelGGL(k_solve, dim3(vh_blocks), dim3(256), 4 * lds64, e->aux2, e->B, e->P, e->D, 3);
         if (ahead) hipEventRecord(e->ev_solved[2], e->aux2);
         launch_render(e, D, restore, 3, e->aux2, false);
         hipEventRecord(e->ev_join2, e->aux2);
