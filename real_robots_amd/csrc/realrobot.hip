@@ -359,11 +359,13 @@ __device__ void fk_all(const BodyParams &bp_, const float *q, m3 *bR, v3 *bp, v3
 
 // ---------------------------------------------------------------------------------------------- k_cmd / k_prep
 // Which env a work item of a per-class launch handles: sel 0 all envs (idx = env); 1 the light envs (idx = env, others are
-// skipped); 2 / 3 entry idx of the heavy / very heavy list of the CURRENT contact frame.  -1: nothing to do.
+// skipped); 4 the light and the heavy ones; 2 / 3 entry idx of the heavy / very heavy list of the CURRENT contact frame.
+// -1: nothing to do.
 __device__ __forceinline__ int pick_env(const DevPtrs &D, int sel, int idx, int N) {
     if (idx >= N) return -1;
     if (sel == 0) return idx;
     if (sel == 1) return D.hgflag[idx] == 0 ? idx : -1;
+    if (sel == 4) return D.hgflag[idx] <= 1 ? idx : -1;
     if (sel == 2) return idx < D.hcount[0] ? D.hlist[idx] : -1;
     return idx < D.hcount2[0] ? D.hlist2[idx] : -1;
 }
@@ -609,6 +611,8 @@ __global__ void __launch_bounds__(64) k_prep_a(BodyParams B, SimParams P, DevPtr
     prep_class<1>(B, P, D, sel);
 }
 __global__ void __launch_bounds__(64) k_prep_b(BodyParams B, SimParams P, DevPtrs D, int sel) { prep_class<2>(B, P, D, sel); }
+// both phases in one launch (the look-ahead behind a class' solve: one kernel instead of two on that stream)
+__global__ void __launch_bounds__(64) k_prep_ab(BodyParams B, SimParams P, DevPtrs D, int sel) { prep_class<0>(B, P, D, sel); }
 
 // ---------------------------------------------------------------------------------------------- k_collide
 struct Xf { m3 R; v3 p; };
@@ -3458,16 +3462,14 @@ struct rr_env {
     bool images_valid;       // every env's image holds its previous frame (static layer + the pixels of its fragment list)
     hipEvent_t ev[2 * RR_NUM_KERNELS];
     hipStream_t aux;         // side stream: the HBM-bound static-layer copy runs beside the VALU-bound physics / visibility kernels
-    hipEvent_t ev_fork, ev_join, ev_dyn, ev_join2;
+    hipEvent_t ev_fork, ev_join, ev_dyn, ev_join2, ev_vsolved;
     hipStream_t aux2;              // the very heavy envs' solve + render (RR_HEAVY2_MIN)
-    // Look-ahead: the state part of step t+1 (k_prep_a, k_prep_b, k_collide) runs behind the solve of step t,
-    // class by class, under the render of step t -- on the streams la (k_prep_a -> k_collide) and la2 (k_prep_b).
+    // Look-ahead: the state part of step t+1 (k_prep_ab, k_collide) runs on the side streams behind the render
+    // of the heavy / very heavy envs of step t, beside the main stream's shading.
     struct Frame { float4 *clist; int *ccount; float *cwarm; int *hgflag, *hlist, *hcount, *hlist2, *hcount2; } fr[2];
     int cur;                       // fr[cur]: the frame of the last solved step (rr_get_contacts, contact history); fr[cur ^ 1]: the look-ahead's
     bool la_valid;                 // fr[cur ^ 1] and the scratch slab hold the collision pass / dynamics of the next step for the present state
     bool lookahead;                // RR_NO_LOOKAHEAD=1: never ahead, every step prepares itself in line (A/B, tests)
-    hipStream_t la, la2;
-    hipEvent_t ev_solved[3], ev_la, ev_la2;
     int n_shapes;
     float table_pos[3];            // target of the default eye camera (env.py:253-255)
     float t_ms[RR_NUM_KERNELS];
@@ -3541,12 +3543,9 @@ int rr_destroy(rr_env *e) {
     for (int i = 0; i < 2 * RR_NUM_KERNELS; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
     if (e->aux) { hipStreamSynchronize(e->aux); hipStreamDestroy(e->aux); }
     if (e->aux2) { hipStreamSynchronize(e->aux2); hipStreamDestroy(e->aux2); }
-    if (e->la) { hipStreamSynchronize(e->la); hipStreamDestroy(e->la); }
-    if (e->la2) { hipStreamSynchronize(e->la2); hipStreamDestroy(e->la2); }
-    if (e->ev_la) hipEventDestroy(e->ev_la);
-    if (e->ev_la2) hipEventDestroy(e->ev_la2);
-    for (int i = 0; i < 3; i++) if (e->ev_solved[i]) hipEventDestroy(e->ev_solved[i]);
+
     if (e->ev_join2) hipEventDestroy(e->ev_join2);
+    if (e->ev_vsolved) hipEventDestroy(e->ev_vsolved);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
     if (e->ev_dyn) hipEventDestroy(e->ev_dyn);
@@ -3629,7 +3628,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->sep_restore = getenv("RR_SEPARATE_RESTORE") != nullptr;
     e->split_heavy = getenv("RR_NO_SPLIT") == nullptr;
     e->lookahead = getenv("RR_NO_LOOKAHEAD") == nullptr;
-    e->la = nullptr; e->la2 = nullptr; e->ev_la = nullptr; e->ev_la2 = nullptr; memset(e->ev_solved, 0, sizeof e->ev_solved);
+
     e->h_hcount = nullptr;
     e->split_max_pct = getenv("RR_SPLIT_MAX_PCT") ? atoi(getenv("RR_SPLIT_MAX_PCT")) : 60;
     if (hipHostMalloc((void **)&e->h_hcount, sizeof(int), hipHostMallocMapped) == hipSuccess) *e->h_hcount = 0; else e->h_hcount = nullptr;
@@ -3860,13 +3859,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         auto side_stream = [&](hipStream_t *st) { return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio) == hipSuccess || hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess; };
         if (!side_stream(&e->aux) || hipEventCreateWithFlags(&e->ev_fork, evf) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_join, evf) != hipSuccess || hipEventCreateWithFlags(&e->ev_dyn, evf) != hipSuccess ||
-            !side_stream(&e->aux2) || hipEventCreateWithFlags(&e->ev_join2, evf) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
-        // the look-ahead streams: RR_LA_PRIORITY=1 gives them the side streams' priority (default: the main stream's)
-        const int la_prio = getenv("RR_LA_PRIORITY") && atoi(getenv("RR_LA_PRIORITY")) ? prio : prio_lo;
-        auto la_stream = [&](hipStream_t *st) { return hipStreamCreateWithPriority(st, hipStreamNonBlocking, la_prio) == hipSuccess || hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess; };
-        bool ok = la_stream(&e->la) && la_stream(&e->la2) && hipEventCreateWithFlags(&e->ev_la, evf) == hipSuccess && hipEventCreateWithFlags(&e->ev_la2, evf) == hipSuccess;
-        for (int i = 0; i < 3 && ok; i++) ok = hipEventCreateWithFlags(&e->ev_solved[i], evf) == hipSuccess;
-        if (!ok) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: look-ahead streams"); }
+            !side_stream(&e->aux2) || hipEventCreateWithFlags(&e->ev_join2, evf) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_vsolved, evf) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
     }
     e->field_ptr[RR_F_JOINTS] = D.joints; e->field_bytes[RR_F_JOINTS] = (size_t)N * 9 * 4;
     e->field_ptr[RR_F_TOUCH] = D.touch; e->field_bytes[RR_F_TOUCH] = (size_t)N * 4 * 4;
@@ -4071,9 +4065,29 @@ static void launch_prep_b(rr_env *e, int sel, hipStream_t st) {
 static void launch_collide(rr_env *e, int sel, hipStream_t st) {
     hipLaunchKernelGGL(k_collide, dim3(e->P.N), dim3(COLLIDE_THREADS), 0, st, e->P, e->D, e->n_shapes, sel);
 }
+static void launch_prep_ab(rr_env *e, int sel, hipStream_t st) {
+    hipLaunchKernelGGL(k_prep_ab, env_grid(e), dim3(e->epb), 0, st, e->B, e->P, e->D, sel);
+}
 static void launch_prep_serial(rr_env *e, int sel, int zero_counts) {
     launch_prep_a(e, sel, zero_counts, e->stream);
     launch_prep_b(e, sel, e->stream);
+}
+
+// The state part of a step for all envs on the main stream (k_prep_b beside k_collide on the side stream when `overlap`): at
+// the start of a step whose look-ahead is missing or stale, or at the end of a step that has a single class.
+static void state_part_all(rr_env *e, bool overlap) {
+    if (overlap) {
+        launch_prep_a(e, 0, 1, e->stream);
+        hipEventRecord(e->ev_fork, e->stream);
+        hipStreamWaitEvent(e->aux, e->ev_fork, 0);
+        launch_prep_b(e, 0, e->aux);
+        hipEventRecord(e->ev_dyn, e->aux);
+        launch_collide(e, 0, e->stream);
+        hipStreamWaitEvent(e->stream, e->ev_dyn, 0);
+    } else {
+        TIMED(0, launch_prep_serial(e, 0, 1));
+        TIMED(1, launch_collide(e, 0, e->stream));
+    }
 }
 
 // Next slot of the pinned ring (allocated on first use: N * 37 bytes per slot = commands + render flags).
@@ -4110,21 +4124,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     if (pin_idx >= 0) { HIPCHK(hipEventRecord(e->pin_ev[pin_idx], e->stream)); e->pin_used[pin_idx] = true; }
     const bool overlap = e->aux && !e->timing && !g_skip;      // side streams in use (timing leg / diagnostics: everything on the main stream)
     // ---- the state part of this step, unless the previous step already computed it (look-ahead) for exactly this state
-    if (!e->la_valid) {
-        if (overlap) {
-            // phase 1 on the main stream, phase 2 (dynamics, needed by k_solve only) on the side stream beside k_collide
-            launch_prep_a(e, 0, 1, e->stream);
-            hipEventRecord(e->ev_fork, e->stream);
-            hipStreamWaitEvent(e->aux, e->ev_fork, 0);
-            launch_prep_b(e, 0, e->aux);
-            hipEventRecord(e->ev_dyn, e->aux);
-            launch_collide(e, 0, e->stream);
-            hipStreamWaitEvent(e->stream, e->ev_dyn, 0);
-        } else {
-            TIMED(0, launch_prep_serial(e, 0, 1));
-            TIMED(1, launch_collide(e, 0, e->stream));
-        }
-    }
+    if (!e->la_valid) state_part_all(e, overlap);
     e->cur ^= 1; e->la_valid = false;           // the frame the collision pass filled is the one this step solves
     bind_frames(e);
     DevPtrs Dp = e->D;
@@ -4150,49 +4150,44 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         if (e->timing) {
             // timing leg: the very same launches, one after the other on the main stream, each under its timer -- 2 / 3 / 4 / 6
             // what the main stream runs in an untimed step (the light envs), 7 / 8 what the side streams run beside it, 0 / 1 the
-            // look-ahead of the next step, which an untimed step runs under the render
+            // look-ahead of the next step, which an untimed step runs on the heavy stream behind the heavy envs' render
             TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1));
             TIMED(7, { hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->stream, e->B, e->P, e->D, 2);
                        hipLaunchKernelGGL(k_solve, dim3(vh_blocks), dim3(256), 4 * lds64, e->stream, e->B, e->P, e->D, 3); });
             launch_render(e, D, restore, 1, e->stream, true);
             TIMED(8, { launch_render(e, D, restore, 2, e->stream, false); launch_render(e, D, restore, 3, e->stream, false); });
             if (ahead) {
-                TIMED(0, { launch_prep_serial(e, 1, 0); launch_prep_serial(e, 2, 0); launch_prep_serial(e, 3, 0); });
-                TIMED(1, { launch_collide(e, 1, e->stream); launch_collide(e, 2, e->stream); launch_collide(e, 3, e->stream); });
+                TIMED(0, launch_prep_ab(e, 0, e->stream));
+                TIMED(1, launch_collide(e, 0, e->stream));
                 e->la_valid = true;
             }
             HIPCHK(hipGetLastError());
             return RR_OK;
         }
+        // Look-ahead: behind the render of the heavy envs, the heavy stream runs the state part of the NEXT step
+        // for all envs -- by then every solve of this step has finished (light: long ago on the main stream; very heavy: event),
+        // and the collision pass runs beside the main stream's shading, whose workgroups leave the LDS free (beside the
+        // visibility pass it would only queue up behind the LDS-filling raster workgroups: measured, profiles/README.md).
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux2, e->ev_fork, 0);      // the longest chain first
         hipLaunchKernelGGL(k_solve, dim3(vh_blocks), dim3(256), 4 * lds64, e->aux2, e->B, e->P, e->D, 3);
-        if (ahead) hipEventRecord(e->ev_solved[2], e->aux2);
+        if (ahead) hipEventRecord(e->ev_vsolved, e->aux2);
         launch_render(e, D, restore, 3, e->aux2, false);
         hipEventRecord(e->ev_join2, e->aux2);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
         hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->aux, e->B, e->P, e->D, 2);
-        if (ahead) hipEventRecord(e->ev_solved[1], e->aux);
         launch_render(e, D, restore, 2, e->aux, false);
-        hipEventRecord(e->ev_join, e->aux);
         hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1);
-        if (ahead) hipEventRecord(e->ev_solved[0], e->stream);
-        launch_render(e, D, restore, 1, e->stream, false);
         if (ahead) {
-            // look-ahead, class by class in the order the solves finish: k_prep_a -> k_collide on `la`, k_prep_b on `la2`
-            for (int c = 0; c < 3; c++) {
-                hipStreamWaitEvent(e->la, e->ev_solved[c], 0);
-                launch_prep_a(e, 1 + c, 0, e->la);
-                launch_collide(e, 1 + c, e->la);
-                hipStreamWaitEvent(e->la2, e->ev_solved[c], 0);
-                launch_prep_b(e, 1 + c, e->la2);
-            }
-            hipEventRecord(e->ev_la, e->la);
-            hipEventRecord(e->ev_la2, e->la2);
-            hipStreamWaitEvent(e->stream, e->ev_la, 0);
-            hipStreamWaitEvent(e->stream, e->ev_la2, 0);
+            hipEventRecord(e->ev_dyn, e->stream);             // (the light envs' solve)
+            hipStreamWaitEvent(e->aux, e->ev_dyn, 0);
+            hipStreamWaitEvent(e->aux, e->ev_vsolved, 0);
+            hipLaunchKernelGGL(k_prep_ab, env_grid(e), dim3(e->epb), 0, e->aux, e->B, e->P, e->D, 0);
+            launch_collide(e, 0, e->aux);
             e->la_valid = true;
         }
+        hipEventRecord(e->ev_join, e->aux);
+        launch_render(e, D, restore, 1, e->stream, false);
         hipStreamWaitEvent(e->stream, e->ev_join, 0);
         hipStreamWaitEvent(e->stream, e->ev_join2, 0);
         HIPCHK(hipGetLastError());
@@ -4200,28 +4195,10 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     }
     TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 0));
     HIPCHK(hipGetLastError());
-    if (ahead && overlap) {
-        // all envs in one class: the look-ahead runs beside the render (if any) of this step
-        hipEventRecord(e->ev_solved[0], e->stream);
-        hipStreamWaitEvent(e->la, e->ev_solved[0], 0);
-        launch_prep_a(e, 0, 0, e->la);
-        launch_collide(e, 0, e->la);
-        hipEventRecord(e->ev_la, e->la);
-        hipStreamWaitEvent(e->la2, e->ev_solved[0], 0);
-        launch_prep_b(e, 0, e->la2);
-        hipEventRecord(e->ev_la2, e->la2);
-        int rc = RR_OK;
-        if (render_mode) rc = do_render(e, render_mode == 2);
-        hipStreamWaitEvent(e->stream, e->ev_la, 0);
-        hipStreamWaitEvent(e->stream, e->ev_la2, 0);
-        e->la_valid = true;
-        return rc;
-    }
     int rc = RR_OK;
     if (render_mode) rc = do_render(e, render_mode == 2);
-    if (ahead) {
-        TIMED(0, launch_prep_serial(e, 0, 0));
-        TIMED(1, launch_collide(e, 0, e->stream));
+    if (ahead) {                // (one class: nothing to run beside -- the state part of the next step follows in line)
+        state_part_all(e, overlap);
         e->la_valid = true;
     }
     return rc;

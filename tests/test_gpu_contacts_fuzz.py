@@ -31,7 +31,7 @@ def state_bounds(fmax):
     force of the step: (joints q / qd [rad, rad/s], object pose, object velocity).  Up to CRUSH_FORCE the bounds are the flat
     ones measured over 1200 seeded cases (about twice the worst seen: 1.6e-4 / 4.6e-7 / 1.8e-4); above it they scale with the
     force -- a rounding error of relative size 1e-7 in an impulse of f dt acts on the same inverse inertias."""
-    k = max(1.0, fmax / CRUSH_FORCE)
+    k = max(1.0, fmax / (2 * CRUSH_FORCE))      # (measured over 300 cases, 343 checks above 2 kN: at most 0.3 of these bounds)
     return 3e-4 * k, 1e-6 * k, 4e-4 * k
 
 

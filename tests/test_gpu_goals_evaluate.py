@@ -110,3 +110,74 @@ def test_generated_goals_are_rest_states_of_the_oracle_and_render_the_same():
                 assert np.linalg.norm(s[i, :3] - state[name][:3]) < 1e-3, (g.challenge, name, s[i, :3], state[name][:3])
                 qdot = abs(np.dot(s[i, 3:7], state[name][3:7]))
                 assert qdot > np.cos(np.radians(0.25)), (g.challenge, name, qdot)      # rotated by < 0.5 deg
+
+
+def test_evaluate_batched_at_4096_envs_matches_the_single_env_harness(tmp_path):
+    """BASELINE config 5 at its size: 4096 envs, REALRobot2020-R1M3 (macro actions, 3 objects), a seeded 4096-goal dataset
+    from generate_goals, ONE BatchedPolicy object driving all envs (images stay on the device, low-dim read-back only, scores
+    from rr_evaluate_goals on the device), intrinsic phase + 2 extrinsic trials.  Envs 0..7 reproduce the scores the single-env
+    harness (real_robots.evaluate, per-env BasePolicy, facade env) gets for the goals they were given."""
+    import time
+    import real_robots_amd as rr
+    from real_robots_amd.evaluate import _evaluate_batched_policy
+    from real_robots_amd.generate_goals import generate_goals, save_goals
+    N, W, H = 4096, 64, 64
+    t0 = time.time()
+    goals = generate_goals(n_2d_goals=2048, n_25d_goals=1229, n_3d_goals=819, n_obj=3, seed=2020, batch=2048, width=W, height=H,
+                           max_rounds=80)
+    assert len(goals) == N
+    path = str(tmp_path / 'goals4096.npy.npz')
+    save_goals(path, goals)
+    t_goals = time.time() - t0
+    macro = np.array([[-0.1, -0.25], [-0.1, 0.25]])
+    calls = []
+
+    class ScriptedB(rr.BatchedPolicy):
+        def start_intrinsic_phase(self):
+            calls.append('si')
+
+        def start_extrinsic_trial(self):
+            calls.append('st')
+
+        def end_extrinsic_trial(self, observations, reward, done):
+            calls.append('et')
+            assert done and observations["object_positions"].shape == (self.num_envs, 3, 7)
+
+        def step(self, observations, reward, done):
+            n = self.num_envs
+            assert observations["joint_positions"].shape == (n, 9) and observations["touch_sensors"].shape == (n, 4)
+            assert hasattr(observations["retina"], '__dlpack__') and observations["goal"].shape == (n, H, W, 3)
+            return np.broadcast_to(macro, (n, 2, 2))
+
+    t0 = time.time()
+    so, scores, per_env, timing = _evaluate_batched_policy(ScriptedB, N, 'R1', 'macro_action', 3, 200, 200, 2, path, W, H, 0, 0)
+    t_eval = time.time() - t0
+    print("config 5 at size: %d goals in %.1f s; evaluate_batched %.1f s, %.0f env-steps/s in the stepping loops"
+          % (N, t_goals, t_eval, timing["env_steps"] / timing["step_seconds"]))
+    assert calls == ['si', 'st', 'et', 'st', 'et'] and timing["env_steps"] == N * 600
+    del calls[:]
+    assert sum(len(v) for v in scores.values()) == 2 * N and set(scores) == {'2D', '2.5D', '3D'}
+    assert len(per_env) == 2 and per_env[0].shape == (N,) and 0 < so['score_total'] <= 3
+    # public entry point, same run
+    so2, scores2 = rr.evaluate_batched(ScriptedB, 64, environment='R1', action_type='macro_action', n_objects=3,
+                                       intrinsic_timesteps=20, extrinsic_timesteps=30, extrinsic_trials=1,
+                                       goals_dataset_path=path, eye_width=W, eye_height=H)
+    assert sum(len(v) for v in scores2.values()) == 64
+
+    class Scripted(rr.BasePolicy):
+        def step(self, observation, reward, done):
+            return {'macro_action': macro, 'render': False}
+
+    for i in range(8):
+        sub = str(tmp_path / ('g%d.npy.npz' % i))
+        save_goals(sub, [goals[i], goals[(i + 1) % N]])
+        _, sc = rr.evaluate(Scripted, environment='R1', action_type='macro_action', n_objects=3, intrinsic_timesteps=200,
+                            extrinsic_timesteps=200, extrinsic_trials=2, visualize=False, goals_dataset_path=sub,
+                            env_kwargs=dict(eye_width=W, eye_height=H))
+        flat = [sc[goals[i].challenge][0]] if goals[i].challenge != goals[(i + 1) % N].challenge else None
+        single = [s for k in (goals[i].challenge, goals[(i + 1) % N].challenge) for s in sc[k]]
+        if flat is None:
+            single = sc[goals[i].challenge]                   # both trials under one challenge, in trial order
+        else:
+            single = [sc[goals[i].challenge][0], sc[goals[(i + 1) % N].challenge][0]]
+        assert abs(single[0] - per_env[0][i]) < 1e-3 and abs(single[1] - per_env[1][i]) < 1e-3, (i, single, per_env[0][i], per_env[1][i])
