@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(64) k_cmd(BodyParams B, SimParams P, DevPtrs D
     float *state = D.state;
     if (env == 0) {
         // (the number of heavy envs of this step goes to pinned host memory on the way: a posted write, nobody waits for it)
-        if (D.hcount_host) *D.hcount_host = D.hcount[0];
+        if (D.hcount_host) { D.hcount_host[0] = D.hcount[0]; D.hcount_host[1] = D.hcount2[0]; }
         D.hcount_next[0] = 0; D.hcount_next[1] = 0; D.hcount2_next[0] = 0; D.hcount2_next[1] = 0;
     }
     if (D.errflags[env] & 1u) return;   // frozen env
@@ -693,7 +693,8 @@ extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
 #define CAND_MAX 128     // candidates kept per pair (the oracle applies the same cap)
 #define CSHAPES 24       // collision shapes staged in LDS (rr_create checks the model: 22)
 #define COLLIDE_WAVES_ 4
-#define VH_MAX 256          // cap of the very heavy list (k_collide), = waves of the coop form of k_solve's launch for it
+#define VH_MAX 1024         // cap of the very heavy list (k_collide)
+#define COOP_MAX 256        // lists up to this long (lagged host count) are solved one env per wave (coop row build); longer ones four to a wave
 #ifdef RR_RASTER_STATS
 #define CABL(bit) (P.ablate & (bit))      // development build: phase ablations (256 stage only, 512 no pairs, 1024 cull only)
 // per-env phase cycles of k_collide (scratch/cprof.py): 0 stage, 1 sphere tests, 2 loads + cull, 3 prefilter, 4 all-plane pass,
@@ -1459,14 +1460,16 @@ __device__ __forceinline__ float4 sel4(bool has, float4 v) {
 // 2: wave w of the launch handles the heavy envs 4 w .. 4 w + 3 of D.hlist -- packed four to a wave whichever groups they
 // come from (256-thread workgroups: sixteen heavy envs fill a CU's LDS and leave the other CUs to the render of the light
 // envs).  No result depends on which envs share a wave: only trip counts and the choice between equivalent code paths do.
-__global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtrs D, int sel) {
+__global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtrs D, int sel, int coop_launch) {
     const int N = P.N;
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // the wave's index in the launch
-    // coop (very heavy envs, sel 3): ONE env per wave -- its four 16-lane groups build the rows of four contacts at a time (the
-    // row build of an env at the contact cap is a fifth of its chain with 16 lanes); group 0 then sweeps, groups 1..3 run along
-    // as no-ops.  Same arithmetic per row whichever group builds it: results do not depend on the mode (tested bitwise).
-    const bool coop = sel == 3 && P.coop_build;
+    // coop (a heavy / very heavy list of at most COOP_MAX envs -- the host's lagged count decides, any actual count is handled):
+    // ONE env per wave -- its four 16-lane groups build the rows of four contacts at a time (the row build of an env at the
+    // contact cap is a fifth of its chain with 16 lanes); group 0 then sweeps, groups 1..3 run along as no-ops.  The wave has
+    // one LDS region (the launch asks for a quarter of the LDS of the packed form: the same sixteen envs per CU).  Same
+    // arithmetic per row whichever group builds it: results do not depend on the mode (tested bitwise).
+    const bool coop = sel >= 2 && coop_launch;
     const int cg = coop ? (grp & 3) : 0;                              // this group's place among the builders of its env
     int env_raw = coop ? unit : 4 * unit + (grp & 3);
     bool mine = true;                                                 // this 16-lane group has an env to solve in this launch
@@ -1481,7 +1484,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
     // it, so that the normal forces of the last solved step (cforce) are never matched against a list they do not belong to
     if (mine && env_raw < N && l == 0 && (D.errflags[env] & 2u)) D.ccount[env] = 0;
     const ShapeData *S = D.shapes;
-    const int fix = (coop ? (grp & ~3) : grp) * LF_TOTAL;            // (coop: the four groups share the LDS region of the wave's first group)
+    const int fix = (coop ? (grp >> 2) : grp) * LF_TOTAL;            // (coop: the four groups of a wave share its one LDS region)
     const int L_MINV = fix + LF_MINV, L_MOT = fix + LF_MOT, L_LIM = fix + LF_LIM, L_META = fix + LF_META, L_MU = fix + LF_MU,
               L_SPIN = fix + LF_SPIN, L_ROLL = fix + LF_ROLL, L_OSL = fix + LF_OSL, L_OST = fix + LF_OST, L_GSC = fix + LF_GSC,
               L_OBJ = fix + LF_OBJ, L_CST = fix + LF_CST;
@@ -3462,7 +3465,7 @@ struct rr_env {
     bool images_valid;       // every env's image holds its previous frame (static layer + the pixels of its fragment list)
     hipEvent_t ev[2 * RR_NUM_KERNELS];
     hipStream_t aux;         // side stream: the HBM-bound static-layer copy runs beside the VALU-bound physics / visibility kernels
-    hipEvent_t ev_fork, ev_join, ev_dyn, ev_join2, ev_vsolved;
+    hipEvent_t ev_fork, ev_join, ev_dyn, ev_join2, ev_vsolved, ev_hsolved;
     hipStream_t aux2;              // the very heavy envs' solve + render (RR_HEAVY2_MIN)
     // Look-ahead: the state part of step t+1 (k_prep_ab, k_collide) runs on the side streams behind the render
     // of the heavy / very heavy envs of step t, beside the main stream's shading.
@@ -3546,6 +3549,7 @@ int rr_destroy(rr_env *e) {
 
     if (e->ev_join2) hipEventDestroy(e->ev_join2);
     if (e->ev_vsolved) hipEventDestroy(e->ev_vsolved);
+    if (e->ev_hsolved) hipEventDestroy(e->ev_hsolved);
     if (e->ev_fork) hipEventDestroy(e->ev_fork);
     if (e->ev_join) hipEventDestroy(e->ev_join);
     if (e->ev_dyn) hipEventDestroy(e->ev_dyn);
@@ -3631,7 +3635,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
 
     e->h_hcount = nullptr;
     e->split_max_pct = getenv("RR_SPLIT_MAX_PCT") ? atoi(getenv("RR_SPLIT_MAX_PCT")) : 60;
-    if (hipHostMalloc((void **)&e->h_hcount, sizeof(int), hipHostMallocMapped) == hipSuccess) *e->h_hcount = 0; else e->h_hcount = nullptr;
+    if (hipHostMalloc((void **)&e->h_hcount, 2 * sizeof(int), hipHostMallocMapped) == hipSuccess) { e->h_hcount[0] = 0; e->h_hcount[1] = 0; } else e->h_hcount = nullptr;
     e->plan = nullptr; e->plan_step = nullptr; e->ik_in = nullptr; e->ik_out = nullptr; e->ik_err = nullptr;
     e->score_out = nullptr; e->score_mask = nullptr;
     e->cfg = *cfg;
@@ -3860,7 +3864,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         if (!side_stream(&e->aux) || hipEventCreateWithFlags(&e->ev_fork, evf) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_join, evf) != hipSuccess || hipEventCreateWithFlags(&e->ev_dyn, evf) != hipSuccess ||
             !side_stream(&e->aux2) || hipEventCreateWithFlags(&e->ev_join2, evf) != hipSuccess ||
-            hipEventCreateWithFlags(&e->ev_vsolved, evf) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
+            hipEventCreateWithFlags(&e->ev_vsolved, evf) != hipSuccess || hipEventCreateWithFlags(&e->ev_hsolved, evf) != hipSuccess) { rr_destroy(e); return fail(RR_EDEVICE, "rr_create: side stream"); }
     }
     e->field_ptr[RR_F_JOINTS] = D.joints; e->field_bytes[RR_F_JOINTS] = (size_t)N * 9 * 4;
     e->field_ptr[RR_F_TOUCH] = D.touch; e->field_bytes[RR_F_TOUCH] = (size_t)N * 4 * 4;
@@ -4073,6 +4077,19 @@ static void launch_prep_serial(rr_env *e, int sel, int zero_counts) {
     launch_prep_b(e, sel, e->stream);
 }
 
+// The solve of the heavy (sel 2) / very heavy (sel 3) envs on `st`.  A list the lagged host count puts at <= COOP_MAX entries is
+// launched in the coop form: one env per wave, four waves per workgroup with one LDS region each (N waves: whatever the
+// list's actual length, every entry has its wave; the others exit at once); a longer one four envs to a wave.
+static void launch_solve_class(rr_env *e, int sel, hipStream_t st) {
+    const int N = e->P.N;
+    const int ngroups = (N + SGRP - 1) / SGRP;
+    const size_t lds64 = (size_t)SGRP * LF_TOTAL * sizeof(float);
+    const int lagged = e->h_hcount ? ((volatile int *)e->h_hcount)[sel == 2 ? 0 : 1] : N;
+    const bool coop = e->P.coop_build && lagged <= COOP_MAX;
+    if (coop) hipLaunchKernelGGL(k_solve, dim3((N + 3) / 4), dim3(256), lds64, st, e->B, e->P, e->D, sel, 1);
+    else hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, st, e->B, e->P, e->D, sel, 0);
+}
+
 // The state part of a step for all envs on the main stream (k_prep_b beside k_collide on the side stream when `overlap`): at
 // the start of a step whose look-ahead is missing or stale, or at the end of a step that has a single class.
 static void state_part_all(rr_env *e, bool overlap) {
@@ -4133,8 +4150,6 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     TIMED(9, hipLaunchKernelGGL(k_cmd, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp));
     const int ngroups = (N + SGRP - 1) / SGRP;
     const size_t lds64 = (size_t)SGRP * LF_TOTAL * sizeof(float);
-    // the very heavy envs: one wave per env (coop build, <= VH_MAX of them: k_collide) or four to a wave like the heavy ones
-    const int vh_blocks = e->P.coop_build ? std::min(VH_MAX / 4, (N + 3) / 4) : (ngroups + 3) / 4;
     // (the number of heavy envs of a recent step, written to pinned host memory by k_cmd without anybody waiting for it: when most are
     // heavy -- macro actions, every gripper pushing -- there is nothing to gain from the split)
     const bool mostly_heavy = e->h_hcount && (long long)*(volatile int *)e->h_hcount * 100 > (long long)N * e->split_max_pct;
@@ -4151,9 +4166,8 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
             // timing leg: the very same launches, one after the other on the main stream, each under its timer -- 2 / 3 / 4 / 6
             // what the main stream runs in an untimed step (the light envs), 7 / 8 what the side streams run beside it, 0 / 1 the
             // look-ahead of the next step, which an untimed step runs on the heavy stream behind the heavy envs' render
-            TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1));
-            TIMED(7, { hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->stream, e->B, e->P, e->D, 2);
-                       hipLaunchKernelGGL(k_solve, dim3(vh_blocks), dim3(256), 4 * lds64, e->stream, e->B, e->P, e->D, 3); });
+            TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1, 0));
+            TIMED(7, { launch_solve_class(e, 2, e->stream); launch_solve_class(e, 3, e->stream); });
             launch_render(e, D, restore, 1, e->stream, true);
             TIMED(8, { launch_render(e, D, restore, 2, e->stream, false); launch_render(e, D, restore, 3, e->stream, false); });
             if (ahead) {
@@ -4164,36 +4178,45 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
             HIPCHK(hipGetLastError());
             return RR_OK;
         }
-        // Look-ahead: behind the render of the heavy envs, the heavy stream runs the state part of the NEXT step
-        // for all envs -- by then every solve of this step has finished (light: long ago on the main stream; very heavy: event),
-        // and the collision pass runs beside the main stream's shading, whose workgroups leave the LDS free (beside the
-        // visibility pass it would only queue up behind the LDS-filling raster workgroups: measured, profiles/README.md).
+        // Look-ahead: the state part of the NEXT step for all envs, once every solve of this step has finished.  Beside
+        // the visibility pass it would only queue up behind the LDS-filling raster workgroups (measured, profiles/README.md); it
+        // runs beside the shading of the main stream / the render of the heavy envs.
+        // Where the look-ahead goes: behind the very heavy envs' render when they are a handful (their stream is then the first to
+        // be done), else at the tail of the main stream (macro actions: hundreds of very heavy envs make theirs the longest chain).
+        const bool la_on_vh = !e->h_hcount || ((volatile int *)e->h_hcount)[1] <= 64;
         hipEventRecord(e->ev_fork, e->stream);
-        hipStreamWaitEvent(e->aux2, e->ev_fork, 0);      // the longest chain first
-        hipLaunchKernelGGL(k_solve, dim3(vh_blocks), dim3(256), 4 * lds64, e->aux2, e->B, e->P, e->D, 3);
-        if (ahead) hipEventRecord(e->ev_vsolved, e->aux2);
-        launch_render(e, D, restore, 3, e->aux2, false);
-        hipEventRecord(e->ev_join2, e->aux2);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
-        hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, e->aux, e->B, e->P, e->D, 2);
+        launch_solve_class(e, 2, e->aux);
+        if (ahead) hipEventRecord(e->ev_hsolved, e->aux);
         launch_render(e, D, restore, 2, e->aux, false);
-        hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1);
-        if (ahead) {
-            hipEventRecord(e->ev_dyn, e->stream);             // (the light envs' solve)
-            hipStreamWaitEvent(e->aux, e->ev_dyn, 0);
-            hipStreamWaitEvent(e->aux, e->ev_vsolved, 0);
-            hipLaunchKernelGGL(k_prep_ab, env_grid(e), dim3(e->epb), 0, e->aux, e->B, e->P, e->D, 0);
-            launch_collide(e, 0, e->aux);
-            e->la_valid = true;
-        }
         hipEventRecord(e->ev_join, e->aux);
+        hipStreamWaitEvent(e->aux2, e->ev_fork, 0);
+        launch_solve_class(e, 3, e->aux2);
+        if (ahead && !la_on_vh) hipEventRecord(e->ev_vsolved, e->aux2);
+        launch_render(e, D, restore, 3, e->aux2, false);
+        hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1, 0);
+        if (ahead && la_on_vh) {
+            hipEventRecord(e->ev_dyn, e->stream);             // the light envs' solve
+            hipStreamWaitEvent(e->aux2, e->ev_dyn, 0);
+            hipStreamWaitEvent(e->aux2, e->ev_hsolved, 0);    // the heavy envs' solve
+            hipLaunchKernelGGL(k_prep_ab, env_grid(e), dim3(e->epb), 0, e->aux2, e->B, e->P, e->D, 0);
+            launch_collide(e, 0, e->aux2);
+        }
+        hipEventRecord(e->ev_join2, e->aux2);
         launch_render(e, D, restore, 1, e->stream, false);
+        if (ahead && !la_on_vh) {
+            hipStreamWaitEvent(e->stream, e->ev_hsolved, 0);
+            hipStreamWaitEvent(e->stream, e->ev_vsolved, 0);
+            hipLaunchKernelGGL(k_prep_ab, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, e->D, 0);
+            launch_collide(e, 0, e->stream);
+        }
+        if (ahead) e->la_valid = true;
         hipStreamWaitEvent(e->stream, e->ev_join, 0);
         hipStreamWaitEvent(e->stream, e->ev_join2, 0);
         HIPCHK(hipGetLastError());
         return RR_OK;
     }
-    TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 0));
+    TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 0, 0));
     HIPCHK(hipGetLastError());
     int rc = RR_OK;
     if (render_mode) rc = do_render(e, render_mode == 2);

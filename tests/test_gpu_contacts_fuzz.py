@@ -200,13 +200,17 @@ def _check_forces(env, o, i, st0, cache, cmd, where, stats):
     assert _lists_identical(cd, co), where
     if len(cd):
         f_dev, f_orc = cd[:, 10].astype(np.float64), co[:, 10]
-        if f_orc.max() > 3 * CRUSH_FORCE:       # (the warm-started squeeze of the gripper reaches 2.8 kN on a skin)
-            return
-        assert np.abs(f_dev - f_orc).max() <= 1e-3 * f_orc.max() + 0.02, (where, float(np.abs(f_dev - f_orc).max()), float(f_orc.max()))
+        # 0.1 % of the largest force (+ 0.02 N) up to CRUSH_FORCE; above it the relative bound grows with the force like the state
+        # bounds do (the warm-started squeeze of the gripper reaches 2.8 kN on a skin) -- no check is waived
+        rel = 1e-3 * max(1.0, f_orc.max() / CRUSH_FORCE)
+        err = float(np.abs(f_dev - f_orc).max())
+        stats['worst_force_share'] = max(stats.get('worst_force_share', 0.0), err / (rel * f_orc.max() + 0.02))
+        assert err <= rel * f_orc.max() + 0.02, (where, err, float(f_orc.max()))
         stats['forces'] += int((f_orc > 1.0).sum())
     touch = env.host(nat.F_TOUCH)[i].astype(np.float64)
     t_orc = o.obs()[1]
-    assert np.abs(touch - t_orc).max() <= 1e-3 * max(t_orc.max(), 1.0) + 0.02, (where, touch, t_orc)
+    rel = 1e-3 * max(1.0, t_orc.max() / CRUSH_FORCE)
+    assert np.abs(touch - t_orc).max() <= rel * max(t_orc.max(), 1.0) + 0.02, (where, touch, t_orc)
     stats['touch'] += int((t_orc > 1.0).sum())
 
 
@@ -247,6 +251,7 @@ def test_touch_sensors_and_normal_forces_match_the_oracle():
             for i in sel:
                 _check_forces(env, o, int(i), st0, cache[int(i)], plans[i][t], ('push', t, int(i)), stats)
     assert stats['forces'] - before['forces'] > 200, stats
+    print("normal forces / touch sensors vs the float oracle: %d loaded contacts compared, worst share of the bound %.2f" % (stats['forces'], stats['worst_force_share']))
     env.close()
 
 
