@@ -694,7 +694,7 @@ extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
 #define CSHAPES 24       // collision shapes staged in LDS (rr_create checks the model: 22)
 #define COLLIDE_WAVES_ 4
 #define VH_MAX 1024         // cap of the very heavy list (k_collide)
-#define COOP_MAX 256        // lists up to this long (lagged host count) are solved one env per wave (coop row build); longer ones four to a wave
+#define COOP_MAX 256        // (1024 measured on the macro workload, 388 very heavy envs: no gain) lists up to this long (lagged host count) are solved one env per wave (coop row build); longer ones four to a wave
 #ifdef RR_RASTER_STATS
 #define CABL(bit) (P.ablate & (bit))      // development build: phase ablations (256 stage only, 512 no pairs, 1024 cull only)
 // per-env phase cycles of k_collide (scratch/cprof.py): 0 stage, 1 sphere tests, 2 loads + cull, 3 prefilter, 4 all-plane pass,
@@ -4162,22 +4162,26 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     // heavy -- macro actions, every gripper pushing -- there is nothing to gain from the split)
     const bool mostly_heavy = e->h_hcount && (long long)*(volatile int *)e->h_hcount * 100 > (long long)N * e->split_max_pct;
     const bool ahead = e->lookahead;            // this step ends with the state part of the next one
+    // (a step without camera runs all envs in one launch: its classes side by side were measured -- config 2: 0.525 instead of 0.452 ms)
     if (e->aux && !g_skip && render_mode && e->split_heavy && !mostly_heavy) {
+        const bool rendering = true;
         // The few envs with generic contact rows take several times as long as the others (the kernel lasts as long
         // as its longest Gauss-Seidel chain).  They are solved and rendered on the side streams -- four groups per 256-thread
         // workgroup, so that they fill the LDS of a few CUs and leave the rest to the raster workgroups of the light envs --
         // while the main stream solves and renders everybody else.
         DevPtrs D = e->D;
         if (render_mode != 2) D.render_flags = nullptr;
-        const int restore = ensure_images(e, D);
+        const int restore = rendering ? ensure_images(e, D) : 0;
         if (e->timing) {
             // timing leg: the very same launches, one after the other on the main stream, each under its timer -- 2 / 3 / 4 / 6
             // what the main stream runs in an untimed step (the light envs), 7 / 8 what the side streams run beside it, 0 / 1 the
             // look-ahead of the next step, which an untimed step runs on the heavy stream behind the heavy envs' render
             TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1, 0));
             TIMED(7, { launch_solve_class(e, 2, e->stream); launch_solve_class(e, 3, e->stream); });
-            launch_render(e, D, restore, 1, e->stream, true);
-            TIMED(8, { launch_render(e, D, restore, 2, e->stream, false); launch_render(e, D, restore, 3, e->stream, false); });
+            if (rendering) {
+                launch_render(e, D, restore, 1, e->stream, true);
+                TIMED(8, { launch_render(e, D, restore, 2, e->stream, false); launch_render(e, D, restore, 3, e->stream, false); });
+            }
             if (ahead) {
                 TIMED(0, launch_prep_ab(e, 0, e->stream));
                 TIMED(1, launch_collide(e, 0, e->stream));
@@ -4191,17 +4195,19 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         // runs beside the shading of the main stream / the render of the heavy envs.
         // Where the look-ahead goes: behind the very heavy envs' render when they are a handful (their stream is then the first to
         // be done), else at the tail of the main stream (macro actions: hundreds of very heavy envs make theirs the longest chain).
+        // (a fourth stream just for it was measured: with one more hardware queue in play every kernel of the step slows down --
+        // k_cmd 6 -> 44 us, 60 us gaps, 1.19 instead of 0.81 ms)
         const bool la_on_vh = !e->h_hcount || ((volatile int *)e->h_hcount)[1] <= 64;
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
         launch_solve_class(e, 2, e->aux);
         if (ahead) hipEventRecord(e->ev_hsolved, e->aux);
-        launch_render(e, D, restore, 2, e->aux, false);
+        if (rendering) launch_render(e, D, restore, 2, e->aux, false);
         hipEventRecord(e->ev_join, e->aux);
         hipStreamWaitEvent(e->aux2, e->ev_fork, 0);
         launch_solve_class(e, 3, e->aux2);
         if (ahead && !la_on_vh) hipEventRecord(e->ev_vsolved, e->aux2);
-        launch_render(e, D, restore, 3, e->aux2, false);
+        if (rendering) launch_render(e, D, restore, 3, e->aux2, false);
         hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1, 0);
         if (ahead && la_on_vh) {
             hipEventRecord(e->ev_dyn, e->stream);             // the light envs' solve
@@ -4211,7 +4217,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
             launch_collide(e, 0, e->aux2);
         }
         hipEventRecord(e->ev_join2, e->aux2);
-        launch_render(e, D, restore, 1, e->stream, false);
+        if (rendering) launch_render(e, D, restore, 1, e->stream, false);
         if (ahead && !la_on_vh) {
             hipStreamWaitEvent(e->stream, e->ev_hsolved, 0);
             hipStreamWaitEvent(e->stream, e->ev_vsolved, 0);
