@@ -359,13 +359,11 @@ __device__ void fk_all(const BodyParams &bp_, const float *q, m3 *bR, v3 *bp, v3
 
 // ---------------------------------------------------------------------------------------------- k_cmd / k_prep
 // Which env a work item of a per-class launch handles: sel 0 all envs (idx = env); 1 the light envs (idx = env, others are
-// skipped); 4 the light and the heavy ones; 2 / 3 entry idx of the heavy / very heavy list of the CURRENT contact frame.
-// -1: nothing to do.
+// skipped); 2 / 3 entry idx of the heavy / very heavy list of the CURRENT contact frame.  -1: nothing to do.
 __device__ __forceinline__ int pick_env(const DevPtrs &D, int sel, int idx, int N) {
     if (idx >= N) return -1;
     if (sel == 0) return idx;
     if (sel == 1) return D.hgflag[idx] == 0 ? idx : -1;
-    if (sel == 4) return D.hgflag[idx] <= 1 ? idx : -1;
     if (sel == 2) return idx < D.hcount[0] ? D.hlist[idx] : -1;
     return idx < D.hcount2[0] ? D.hlist2[idx] : -1;
 }
@@ -620,7 +618,7 @@ struct Xf { m3 R; v3 p; };
 // World transform of the owner of shape s.  All loads are unconditional and from always-valid addresses (the values are
 // selected afterwards): with loads under the owner-type branches the compiler merges the branches into a select of base
 // pointers whose value is undefined on the static path and may still issue the load -- a fault at a garbage address.
-__device__ __forceinline__ Xf load_xf(const ShapeData *S, int s, const float *state, const float *scratch, int N, int env) {
+__device__ __forceinline__ Xf load_xf(const ShapeData *S, int s, const float *scratch, int env) {
     Xf X;
     const int ot = S->otype[s];
     const int oi = ot == 0 ? 0 : S->oidx[s];
@@ -879,7 +877,7 @@ __device__ __forceinline__ void collide_env(const SimParams &P, const DevPtrs &D
     }
     if (tid < ns) {
         shape_n[tid] = S->nv[tid] | (S->nf[tid] << 8) | (S->ne[tid] << 16);
-        const Xf X = load_xf(S, tid, state, scratch, N, env);
+        const Xf X = load_xf(S, tid, scratch, env);
 #pragma unroll
         for (int k = 0; k < 9; k++) xf[tid][k] = X.R.m[k];
         xf[tid][9] = X.p.x; xf[tid][10] = X.p.y; xf[tid][11] = X.p.z;
