@@ -42,7 +42,8 @@ enum {
     RR_F_DEPTH = 4,     /* f32 [N, H, W]     GL depth in [0,1]            env.py:564-565 */
     RR_F_MASK = 5,      /* i32 [N, H, W]     body unique id, -1 background  env.py:552-558 */
     RR_F_TIMESTEP = 6,  /* i32 [N]           env.timestep                 env.py:217,346 */
-    RR_F_ERRFLAGS = 7,  /* u32 [N]           bit0: non-finite state detected (env auto-frozen) */
+    RR_F_ERRFLAGS = 7,  /* u32 [N]           1: non-finite state detected (env frozen until reset / set_state); 2: this step's command was
+                                             not finite (env not stepped, robot.py:189); 4: internal consistency (never expected) */
     RR_F_STATE = 8,     /* f32 [N, 61]       q[11] qd[11] 3x(pos3 quat4 lin3 ang3)  (checkpoint / parity) */
     RR_F_FRAG_COUNT = 9,/* u32 [N, tiles]    diagnostic: entries of k_shade's work list in the last render (pixels won by moving geometry + pixels vacated since the frame before) */
     RR_F_CONTACT_COUNT = 10, /* i32 [N]      contacts of the last solved step (rr_get_contacts returns them one env at a time) */

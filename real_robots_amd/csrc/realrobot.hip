@@ -1268,7 +1268,9 @@ __device__ __forceinline__ void collide_env(const SimParams &P, const DevPtrs &D
     if (tid == 0) {
         // "heavy": more generic contacts than P.heavy_min (an env with a few generic rows lengthens its wave's chain by a
         // quarter, an arm pressed on the table fourfold -- only the latter are worth the side stream when many envs have some)
-        ngen += max(oscnt0 - 4, 0) + max(oscnt1 - 4, 0) + max(oscnt2 - 4, 0);
+        // generic contacts = all but the object-vs-static ones the solver's object lanes take: up to KOS = 4 per object and
+        // P.os_cap in all, in list order (those pairs come first) -- the row builder's rule, so that a "light" env has none
+        ngen = nct - min(P.os_cap, min(oscnt0, 4) + min(oscnt1, 4) + min(oscnt2, 4));
         const bool heavy = ngen > P.heavy_min;
         D.ccount_next[env] = nct;
         // (the very heavy list is capped at VH_MAX entries -- its solve is launched with one wave per entry; beyond that an env is
@@ -1458,7 +1460,13 @@ __device__ __forceinline__ float4 sel4(bool has, float4 v) {
 // 2: wave w of the launch handles the heavy envs 4 w .. 4 w + 3 of D.hlist -- packed four to a wave whichever groups they
 // come from (256-thread workgroups: sixteen heavy envs fill a CU's LDS and leave the other CUs to the render of the light
 // envs).  No result depends on which envs share a wave: only trip counts and the choice between equivalent code paths do.
-__global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtrs D, int sel, int coop_launch) {
+// GEN = false is the form for the light envs (sel 1): no generic contact row can occur there (k_collide classifies by the
+// very rule the row builder uses), so everything of the generic path -- the row builder, the streamed sweeps, their register
+// queue -- folds away at compile time and the sweep of motors, limits and object-lane rows runs without the register
+// spills (v_accvgpr_read: a third of the torsional steps' instructions) the full kernel needs.  Same source, same
+// arithmetic: results do not depend on which form solved an env (split-equivalence tests, bitwise).
+template <bool GEN>
+__device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams &P, const DevPtrs &D, int sel, int coop_launch) {
     const int N = P.N;
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // the wave's index in the launch
@@ -1467,7 +1475,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
     // contact cap is a fifth of its chain with 16 lanes); group 0 then sweeps, groups 1..3 run along as no-ops.  The wave has
     // one LDS region (the launch asks for a quarter of the LDS of the packed form: the same sixteen envs per CU).  Same
     // arithmetic per row whichever group builds it: results do not depend on the mode (tested bitwise).
-    const bool coop = sel >= 2 && coop_launch;
+    const bool coop = GEN && sel >= 2 && coop_launch;
     const int cg = coop ? (grp & 3) : 0;                              // this group's place among the builders of its env
     int env_raw = coop ? unit : 4 * unit + (grp & 3);
     bool mine = true;                                                 // this 16-lane group has an env to solve in this launch
@@ -1564,6 +1572,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
     unsigned fcnt = 0;                // ... per object, 4 bits each
     unsigned gobj = 0;                // objects touched by generic contacts of this env (bit o)
     int nc = 0, ng = 0;               // contacts; generic contacts
+    bool class_mismatch = false;      // GEN = false only: a contact that needs generic rows
     const int nct_max = max(max(__builtin_amdgcn_readlane(nct, 0), __builtin_amdgcn_readlane(nct, 16)),
                             max(__builtin_amdgcn_readlane(nct, 32), __builtin_amdgcn_readlane(nct, 48)));
 #pragma unroll 1        // one copy of the (large) row-building body: the kernel must stay inside the instruction cache
@@ -1625,7 +1634,8 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                     n_os++;
                     fcnt += 1u << (4 * ob_j);
                     if (lo_ >= 0 && ob_j == lo_) own_os |= 1u << slot_j;
-                } else ng++;
+                } else if (GEN) ng++;
+                else class_mismatch = true;       // (cannot happen: k_collide counts generic contacts by this very rule)
                 nc++;
             }
             const int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | ((fast ? 1 : 0) << 24) | (slot << 25) |
@@ -1667,7 +1677,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
                 }
                 continue;
             }
-            if (!have) continue;
+            if (!GEN || !have) continue;
             // generic contact j = slot: six rows in the slot layout
             const int r0 = 6 * slot;
             if (bodyA >= 16) gobj |= 1u << (bodyA - 16);
@@ -1739,6 +1749,7 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // the staging area is rewritten by the next batch
         __builtin_amdgcn_wave_barrier();
     }
+    if (!GEN && class_mismatch && l == 0 && !dead) atomicOr(&D.errflags[env], 4u);      // (internal consistency: never seen)
     if (coop) {
         // the warm-start velocity change of the generic normal rows, in list order, from the stored rows: the very fma sequence
         // a single builder runs in line (each of the four builders holds only its own contacts' share)
@@ -2134,6 +2145,9 @@ __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtr
     }
     SPROF(6);
 }
+__global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtrs D, int sel, int coop_launch) { solve_body<true>(B, P, D, sel, coop_launch); }
+// the light envs of a split step (sel 1), 64-thread workgroups
+__global__ void __launch_bounds__(64) k_solve_light(BodyParams B, SimParams P, DevPtrs D) { solve_body<false>(B, P, D, 1, 0); }
 
 // obs pack without stepping (after reset / set_state)
 __global__ void k_obs(SimParams P, DevPtrs D) {
@@ -4174,7 +4188,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
             // timing leg: the very same launches, one after the other on the main stream, each under its timer -- 2 / 3 / 4 / 6
             // what the main stream runs in an untimed step (the light envs), 7 / 8 what the side streams run beside it, 0 / 1 the
             // look-ahead of the next step, which an untimed step runs on the heavy stream behind the heavy envs' render
-            TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1, 0));
+            TIMED(2, hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D));
             TIMED(7, { launch_solve_class(e, 2, e->stream); launch_solve_class(e, 3, e->stream); });
             if (rendering) {
                 launch_render(e, D, restore, 1, e->stream, true);
@@ -4206,7 +4220,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         launch_solve_class(e, 3, e->aux2);
         if (ahead && !la_on_vh) hipEventRecord(e->ev_vsolved, e->aux2);
         if (rendering) launch_render(e, D, restore, 3, e->aux2, false);
-        hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 1, 0);
+        hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D);
         if (ahead && la_on_vh) {
             hipEventRecord(e->ev_dyn, e->stream);             // the light envs' solve
             hipStreamWaitEvent(e->aux2, e->ev_dyn, 0);
