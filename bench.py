@@ -53,7 +53,6 @@ def algo_bytes(n_obj, w, h):
     state = (22 + 13 * n_obj + 11) * 4 * 2 + 9 * 4 + (9 + 4 + 7 * n_obj) * 4          # state R/W + command + low-dim obs
     inst = 22 * 12 * 4
     return {'k_prep': state, 'k_collide': state, 'k_solve': state, 'k_render_setup': 11 * 4 + 13 * n_obj * 4 + inst,
-            'k_cmd': 9 * 4 + 9 * 4 + 11 * 4,   # command in, joint angles in, motor targets out
             'k_raster': inst,           # instance matrices in; + 8 B per listed fragment out (measured, added at run time)
             'k_image_setup': 0,         # steady state: does not run (first frame / earlier image-update schemes only)
             'k_shade': inst,            # + (8 B list entry in + 7 B pixel out) per list entry (measured, added at run time)

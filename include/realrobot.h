@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 3   /* 3: RR_NUM_KERNELS 10 (k_cmd), RR_F_CONTACT_COUNT, rr_checkpoint_* */
+#define RR_ABI_VERSION 3   /* 3: RR_F_CONTACT_COUNT, RR_F_ENV_CLASS, rr_checkpoint_*, rr_evaluate_goals */
 
 enum {
     RR_OK = 0,
@@ -175,14 +175,14 @@ int rr_step_plan_masked(rr_env *env, const uint8_t *idle_mask_host, int32_t rend
 /* Per-kernel device timing with HIP events on the library's stream (bench.py roofline leg).
  * After rr_set_timing(env, 1), each rr_step/rr_render records events; rr_get_timing returns accumulated
  * milliseconds and launch counts per kernel since the last call and resets them.
- * kernel ids: 0 prep (state part: forward kinematics, object terms, joint-space dynamics), 1 collide, 2 solve, 3 render_setup,
- * 4 raster, 5 image set-up outside the two render kernels (the full static copy of the first frame; the separate restore pass
- * with RR_SEPARATE_RESTORE), 6 shade, 9 cmd (command part: rate limit, clipping, motor targets).
+ * kernel ids: 0 prep (state part: forward kinematics, object terms, joint-space dynamics), 1 collide, 2 solve (command part --
+ * rate limit, clipping, motor targets -- then rows, Gauss-Seidel, integration), 3 render_setup, 4 raster, 5 image set-up outside
+ * the two render kernels (the full static copy of the first frame; the separate restore pass with RR_SEPARATE_RESTORE), 6 shade.
  * When the step would run its heavy envs on the side stream, the timed step runs the same launches one
  * after the other: 2 / 3 / 4 / 6 then hold what the main stream runs (the light envs), 7 the solve and 8 the render
  * (set-up + raster + shade) of the heavy envs, which run beside them in an untimed step.  0 and 1 are the LOOK-AHEAD of the
  * next step, which an untimed step runs under its render. */
-#define RR_NUM_KERNELS 10
+#define RR_NUM_KERNELS 9
 int rr_set_timing(rr_env *env, int32_t enable);
 int rr_get_timing(rr_env *env, float *ms_out /*[RR_NUM_KERNELS]*/, int32_t *launches_out /*[RR_NUM_KERNELS]*/);
 

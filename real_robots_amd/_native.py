@@ -17,12 +17,12 @@ LINK_NAMES = open(os.path.join(_HERE, 'data', 'realrobot_model_links.txt')).read
 RR_ABI_VERSION = 3
 (F_JOINTS, F_TOUCH, F_OBJ_POSE, F_RGB, F_DEPTH, F_MASK, F_TIMESTEP, F_ERRFLAGS, F_STATE, F_FRAG_COUNT, F_CONTACT_COUNT,
  F_ENV_CLASS) = range(12)
-NUM_KERNELS = 10
+NUM_KERNELS = 9
 # id 5 = image set-up outside the two render kernels: the full static copy of the first frame (and the earlier schemes
 # RR_FULL_COPY / RR_SEPARATE_RESTORE); it does not run in steady state
 KERNEL_NAMES = ('k_prep', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster', 'k_image_setup', 'k_shade',
-                'k_solve_heavy', 'render_heavy',      # 7, 8: the heavy envs' solve / render (side stream in an untimed step)
-                'k_cmd')                              # 9: command part of the step (k_prep / k_collide = the look-ahead of the next step)
+                'k_solve_heavy', 'render_heavy')      # 7, 8: the heavy envs' solve / render (side streams in an untimed step);
+                                                      # k_prep / k_collide = the look-ahead of the next step
 
 # every symbol include/realrobot.h declares (tests check the library exports all of them)
 SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_object_pose', 'rr_set_object_home', 'rr_step', 'rr_render',

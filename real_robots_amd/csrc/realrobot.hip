@@ -146,6 +146,7 @@ struct DevPtrs {
     float *obj_home;   // [NOBJ*7][N] per-env pose an object is put back to by reset / the out-of-bounds rule (robot.py:19-24, mutable there)
     float4 *grows;     // [N * 6 MAXC + 1][16] generic solver rows in the slot layout {J_A, MJ_A, J_B, MJ_B} per lane; the last row is all zero
     float *cmd;        // [N][9]
+    const float *cmd_in; // [N][9] the command buffer of this step: cmd, or the caller's device buffer (read in place)
     float *joints;     // [N][9]
     float *touch;      // [N][4]
     float *objpose;    // [N][nobj][7]
@@ -357,7 +358,7 @@ __device__ void fk_all(const BodyParams &bp_, const float *q, m3 *bR, v3 *bp, v3
     }
 }
 
-// ---------------------------------------------------------------------------------------------- k_cmd / k_prep
+// ---------------------------------------------------------------------------------------------- k_prep
 // Which env a work item of a per-class launch handles: sel 0 all envs (idx = env); 1 the light envs (idx = env, others are
 // skipped); 2 / 3 entry idx of the heavy / very heavy list of the CURRENT contact frame.  -1: nothing to do.
 __device__ __forceinline__ int pick_env(const DevPtrs &D, int sel, int idx, int N) {
@@ -370,57 +371,6 @@ __device__ __forceinline__ int pick_env(const DevPtrs &D, int sel, int idx, int 
 
 // The out-of-bounds rule of control_objects_limits (env.py:257-264) as a function of the object's position.
 __device__ __forceinline__ bool object_out_of_bounds(float x, float z, float table_z) { return z < table_z || (x > 0.11f && z < 0.29f); }
-
-// The command part of a step -- everything that needs the action: limitActionByJoint (env.py:314-321), the clipping and
-// gripper coupling of Kuka.apply_action (robot.py:188-201) -> 11 motor targets; a non-finite command flags the env
-// (robot.py:189 asserts).  It also APPLIES the out-of-bounds rule to the state (the state part of the preparation, which may
-// have run under the previous step's render, only derived the collision inputs from the re-posed object) and resets the
-// bookkeeping of the contact frame that this step's look-ahead collision pass will fill.
-__global__ void __launch_bounds__(64) k_cmd(BodyParams B, SimParams P, DevPtrs D) {
-    const int N = P.N;
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= N) return;
-    float *state = D.state;
-    if (env == 0) {
-        // (the number of heavy envs of this step goes to pinned host memory on the way: a posted write, nobody waits for it)
-        if (D.hcount_host) { D.hcount_host[0] = D.hcount[0]; D.hcount_host[1] = D.hcount2[0]; }
-        D.hcount_next[0] = 0; D.hcount_next[1] = 0; D.hcount2_next[0] = 0; D.hcount2_next[1] = 0;
-    }
-    if (D.errflags[env] & 1u) return;   // frozen env
-    unsigned ef = D.errflags[env] & ~2u;
-    float a[9], cur[9];
-#pragma unroll
-    for (int i = 0; i < 7; i++) cur[i] = STT(ST_Q + i);
-    cur[7] = STT(ST_Q + 7); cur[8] = -STT(ST_Q + 8);                 // robot.py:203-211
-    bool bad = false;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        float v = D.cmd[(size_t)env * 9 + i];
-        if (!isfinite(v)) bad = true;
-        float d = v - cur[i];                                        // env.py:314-321
-        d = fminf(d, B.act_maxdiff[i]);
-        d = fmaxf(d, -B.act_maxdiff[i]);
-        a[i] = cur[i] + d;
-    }
-    D.errflags[env] = bad ? (ef | 2u) : ef;
-    if (bad) return;                                                 // robot.py:189 (assert in the reference)
-    for (int i = 0; i < P.nobj; i++) {                               // env.py:257-264
-        float x = STT(ST_OPOS + 3 * i), z = STT(ST_OPOS + 3 * i + 2);
-        if (object_out_of_bounds(x, z, B.table_z)) {
-            for (int k = 0; k < 3; k++) { STT(ST_OPOS + 3 * i + k) = D.obj_home[(size_t)(7 * i + k) * N + env]; STT(ST_OVEL + 3 * i + k) = 0; STT(ST_OANG + 3 * i + k) = 0; }
-            for (int k = 0; k < 4; k++) STT(ST_OQUAT + 4 * i + k) = D.obj_home[(size_t)(7 * i + 3 + k) * N + env];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 9; i++) a[i] = fmaxf(B.act_min[i], fminf(a[i], B.act_max[i]));   // robot.py:192
-    a[8] = fmaxf(0.0f, fminf(2.0f * a[7], a[8]));                                        // robot.py:193
-    float tgt[NB];
-#pragma unroll
-    for (int i = 0; i < 7; i++) tgt[i] = a[i];
-    tgt[7] = a[7]; tgt[9] = a[7]; tgt[8] = -a[8]; tgt[10] = -a[8];                        // robot.py:195-201
-#pragma unroll
-    for (int i = 0; i < NB; i++) STT(ST_TGT + i) = tgt[i];
-}
 
 // The state part of the preparation -- everything of a step that does NOT need the action, i.e. a function of the state the
 // previous step left: PHASE 1 = forward kinematics and object terms (rotation, world inverse inertia, unconstrained
@@ -567,7 +517,7 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
     }
     if (PHASE == 2) return;
     // ---- objects: rotation, inverse inertia, unconstrained velocities -- of the pose that counts: an object the out-of-bounds
-    // rule (env.py:257-264) sends home is taken at its home pose, at rest (k_cmd writes that pose into the state when the step starts)
+    // rule (env.py:257-264) sends home is taken at its home pose, at rest (the solve kernel writes that pose into the state when the step starts)
     for (int i = 0; i < P.nobj; i++) {
         float px = STT(ST_OPOS + 3 * i), py = STT(ST_OPOS + 3 * i + 1), pz = STT(ST_OPOS + 3 * i + 2);
         float qx = STT(ST_OQUAT + 4 * i), qy = STT(ST_OQUAT + 4 * i + 1), qz = STT(ST_OQUAT + 4 * i + 2), qw = STT(ST_OQUAT + 4 * i + 3);
@@ -1469,6 +1419,12 @@ template <bool GEN>
 __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams &P, const DevPtrs &D, int sel, int coop_launch) {
     const int N = P.N;
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+    if (sel <= 1 && blockIdx.x == 0 && threadIdx.x == 0) {
+        // (once per step, by the launch every step has: the bookkeeping of the contact frame this step's look-ahead will fill;
+        // the number of heavy / very heavy envs of this step goes to pinned host memory on the way -- a posted write)
+        if (D.hcount_host) { D.hcount_host[0] = D.hcount[0]; D.hcount_host[1] = D.hcount2[0]; }
+        D.hcount_next[0] = 0; D.hcount_next[1] = 0; D.hcount2_next[0] = 0; D.hcount2_next[1] = 0;
+    }
     const int unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // the wave's index in the launch
     // coop (a heavy / very heavy list of at most COOP_MAX envs -- the host's lagged count decides, any actual count is handled):
     // ONE env per wave -- its four 16-lane groups build the rows of four contacts at a time (the row build of an env at the
@@ -1485,10 +1441,48 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     if (__ballot(mine) == 0ull) return;                               // (wave-uniform; the kernel has no workgroup barrier)
     const int env = env_raw < N ? env_raw : N - 1;                    // groups without an env run along as no-ops
     float *state = D.state, *scratch = D.scratch;
-    bool dead = !mine || env_raw >= N || D.errflags[env] != 0;
-    // an env whose command was rejected (robot.py:189) does not step; the list the look-ahead made for this step is dropped with
-    // it, so that the normal forces of the last solved step (cforce) are never matched against a list they do not belong to
-    if (mine && env_raw < N && l == 0 && (D.errflags[env] & 2u)) D.ccount[env] = 0;
+    const int lj = l < NB ? l : 0;               // joint owned by this lane (lanes >= 11 alias joint 0, masked)
+    const int lo_ = (l >= NB && l < NB + NOBJ) ? l - NB : -1;   // object owned by this lane
+    // ---- the command part of the step -- everything that needs the action: limitActionByJoint (env.py:314-321), the clipping
+    // and gripper coupling of Kuka.apply_action (robot.py:188-201) -> the motor target of this lane's joint; a non-finite
+    // command flags the env (robot.py:189 asserts) and the env does not step.  It also APPLIES the out-of-bounds rule
+    // (env.py:257-264) to the state: the state part of the preparation only derived the collision inputs from the re-posed object.
+    const unsigned ef0 = (mine && env_raw < N) ? D.errflags[env] : 1u;
+    float tgt_l = 0.0f;
+    bool rejected = false;
+    {
+        const int lc = l < 9 ? l : 0;
+        const float v = D.cmd_in[(size_t)env * 9 + lc];
+        const float qv = STT(ST_Q + lc);
+        const float cur = l == 8 ? -qv : qv;                             // robot.py:203-211
+        float d = v - cur;                                               // env.py:314-321
+        d = fminf(d, B.act_maxdiff[lc]);
+        d = fmaxf(d, -B.act_maxdiff[lc]);
+        float a = cur + d;
+        a = fmaxf(B.act_min[lc], fminf(a, B.act_max[lc]));               // robot.py:192
+        const float a7 = row_bcast<7>(a);
+        if (l == 8) a = fmaxf(0.0f, fminf(2.0f * a7, a));                // robot.py:193
+        const float a8 = row_bcast<8>(a);
+        tgt_l = l < 7 ? a : ((l == 7 || l == 9) ? a7 : -a8);             // robot.py:195-201 (lanes 8, 10: -a8)
+        rejected = ((unsigned)(__ballot(l < 9 && !isfinite(v)) >> (16 * (grp & 3))) & 0xffffu) != 0u;
+    }
+    const bool frozen = (ef0 & 1u) != 0u;
+    if (!frozen && l == 0) D.errflags[env] = rejected ? ((ef0 & ~2u) | 2u) : (ef0 & ~2u);
+    bool dead = frozen || (ef0 & ~3u) != 0u || rejected;
+    // an env whose command was rejected does not step; the list the look-ahead made for this step is dropped with it, so that
+    // the normal forces of the last solved step (cforce) are never matched against a list they do not belong to
+    if (!frozen && rejected && l == 0) D.ccount[env] = 0;
+    if (!dead) {
+        if (l < NB) STT(ST_TGT + l) = tgt_l;
+        if (lo_ >= 0 && lo_ < P.nobj) {                                  // env.py:257-264
+            const int i = lo_;
+            const float x = STT(ST_OPOS + 3 * i), z = STT(ST_OPOS + 3 * i + 2);
+            if (object_out_of_bounds(x, z, B.table_z)) {
+                for (int k = 0; k < 3; k++) { STT(ST_OPOS + 3 * i + k) = D.obj_home[(size_t)(7 * i + k) * N + env]; STT(ST_OVEL + 3 * i + k) = 0; STT(ST_OANG + 3 * i + k) = 0; }
+                for (int k = 0; k < 4; k++) STT(ST_OQUAT + 4 * i + k) = D.obj_home[(size_t)(7 * i + 3 + k) * N + env];
+            }
+        }
+    }
     const ShapeData *S = D.shapes;
     const int fix = (coop ? (grp >> 2) : grp) * LF_TOTAL;            // (coop: the four groups of a wave share its one LDS region)
     const int L_MINV = fix + LF_MINV, L_MOT = fix + LF_MOT, L_LIM = fix + LF_LIM, L_META = fix + LF_META, L_MU = fix + LF_MU,
@@ -1496,8 +1490,6 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
               L_OBJ = fix + LF_OBJ, L_CST = fix + LF_CST;
     unsigned short *listF = (unsigned short *)&LD(fix + LF_LISTF), *listT = (unsigned short *)&LD(fix + LF_LISTT);
     const float dt = P.dt, inv_dt = 1.0f / P.dt;
-    const int lj = l < NB ? l : 0;               // joint owned by this lane (lanes >= 11 alias joint 0, masked)
-    const int lo_ = (l >= NB && l < NB + NOBJ) ? l - NB : -1;   // object owned by this lane
     SPROF_INIT
     SBLK_BEGIN
     // ---- stage Minv in LDS; the lane's joint frame and unconstrained velocity go to registers (same round trip)
@@ -1766,7 +1758,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     // ---- motor + limit rows: lane j < 11 builds the rows of joint j
     if (l < NB) {
         float dinv = 1.0f / LD(L_MINV + l * NB + l);
-        float vt = P.kp * (STT(ST_TGT + l) - q_l) / dt + qds_l + P.kd * (0.0f - qds_l);
+        float vt = P.kp * (tgt_l - q_l) / dt + qds_l + P.kd * (0.0f - qds_l);
         LD(L_MOT + 3 * l) = (vt - qds_l) * dinv;
         LD(L_MOT + 3 * l + 1) = dinv;
         LD(L_MOT + 3 * l + 2) = 0.0f;
@@ -4164,13 +4156,11 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     if (!e->la_valid) state_part_all(e, overlap);
     e->cur ^= 1; e->la_valid = false;           // the frame the collision pass filled is the one this step solves
     bind_frames(e);
-    DevPtrs Dp = e->D;
-    // a device-resident command buffer is read in place by k_cmd (stream order protects it like a copy would)
-    if (joint_cmd && cmd_on_device) Dp.cmd = const_cast<float *>(joint_cmd);
-    TIMED(9, hipLaunchKernelGGL(k_cmd, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, Dp));
+    // a device-resident command buffer is read in place by the solve kernels (stream order protects it like a copy would)
+    e->D.cmd_in = (joint_cmd && cmd_on_device) ? joint_cmd : e->D.cmd;
     const int ngroups = (N + SGRP - 1) / SGRP;
     const size_t lds64 = (size_t)SGRP * LF_TOTAL * sizeof(float);
-    // (the number of heavy envs of a recent step, written to pinned host memory by k_cmd without anybody waiting for it: when most are
+    // (the number of heavy envs of a recent step, written to pinned host memory by the solve kernel without anybody waiting for it: when most are
     // heavy -- macro actions, every gripper pushing -- there is nothing to gain from the split)
     const bool mostly_heavy = e->h_hcount && (long long)*(volatile int *)e->h_hcount * 100 > (long long)N * e->split_max_pct;
     const bool ahead = e->lookahead;            // this step ends with the state part of the next one
@@ -4208,7 +4198,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         // Where the look-ahead goes: behind the very heavy envs' render when they are a handful (their stream is then the first to
         // be done), else at the tail of the main stream (macro actions: hundreds of very heavy envs make theirs the longest chain).
         // (a fourth stream just for it was measured: with one more hardware queue in play every kernel of the step slows down --
-        // k_cmd 6 -> 44 us, 60 us gaps, 1.19 instead of 0.81 ms)
+        // the 6 us command kernel of that build took 44 us, 60 us gaps, 1.19 instead of 0.81 ms)
         const bool la_on_vh = !e->h_hcount || ((volatile int *)e->h_hcount)[1] <= 64;
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);

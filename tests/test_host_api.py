@@ -279,7 +279,7 @@ def test_bench_bookkeeping_and_committed_profiles():
 
 def nat_names():
     from real_robots_amd import _native as nat
-    assert len(nat.KERNEL_NAMES) == nat.NUM_KERNELS == 10
+    assert len(nat.KERNEL_NAMES) == nat.NUM_KERNELS == 9
     return nat.KERNEL_NAMES
 
 
