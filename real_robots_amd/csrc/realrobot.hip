@@ -1410,6 +1410,38 @@ __device__ __forceinline__ float4 sel4(bool has, float4 v) {
 // 2: wave w of the launch handles the heavy envs 4 w .. 4 w + 3 of D.hlist -- packed four to a wave whichever groups they
 // come from (256-thread workgroups: sixteen heavy envs fill a CU's LDS and leave the other CUs to the render of the light
 // envs).  No result depends on which envs share a wave: only trip counts and the choice between equivalent code paths do.
+// One object-vs-static contact row pair along / about `dir` (k = 0: the normal, 1 2: the tangents): the linear row
+// {dir, ang, I^-1 ang, rhs, 1/diag} and the torsional row about the same axis {I^-1 dir, rhs, 1/diag}, written to the LDS
+// row areas of slot `slot`.  Used by the sequential row builder (lanes 0..2 of a group take k = lane) and by the
+// lane-per-contact builder of the light form (one lane, k = 0..2): the same expressions, hence the same bits.
+__device__ __forceinline__ void os_row_pair(int k, v3 dir, v3 x, const ObjData &oA, float dist, float rest, float spin, float roll, float lam0,
+                                            float dt, float erp, float rest_thresh, int row_osl, int row_ost) {
+    const v3 ang = cross(x - oA.op, dir);
+    const v3 mang = mulv(oA.Iinv, ang);
+    const float diag = dot(dir, dir) * oA.imass + dot(ang, mang);
+    const float rel = dot(dir, oA.vs) + dot(ang, oA.ws);
+    const float dinv = diag > 0 ? 1.0f / diag : 0.0f;
+    float rr = 0;
+    if (fabsf(rel) >= rest_thresh) { rr = rest * -rel; if (rr < 0) rr = 0; }
+    float verr = rr - rel, perr = 0;
+    if (dist > 0) verr -= dist / dt;
+    else perr = -dist * erp / dt;
+    const float rhs = k == 0 ? (perr + verr) * dinv : -rel * dinv;
+    // torsional: pure rotation about dir; absent (coefficient 0) rows are all-zero
+    const float coef = k == 0 ? spin : roll;
+    const v3 tm = mulv(oA.Iinv, dir);
+    const float tdiag = dot(dir, tm);
+    const float tdinv = (coef > 0 && tdiag > 0) ? 1.0f / tdiag : 0.0f;
+    const float trhs = -dot(dir, oA.ws) * tdinv;
+    float4 *bp4 = (float4 *)&LD(row_osl);
+    bp4[0] = make_float4(dir.x, dir.y, dir.z, ang.x);
+    bp4[1] = make_float4(ang.y, ang.z, mang.x, mang.y);
+    bp4[2] = make_float4(mang.z, rhs, dinv, k == 0 ? lam0 : 0.0f);      // (.w of the normal row: warm-start impulse)
+    float4 *tp4 = (float4 *)&LD(row_ost);
+    tp4[0] = make_float4(tm.x, tm.y, tm.z, trhs);
+    tp4[1] = make_float4(tdinv, 0.0f, 0.0f, 0.0f);
+}
+
 // GEN = false is the form for the light envs (sel 1): no generic contact row can occur there (k_collide classifies by the
 // very rule the row builder uses), so everything of the generic path -- the row builder, the streamed sweeps, their register
 // queue -- folds away at compile time and the sweep of motors, limits and object-lane rows runs without the register
@@ -1510,7 +1542,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         for (int i = 0; i < 3; i++) crec[i] = cl[16 * i + l];
 #pragma unroll
         for (int i = 3; i < 9; i++) crec[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (__ballot(nct > 16) != 0ull) {
+        if (GEN && __ballot(nct > 16) != 0ull) {        // (a light env has at most 12 contacts, all on the object lanes)
 #pragma unroll
             for (int i = 3; i < 9; i++) crec[i] = cl[16 * i + l];
         }
@@ -1567,6 +1599,63 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     bool class_mismatch = false;      // GEN = false only: a contact that needs generic rows
     const int nct_max = max(max(__builtin_amdgcn_readlane(nct, 0), __builtin_amdgcn_readlane(nct, 16)),
                             max(__builtin_amdgcn_readlane(nct, 32), __builtin_amdgcn_readlane(nct, 48)));
+    if (!GEN) {
+        // ---- light form: every contact is an object-vs-static one on the object lanes (<= 12 of them), so there is no slot
+        // to hand out in list order -- contact c is slot c -- and LANE c builds all six rows of contact c: one trip instead of
+        // one per contact (each a chain of LDS round trips at one wave per SIMD).  Same expressions as the walk below
+        // (os_row_pair), same bits.
+        {
+            float4 *st = (float4 *)&LD(L_CST);
+#pragma unroll
+            for (int i = 0; i < 3; i++) st[16 * i + l] = crec[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool have = l < nct;
+        const int ci = l;
+        const float4 ra = *(const float4 *)&LD(L_CST + 12 * ci), rb_ = *(const float4 *)&LD(L_CST + 12 * ci + 4), rc = *(const float4 *)&LD(L_CST + 12 * ci + 8);
+        const v3 x = mk(ra.x, ra.y, ra.z), n = mk(ra.w, rb_.x, rb_.y);
+        const float dist = rb_.z;
+        const int cm = __float_as_int(rb_.w);
+        const int bodyA = (signed char)(cm & 255), bodyB = (signed char)((cm >> 8) & 255), linkA = (signed char)((cm >> 16) & 255);
+        const float mu = rc.x, rest = rc.y, roll = rc.z, spin = rc.w;
+        const bool ospair = bodyA >= 16 && bodyB < 0;
+        const int obA = bodyA >= 16 ? min(bodyA - 16, NOBJ - 1) : 0;
+        ObjData oA;
+        {
+            const float4 *od = (const float4 *)&LD(L_OBJ + 20 * obA);
+            const float4 d0 = od[0], d1 = od[1], d2 = od[2], d3 = od[3], d4 = od[4];
+            oA.op = mk(d0.x, d0.y, d0.z); oA.imass = d0.w;
+            oA.Iinv.m[0] = d1.x; oA.Iinv.m[1] = d1.y; oA.Iinv.m[2] = d1.z; oA.Iinv.m[3] = d1.w;
+            oA.Iinv.m[4] = d2.x; oA.Iinv.m[5] = d2.y; oA.Iinv.m[6] = d2.z; oA.Iinv.m[7] = d2.w;
+            oA.Iinv.m[8] = d3.x; oA.vs = mk(d3.y, d3.z, d3.w); oA.ws = mk(d4.x, d4.y, d4.z);
+        }
+        // which contacts belong to which object: the masks the object lanes own, and this contact's place among its object's
+        const int gsh = 16 * (grp & 3);
+        const unsigned m0 = (unsigned)(__ballot(have && ospair && obA == 0) >> gsh) & 0xffffu, m1 = (unsigned)(__ballot(have && ospair && obA == 1) >> gsh) & 0xffffu,
+                       m2 = (unsigned)(__ballot(have && ospair && obA == 2) >> gsh) & 0xffffu;
+        const unsigned mine_m = obA == 0 ? m0 : (obA == 1 ? m1 : m2);
+        const int before = __popc(mine_m & ((1u << l) - 1u));
+        // (the row builder's rule: an object-vs-static pair, among the first KOS of its object and the first P.os_cap in all)
+        class_mismatch = have && !(ospair && before < KOS && l < P.os_cap);
+        own_os = lo_ == 0 ? m0 : (lo_ == 1 ? m1 : (lo_ == 2 ? m2 : 0u));
+        n_os = nct; nc = nct;
+        if (have) {
+            const int meta = (bodyA & 255) | ((bodyB & 255) << 8) | ((linkA & 255) << 16) | (1 << 24) | (ci << 25) |
+                             (fabsf(dist) < 0.1f ? (int)0x80000000u : 0);        // robot.py:136 contact_threshold
+            *(int *)&LD(L_META + ci) = meta;
+            LD(L_MU + ci) = mu; LD(L_SPIN + ci) = spin; LD(L_ROLL + ci) = roll;
+            v3 t1, t2;
+            plane_space(n, t1, t2);
+            const float lam0 = cw0;           // (this lane holds the warm-start impulse of contact l)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                os_row_pair(k, k == 0 ? n : (k == 1 ? t1 : t2), x, oA, dist, rest, spin, roll, lam0, dt, P.erp, P.rest_thresh,
+                            L_OSL + (3 * ci + k) * 12, L_OST + (3 * ci + k) * 8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else
 #pragma unroll 1        // one copy of the (large) row-building body: the kernel must stay inside the instruction cache
     for (int bt = 0; 16 * bt < nct_max; bt++) {
         {   // batch bt = records 16 bt .. 16 bt + 15 = float4 48 bt .. 48 bt + 47 of the list = crec[3 bt .. 3 bt + 2] of the lanes
@@ -1640,33 +1729,9 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
             plane_space(n, t1, t2);
             if (fast) {
                 // the three linear rows (n, t1, t2) and the three torsional rows about the same axes are built by lanes 0, 1, 2
-                const v3 dir = l == 0 ? n : (l == 1 ? t1 : t2);
-                const v3 ang = cross(x - oA.op, dir);
-                const v3 mang = mulv(oA.Iinv, ang);
-                const float diag = dot(dir, dir) * oA.imass + dot(ang, mang);
-                const float rel = dot(dir, oA.vs) + dot(ang, oA.ws);
-                const float dinv = diag > 0 ? 1.0f / diag : 0.0f;
-                float rr = 0;
-                if (fabsf(rel) >= P.rest_thresh) { rr = rest * -rel; if (rr < 0) rr = 0; }
-                float verr = rr - rel, perr = 0;
-                if (dist > 0) verr -= dist / dt;
-                else perr = -dist * P.erp / dt;
-                const float rhs = l == 0 ? (perr + verr) * dinv : -rel * dinv;
-                // torsional: pure rotation about dir; absent (coefficient 0) rows are all-zero
-                const float coef = l == 0 ? spin : roll;
-                const v3 tm = mulv(oA.Iinv, dir);
-                const float tdiag = dot(dir, tm);
-                const float tdinv = (coef > 0 && tdiag > 0) ? 1.0f / tdiag : 0.0f;
-                const float trhs = -dot(dir, oA.ws) * tdinv;
-                if (l < 3 && have) {
-                    float4 *bp4 = (float4 *)&LD(L_OSL + (3 * slot + l) * 12);
-                    bp4[0] = make_float4(dir.x, dir.y, dir.z, ang.x);
-                    bp4[1] = make_float4(ang.y, ang.z, mang.x, mang.y);
-                    bp4[2] = make_float4(mang.z, rhs, dinv, l == 0 ? lam0 : 0.0f);      // (.w of the normal row: warm-start impulse)
-                    float4 *tp4 = (float4 *)&LD(L_OST + (3 * slot + l) * 8);
-                    tp4[0] = make_float4(tm.x, tm.y, tm.z, trhs);
-                    tp4[1] = make_float4(tdinv, 0.0f, 0.0f, 0.0f);
-                }
+                if (l < 3 && have)
+                    os_row_pair(l, l == 0 ? n : (l == 1 ? t1 : t2), x, oA, dist, rest, spin, roll, lam0, dt, P.erp, P.rest_thresh,
+                                L_OSL + (3 * slot + l) * 12, L_OST + (3 * slot + l) * 8);
                 continue;
             }
             if (!GEN || !have) continue;
@@ -1741,7 +1806,10 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // the staging area is rewritten by the next batch
         __builtin_amdgcn_wave_barrier();
     }
-    if (!GEN && class_mismatch && l == 0 && !dead) atomicOr(&D.errflags[env], 4u);      // (internal consistency: never seen)
+    if (!GEN) {
+        const unsigned mm = (unsigned)(__ballot(class_mismatch) >> (16 * (grp & 3))) & 0xffffu;
+        if (mm != 0u && l == 0 && !dead) atomicOr(&D.errflags[env], 4u);      // (internal consistency: never seen)
+    }
     if (coop) {
         // the warm-start velocity change of the generic normal rows, in list order, from the stored rows: the very fma sequence
         // a single builder runs in line (each of the four builders holds only its own contacts' share)
@@ -4197,6 +4265,8 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         // runs beside the shading of the main stream / the render of the heavy envs.
         // Where the look-ahead goes: behind the very heavy envs' render when they are a handful (their stream is then the first to
         // be done), else at the tail of the main stream (macro actions: hundreds of very heavy envs make theirs the longest chain).
+        // (k_prep_ab on the heavy stream in front of its render, k_collide behind the very heavy envs' render: measured, 0.730
+        // instead of 0.710 ms -- the heavy envs' render, the shading and the collision pass then all start together)
         // (a fourth stream just for it was measured: with one more hardware queue in play every kernel of the step slows down --
         // the 6 us command kernel of that build took 44 us, 60 us gaps, 1.19 instead of 0.81 ms)
         const bool la_on_vh = !e->h_hcount || ((volatile int *)e->h_hcount)[1] <= 64;
