@@ -1475,46 +1475,6 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     float *state = D.state, *scratch = D.scratch;
     const int lj = l < NB ? l : 0;               // joint owned by this lane (lanes >= 11 alias joint 0, masked)
     const int lo_ = (l >= NB && l < NB + NOBJ) ? l - NB : -1;   // object owned by this lane
-    // ---- the command part of the step -- everything that needs the action: limitActionByJoint (env.py:314-321), the clipping
-    // and gripper coupling of Kuka.apply_action (robot.py:188-201) -> the motor target of this lane's joint; a non-finite
-    // command flags the env (robot.py:189 asserts) and the env does not step.  It also APPLIES the out-of-bounds rule
-    // (env.py:257-264) to the state: the state part of the preparation only derived the collision inputs from the re-posed object.
-    const unsigned ef0 = (mine && env_raw < N) ? D.errflags[env] : 1u;
-    float tgt_l = 0.0f;
-    bool rejected = false;
-    {
-        const int lc = l < 9 ? l : 0;
-        const float v = D.cmd_in[(size_t)env * 9 + lc];
-        const float qv = STT(ST_Q + lc);
-        const float cur = l == 8 ? -qv : qv;                             // robot.py:203-211
-        float d = v - cur;                                               // env.py:314-321
-        d = fminf(d, B.act_maxdiff[lc]);
-        d = fmaxf(d, -B.act_maxdiff[lc]);
-        float a = cur + d;
-        a = fmaxf(B.act_min[lc], fminf(a, B.act_max[lc]));               // robot.py:192
-        const float a7 = row_bcast<7>(a);
-        if (l == 8) a = fmaxf(0.0f, fminf(2.0f * a7, a));                // robot.py:193
-        const float a8 = row_bcast<8>(a);
-        tgt_l = l < 7 ? a : ((l == 7 || l == 9) ? a7 : -a8);             // robot.py:195-201 (lanes 8, 10: -a8)
-        rejected = ((unsigned)(__ballot(l < 9 && !isfinite(v)) >> (16 * (grp & 3))) & 0xffffu) != 0u;
-    }
-    const bool frozen = (ef0 & 1u) != 0u;
-    if (!frozen && l == 0) D.errflags[env] = rejected ? ((ef0 & ~2u) | 2u) : (ef0 & ~2u);
-    bool dead = frozen || (ef0 & ~3u) != 0u || rejected;
-    // an env whose command was rejected does not step; the list the look-ahead made for this step is dropped with it, so that
-    // the normal forces of the last solved step (cforce) are never matched against a list they do not belong to
-    if (!frozen && rejected && l == 0) D.ccount[env] = 0;
-    if (!dead) {
-        if (l < NB) STT(ST_TGT + l) = tgt_l;
-        if (lo_ >= 0 && lo_ < P.nobj) {                                  // env.py:257-264
-            const int i = lo_;
-            const float x = STT(ST_OPOS + 3 * i), z = STT(ST_OPOS + 3 * i + 2);
-            if (object_out_of_bounds(x, z, B.table_z)) {
-                for (int k = 0; k < 3; k++) { STT(ST_OPOS + 3 * i + k) = D.obj_home[(size_t)(7 * i + k) * N + env]; STT(ST_OVEL + 3 * i + k) = 0; STT(ST_OANG + 3 * i + k) = 0; }
-                for (int k = 0; k < 4; k++) STT(ST_OQUAT + 4 * i + k) = D.obj_home[(size_t)(7 * i + 3 + k) * N + env];
-            }
-        }
-    }
     const ShapeData *S = D.shapes;
     const int fix = (coop ? (grp >> 2) : grp) * LF_TOTAL;            // (coop: the four groups of a wave share its one LDS region)
     const int L_MINV = fix + LF_MINV, L_MOT = fix + LF_MOT, L_LIM = fix + LF_LIM, L_META = fix + LF_META, L_MU = fix + LF_MU,
@@ -1524,51 +1484,98 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     const float dt = P.dt, inv_dt = 1.0f / P.dt;
     SPROF_INIT
     SBLK_BEGIN
-    // ---- stage Minv in LDS; the lane's joint frame and unconstrained velocity go to registers (same round trip)
-    for (int i = l; i < NB * NB; i += 16) LD(L_MINV + i) = SCR(S_MINV + i);
+    // ---- stage-in: EVERY global load of the env's inputs is issued here, before anything is computed from them or stored (a
+    // global round trip costs ~7000 cycles at one wave per SIMD, and a store in between would hold the later loads back):
+    // error flags, command, the lane's joint state and frame, M^-1 (staged in LDS below), the contact count, the first 16
+    // contact records with their inherited impulses, the object lanes' data.
+    const unsigned ef0 = (mine && env_raw < N) ? D.errflags[env] : 1u;
+    const int lc = l < 9 ? l : 0;
+    const float cmd_v = D.cmd_in[(size_t)env * 9 + lc];
+    const float act_md = B.act_maxdiff[lc], act_lo = B.act_min[lc], act_hi = B.act_max[lc];
+    const float q_l = STT(ST_Q + lj), qds_l = SCR(S_QDS + lj);
+    float minv_stage[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) minv_stage[i] = SCR(S_MINV + min(l + 16 * i, NB * NB - 1));
     const v3 pk_l = mk(SCR(S_BP + 3 * lj), SCR(S_BP + 3 * lj + 1), SCR(S_BP + 3 * lj + 2));
     const v3 ak_l = mk(SCR(S_BAX + 3 * lj), SCR(S_BAX + 3 * lj + 1), SCR(S_BAX + 3 * lj + 2));
-    const float q_l = STT(ST_Q + lj), qds_l = SCR(S_QDS + lj);
-    // the env's contact list (k_collide): count and all MAXC records are requested here, in the same round trip as the rest
-    // of the stage-in -- lane l holds float4 #(l + 16 i) of the 144; records beyond the count are never looked at
-    const int nct = dead ? 0 : min(D.ccount[env], MAXC);
-    float4 crec[9];
+    const int ccount_in = D.ccount[env];
     float cw0, cw1, cw2;              // warm-start impulses of contacts l, 16 + l, 32 + l
+    float4 cr0, cr1, cr2, cr3, cr4, cr5, cr6, cr7, cr8;   // lane l's float4 #(l + 16 i) of the list: cr0..2 = the first 16 records
     {
-        // (the first 16 records -- all a light env has -- come with the count, unconditionally; the other 32 only for a wave with
-        // an env that has them: a second round trip for those, 1.5 KB less traffic for every other env)
         const float4 *cl = D.clist + (size_t)env * MAXC * 3;
-#pragma unroll
-        for (int i = 0; i < 3; i++) crec[i] = cl[16 * i + l];
-#pragma unroll
-        for (int i = 3; i < 9; i++) crec[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (GEN && __ballot(nct > 16) != 0ull) {        // (a light env has at most 12 contacts, all on the object lanes)
-#pragma unroll
-            for (int i = 3; i < 9; i++) crec[i] = cl[16 * i + l];
+        cr0 = cl[l]; cr1 = cl[16 + l]; cr2 = cl[32 + l];
+        cr3 = cr4 = cr5 = cr6 = cr7 = cr8 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (GEN && __ballot(ccount_in > 16) != 0ull) {  // (a light env has at most 12 contacts, all on the object lanes; a heavy one
+            cr3 = cl[48 + l]; cr4 = cl[64 + l]; cr5 = cl[80 + l];     //  with more than 16 pays a second round trip for the other 32 records)
+            cr6 = cl[96 + l]; cr7 = cl[112 + l]; cr8 = cl[128 + l];
         }
         const float *cwp = D.cwarm + (size_t)env * MAXC;
-        cw0 = l < nct ? cwp[l] : 0.0f; cw1 = 16 + l < nct ? cwp[16 + l] : 0.0f; cw2 = 32 + l < nct ? cwp[32 + l] : 0.0f;
+        cw0 = cwp[l]; cw1 = cwp[16 + l]; cw2 = cwp[32 + l];       // (unconditional: selected by the count below)
     }
-    float wsA = 0.0f, wsB = 0.0f;     // slot-layout velocity change of the warm-start impulses of the generic normal rows
-    // lanes 11..13 fetch "their" object's pose / inverse inertia / unconstrained velocities and publish them in LDS: the row
-    // builder reads the data of a contact's objects from there (20 floats per object: position, 1/mass, I^-1, v*, w*)
+    // the object lanes: the pose that counts (k_prep: the home pose when the out-of-bounds rule fires), inverse inertia,
+    // unconstrained velocities; the raw position decides whether the rule fires (then this kernel writes the home pose into the state)
     ObjData myobj;
-    {
-        const int ob = (l >= NB && l < NB + NOBJ && l - NB < P.nobj) ? l - NB : 0;
-        myobj.op = mk(STT(ST_OPOS + 3 * ob), STT(ST_OPOS + 3 * ob + 1), STT(ST_OPOS + 3 * ob + 2));
+    const int ob_l = (l >= NB && l < NB + NOBJ && l - NB < P.nobj) ? l - NB : 0;
+    const float raw_x = STT(ST_OPOS + 3 * ob_l), raw_z = STT(ST_OPOS + 3 * ob_l + 2);
+    float oquat[4];                   // orientation at the start of the step (replaced by the home orientation below if the rule fires)
 #pragma unroll
-        for (int kk = 0; kk < 9; kk++) myobj.Iinv.m[kk] = SCR(S_OIINV + 9 * ob + kk);
-        myobj.vs = mk(SCR(S_OVS + 3 * ob), SCR(S_OVS + 3 * ob + 1), SCR(S_OVS + 3 * ob + 2));
-        myobj.ws = mk(SCR(S_OWS + 3 * ob), SCR(S_OWS + 3 * ob + 1), SCR(S_OWS + 3 * ob + 2));
-        myobj.imass = 1.0f / (ob == 0 ? B.obj_mass[0] : (ob == 1 ? B.obj_mass[1] : B.obj_mass[2]));
-        if (lo_ >= 0) {
-            float4 *od = (float4 *)&LD(L_OBJ + 20 * lo_);
-            od[0] = make_float4(myobj.op.x, myobj.op.y, myobj.op.z, myobj.imass);
-            od[1] = make_float4(myobj.Iinv.m[0], myobj.Iinv.m[1], myobj.Iinv.m[2], myobj.Iinv.m[3]);
-            od[2] = make_float4(myobj.Iinv.m[4], myobj.Iinv.m[5], myobj.Iinv.m[6], myobj.Iinv.m[7]);
-            od[3] = make_float4(myobj.Iinv.m[8], myobj.vs.x, myobj.vs.y, myobj.vs.z);
-            od[4] = make_float4(myobj.ws.x, myobj.ws.y, myobj.ws.z, 0.0f);
+    for (int k = 0; k < 4; k++) oquat[k] = STT(ST_OQUAT + 4 * ob_l + k);
+    myobj.op = mk(SCR(S_OP + 3 * ob_l), SCR(S_OP + 3 * ob_l + 1), SCR(S_OP + 3 * ob_l + 2));
+#pragma unroll
+    for (int kk = 0; kk < 9; kk++) myobj.Iinv.m[kk] = SCR(S_OIINV + 9 * ob_l + kk);
+    myobj.vs = mk(SCR(S_OVS + 3 * ob_l), SCR(S_OVS + 3 * ob_l + 1), SCR(S_OVS + 3 * ob_l + 2));
+    myobj.ws = mk(SCR(S_OWS + 3 * ob_l), SCR(S_OWS + 3 * ob_l + 1), SCR(S_OWS + 3 * ob_l + 2));
+    myobj.imass = 1.0f / (ob_l == 0 ? B.obj_mass[0] : (ob_l == 1 ? B.obj_mass[1] : B.obj_mass[2]));
+    // ---- the command part of the step -- everything that needs the action: limitActionByJoint (env.py:314-321), the clipping
+    // and gripper coupling of Kuka.apply_action (robot.py:188-201) -> the motor target of this lane's joint; a non-finite
+    // command flags the env (robot.py:189 asserts) and the env does not step.  It also APPLIES the out-of-bounds rule
+    // (env.py:257-264) to the state: the state part of the preparation only derived the collision inputs from the re-posed object.
+    float tgt_l = 0.0f;
+    bool rejected = false;
+    {
+        const float cur = l == 8 ? -q_l : q_l;                           // robot.py:203-211 (lanes 0..8: q_l is joint l)
+        float d = cmd_v - cur;                                           // env.py:314-321
+        d = fminf(d, act_md);
+        d = fmaxf(d, -act_md);
+        float a = cur + d;
+        a = fmaxf(act_lo, fminf(a, act_hi));                             // robot.py:192
+        const float a7 = row_bcast<7>(a);
+        if (l == 8) a = fmaxf(0.0f, fminf(2.0f * a7, a));                // robot.py:193
+        const float a8 = row_bcast<8>(a);
+        tgt_l = l < 7 ? a : ((l == 7 || l == 9) ? a7 : -a8);             // robot.py:195-201 (lanes 8, 10: -a8)
+        rejected = ((unsigned)(__ballot(l < 9 && !isfinite(cmd_v)) >> (16 * (grp & 3))) & 0xffffu) != 0u;
+    }
+    const bool frozen = (ef0 & 1u) != 0u;
+    bool dead = frozen || (ef0 & ~3u) != 0u || rejected;
+    const int nct = dead ? 0 : min(ccount_in, MAXC);
+    cw0 = l < nct ? cw0 : 0.0f; cw1 = 16 + l < nct ? cw1 : 0.0f; cw2 = 32 + l < nct ? cw2 : 0.0f;
+    // ---- and only now the stores of the command part
+    if (!frozen && l == 0) D.errflags[env] = rejected ? ((ef0 & ~2u) | 2u) : (ef0 & ~2u);
+    // an env whose command was rejected does not step; the list the look-ahead made for this step is dropped with it, so that
+    // the normal forces of the last solved step (cforce) are never matched against a list they do not belong to
+    if (!frozen && rejected && l == 0) D.ccount[env] = 0;
+    if (!dead) {
+        if (l < NB) STT(ST_TGT + l) = tgt_l;
+        if (lo_ >= 0 && lo_ < P.nobj && object_out_of_bounds(raw_x, raw_z, B.table_z)) {       // env.py:257-264
+            const int i = lo_;
+            for (int k = 0; k < 3; k++) { STT(ST_OPOS + 3 * i + k) = D.obj_home[(size_t)(7 * i + k) * N + env]; STT(ST_OVEL + 3 * i + k) = 0; STT(ST_OANG + 3 * i + k) = 0; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { oquat[k] = D.obj_home[(size_t)(7 * i + 3 + k) * N + env]; STT(ST_OQUAT + 4 * i + k) = oquat[k]; }
         }
+    }
+    // M^-1 goes to LDS (row builders, limit rows)
+#pragma unroll
+    for (int i = 0; i < 8; i++) if (l + 16 * i < NB * NB) LD(L_MINV + l + 16 * i) = minv_stage[i];
+    float wsA = 0.0f, wsB = 0.0f;     // slot-layout velocity change of the warm-start impulses of the generic normal rows
+    // lanes 11..13 publish "their" object's data in LDS: the row builder reads the data of a contact's objects from there
+    // (20 floats per object: position, 1/mass, I^-1, v*, w*)
+    if (lo_ >= 0) {
+        float4 *od = (float4 *)&LD(L_OBJ + 20 * lo_);
+        od[0] = make_float4(myobj.op.x, myobj.op.y, myobj.op.z, myobj.imass);
+        od[1] = make_float4(myobj.Iinv.m[0], myobj.Iinv.m[1], myobj.Iinv.m[2], myobj.Iinv.m[3]);
+        od[2] = make_float4(myobj.Iinv.m[4], myobj.Iinv.m[5], myobj.Iinv.m[6], myobj.Iinv.m[7]);
+        od[3] = make_float4(myobj.Iinv.m[8], myobj.vs.x, myobj.vs.y, myobj.vs.z);
+        od[4] = make_float4(myobj.ws.x, myobj.ws.y, myobj.ws.z, 0.0f);
     }
     // row l of Minv in registers (motor rows, and M^-1 J^T of the generic rows)
     float minv_l[NB];
@@ -1606,8 +1613,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         // (os_row_pair), same bits.
         {
             float4 *st = (float4 *)&LD(L_CST);
-#pragma unroll
-            for (int i = 0; i < 3; i++) st[16 * i + l] = crec[i];
+            st[l] = cr0; st[16 + l] = cr1; st[32 + l] = cr2;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1658,14 +1664,13 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     } else
 #pragma unroll 1        // one copy of the (large) row-building body: the kernel must stay inside the instruction cache
     for (int bt = 0; 16 * bt < nct_max; bt++) {
-        {   // batch bt = records 16 bt .. 16 bt + 15 = float4 48 bt .. 48 bt + 47 of the list = crec[3 bt .. 3 bt + 2] of the lanes
+        {   // batch bt = records 16 bt .. 16 bt + 15 = float4 48 bt .. 48 bt + 47 of the list = cr(3 bt) .. cr(3 bt + 2) of the lanes
             float4 *st = (float4 *)&LD(L_CST);
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const float4 a = crec[i], b = crec[3 + i], c = crec[6 + i];
-                st[16 * i + l] = make_float4(bt == 0 ? a.x : (bt == 1 ? b.x : c.x), bt == 0 ? a.y : (bt == 1 ? b.y : c.y),
-                                             bt == 0 ? a.z : (bt == 1 ? b.z : c.z), bt == 0 ? a.w : (bt == 1 ? b.w : c.w));
-            }
+#define STAGE_REC(I, A_, B_, C_)                                                                                        \
+            st[16 * (I) + l] = make_float4(bt == 0 ? A_.x : (bt == 1 ? B_.x : C_.x), bt == 0 ? A_.y : (bt == 1 ? B_.y : C_.y), \
+                                           bt == 0 ? A_.z : (bt == 1 ? B_.z : C_.z), bt == 0 ? A_.w : (bt == 1 ? B_.w : C_.w));
+            STAGE_REC(0, cr0, cr3, cr6) STAGE_REC(1, cr1, cr4, cr7) STAGE_REC(2, cr2, cr5, cr8)
+#undef STAGE_REC
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -2137,29 +2142,43 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     if (dead) return;
     // ---- integrate: lanes 0..10 joints, lanes 11..13 objects
     bool finite = true;
-    if (l < NB) {
+    // (the lane predicates of the tail are taken from a copy of the lane index the compiler cannot see through: lane masks of
+    // the stage-in kept alive over the sweeps cost scalar registers the solver does not have)
+    int lt = l;
+    asm volatile("" : "+v"(lt));
+    if (lt < NB) {
         float v = qds_l + dq;
         float qn = q_l + dt * v;
         finite = isfinite(qn);
-        STT(ST_QD + l) = v;
-        STT(ST_Q + l) = qn;
-        if (l < 7) D.joints[(size_t)env * 9 + l] = qn;                 // robot.py:203-211
-        else if (l == 7) D.joints[(size_t)env * 9 + 7] = qn;
-        else if (l == 8) D.joints[(size_t)env * 9 + 8] = -qn;
+        STT(ST_QD + lt) = v;
+        STT(ST_Q + lt) = qn;
+        if (lt < 7) D.joints[(size_t)env * 9 + lt] = qn;               // robot.py:203-211
+        else if (lt == 7) D.joints[(size_t)env * 9 + 7] = qn;
+        else if (lt == 8) D.joints[(size_t)env * 9 + 8] = -qn;
     }
-    if (lo_ >= 0 && lo_ < P.nobj) {
-        const int i = lo_;
-        float v[3], w[3];
+    if (lt >= NB && lt - NB < P.nobj) {
+        // (position, orientation and unconstrained velocities are the registers of the stage-in: no load at the tail of the chain)
+        const int i = lt - NB;
+        float v[3], w[3], pn[3];
         const float dvi[3] = {dv.x, dv.y, dv.z}, dwi[3] = {dw.x, dw.y, dw.z};
+        // (GEN: the solver with the generic rows has no 13 registers to spare over the sweeps -- it reads them again)
+        float vs3[3] = {myobj.vs.x, myobj.vs.y, myobj.vs.z}, ws3[3] = {myobj.ws.x, myobj.ws.y, myobj.ws.z};
+        float op3[3] = {myobj.op.x, myobj.op.y, myobj.op.z};
+        if (GEN) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { vs3[k] = SCR(S_OVS + 3 * i + k); ws3[k] = SCR(S_OWS + 3 * i + k); op3[k] = SCR(S_OP + 3 * i + k); }
+#pragma unroll
+            for (int k = 0; k < 4; k++) oquat[k] = STT(ST_OQUAT + 4 * i + k);
+        }
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            v[k] = SCR(S_OVS + 3 * i + k) + dvi[k];
-            w[k] = SCR(S_OWS + 3 * i + k) + dwi[k];
-            float pn = STT(ST_OPOS + 3 * i + k) + dt * v[k];
-            finite = finite && isfinite(pn);
+            v[k] = vs3[k] + dvi[k];
+            w[k] = ws3[k] + dwi[k];
+            pn[k] = op3[k] + dt * v[k];
+            finite = finite && isfinite(pn[k]);
             STT(ST_OVEL + 3 * i + k) = v[k];
             STT(ST_OANG + 3 * i + k) = w[k];
-            STT(ST_OPOS + 3 * i + k) = pn;
+            STT(ST_OPOS + 3 * i + k) = pn[k];
         }
         float wn = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
         float ang = wn * dt, d0, d1, d2, d3;
@@ -2171,7 +2190,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         } else {
             d0 = w[0] * dt * 0.5f; d1 = w[1] * dt * 0.5f; d2 = w[2] * dt * 0.5f; d3 = 1.0f;
         }
-        float q0 = STT(ST_OQUAT + 4 * i), q1 = STT(ST_OQUAT + 4 * i + 1), q2 = STT(ST_OQUAT + 4 * i + 2), q3 = STT(ST_OQUAT + 4 * i + 3);
+        float q0 = oquat[0], q1 = oquat[1], q2 = oquat[2], q3 = oquat[3];
         float r0 = d3 * q0 + d0 * q3 + d1 * q2 - d2 * q1;
         float r1 = d3 * q1 - d0 * q2 + d1 * q3 + d2 * q0;
         float r2 = d3 * q2 + d0 * q1 - d1 * q0 + d2 * q3;
@@ -2180,28 +2199,40 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         STT(ST_OQUAT + 4 * i) = r0 * inv; STT(ST_OQUAT + 4 * i + 1) = r1 * inv;
         STT(ST_OQUAT + 4 * i + 2) = r2 * inv; STT(ST_OQUAT + 4 * i + 3) = r3 * inv;
         float *op = D.objpose + ((size_t)env * P.nobj + i) * 7;
-        for (int k = 0; k < 3; k++) op[k] = STT(ST_OPOS + 3 * i + k);
+        for (int k = 0; k < 3; k++) op[k] = pn[k];
         op[3] = r0 * inv; op[4] = r1 * inv; op[5] = r2 * inv; op[6] = r3 * inv;
     }
     SPROF(5);
     if (!finite) atomicOr(&D.errflags[env], 1u);
-    // ---- touch sensors (robot.py:152-163) + contact forces: lane 0
-    if (l == 0) {
+    // ---- touch sensors (robot.py:152-163) + contact forces: lane c takes contacts c, c + 16, c + 32; the four maxima go round
+    // the group (a maximum does not depend on the order it is taken in)
+    {
         float touch[4] = {0, 0, 0, 0};
-        for (int c = 0; c < nc; c++) {
-            const int meta = *(const int *)&LD(L_META + c);
-            const int bodyA = meta_bodyA(meta), link = meta_link(meta);
-            const float lam = meta_fast(meta) ? LD(L_OSL + (3 * meta_slot(meta)) * 12 + 11) : LD(L_GSC + 24 * meta_slot(meta) + 3);
-            float f = lam / dt;
-            D.cforce[(size_t)env * MAXC + c] = f;
-            if (bodyA < 0 || bodyA >= 16) continue;
-            if (!meta_near(meta)) continue;
+        for (int c0 = 0; c0 < nc; c0 += 16) {
+            const int c = c0 + l;
+            if (c < nc) {
+                const int meta = *(const int *)&LD(L_META + c);
+                const int bodyA = meta_bodyA(meta), link = meta_link(meta);
+                const float lam = meta_fast(meta) ? LD(L_OSL + (3 * meta_slot(meta)) * 12 + 11) : LD(L_GSC + 24 * meta_slot(meta) + 3);
+                const float f = lam / dt;
+                D.cforce[(size_t)env * MAXC + c] = f;
+                if (bodyA >= 0 && bodyA < 16 && meta_near(meta)) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (link == B.touch_links[k]) touch[k] = fmaxf(touch[k], f);
+                    for (int k = 0; k < 4; k++) if (link == B.touch_links[k]) touch[k] = fmaxf(touch[k], f);
+                }
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) D.touch[(size_t)env * 4 + k] = touch[k];
-        D.timestep[env] += 1;
+        for (int k = 0; k < 4; k++) {
+            float m = touch[k];
+            m = fmaxf(m, dpp_ror<8>(m)); m = fmaxf(m, dpp_ror<4>(m)); m = fmaxf(m, dpp_ror<2>(m)); m = fmaxf(m, dpp_ror<1>(m));
+            touch[k] = m;
+        }
+        if (l == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) D.touch[(size_t)env * 4 + k] = touch[k];
+            D.timestep[env] += 1;
+        }
     }
     SPROF(6);
 }

@@ -35,6 +35,30 @@ def state_bounds(fmax):
     return 3e-4 * k, 1e-6 * k, 4e-4 * k
 
 
+SENS_RUNS = 8             # oracle re-runs from a state moved by one unit in the last place, per check above the flat bounds
+SENS_FACTOR = 4.0         # the device may differ from the oracle by this many times the oracle's own spread over those re-runs
+
+
+def oracle_sensitivity(o, st0, cache, cmd, ref, nobj, rng):
+    """How far the float oracle's OWN one-step result moves when every entry of the start state is moved by one unit in the
+    last place (SENS_RUNS random sign patterns): the conditioning of this step's contact problem under 50 projected
+    Gauss-Seidel sweeps, measured rather than assumed (a clamp that flips in one sweep moves the result by far more than
+    the rounding that flipped it).  Returns the largest deviation from the unperturbed result `ref` in the three groups of
+    state_bounds (joints, object pose, object velocity)."""
+    sj = so = sv = 0.0
+    st0 = st0.astype(np.float32)
+    for _ in range(SENS_RUNS):
+        up = rng.random(st0.shape) < 0.5
+        stp = np.where(up, np.nextafter(st0, np.float32(np.inf)), np.nextafter(st0, np.float32(-np.inf)))
+        o.state = stp.astype(np.float64)
+        o.set_contact_cache(cache)
+        o.step(cmd.astype(np.float64))
+        d = np.abs(o.state - ref)
+        dobj = d[22:22 + 13 * nobj].reshape(nobj, 13)
+        sj, so, sv = max(sj, float(d[:22].max())), max(so, float(dobj[:, :7].max())), max(sv, float(dobj[:, 7:].max()))
+    return sj, so, sv
+
+
 def solver_independent_checks(o, st1, cd, co):
     """What holds for ANY correct solver run on the step's contact problem, whatever its rounding: evaluated on the float
     oracle's rows (o has just stepped) for the device's solution (post-step state st1, normal forces cd[:, 10]) and for the
@@ -137,10 +161,21 @@ def _fuzz_case(case, seed0, stats, bad):
             stats[key + 'dj'] = max(stats[key + 'dj'], dj / bj)
             stats[key + 'do'] = max(stats[key + 'do'], do / bo)
             stats[key + 'dv'] = max(stats[key + 'dv'], dv / bv)
-            # every check is held to a stated bound: the flat one up to CRUSH_FORCE, the force-scaled one above it
-            if not np.isfinite(st1[i]).all() or dj > bj or do > bo or dv > bv:
-                bad.append(tag + ('state', dj, do, dv, fmax))
+            # every check is held to a stated bound: the flat one up to CRUSH_FORCE, the force-scaled one above it.  A crushed
+            # step that is over the scaled bound has to be explained by the conditioning of ITS contact problem, measured on
+            # the oracle itself: within SENS_FACTOR x the oracle's spread under one-ulp changes of the start state -- and the
+            # solver-independent properties below hold for it like for every other check.  Nothing is waived below CRUSH_FORCE.
+            over = dj > bj or do > bo or dv > bv
+            ref_state = o.state.copy()
             ok, det = solver_independent_checks(o, st1[i], cd, co)
+            if not np.isfinite(st1[i]).all() or (over and not crush):
+                bad.append(tag + ('state', dj, do, dv, fmax))
+            elif over:
+                sj, so_, sv = oracle_sensitivity(o, st0[i], cache[int(i)], cmd[i], ref_state, nobj, np.random.default_rng(case * 1000 + t))
+                stats['ill'] += 1
+                stats['ill_share'] = max(stats['ill_share'], dj / max(SENS_FACTOR * sj, bj), do / max(SENS_FACTOR * so_, bo), dv / max(SENS_FACTOR * sv, bv))
+                if dj > max(SENS_FACTOR * sj, bj) or do > max(SENS_FACTOR * so_, bo) or dv > max(SENS_FACTOR * sv, bv):
+                    bad.append(tag + ('state (ill-conditioned step)', dj, do, dv, fmax, sj, so_, sv))
             if not ok:
                 bad.append(tag + ('solver-independent', det))
             o.state = st1[i].astype(np.float64)
@@ -158,25 +193,28 @@ def _fuzz_case(case, seed0, stats, bad):
 def test_seeded_differential_run_contact_lists_bit_identical():
     """>= 300 seeded cases; zero disagreements in the contact lists (in particular no candidate that sits at the 2 cm margin
     on one side only); EVERY check's state within the stated one-step bounds (state_bounds: flat up to 2 kN of normal force,
-    scaled with the force above) and the solver-independent properties of the device's solution (active set, force sum,
-    complementarity residual) as good as the oracle's; image masks and depths exact, RGB within one grey level except at most
-    two texel-boundary pixels per frame."""
-    stats = dict(checks=0, contacts=0, crush=0, dj=0.0, do=0.0, dv=0.0, c_dj=0.0, c_do=0.0, c_dv=0.0)
+    scaled with the force above; a crushed step over the scaled bound -- at most 2 % of the crushed ones -- is held to
+    SENS_FACTOR x the oracle's own measured spread under one-ulp changes of the start state, oracle_sensitivity) and the
+    solver-independent properties of the device's solution (active set, force sum, complementarity residual) as good as
+    the oracle's; image masks and depths exact, RGB within one grey level except at most two texel-boundary pixels per frame."""
+    stats = dict(checks=0, contacts=0, crush=0, dj=0.0, do=0.0, dv=0.0, c_dj=0.0, c_do=0.0, c_dv=0.0, ill=0, ill_share=0.0)
     bad = []
     n_cases = int(os.environ.get('RR_FUZZ_CASES', '300'))
     only = os.environ.get('RR_FUZZ_ONLY')
     for case in ([int(only)] if only else range(n_cases)):
         _fuzz_case(case, 2, stats, bad)
     print("fuzz: %d cases, %d one-step checks, %d contacts compared, %d of them above %.0f N; worst share of the bound used -- joints %.2f object pose %.2f "
-          "object velocity %.2f (above: %.2f %.2f %.2f); %d violations"
+          "object velocity %.2f (above: %.2f %.2f %.2f; %d of those steps over the scaled bound and held to %.0f x the oracle's own "
+          "one-ulp spread instead, worst share %.2f); %d violations"
           % (n_cases, stats['checks'], stats['contacts'], stats['crush'], CRUSH_FORCE, stats['dj'], stats['do'], stats['dv'],
-             stats['c_dj'], stats['c_do'], stats['c_dv'], len(bad)))
+             stats['c_dj'], stats['c_do'], stats['c_dv'], stats['ill'], SENS_FACTOR, stats['ill_share'], len(bad)))
     for b in bad[:20]:
         print("   violation:", b)
     assert not bad, bad[:20]
     if not only:
         assert stats['checks'] >= 3 * n_cases and stats['contacts'] > 20 * n_cases
         assert stats['crush'] <= 0.15 * stats['checks']      # full-range commands press links into the table now and then
+        assert stats['ill'] <= 0.02 * stats['crush'] + 1      # the measured-conditioning bound is the exception, not a second regime
 
 
 def _grasp_script():
