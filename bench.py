@@ -146,6 +146,8 @@ def kernel_table(env, nat, n_local, n_obj, w, h, render, step_fn, nprof):
         frags = float(env.host(nat.F_FRAG_COUNT).sum()) / n_local      # list entries (won + vacated pixels), mean per env
         algo['k_raster'] += 8 * frags
         algo['k_shade'] += 15 * frags
+    if render and not timing.get('k_render_setup', (0.0, 0))[1]:
+        algo['k_solve'] += algo['k_render_setup']      # the light solve sets up the render instances of its envs itself
     kernels = {}
     for k, (ms, n) in timing.items():
         if not n:

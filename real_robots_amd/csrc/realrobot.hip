@@ -1442,13 +1442,91 @@ __device__ __forceinline__ void os_row_pair(int k, v3 dir, v3 x, const ObjData &
     tp4[1] = make_float4(tdinv, 0.0f, 0.0f, 0.0f);
 }
 
+// ---------------------------------------------------------------------------------------------- render setup
+// Instance transforms for the rasteriser, one thread per (env, instance): a robot-link thread composes the joint
+// transforms of its body's ancestors only (same operations, in the same order, as fk_all() for that chain), an object
+// thread converts the object's quaternion; the 12 floats of an instance are stored as three 16-byte words, so a wave
+// writes a contiguous span.  (One thread per env needed 264 stores with a 1.5 KB stride between lanes.)
+// instance i of env: FK of its owner's ancestor chain -> model-view-projection matrix and shading constants (D.inst_xf).
+// qj: the robot's joint angles; op7: pose {x y z, quaternion} of the instance's object (read for an object instance only).
+// Two callers: k_render_setup (values from the state) and the light solve, which runs it on the values it has just
+// integrated (registers / LDS) -- the same operations on the same floats, hence the same bits.
+__device__ __forceinline__ void instance_setup_core(const BodyParams &B, const RenderModel &RM, const DevPtrs &D, int env, int i, int ot, int oi,
+                                                    const float (&qj)[NB], const float (&op7)[7]) {
+    m3 R = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+    v3 p = mk(0, 0, 0);
+    if (ot == 1) {
+        unsigned anc = 0;
+#pragma unroll
+        for (int b = 0; b < NB; b++) if (oi == b) anc = ANC[b];
+        p = mk(B.robot_pos[0], B.robot_pos[1], B.robot_pos[2]);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if (!((anc >> b) & 1u)) continue;
+            m3 jr;
+#pragma unroll
+            for (int k = 0; k < 9; k++) jr.m[k] = B.jrot[b][k];
+            const m3 Rj = nc::mul(R, jr);
+            const v3 ax = mk(B.axis[b][0], B.axis[b][1], B.axis[b][2]);
+            p = nc::add(p, nc::mulv(R, mk(B.jpos[b][0], B.jpos[b][1], B.jpos[b][2])));
+            R = nc::mul(Rj, nc::axis_angle(ax, qj[b]));
+        }
+    } else if (ot == 2) {
+        R = nc::quat_to_m3(op7[3], op7[4], op7[5], op7[6]);
+        p = mk(op7[0], op7[1], op7[2]);
+    }
+    // mvp = VP * [R p; 0 1] (same summation order as the oracle's 4x4 product, no FMA contraction), then the shading
+    // constants: the raster and shading workgroups just copy these 128 bytes per instance into LDS
+    float mvp[16];
+    {
+#pragma clang fp contract(off)
+        const float xf[12] = {R.m[0], R.m[1], R.m[2], R.m[3], R.m[4], R.m[5], R.m[6], R.m[7], R.m[8], p.x, p.y, p.z};
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int r = e >> 2, c = e & 3;
+            float a = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) a += RM.VP[4 * r + k] * (c < 3 ? xf[3 * k + c] : xf[9 + k]);
+            a += RM.VP[4 * r + 3] * (c == 3 ? 1.0f : 0.0f);
+            mvp[e] = a;
+        }
+    }
+    const int tidx = RM.in_tex[i];
+    float4 *o = (float4 *)(D.inst_xf + ((size_t)env * MAXINST + i) * 32);
+    o[0] = make_float4(mvp[0], mvp[1], mvp[2], mvp[3]);
+    o[1] = make_float4(mvp[4], mvp[5], mvp[6], mvp[7]);
+    o[2] = make_float4(mvp[8], mvp[9], mvp[10], mvp[11]);
+    o[3] = make_float4(mvp[12], mvp[13], mvp[14], mvp[15]);
+    o[4] = make_float4(R.m[0], R.m[1], R.m[2], R.m[3]);
+    o[5] = make_float4(R.m[4], R.m[5], R.m[6], R.m[7]);
+    o[6] = make_float4(R.m[8], RM.in_color[i][0], RM.in_color[i][1], RM.in_color[i][2]);
+    o[7] = make_float4(__int_as_float(tidx >= 0 ? RM.tex_off[tidx] : 0), __int_as_float(tidx >= 0 ? RM.tex_w[tidx] : 0),
+                       __int_as_float(tidx >= 0 ? RM.tex_h[tidx] : 0), __int_as_float(RM.in_uid[i]));
+}
+__device__ __forceinline__ void instance_setup(const BodyParams &B, const SimParams &P, const RenderModel &RM, const DevPtrs &D, int env, int i) {
+    const int N = P.N;
+    const float *state = D.state;
+    const int ot = RM.in_otype[i], oi = RM.in_oidx[i];
+    float qj[NB] = {0}, op7[7] = {0};
+    if (ot == 1) {                 // all joint angles requested up front: one round trip instead of one per ancestor
+#pragma unroll
+        for (int b = 0; b < NB; b++) qj[b] = STT(ST_Q + b);
+    } else if (ot == 2) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) op7[k] = STT(ST_OPOS + 3 * oi + k);
+#pragma unroll
+        for (int k = 0; k < 4; k++) op7[3 + k] = STT(ST_OQUAT + 4 * oi + k);
+    }
+    instance_setup_core(B, RM, D, env, i, ot, oi, qj, op7);
+}
+
 // GEN = false is the form for the light envs (sel 1): no generic contact row can occur there (k_collide classifies by the
 // very rule the row builder uses), so everything of the generic path -- the row builder, the streamed sweeps, their register
 // queue -- folds away at compile time and the sweep of motors, limits and object-lane rows runs without the register
 // spills (v_accvgpr_read: a third of the torsional steps' instructions) the full kernel needs.  Same source, same
 // arithmetic: results do not depend on which form solved an env (split-equivalence tests, bitwise).
 template <bool GEN>
-__device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams &P, const DevPtrs &D, int sel, int coop_launch) {
+__device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams &P, const DevPtrs &D, int sel, int coop_launch, const RenderModel *RMp = nullptr) {
     const int N = P.N;
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
     if (sel <= 1 && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -2139,17 +2217,31 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         const int c = (os_cs >> (8 * i)) & 255;
         if (c != 255) LD(L_OSL + (3 * c) * 12 + 11) = os_ln[i];
     }
-    if (dead) return;
-    // ---- integrate: lanes 0..10 joints, lanes 11..13 objects
-    bool finite = true;
+    // (the light solve of a step with camera also sets up the render instances of its envs -- below; an env that does not
+    // step is drawn as it stands)
+    const bool setup = !GEN && RMp != nullptr && mine && env_raw < N;
+    if (dead && !setup) return;
     // (the lane predicates of the tail are taken from a copy of the lane index the compiler cannot see through: lane masks of
     // the stage-in kept alive over the sweeps cost scalar registers the solver does not have)
     int lt = l;
     asm volatile("" : "+v"(lt));
+    float q_fin = q_l;                 // joint angle / object pose after this step: what the render instances are set up from
+    float o_fin[7] = {0, 0, 0, 0, 0, 0, 1};
+    if (dead) {
+        if (lt >= NB && lt - NB < P.nobj) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) o_fin[k] = STT(ST_OPOS + 3 * (lt - NB) + k);
+#pragma unroll
+            for (int k = 0; k < 4; k++) o_fin[3 + k] = STT(ST_OQUAT + 4 * (lt - NB) + k);
+        }
+    } else {
+    // ---- integrate: lanes 0..10 joints, lanes 11..13 objects
+    bool finite = true;
     if (lt < NB) {
         float v = qds_l + dq;
         float qn = q_l + dt * v;
         finite = isfinite(qn);
+        q_fin = qn;
         STT(ST_QD + lt) = v;
         STT(ST_Q + lt) = qn;
         if (lt < 7) D.joints[(size_t)env * 9 + lt] = qn;               // robot.py:203-211
@@ -2201,6 +2293,8 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         float *op = D.objpose + ((size_t)env * P.nobj + i) * 7;
         for (int k = 0; k < 3; k++) op[k] = pn[k];
         op[3] = r0 * inv; op[4] = r1 * inv; op[5] = r2 * inv; op[6] = r3 * inv;
+        o_fin[0] = pn[0]; o_fin[1] = pn[1]; o_fin[2] = pn[2];
+        o_fin[3] = r0 * inv; o_fin[4] = r1 * inv; o_fin[5] = r2 * inv; o_fin[6] = r3 * inv;
     }
     SPROF(5);
     if (!finite) atomicOr(&D.errflags[env], 1u);
@@ -2234,11 +2328,39 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
             D.timestep[env] += 1;
         }
     }
+    }       // (!dead)
     SPROF(6);
+    // ---- render set-up of this env's instances (k_render_setup's work, from the values just integrated: the joint angles
+    // go round the group by DPP, the object poses through LDS; lane l takes instances l and 16 + l)
+    if (!GEN) {
+        if (!setup) return;
+        const RenderModel &RM = *RMp;
+        if (lt >= NB && lt < NB + NOBJ) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) LD(L_OBJ + 20 * (lt - NB) + k) = o_fin[k];
+        }
+        float qj[NB];
+        static_assert(NB == 11, "joint angles round the group");
+        qj[0] = row_bcast<0>(q_fin); qj[1] = row_bcast<1>(q_fin); qj[2] = row_bcast<2>(q_fin); qj[3] = row_bcast<3>(q_fin);
+        qj[4] = row_bcast<4>(q_fin); qj[5] = row_bcast<5>(q_fin); qj[6] = row_bcast<6>(q_fin); qj[7] = row_bcast<7>(q_fin);
+        qj[8] = row_bcast<8>(q_fin); qj[9] = row_bcast<9>(q_fin); qj[10] = row_bcast<10>(q_fin);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int i = lt; i < RM.ni; i += 16) {
+            const int ot = RM.in_otype[i], oi = RM.in_oidx[i];
+            float op7[7];
+            const int ob = ot == 2 ? min(max(oi, 0), NOBJ - 1) : 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) op7[k] = LD(L_OBJ + 20 * ob + k);
+            instance_setup_core(B, RM, D, env, i, ot, oi, qj, op7);
+        }
+    }
 }
 __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtrs D, int sel, int coop_launch) { solve_body<true>(B, P, D, sel, coop_launch); }
 // the light envs of a split step (sel 1), 64-thread workgroups
-__global__ void __launch_bounds__(64) k_solve_light(BodyParams B, SimParams P, DevPtrs D) { solve_body<false>(B, P, D, 1, 0); }
+// (RMp: the render model when the step draws -- the kernel then sets up the render instances of its envs; else nullptr)
+__global__ void __launch_bounds__(64) k_solve_light(BodyParams B, SimParams P, DevPtrs D, const RenderModel *RMp) { solve_body<false>(B, P, D, 1, 0, RMp); }
 
 // obs pack without stepping (after reset / set_state)
 __global__ void k_obs(SimParams P, DevPtrs D) {
@@ -2336,68 +2458,6 @@ __global__ void k_goal_score(SimParams P, DevPtrs D, const float *goal_pos /*[N]
 }
 
 // ---------------------------------------------------------------------------------------------- render setup
-// Instance transforms for the rasteriser, one thread per (env, instance): a robot-link thread composes the joint
-// transforms of its body's ancestors only (same operations, in the same order, as fk_all() for that chain), an object
-// thread converts the object's quaternion; the 12 floats of an instance are stored as three 16-byte words, so a wave
-// writes a contiguous span.  (One thread per env needed 264 stores with a 1.5 KB stride between lanes.)
-// instance i of env: FK of its owner's ancestor chain -> model-view-projection matrix and shading constants (D.inst_xf)
-__device__ __forceinline__ void instance_setup(const BodyParams &B, const SimParams &P, const RenderModel &RM, const DevPtrs &D, int env, int i) {
-    const int N = P.N;
-    const float *state = D.state;
-    m3 R = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
-    v3 p = mk(0, 0, 0);
-    const int ot = RM.in_otype[i], oi = RM.in_oidx[i];
-    if (ot == 1) {
-        unsigned anc = 0;
-#pragma unroll
-        for (int b = 0; b < NB; b++) if (oi == b) anc = ANC[b];
-        p = mk(B.robot_pos[0], B.robot_pos[1], B.robot_pos[2]);
-        float qj[NB];              // all joint angles requested up front: one round trip instead of one per ancestor
-#pragma unroll
-        for (int b = 0; b < NB; b++) qj[b] = STT(ST_Q + b);
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            if (!((anc >> b) & 1u)) continue;
-            m3 jr;
-#pragma unroll
-            for (int k = 0; k < 9; k++) jr.m[k] = B.jrot[b][k];
-            const m3 Rj = nc::mul(R, jr);
-            const v3 ax = mk(B.axis[b][0], B.axis[b][1], B.axis[b][2]);
-            p = nc::add(p, nc::mulv(R, mk(B.jpos[b][0], B.jpos[b][1], B.jpos[b][2])));
-            R = nc::mul(Rj, nc::axis_angle(ax, qj[b]));
-        }
-    } else if (ot == 2) {
-        R = nc::quat_to_m3(STT(ST_OQUAT + 4 * oi), STT(ST_OQUAT + 4 * oi + 1), STT(ST_OQUAT + 4 * oi + 2), STT(ST_OQUAT + 4 * oi + 3));
-        p = mk(STT(ST_OPOS + 3 * oi), STT(ST_OPOS + 3 * oi + 1), STT(ST_OPOS + 3 * oi + 2));
-    }
-    // mvp = VP * [R p; 0 1] (same summation order as the oracle's 4x4 product, no FMA contraction), then the shading
-    // constants: the raster and shading workgroups just copy these 128 bytes per instance into LDS
-    float mvp[16];
-    {
-#pragma clang fp contract(off)
-        const float xf[12] = {R.m[0], R.m[1], R.m[2], R.m[3], R.m[4], R.m[5], R.m[6], R.m[7], R.m[8], p.x, p.y, p.z};
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int r = e >> 2, c = e & 3;
-            float a = 0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) a += RM.VP[4 * r + k] * (c < 3 ? xf[3 * k + c] : xf[9 + k]);
-            a += RM.VP[4 * r + 3] * (c == 3 ? 1.0f : 0.0f);
-            mvp[e] = a;
-        }
-    }
-    const int tidx = RM.in_tex[i];
-    float4 *o = (float4 *)(D.inst_xf + ((size_t)env * MAXINST + i) * 32);
-    o[0] = make_float4(mvp[0], mvp[1], mvp[2], mvp[3]);
-    o[1] = make_float4(mvp[4], mvp[5], mvp[6], mvp[7]);
-    o[2] = make_float4(mvp[8], mvp[9], mvp[10], mvp[11]);
-    o[3] = make_float4(mvp[12], mvp[13], mvp[14], mvp[15]);
-    o[4] = make_float4(R.m[0], R.m[1], R.m[2], R.m[3]);
-    o[5] = make_float4(R.m[4], R.m[5], R.m[6], R.m[7]);
-    o[6] = make_float4(R.m[8], RM.in_color[i][0], RM.in_color[i][1], RM.in_color[i][2]);
-    o[7] = make_float4(__int_as_float(tidx >= 0 ? RM.tex_off[tidx] : 0), __int_as_float(tidx >= 0 ? RM.tex_w[tidx] : 0),
-                       __int_as_float(tidx >= 0 ? RM.tex_h[tidx] : 0), __int_as_float(RM.in_uid[i]));
-}
 __global__ void __launch_bounds__(64) k_render_setup(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D, int sel) {
     const RenderModel &RM = *RMp;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -4138,11 +4198,12 @@ static int ensure_images(rr_env *e, DevPtrs &D) {
 
 // The three render kernels for the envs selected by `sel` (env_selected) on `st`.  The images persist in HBM from frame to
 // frame: only the pixels of the previous frame's fragment lists are put back to the static layer (`restore`), DESIGN.md 5.
-static void launch_render(rr_env *e, const DevPtrs &D, int restore, int sel, hipStream_t st, bool timed) {
+// `setup_done`: the instances of these envs are set up already (by the light solve).
+static void launch_render(rr_env *e, const DevPtrs &D, int restore, int sel, hipStream_t st, bool timed, bool setup_done = false) {
     const int N = e->P.N;
     const ImageOut io = env_images(e);
     if (timed) {
-        TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, st, e->B, e->P, e->RM_dev, D, sel));
+        if (!setup_done) TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, st, e->B, e->P, e->RM_dev, D, sel));
         TIMED(4, hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, 0, 0, restore, sel));
         TIMED(6, hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel));
     } else {
@@ -4153,7 +4214,7 @@ static void launch_render(rr_env *e, const DevPtrs &D, int restore, int sel, hip
             hipLaunchKernelGGL(k_render_list, dim3(std::min(N * e->RM.ntiles, sel == 3 ? 256 : RENDER_LIST_WGS)), dim3(RASTER_THREADS), 0, st, e->B, e->P, e->RM_dev, D, io, e->n_inst_used, restore, sel == 3 ? 1 : 0);
             return;
         }
-        hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, st, e->B, e->P, e->RM_dev, D, sel);
+        if (!setup_done) hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, st, e->B, e->P, e->RM_dev, D, sel);
         if (sel == 2) hipLaunchKernelGGL(k_raster_list, dim3(std::min(N * e->RM.ntiles, RASTER_LIST_WGS)), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, restore, 0);
         else hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, 0, 0, restore, sel);
         hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel);
@@ -4265,24 +4326,25 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     const bool ahead = e->lookahead;            // this step ends with the state part of the next one
     // (a step without camera runs all envs in one launch: its classes side by side were measured -- config 2: 0.525 instead of 0.452 ms)
     if (e->aux && !g_skip && render_mode && e->split_heavy && !mostly_heavy) {
-        const bool rendering = true;
         // The few envs with generic contact rows take several times as long as the others (the kernel lasts as long
         // as its longest Gauss-Seidel chain).  They are solved and rendered on the side streams -- four groups per 256-thread
         // workgroup, so that they fill the LDS of a few CUs and leave the rest to the raster workgroups of the light envs --
         // while the main stream solves and renders everybody else.
         DevPtrs D = e->D;
         if (render_mode != 2) D.render_flags = nullptr;
-        const int restore = rendering ? ensure_images(e, D) : 0;
+        const int restore = ensure_images(e, D);
+        // (the light solve sets up the render instances of its envs itself: one launch and a 20 us kernel less at the head of
+        // the step's main chain; RR_NO_FUSED_SETUP: the separate k_render_setup launch -- same bits, tested)
+        static const bool no_fused_setup = getenv("RR_NO_FUSED_SETUP") != nullptr;
+        const RenderModel *fused_rm = no_fused_setup ? nullptr : e->RM_dev;
         if (e->timing) {
             // timing leg: the very same launches, one after the other on the main stream, each under its timer -- 2 / 3 / 4 / 6
             // what the main stream runs in an untimed step (the light envs), 7 / 8 what the side streams run beside it, 0 / 1 the
             // look-ahead of the next step, which an untimed step runs on the heavy stream behind the heavy envs' render
-            TIMED(2, hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D));
+            TIMED(2, hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, fused_rm));
             TIMED(7, { launch_solve_class(e, 2, e->stream); launch_solve_class(e, 3, e->stream); });
-            if (rendering) {
-                launch_render(e, D, restore, 1, e->stream, true);
-                TIMED(8, { launch_render(e, D, restore, 2, e->stream, false); launch_render(e, D, restore, 3, e->stream, false); });
-            }
+            launch_render(e, D, restore, 1, e->stream, true, fused_rm != nullptr);
+            TIMED(8, { launch_render(e, D, restore, 2, e->stream, false); launch_render(e, D, restore, 3, e->stream, false); });
             if (ahead) {
                 TIMED(0, launch_prep_ab(e, 0, e->stream));
                 TIMED(1, launch_collide(e, 0, e->stream));
@@ -4291,27 +4353,34 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
             HIPCHK(hipGetLastError());
             return RR_OK;
         }
-        // Look-ahead: the state part of the NEXT step for all envs, once every solve of this step has finished.  Beside
-        // the visibility pass it would only queue up behind the LDS-filling raster workgroups (measured, profiles/README.md); it
-        // runs beside the shading of the main stream / the render of the heavy envs.
-        // Where the look-ahead goes: behind the very heavy envs' render when they are a handful (their stream is then the first to
-        // be done), else at the tail of the main stream (macro actions: hundreds of very heavy envs make theirs the longest chain).
-        // (k_prep_ab on the heavy stream in front of its render, k_collide behind the very heavy envs' render: measured, 0.730
-        // instead of 0.710 ms -- the heavy envs' render, the shading and the collision pass then all start together)
-        // (a fourth stream just for it was measured: with one more hardware queue in play every kernel of the step slows down --
-        // the 6 us command kernel of that build took 44 us, 60 us gaps, 1.19 instead of 0.81 ms)
+        // Look-ahead: the state part of the NEXT step for all envs, once every solve of this step has finished.
+        // Where it goes (all measured, profiles/README.md):
+        //  * a handful of very heavy envs (lagged count <= 64): on their stream right behind their solve -- the last solve of
+        //    the step to finish -- while their render moves to the heavy stream, behind the heavy envs' render.  The collision
+        //    pass then runs beside the end of the visibility pass and the shading instead of after them (0.728 instead of
+        //    0.758 ms; behind the very heavy envs' render it was the tail of the step's longest chain);
+        //  * hundreds of very heavy envs (macro actions): their solve + render is the longest chain; the look-ahead goes to the
+        //    tail of the main stream.
+        // (both heavy lists rendered by one launch once both solves are done: 0.751 ms -- the heavy envs' render then waits
+        // for the very heavy envs' solve.)
+        // (per-class look-aheads beside the visibility pass only queue up behind the LDS-filling raster workgroups; a fourth
+        // stream for it slows every kernel of the step down -- one more hardware queue: 1.19 instead of 0.81 ms)
         const bool la_on_vh = !e->h_hcount || ((volatile int *)e->h_hcount)[1] <= 64;
+        const bool vh_render_on_h = ahead && la_on_vh;
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
         launch_solve_class(e, 2, e->aux);
         if (ahead) hipEventRecord(e->ev_hsolved, e->aux);
-        if (rendering) launch_render(e, D, restore, 2, e->aux, false);
-        hipEventRecord(e->ev_join, e->aux);
+        launch_render(e, D, restore, 2, e->aux, false);
         hipStreamWaitEvent(e->aux2, e->ev_fork, 0);
         launch_solve_class(e, 3, e->aux2);
-        if (ahead && !la_on_vh) hipEventRecord(e->ev_vsolved, e->aux2);
-        if (rendering) launch_render(e, D, restore, 3, e->aux2, false);
-        hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D);
+        if (ahead) hipEventRecord(e->ev_vsolved, e->aux2);
+        if (vh_render_on_h) {
+            hipStreamWaitEvent(e->aux, e->ev_vsolved, 0);
+            launch_render(e, D, restore, 3, e->aux, false);
+        } else launch_render(e, D, restore, 3, e->aux2, false);
+        hipEventRecord(e->ev_join, e->aux);
+        hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, fused_rm);
         if (ahead && la_on_vh) {
             hipEventRecord(e->ev_dyn, e->stream);             // the light envs' solve
             hipStreamWaitEvent(e->aux2, e->ev_dyn, 0);
@@ -4320,7 +4389,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
             launch_collide(e, 0, e->aux2);
         }
         hipEventRecord(e->ev_join2, e->aux2);
-        if (rendering) launch_render(e, D, restore, 1, e->stream, false);
+        launch_render(e, D, restore, 1, e->stream, false, fused_rm != nullptr);
         if (ahead && !la_on_vh) {
             hipStreamWaitEvent(e->stream, e->ev_hsolved, 0);
             hipStreamWaitEvent(e->stream, e->ev_vsolved, 0);
