@@ -3004,12 +3004,16 @@ extern "C" int rr_debug_raster_stats(unsigned long long *out16, int reset) {
 // rasterised triangle {depth bits, pixel-in-tile << 18 | triangle}, shaded by k_shade; everything else in the image is the
 // static layer, copied by k_static_copy.
 struct ImageOut { unsigned char *rgb; float *depth; int *mask; size_t env_stride; /* pixels between envs */ };
+// the tile's visibility buffer (file scope: the list-walking render kernels stage their shading constants in it once the
+// fragment list is out -- their workgroups then need no more LDS than a raster workgroup)
+__shared__ __attribute__((aligned(16))) unsigned long long g_vis[TILE_PIX];
+template <int NT_>
 __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderModel &RM, const DevPtrs &D, int n_inst_used, int pass, int env, int tile, int restore) {
-    __shared__ unsigned long long vis[TILE_PIX];
+    unsigned long long *vis = g_vis;
     __shared__ __attribute__((aligned(16))) float mvp[RASTER_INST][16];
     __shared__ unsigned nlist, wcount, wnext;
     __shared__ unsigned short wlist[MAXWIN];
-    __shared__ unsigned short wends[RASTER_THREADS / 64][64];      // per wave: running ends of the lanes' left-over points (<= 64 x SMALL_AREA)
+    __shared__ unsigned short wends[NT_ / 64][64];      // per wave: running ends of the lanes' left-over points (<= 64 x SMALL_AREA)
     __shared__ unsigned short clipq[CLIPQ];             // triangles that cross the near plane (rare), clipped after the window loop: position in wlist << 6 | lane
     __shared__ unsigned nclipq;
     const int W = RM.W, H = RM.H;
@@ -3025,9 +3029,9 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     const unsigned en_first = (unsigned)tid < n_old ? old_lst[tid].y : 0xffffffffu;
     // The tile starts empty (an LDS-only fill); the static layer's keys are compared at compaction time and only for the
     // few pixels a moving triangle reached (min is associative) -- no 128 KB read of the static keys per env.
-    for (int i = tid; i < npix; i += RASTER_THREADS) vis[i] = ~0ull;
+    for (int i = tid; i < npix; i += NT_) vis[i] = ~0ull;
     if (tid == 0) { nlist = 0; wcount = 0; wnext = 0; nclipq = 0; }
-    stage_instances(RM, D, env, tid, RASTER_THREADS, mvp, nullptr);
+    stage_instances(RM, D, env, tid, NT_, mvp, nullptr);
     __syncthreads();
     // tile bounds in screen y (py = H-1-row)
     const float ty0 = (float)(H - 1 - (row0 + rows - 1)), ty1 = (float)(H - 1 - row0);
@@ -3052,12 +3056,12 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     // no triangle reaches this time leave the compaction as "vacated" entries, which k_shade puts back to the static layer.
     if (restore) {
         if (en_first != 0xffffffffu && (en_first & 0x3ffffu) != FRAG_VACATED) vis[en_first >> 18] = VIS_WAS_DYNAMIC;
-        for (unsigned i = tid + RASTER_THREADS; i < n_old; i += RASTER_THREADS) {          // more than 1024 entries: rare
+        for (unsigned i = tid + NT_; i < n_old; i += NT_) {          // more than 1024 entries: rare
             const unsigned en = old_lst[i].y;
             if ((en & 0x3ffffu) != FRAG_VACATED) vis[en >> 18] = VIS_WAS_DYNAMIC;     // (a vacated entry was put back last time)
         }
     }
-    for (int wi = tid; wi < nwin; wi += RASTER_THREADS) {
+    for (int wi = tid; wi < nwin; wi += NT_) {
         const int tb = t_begin + (wi << 6);
         const int inst = D.tri_inst[tb];
         const float4 cs = D.cluster_sphere[tb >> 6];
@@ -3249,7 +3253,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     // ---- triangles that cross the near plane (queued above): clipped against w = NEAR_W (Sutherland-Hodgman, the oracle's
     // clip_near()) into a triangle or a fan of two, which a whole wave rasterises under the original triangle id
     __syncthreads();
-    for (unsigned qi = tid >> 6; qi < min(nclipq, (unsigned)CLIPQ); qi += RASTER_THREADS / 64) {
+    for (unsigned qi = tid >> 6; qi < min(nclipq, (unsigned)CLIPQ); qi += NT_ / 64) {
         const int bt = t_begin + ((int)wlist[clipq[qi] >> 6] << 6) + (clipq[qi] & 63);
         const int tb = bt & ~63;
         const int inst = D.tri_inst[tb];
@@ -3354,7 +3358,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
 #endif
     if (pass == 1) {   // publish the static layer's keys
         unsigned long long *sv = D.static_vis_out + (size_t)row0 * W;
-        for (int i = tid; i < npix; i += RASTER_THREADS) sv[i] = vis[i];
+        for (int i = tid; i < npix; i += NT_) sv[i] = vis[i];
     }
     // ---- compaction: pixels owned by a triangle rasterised in this pass go to the fragment list of this (env, tile)
     // (the comparison with the static layer's key is left to k_shade: a dependent global read at the tail of this
@@ -3362,16 +3366,16 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
 #ifdef RR_RASTER_STATS
     __shared__ unsigned win_bits[MAXWIN / 32];      // clusters that own a pixel of the tile at the end
-    for (int i = tid; i < MAXWIN / 32; i += RASTER_THREADS) win_bits[i] = 0;
+    for (int i = tid; i < MAXWIN / 32; i += NT_) win_bits[i] = 0;
     __syncthreads();
-    for (int i = tid; i < npix; i += RASTER_THREADS) {
+    for (int i = tid; i < npix; i += NT_) {
         const unsigned long long key = vis[i];
         if (key != ~0ull && key != VIS_WAS_DYNAMIC) { const unsigned w_ = ((unsigned)(key & 0xffffffffu) - (unsigned)t_begin) >> 6; atomicOr(&win_bits[w_ >> 5], 1u << (w_ & 31)); }
     }
     __syncthreads();
     if (tid < MAXWIN / 32) RSTAT(11, __popc(win_bits[tid]));      // (slot 11 reused: clusters with at least one winning pixel)
 #endif
-    for (int i = tid; i < npix; i += RASTER_THREADS) {
+    for (int i = tid; i < npix; i += NT_) {
         const unsigned long long key = vis[i];
         const unsigned tri = key == VIS_WAS_DYNAMIC ? FRAG_VACATED : (unsigned)(key & 0xffffffffu);
         if (key != ~0ull) {
@@ -3388,7 +3392,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) RASTER_ATTR k_raster(SimParams
     const int env = blockIdx.x + env0, tile = blockIdx.y;
     if (pass == 0 && D.render_flags && !D.render_flags[env]) return;
     if (!env_selected(D.hgflag, env, sel)) return;
-    raster_tile(P, *RMp, D, n_inst_used, pass, env, tile, restore);
+    raster_tile<RASTER_THREADS>(P, *RMp, D, n_inst_used, pass, env, tile, restore);
 }
 
 #define RASTER_LIST_WGS 768      // three per CU: the item loop around the tile needs more than the 64 VGPRs of four (a long list of heavy
@@ -3408,7 +3412,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_pe
         if (it >= nitems) break;
         const int tile = it % RM.ntiles, ge = it / RM.ntiles;
         const int env = hlist[ge];
-        if (env < P.N && !(D.render_flags && !D.render_flags[env])) raster_tile(P, RM, D, n_inst_used, 0, env, tile, restore);
+        if (env < P.N && !(D.render_flags && !D.render_flags[env])) raster_tile<RASTER_THREADS>(P, RM, D, n_inst_used, 0, env, tile, restore);
         __syncthreads();        // the LDS of the tile is reused
     }
 }
@@ -3535,19 +3539,23 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp,
     if (!env_selected(D.hgflag, env, sel)) return;
     shade_block<SHADE_THREADS>(*RMp, D, out, env, tile, blockIdx.z, gridDim.z, mvp, sinst);
 }
+// (Visibility pass and shading of a tile in one workgroup -- k_render_list's body for every env, 64 VGPRs, same LDS -- was
+// measured: 0.470 ms instead of 0.383 + 0.097 alone, but 0.739 instead of 0.725 ms for the step: the heavy lists' render
+// only gets onto the machine when this launch drains, 100 us later than behind the plain visibility pass.)
 // The render of the heavy envs (D.hlist, D.hcount -- known on the device only), which follows their solve on the side stream
 // and is the tail of the step's longest chain: ONE launch instead of three.  A fixed number of workgroups walk the list of
 // (env, tile) items (dynamic assignment: tiles differ a lot in cost; no LDS-filling workgroup is launched just to find that
 // its env is not on the list); for each item: the env's instance matrices (22 threads; the four tiles of an env write the
 // same values), the visibility pass of the tile, the shading of its fragment list.
 #define RENDER_LIST_WGS 768      // (two resident per CU: set-up, visibility and shading in one body need 128 VGPRs -- capped at 80 it spilled)
-__global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
-k_render_list(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D, ImageOut out, int n_inst_used, int restore, int which) {
+template <int NT_>
+__device__ __forceinline__ void render_list_body(const BodyParams &B, const SimParams &P, const RenderModel *RMp, const DevPtrs &D, const ImageOut &out, int n_inst_used, int restore, int which) {
     const RenderModel &RM = *RMp;
     int *hcount = which ? D.hcount2 : D.hcount;
     const int *hlist = which ? D.hlist2 : D.hlist;
-    __shared__ __attribute__((aligned(16))) float smvp[MAXINST][16];
-    __shared__ __attribute__((aligned(16))) float sinst[MAXINST][16];
+    static_assert(TILE_PIX * 8 >= 2 * MAXINST * 16 * 4, "the shading constants are staged in the visibility buffer");
+    float (*smvp)[16] = (float (*)[16])g_vis;                      // (the buffer is dead once raster_tile has written the list)
+    float (*sinst)[16] = (float (*)[16])((float *)g_vis + MAXINST * 16);
     const int nitems = hcount[0] * RM.ntiles;
     __shared__ int s_item;
     for (;;) {
@@ -3560,14 +3568,21 @@ k_render_list(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D, Imag
             if ((int)threadIdx.x < RM.ni) instance_setup(B, P, RM, D, env, threadIdx.x);
             __threadfence_block();
             __syncthreads();
-            raster_tile(P, RM, D, n_inst_used, 0, env, tile, restore);
+            raster_tile<NT_>(P, RM, D, n_inst_used, 0, env, tile, restore);
             __threadfence_block();      // the fragment list and its count, written by this workgroup, are read back below
             __syncthreads();
-            shade_block<RASTER_THREADS>(RM, D, out, env, tile, 0, 1, smvp, sinst);
+            shade_block<NT_>(RM, D, out, env, tile, 0, 1, smvp, sinst);
         }
         __syncthreads();        // the LDS of the tile and the staging arrays are reused
     }
 }
+__global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
+k_render_list(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D, ImageOut out, int n_inst_used, int restore, int which) {
+    render_list_body<RASTER_THREADS>(B, P, RMp, D, out, n_inst_used, restore, which);
+}
+// (The same with 256 threads -- the footprint of one raster workgroup, so that it moves into the hole a retiring raster
+// workgroup leaves -- was measured: 0.762 ms with the heavy list, 0.788 with both, instead of 0.727: an item takes twice as
+// long and the visibility pass of the light envs loses as much as the lists gain.)
 
 // ---------------------------------------------------------------------------------------------- host side
 struct BlobEntry {
