@@ -4390,7 +4390,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         hipStreamWaitEvent(e->aux2, e->ev_fork, 0);
         launch_solve_class(e, 3, e->aux2);
         if (ahead) hipEventRecord(e->ev_vsolved, e->aux2);
-        if (vh_render_on_h) {
+        if (vh_render_on_h) {          // (at the tail of the main stream, behind the shading, instead: 0.733 ms)
             hipStreamWaitEvent(e->aux, e->ev_vsolved, 0);
             launch_render(e, D, restore, 3, e->aux, false);
         } else launch_render(e, D, restore, 3, e->aux2, false);
