@@ -1385,20 +1385,36 @@ __device__ __forceinline__ void grow_slot(int myobj, v3 el, v3 ea, int bodyA, in
 }
 
 // Row step of an object-vs-static contact row held in registers, executed by the lane that owns the object only:
-// b0,b1,b2 = the row's linear part (dir.xyz ang.x | ang.yz mang.xy | mang.z rhs dinv -), lambda in `lam`, bounds [lo, hi].
+// b0,b1,b2 = the row (dir.xy dir.z ang.x | ang.yz dir.z mang.x | mang.yz rhs dinv), lambda in `lam`, bounds [lo, hi]; the
+// object's velocity change lives in three register pairs V01 = (v.x v.y), V23 = (v.z w.x), V45 = (w.y w.z): J.v is three
+// packed multiply-adds and one add, the update three packed FMAs (v_pk_fma_f32: two lanes' worth of fp32 per issue slot).
 // An all-zero row with lam = 0 is a
 // no-op (dl = 0), which is how absent rows are represented -- no predicates, no scalar mask registers.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+#define P2(a, b) (v2f{(a), (b)})
 #define REG_ROW_STEP(b0, b1, b2, lam, lo, hi)                                                                     \
     do {                                                                                                          \
-        const float jv_ = ((b0).x * dv.x + (b0).y * dv.y + (b0).z * dv.z) + ((b0).w * dw.x + (b1).x * dw.y + (b1).y * dw.z);    \
-        const float s0_ = fmaf(-jv_, (b2).z, (lam) + (b2).y);       /* (lambda + rhs) - dinv * J.v */             \
+        v2f p_ = P2((b0).x, (b0).y) * V01;                                                                        \
+        p_ = pk_fma(P2((b0).z, (b0).w), V23, p_);                                                                 \
+        p_ = pk_fma(P2((b1).x, (b1).y), V45, p_);                                                                 \
+        const float jv_ = p_.x + p_.y;                                                                            \
+        const float s0_ = fmaf(-jv_, (b2).w, (lam) + (b2).z);       /* (lambda + rhs) - dinv * J.v */             \
         const float sum_ = __builtin_amdgcn_fmed3f(s0_, (lo), (hi));                                              \
         const float dl_ = sum_ - (lam);                                                                           \
         (lam) = sum_;                                                                                             \
         const float sm_ = dl_ * inv_mass;                                                                         \
-        dv.x += (b0).x * sm_; dv.y += (b0).y * sm_; dv.z += (b0).z * sm_;                                            \
-        dw.x += (b1).z * dl_; dw.y += (b1).w * dl_; dw.z += (b2).x * dl_;                                            \
+        V01 = pk_fma(P2((b0).x, (b0).y), P2(sm_, sm_), V01);                                                      \
+        V23 = pk_fma(P2((b1).z, (b1).w), P2(sm_, dl_), V23);                                                      \
+        V45 = pk_fma(P2((b2).x, (b2).y), P2(dl_, dl_), V45);                                                      \
     } while (0)
+// (the components of the pairs by name)
+#define DVX V01.x
+#define DVY V01.y
+#define DVZ V23.x
+#define DWX V23.y
+#define DWY V45.x
+#define DWZ V45.y
 #define KLIM 2           // joint-limit rows kept in registers (usually two: the finger lower limits)
 #define KOS 4            // object-vs-static contacts per object kept in registers (a resting object has <= 4)
 
@@ -1433,13 +1449,14 @@ __device__ __forceinline__ void os_row_pair(int k, v3 dir, v3 x, const ObjData &
     const float tdiag = dot(dir, tm);
     const float tdinv = (coef > 0 && tdiag > 0) ? 1.0f / tdiag : 0.0f;
     const float trhs = -dot(dir, oA.ws) * tdinv;
+    // (layout: REG_ROW_STEP / REG_TORS_STEP take the row in aligned pairs -- packed fp32 operations on (v.x v.y) (v.z w.x) (w.y w.z))
     float4 *bp4 = (float4 *)&LD(row_osl);
     bp4[0] = make_float4(dir.x, dir.y, dir.z, ang.x);
-    bp4[1] = make_float4(ang.y, ang.z, mang.x, mang.y);
-    bp4[2] = make_float4(mang.z, rhs, dinv, k == 0 ? lam0 : 0.0f);      // (.w of the normal row: warm-start impulse)
+    bp4[1] = make_float4(ang.y, ang.z, dir.z, mang.x);
+    bp4[2] = make_float4(mang.y, mang.z, rhs, dinv);
     float4 *tp4 = (float4 *)&LD(row_ost);
-    tp4[0] = make_float4(tm.x, tm.y, tm.z, trhs);
-    tp4[1] = make_float4(tdinv, 0.0f, 0.0f, 0.0f);
+    tp4[0] = make_float4(tm.x, trhs, tm.y, tm.z);
+    tp4[1] = make_float4(tdinv, k == 0 ? lam0 : 0.0f, 0.0f, 0.0f);      // (.y of the normal row: warm-start impulse)
 }
 
 // ---------------------------------------------------------------------------------------------- render setup
@@ -1936,7 +1953,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     // ---- PGS.  Lane state: dq (slot A: lanes 0..10 joints, lanes 11..15 object 2 during generic sweeps), vb (slot B), and
     // (dv, dw) of object lane-11 on lanes 11..13
     float dq = wsA, vb = wsB;          // (warm start: the inherited impulses of the generic normal rows are already applied)
-    v3 dv = mk(0, 0, 0), dw = mk(0, 0, 0);
+    v2f V01 = P2(0.0f, 0.0f), V23 = P2(0.0f, 0.0f), V45 = P2(0.0f, 0.0f);      // (dv.xy) (dv.z dw.x) (dw.yz), REG_ROW_STEP
     const float inv_mass = lo_ >= 0 ? 1.0f / B.obj_mass[lo_ >= 0 ? lo_ : 0] : 0.0f;
     const float max_imp = P.max_impulse;
     const float m_rhs = l < NB ? LD(L_MOT + 3 * lj) : 0.0f, m_dinv = l < NB ? LD(L_MOT + 3 * lj + 1) : 0.0f;
@@ -1960,7 +1977,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         limmask = rem;                                   // rows left for the LDS loop
     }
     unsigned os_cs = 0;                                  // contact indices of the register rows, one byte each
-    float os_mu[KOS], os_ln[KOS], os_l1[KOS], os_l2[KOS];
+    float os_mu[KOS], os_ln[KOS], os_l1[KOS], os_l2[KOS], os_l0[KOS];      // (os_l0: the inherited normal impulses)
     float4 os_n0[KOS], os_n1[KOS], os_n2[KOS], os_a0[KOS], os_a1[KOS], os_a2[KOS], os_b0[KOS], os_b1[KOS], os_b2[KOS];
     {
         unsigned rem = own_os;
@@ -1971,12 +1988,13 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
             rem &= rem - 1;
             os_cs |= (has ? (unsigned)c : 255u) << (8 * i);
             os_mu[i] = has ? LD(L_MU + c) : 0.0f; os_ln[i] = 0.0f; os_l1[i] = 0.0f; os_l2[i] = 0.0f;
+            os_l0[i] = has ? LD(L_OST + (3 * c) * 8 + 5) : 0.0f;
             os_n0[i] = LDZ4(has, 3 * c, 0); os_n1[i] = LDZ4(has, 3 * c, 4); os_n2[i] = LDZ4(has, 3 * c, 8);
             os_a0[i] = LDZ4(has, 3 * c + 1, 0); os_a1[i] = LDZ4(has, 3 * c + 1, 4); os_a2[i] = LDZ4(has, 3 * c + 1, 8);
             os_b0[i] = LDZ4(has, 3 * c + 2, 0); os_b1[i] = LDZ4(has, 3 * c + 2, 4); os_b2[i] = LDZ4(has, 3 * c + 2, 8);
         }
     }
-    // torsional rows of the same contacts: rotation about the axis of linear row k (its dir), {M^-1 J^T (3), rhs}, 1/diag, lambda
+    // torsional rows of the same contacts: rotation about the axis of linear row k (its dir), {m.x, rhs, m.y, m.z} (m = M^-1 J^T), 1/diag, lambda
     float4 ot_m[KOS][3]; float ot_d[KOS][3], ot_l[KOS][3], os_sp[KOS], os_ro[KOS];
 #pragma unroll
     for (int i = 0; i < KOS; i++) {
@@ -2023,12 +2041,13 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         }
 #define REG_TORS_STEP(AX, i, k, HI)                                                                  \
         {                                                                                             \
-            const float jv_ = (AX).x * dw.x + (AX).y * dw.y + (AX).z * dw.z;                          \
-            const float s0_ = fmaf(-jv_, ot_d[i][k], ot_l[i][k] + ot_m[i][k].w);                      \
+            const float jv_ = fmaf((AX).x, DWX, fmaf((AX).y, DWY, (AX).z * DWZ));                     \
+            const float s0_ = fmaf(-jv_, ot_d[i][k], ot_l[i][k] + ot_m[i][k].y);                      \
             const float sum_ = __builtin_amdgcn_fmed3f(s0_, -(HI), (HI));                             \
             const float dl_ = sum_ - ot_l[i][k];                                                      \
             ot_l[i][k] = sum_;                                                                        \
-            dw.x += ot_m[i][k].x * dl_; dw.y += ot_m[i][k].y * dl_; dw.z += ot_m[i][k].z * dl_;       \
+            DWX = fmaf(ot_m[i][k].x, dl_, DWX);                                                       \
+            V45 = pk_fma(P2(ot_m[i][k].z, ot_m[i][k].w), P2(dl_, dl_), V45);                          \
         }
 #define OST_STEP(i)                                                                                   \
         {                                                                                             \
@@ -2060,18 +2079,19 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
 #define TO_SLOT(O, C, REG, SLOTREG, LANE) { const float t_ = row_bcast<NB + (O)>(REG); SLOTREG = (l == (LANE)) ? t_ : SLOTREG; }
 #define FROM_SLOT(O, C, REG, SLOTREG, LANE) { const float t_ = row_bcast<LANE>(SLOTREG); REG = (l == NB + (O)) ? t_ : REG; }
 #define OBJ_SLOTS(OP)                                                                                                  \
-    if (gobj_w & 1u) { OP(0, 0, dv.x, vb, 0) OP(0, 1, dv.y, vb, 1) OP(0, 2, dv.z, vb, 2) OP(0, 3, dw.x, vb, 3) OP(0, 4, dw.y, vb, 4) OP(0, 5, dw.z, vb, 5) } \
-    if (gobj_w & 2u) { OP(1, 0, dv.x, vb, 6) OP(1, 1, dv.y, vb, 7) OP(1, 2, dv.z, vb, 8) OP(1, 3, dw.x, vb, 9) OP(1, 4, dw.y, vb, 10) OP(1, 5, dw.z, vb, 11) } \
-    if (gobj_w & 4u) { OP(2, 0, dv.x, dq, 11) OP(2, 1, dv.y, dq, 12) OP(2, 2, dv.z, dq, 13) OP(2, 3, dw.x, dq, 14) OP(2, 4, dw.y, dq, 15) OP(2, 5, dw.z, vb, 12) }
+    if (gobj_w & 1u) { OP(0, 0, DVX, vb, 0) OP(0, 1, DVY, vb, 1) OP(0, 2, DVZ, vb, 2) OP(0, 3, DWX, vb, 3) OP(0, 4, DWY, vb, 4) OP(0, 5, DWZ, vb, 5) } \
+    if (gobj_w & 2u) { OP(1, 0, DVX, vb, 6) OP(1, 1, DVY, vb, 7) OP(1, 2, DVZ, vb, 8) OP(1, 3, DWX, vb, 9) OP(1, 4, DWY, vb, 10) OP(1, 5, DWZ, vb, 11) } \
+    if (gobj_w & 4u) { OP(2, 0, DVX, dq, 11) OP(2, 1, DVY, dq, 12) OP(2, 2, DVZ, dq, 13) OP(2, 3, DWX, dq, 14) OP(2, 4, DWY, dq, 15) OP(2, 5, DWZ, vb, 12) }
     // warm start: the object components of the generic rows' initial velocity change go from the slots to the object lanes,
     // then the register rows add theirs (b2.w of a normal row = its inherited impulse; absent rows are all-zero)
     if (ng_max > 0) { OBJ_SLOTS(FROM_SLOT) }
 #pragma unroll
     for (int i = 0; i < KOS; i++) {
-        const float l0_ = os_n2[i].w, sm_ = l0_ * inv_mass;
+        const float l0_ = os_l0[i], sm_ = l0_ * inv_mass;
         os_ln[i] = l0_;
-        dv.x += os_n0[i].x * sm_; dv.y += os_n0[i].y * sm_; dv.z += os_n0[i].z * sm_;
-        dw.x += os_n1[i].z * l0_; dw.y += os_n1[i].w * l0_; dw.z += os_n2[i].x * l0_;
+        V01 = pk_fma(P2(os_n0[i].x, os_n0[i].y), P2(sm_, sm_), V01);
+        V23 = pk_fma(P2(os_n1[i].z, os_n1[i].w), P2(sm_, l0_), V23);
+        V45 = pk_fma(P2(os_n2[i].x, os_n2[i].y), P2(l0_, l0_), V45);
     }
     int nF = 0, nT = 0;                                   // entries of this env's lateral / torsional row lists
     for (int it = 0; it < P.iters; it++) {
@@ -2239,7 +2259,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     bool finite = true;
     if (lt < NB) {
         float v = qds_l + dq;
-        float qn = q_l + dt * v;
+        float qn = fmaf(dt, v, q_l);            // (the integration is written out in fused operations: both forms of the kernel must round alike)
         finite = isfinite(qn);
         q_fin = qn;
         STT(ST_QD + lt) = v;
@@ -2252,7 +2272,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         // (position, orientation and unconstrained velocities are the registers of the stage-in: no load at the tail of the chain)
         const int i = lt - NB;
         float v[3], w[3], pn[3];
-        const float dvi[3] = {dv.x, dv.y, dv.z}, dwi[3] = {dw.x, dw.y, dw.z};
+        const float dvi[3] = {DVX, DVY, DVZ}, dwi[3] = {DWX, DWY, DWZ};
         // (GEN: the solver with the generic rows has no 13 registers to spare over the sweeps -- it reads them again)
         float vs3[3] = {myobj.vs.x, myobj.vs.y, myobj.vs.z}, ws3[3] = {myobj.ws.x, myobj.ws.y, myobj.ws.z};
         float op3[3] = {myobj.op.x, myobj.op.y, myobj.op.z};
@@ -2266,13 +2286,13 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         for (int k = 0; k < 3; k++) {
             v[k] = vs3[k] + dvi[k];
             w[k] = ws3[k] + dwi[k];
-            pn[k] = op3[k] + dt * v[k];
+            pn[k] = fmaf(dt, v[k], op3[k]);
             finite = finite && isfinite(pn[k]);
             STT(ST_OVEL + 3 * i + k) = v[k];
             STT(ST_OANG + 3 * i + k) = w[k];
             STT(ST_OPOS + 3 * i + k) = pn[k];
         }
-        float wn = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        float wn = sqrtf(fmaf(w[0], w[0], fmaf(w[1], w[1], w[2] * w[2])));
         float ang = wn * dt, d0, d1, d2, d3;
         if (ang > 1e-12f) {
             float sn, cs;
@@ -2283,11 +2303,11 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
             d0 = w[0] * dt * 0.5f; d1 = w[1] * dt * 0.5f; d2 = w[2] * dt * 0.5f; d3 = 1.0f;
         }
         float q0 = oquat[0], q1 = oquat[1], q2 = oquat[2], q3 = oquat[3];
-        float r0 = d3 * q0 + d0 * q3 + d1 * q2 - d2 * q1;
-        float r1 = d3 * q1 - d0 * q2 + d1 * q3 + d2 * q0;
-        float r2 = d3 * q2 + d0 * q1 - d1 * q0 + d2 * q3;
-        float r3 = d3 * q3 - d0 * q0 - d1 * q1 - d2 * q2;
-        float inv = 1.0f / sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+        float r0 = fmaf(d3, q0, fmaf(d0, q3, fmaf(d1, q2, -(d2 * q1))));
+        float r1 = fmaf(d3, q1, fmaf(-d0, q2, fmaf(d1, q3, d2 * q0)));
+        float r2 = fmaf(d3, q2, fmaf(d0, q1, fmaf(-d1, q0, d2 * q3)));
+        float r3 = fmaf(d3, q3, fmaf(-d0, q0, fmaf(-d1, q1, -(d2 * q2))));
+        float inv = 1.0f / sqrtf(fmaf(r0, r0, fmaf(r1, r1, fmaf(r2, r2, r3 * r3))));
         STT(ST_OQUAT + 4 * i) = r0 * inv; STT(ST_OQUAT + 4 * i + 1) = r1 * inv;
         STT(ST_OQUAT + 4 * i + 2) = r2 * inv; STT(ST_OQUAT + 4 * i + 3) = r3 * inv;
         float *op = D.objpose + ((size_t)env * P.nobj + i) * 7;
