@@ -1542,9 +1542,22 @@ __device__ __forceinline__ void instance_setup(const BodyParams &B, const SimPar
 // queue -- folds away at compile time and the sweep of motors, limits and object-lane rows runs without the register
 // spills (v_accvgpr_read: a third of the torsional steps' instructions) the full kernel needs.  Same source, same
 // arithmetic: results do not depend on which form solved an env (split-equivalence tests, bitwise).
-template <bool GEN>
+// OW ("object wave", light form only): workgroups of five waves solve sixteen envs -- waves 0..3 are the envs' 16-lane groups
+// (command part, row build, the robot's rows, joint integration), wave 4 runs the object chains of all sixteen envs, one LANE per
+// (env, object) (light_object_wave below).  In a light env the robot's rows and each object's rows are separate problems;
+// with the object rows on lanes 11..13 of every group 62 % of a sweep's instructions ran with 3 of 16 lanes live.
+__device__ void light_object_wave(const BodyParams &B, const SimParams &P, const DevPtrs &D, const RenderModel *RMp);
+#define LIGHT_OW_THREADS 320
+#define OW_FLAGS 0       // L_GSC words of an env that its group publishes for the object wave: flags (1 light env of this launch, 2 does not step)
+#define OW_MASK 1        // .. +3: the contacts (bit = list index) of object 0 / 1 / 2
+#define OW_QUAT 4        // .. +12: the objects' orientations at the start of the step (after the out-of-bounds rule)
+template <bool GEN, bool OW = false>
 __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams &P, const DevPtrs &D, int sel, int coop_launch, const RenderModel *RMp = nullptr) {
+    static_assert(!(GEN && OW), "the object wave belongs to the light form");
     const int N = P.N;
+    // (OW wave roles: J J J J O.  Eight waves O J J J - J - - with the three spare ones exiting at once -- the object wave alone
+    // on its SIMD -- was tried: wrong results, 1.7 ms; a workgroup whose waves end before its barrier is not something to build on.)
+    if (OW && (threadIdx.x >> 6) == 4) { light_object_wave(B, P, D, RMp); return; }
     const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
     if (sel <= 1 && blockIdx.x == 0 && threadIdx.x == 0) {
         // (once per step, by the launch every step has: the bookkeeping of the contact frame this step's look-ahead will fill;
@@ -1560,12 +1573,12 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     // arithmetic per row whichever group builds it: results do not depend on the mode (tested bitwise).
     const bool coop = GEN && sel >= 2 && coop_launch;
     const int cg = coop ? (grp & 3) : 0;                              // this group's place among the builders of its env
-    int env_raw = coop ? unit : 4 * unit + (grp & 3);
+    int env_raw = OW ? 16 * (int)blockIdx.x + grp : (coop ? unit : 4 * unit + (grp & 3));
     bool mine = true;                                                 // this 16-lane group has an env to solve in this launch
     if (sel == 2) { mine = env_raw < *D.hcount; env_raw = mine ? D.hlist[env_raw] : N; }
     else if (sel == 3) { mine = env_raw < *D.hcount2; env_raw = mine ? D.hlist2[env_raw] : N; }
     else if (sel == 1) mine = env_raw < N && D.hgflag[env_raw] == 0;
-    if (__ballot(mine) == 0ull) return;                               // (wave-uniform; the kernel has no workgroup barrier)
+    if (!OW && __ballot(mine) == 0ull) return;                        // (wave-uniform; OW: every wave goes to the workgroup's barrier)
     const int env = env_raw < N ? env_raw : N - 1;                    // groups without an env run along as no-ops
     float *state = D.state, *scratch = D.scratch;
     const int lj = l < NB ? l : 0;               // joint owned by this lane (lanes >= 11 alias joint 0, masked)
@@ -1754,8 +1767,22 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
                 os_row_pair(k, k == 0 ? n : (k == 1 ? t1 : t2), x, oA, dist, rest, spin, roll, lam0, dt, P.erp, P.rest_thresh,
                             L_OSL + (3 * ci + k) * 12, L_OST + (3 * ci + k) * 8);
         }
+        if (OW) {
+            // what the object wave needs besides the rows and the objects' data (L_OBJ): who steps, whose contacts, orientations
+            if (l == 0) {
+                *(int *)&LD(L_GSC + OW_FLAGS) = ((mine && env_raw < N) ? 1 : 0) | (dead ? 2 : 0);
+                *(unsigned *)&LD(L_GSC + OW_MASK) = m0; *(unsigned *)&LD(L_GSC + OW_MASK + 1) = m1; *(unsigned *)&LD(L_GSC + OW_MASK + 2) = m2;
+            }
+            if (lo_ >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) LD(L_GSC + OW_QUAT + 4 * lo_ + k) = oquat[k];
+            }
+            own_os = 0;
+            __syncthreads();
+        } else {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        }
     } else
 #pragma unroll 1        // one copy of the (large) row-building body: the kernel must stay inside the instruction cache
     for (int bt = 0; 16 * bt < nct_max; bt++) {
@@ -2086,7 +2113,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     // then the register rows add theirs (b2.w of a normal row = its inherited impulse; absent rows are all-zero)
     if (ng_max > 0) { OBJ_SLOTS(FROM_SLOT) }
 #pragma unroll
-    for (int i = 0; i < KOS; i++) {
+    for (int i = 0; i < (OW ? 0 : KOS); i++) {
         const float l0_ = os_l0[i], sm_ = l0_ * inv_mass;
         os_ln[i] = l0_;
         V01 = pk_fma(P2(os_n0[i].x, os_n0[i].y), P2(sm_, sm_), V01);
@@ -2101,9 +2128,11 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         if (simple) {
             SWEEP_MOTORS
             LIMIT_STEP(0) LIMIT_STEP(1)
-            OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3)
-            OSF_STEP(0) OSF_STEP(1) OSF_STEP(2) OSF_STEP(3)
-            OST_STEP(0) OST_STEP(1) OST_STEP(2) OST_STEP(3)
+            if (!OW) {
+                OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3)
+                OSF_STEP(0) OSF_STEP(1) OSF_STEP(2) OSF_STEP(3)
+                OST_STEP(0) OST_STEP(1) OST_STEP(2) OST_STEP(3)
+            }
             continue;
         }
         SPROF(4);
@@ -2125,6 +2154,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
             if (l < NB) dq += LD(L_MINV + l * NB + j) * (sg * dl);
         }
         SPROF(7);
+        if (OW) continue;                         // (the object chains are the object wave's)
 #pragma unroll 1
         for (int pass = 0; pass < 3; pass++) {    // all normals, then all lateral frictions, then all torsional frictions
             // ---- the generic sweep of this pass: its first rows are requested before the object lanes' own work
@@ -2233,7 +2263,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     SBLK_END(nc, ng, n_os, nF);
     // normal impulses of the register-resident contact rows go back to their LDS slots (contact forces below)
 #pragma unroll
-    for (int i = 0; i < KOS; i++) {
+    for (int i = 0; i < (OW ? 0 : KOS); i++) {
         const int c = (os_cs >> (8 * i)) & 255;
         if (c != 255) LD(L_OSL + (3 * c) * 12 + 11) = os_ln[i];
     }
@@ -2248,7 +2278,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     float q_fin = q_l;                 // joint angle / object pose after this step: what the render instances are set up from
     float o_fin[7] = {0, 0, 0, 0, 0, 0, 1};
     if (dead) {
-        if (lt >= NB && lt - NB < P.nobj) {
+        if (!OW && lt >= NB && lt - NB < P.nobj) {
 #pragma unroll
             for (int k = 0; k < 3; k++) o_fin[k] = STT(ST_OPOS + 3 * (lt - NB) + k);
 #pragma unroll
@@ -2268,7 +2298,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         else if (lt == 7) D.joints[(size_t)env * 9 + 7] = qn;
         else if (lt == 8) D.joints[(size_t)env * 9 + 8] = -qn;
     }
-    if (lt >= NB && lt - NB < P.nobj) {
+    if (!OW && lt >= NB && lt - NB < P.nobj) {
         // (position, orientation and unconstrained velocities are the registers of the stage-in: no load at the tail of the chain)
         const int i = lt - NB;
         float v[3], w[3], pn[3];
@@ -2320,7 +2350,11 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     if (!finite) atomicOr(&D.errflags[env], 1u);
     // ---- touch sensors (robot.py:152-163) + contact forces: lane c takes contacts c, c + 16, c + 32; the four maxima go round
     // the group (a maximum does not depend on the order it is taken in)
-    {
+    if (OW) {
+        // (a light env has no contact of the robot: the touch sensors read zero; the contact forces are the object wave's)
+        if (l < 4) D.touch[(size_t)env * 4 + l] = 0.0f;
+        if (l == 0) D.timestep[env] += 1;
+    } else {
         float touch[4] = {0, 0, 0, 0};
         for (int c0 = 0; c0 < nc; c0 += 16) {
             const int c = c0 + l;
@@ -2355,7 +2389,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     if (!GEN) {
         if (!setup) return;
         const RenderModel &RM = *RMp;
-        if (lt >= NB && lt < NB + NOBJ) {
+        if (!OW && lt >= NB && lt < NB + NOBJ) {
 #pragma unroll
             for (int k = 0; k < 7; k++) LD(L_OBJ + 20 * (lt - NB) + k) = o_fin[k];
         }
@@ -2369,6 +2403,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
 #pragma unroll 1
         for (int i = lt; i < RM.ni; i += 16) {
             const int ot = RM.in_otype[i], oi = RM.in_oidx[i];
+            if (OW && ot == 2) continue;          // (an object's instances are set up by the object wave, from what it integrated)
             float op7[7];
             const int ob = ot == 2 ? min(max(oi, 0), NOBJ - 1) : 0;
 #pragma unroll
@@ -2377,10 +2412,179 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         }
     }
 }
+// Wave 4 of a k_solve_light workgroup (solve_body<false, true>): the object chains of the workgroup's sixteen envs, lane 3 e + o =
+// object o of env e.  Everything it needs was staged in LDS by the env's group before the workgroup's barrier: the objects'
+// data (L_OBJ), the rows of the contacts (L_OSL / L_OST, coefficients), flags, contact masks and orientations (OW_*).  Same
+// row steps, same order within a chain, same integration as the object lanes of the one-kernel form: same bits.
+__device__ __forceinline__ void light_object_wave(const BodyParams &B, const SimParams &P, const DevPtrs &D, const RenderModel *RMp) {
+    const int N = P.N;
+    const int t = threadIdx.x & 63;
+    const int e = min(t / 3, 15), o = t - 3 * (t / 3);
+    const int env_raw = 16 * (int)blockIdx.x + e;
+    const bool lane_on = t < 48 && o < P.nobj && env_raw < N;
+    const int env = env_raw < N ? env_raw : N - 1;
+    const int fix = e * LF_TOTAL;
+    const int L_MU = fix + LF_MU, L_SPIN = fix + LF_SPIN, L_ROLL = fix + LF_ROLL, L_OSL = fix + LF_OSL, L_OST = fix + LF_OST,
+              L_GSC = fix + LF_GSC, L_OBJ = fix + LF_OBJ;
+    float *state = D.state;
+    const float dt = P.dt;
+    __syncthreads();
+    const int flags = *(const int *)&LD(L_GSC + OW_FLAGS);
+    if (!lane_on || !(flags & 1)) return;          // (per lane: nothing below crosses lanes)
+    const bool dead = (flags & 2) != 0;
+    const unsigned own_os = dead ? 0u : *(const unsigned *)&LD(L_GSC + OW_MASK + o);
+    const float inv_mass = LD(L_OBJ + 20 * o + 3);
+    float o_fin[7] = {0, 0, 0, 0, 0, 0, 1};
+    if (dead) {
+        if (!RMp) return;
+#pragma unroll
+        for (int k = 0; k < 3; k++) o_fin[k] = STT(ST_OPOS + 3 * o + k);
+#pragma unroll
+        for (int k = 0; k < 4; k++) o_fin[3 + k] = STT(ST_OQUAT + 4 * o + k);
+    } else {
+    // ---- this object's contacts: all six rows of each in registers (as the object lanes of solve_body hold them)
+    unsigned os_cs = 0;
+    float os_mu[KOS], os_ln[KOS], os_l1[KOS], os_l2[KOS], os_l0[KOS];
+    float4 os_n0[KOS], os_n1[KOS], os_n2[KOS], os_a0[KOS], os_a1[KOS], os_a2[KOS], os_b0[KOS], os_b1[KOS], os_b2[KOS];
+    {
+        unsigned rem = own_os;
+#pragma unroll
+        for (int i = 0; i < KOS; i++) {
+            const bool has = rem != 0;
+            const int c = has ? __ffs(rem) - 1 : 0;
+            rem &= rem - 1;
+            os_cs |= (has ? (unsigned)c : 255u) << (8 * i);
+            os_mu[i] = has ? LD(L_MU + c) : 0.0f; os_ln[i] = 0.0f; os_l1[i] = 0.0f; os_l2[i] = 0.0f;
+            os_l0[i] = has ? LD(L_OST + (3 * c) * 8 + 5) : 0.0f;
+            os_n0[i] = LDZ4(has, 3 * c, 0); os_n1[i] = LDZ4(has, 3 * c, 4); os_n2[i] = LDZ4(has, 3 * c, 8);
+            os_a0[i] = LDZ4(has, 3 * c + 1, 0); os_a1[i] = LDZ4(has, 3 * c + 1, 4); os_a2[i] = LDZ4(has, 3 * c + 1, 8);
+            os_b0[i] = LDZ4(has, 3 * c + 2, 0); os_b1[i] = LDZ4(has, 3 * c + 2, 4); os_b2[i] = LDZ4(has, 3 * c + 2, 8);
+        }
+    }
+    float4 ot_m[KOS][3]; float ot_d[KOS][3], ot_l[KOS][3], os_sp[KOS], os_ro[KOS];
+#pragma unroll
+    for (int i = 0; i < KOS; i++) {
+        const int c = (os_cs >> (8 * i)) & 255;
+        const bool has = c != 255;
+        const int cc = has ? c : 0;
+        os_sp[i] = has ? LD(L_SPIN + cc) : 0.0f; os_ro[i] = has ? LD(L_ROLL + cc) : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            ot_m[i][k] = sel4(has, LDT4(3 * cc + k, 0));
+            ot_d[i][k] = has ? LD(L_OST + (3 * cc + k) * 8 + 4) : 0.0f;
+            ot_l[i][k] = 0.0f;
+        }
+    }
+    v2f V01 = P2(0.0f, 0.0f), V23 = P2(0.0f, 0.0f), V45 = P2(0.0f, 0.0f);
+    // warm start: the inherited normal impulses
+#pragma unroll
+    for (int i = 0; i < KOS; i++) {
+        const float l0_ = os_l0[i], sm_ = l0_ * inv_mass;
+        os_ln[i] = l0_;
+        V01 = pk_fma(P2(os_n0[i].x, os_n0[i].y), P2(sm_, sm_), V01);
+        V23.x = fmaf(os_n0[i].z, sm_, V23.x); V23.y = fmaf(os_n1[i].w, l0_, V23.y);
+        V45 = pk_fma(P2(os_n2[i].x, os_n2[i].y), P2(l0_, l0_), V45);
+    }
+    // (the middle pair's update as two scalar FMAs on dir.z of the first pair: the same two operations as the packed one, and the
+    // twelve registers of the rows' second copy of dir.z go to row data the wave would otherwise spill -- it shares its SIMD)
+#pragma push_macro("REG_ROW_STEP")
+#undef REG_ROW_STEP
+#define REG_ROW_STEP(b0, b1, b2, lam, lo, hi)                                                                     \
+    do {                                                                                                          \
+        v2f p_ = P2((b0).x, (b0).y) * V01;                                                                        \
+        p_ = pk_fma(P2((b0).z, (b0).w), V23, p_);                                                                 \
+        p_ = pk_fma(P2((b1).x, (b1).y), V45, p_);                                                                 \
+        const float jv_ = p_.x + p_.y;                                                                            \
+        const float s0_ = fmaf(-jv_, (b2).w, (lam) + (b2).z);                                                     \
+        const float sum_ = __builtin_amdgcn_fmed3f(s0_, (lo), (hi));                                              \
+        const float dl_ = sum_ - (lam);                                                                           \
+        (lam) = sum_;                                                                                             \
+        const float sm_ = dl_ * inv_mass;                                                                         \
+        V01 = pk_fma(P2((b0).x, (b0).y), P2(sm_, sm_), V01);                                                      \
+        V23.x = fmaf((b0).z, sm_, V23.x); V23.y = fmaf((b1).w, dl_, V23.y);                                       \
+        V45 = pk_fma(P2((b2).x, (b2).y), P2(dl_, dl_), V45);                                                      \
+    } while (0)
+    for (int it = 0; it < P.iters; it++) {
+        asm volatile("" ::: "memory");
+        OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3)
+        OSF_STEP(0) OSF_STEP(1) OSF_STEP(2) OSF_STEP(3)
+        OST_STEP(0) OST_STEP(1) OST_STEP(2) OST_STEP(3)
+    }
+#pragma pop_macro("REG_ROW_STEP")
+    // ---- contact forces of this object's contacts (robot.py:131-150 reads them)
+#pragma unroll
+    for (int i = 0; i < KOS; i++) {
+        const int c = (os_cs >> (8 * i)) & 255;
+        if (c != 255) D.cforce[(size_t)env * MAXC + c] = os_ln[i] / dt;
+    }
+    // ---- integrate (the object lanes' code of solve_body, same operations); the object's pose and unconstrained velocities are
+    // fetched from LDS only now: thirteen registers the sweeps need for row data
+    bool finite = true;
+    {
+        const int i = o;
+        float op3[3], vs3[3], ws3[3], oquat[4];
+        {
+            asm volatile("" ::: "memory");
+            const float4 *od = (const float4 *)&LD(L_OBJ + 20 * o);
+            const float4 d0 = od[0], d3 = od[3], d4 = od[4];
+            op3[0] = d0.x; op3[1] = d0.y; op3[2] = d0.z;
+            vs3[0] = d3.y; vs3[1] = d3.z; vs3[2] = d3.w; ws3[0] = d4.x; ws3[1] = d4.y; ws3[2] = d4.z;
+#pragma unroll
+            for (int k = 0; k < 4; k++) oquat[k] = LD(L_GSC + OW_QUAT + 4 * o + k);
+        }
+        float v[3], w[3], pn[3];
+        const float dvi[3] = {DVX, DVY, DVZ}, dwi[3] = {DWX, DWY, DWZ};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            v[k] = vs3[k] + dvi[k];
+            w[k] = ws3[k] + dwi[k];
+            pn[k] = fmaf(dt, v[k], op3[k]);
+            finite = finite && isfinite(pn[k]);
+            STT(ST_OVEL + 3 * i + k) = v[k];
+            STT(ST_OANG + 3 * i + k) = w[k];
+            STT(ST_OPOS + 3 * i + k) = pn[k];
+        }
+        float wn = sqrtf(fmaf(w[0], w[0], fmaf(w[1], w[1], w[2] * w[2])));
+        float ang = wn * dt, d0, d1, d2, d3;
+        if (ang > 1e-12f) {
+            float sn, cs;
+            sincosf(ang * 0.5f, &sn, &cs);
+            float s_ = sn / wn;
+            d0 = w[0] * s_; d1 = w[1] * s_; d2 = w[2] * s_; d3 = cs;
+        } else {
+            d0 = w[0] * dt * 0.5f; d1 = w[1] * dt * 0.5f; d2 = w[2] * dt * 0.5f; d3 = 1.0f;
+        }
+        float q0 = oquat[0], q1 = oquat[1], q2 = oquat[2], q3 = oquat[3];
+        float r0 = fmaf(d3, q0, fmaf(d0, q3, fmaf(d1, q2, -(d2 * q1))));
+        float r1 = fmaf(d3, q1, fmaf(-d0, q2, fmaf(d1, q3, d2 * q0)));
+        float r2 = fmaf(d3, q2, fmaf(d0, q1, fmaf(-d1, q0, d2 * q3)));
+        float r3 = fmaf(d3, q3, fmaf(-d0, q0, fmaf(-d1, q1, -(d2 * q2))));
+        float inv = 1.0f / sqrtf(fmaf(r0, r0, fmaf(r1, r1, fmaf(r2, r2, r3 * r3))));
+        STT(ST_OQUAT + 4 * i) = r0 * inv; STT(ST_OQUAT + 4 * i + 1) = r1 * inv;
+        STT(ST_OQUAT + 4 * i + 2) = r2 * inv; STT(ST_OQUAT + 4 * i + 3) = r3 * inv;
+        float *op = D.objpose + ((size_t)env * P.nobj + i) * 7;
+        for (int k = 0; k < 3; k++) op[k] = pn[k];
+        op[3] = r0 * inv; op[4] = r1 * inv; op[5] = r2 * inv; op[6] = r3 * inv;
+        o_fin[0] = pn[0]; o_fin[1] = pn[1]; o_fin[2] = pn[2];
+        o_fin[3] = r0 * inv; o_fin[4] = r1 * inv; o_fin[5] = r2 * inv; o_fin[6] = r3 * inv;
+    }
+    if (!finite) atomicOr(&D.errflags[env], 1u);
+    }       // (!dead)
+    // ---- the render instances of this object
+    if (RMp) {
+        const RenderModel &RM = *RMp;
+        const float qj[NB] = {0};
+#pragma unroll 1
+        for (int i = 0; i < RM.ni; i++)
+            if (RM.in_otype[i] == 2 && RM.in_oidx[i] == o) instance_setup_core(B, RM, D, env, i, 2, o, qj, o_fin);
+    }
+}
 __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtrs D, int sel, int coop_launch) { solve_body<true>(B, P, D, sel, coop_launch); }
 // the light envs of a split step (sel 1), 64-thread workgroups
 // (RMp: the render model when the step draws -- the kernel then sets up the render instances of its envs; else nullptr)
 __global__ void __launch_bounds__(64) k_solve_light(BodyParams B, SimParams P, DevPtrs D, const RenderModel *RMp) { solve_body<false>(B, P, D, 1, 0, RMp); }
+// ... in workgroups for sixteen envs with one wave running the object chains (OW)
+__global__ void __launch_bounds__(LIGHT_OW_THREADS) k_solve_light_ow(BodyParams B, SimParams P, DevPtrs D, const RenderModel *RMp) { solve_body<false, true>(B, P, D, 1, 0, RMp); }
 
 // obs pack without stepping (after reset / set_state)
 __global__ void k_obs(SimParams P, DevPtrs D) {
@@ -3667,6 +3871,7 @@ struct rr_env {
     bool full_copy, sep_restore;   // RR_FULL_COPY / RR_SEPARATE_RESTORE at create: the two earlier image-update schemes (tests, A/B)
     int split_max_pct;             // the heavy / light split is used while at most this share of the solver groups is heavy (RR_SPLIT_MAX_PCT)
     int *h_hcount;                 // pinned host copy of D.hcount[0] (device-mapped: written by k_prep_a of the following step)
+    bool light_ow;                 // k_solve_light_ow available and wanted (RR_NO_OBJECT_WAVE=1: k_solve_light; A/B, tests)
     bool split_heavy;              // heavy solver groups + their render on the side stream (RR_NO_SPLIT=1 turns it off: A/B, tests)
     bool images_valid;       // every env's image holds its previous frame (static layer + the pixels of its fragment list)
     hipEvent_t ev[2 * RR_NUM_KERNELS];
@@ -4107,6 +4312,13 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         (void)hipGetLastError();
         e->split_heavy = false;
     }
+    // the light envs' solve with an object wave (five waves, sixteen envs and the same 158 KiB per workgroup); without the
+    // attribute (or with RR_NO_OBJECT_WAVE) the one-group-per-env form in 64-thread workgroups -- same results
+    e->light_ow = e->split_heavy && !getenv("RR_NO_OBJECT_WAVE");
+    if (e->light_ow && hipFuncSetAttribute((const void *)k_solve_light_ow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * SGRP * LF_TOTAL * sizeof(float))) != hipSuccess) {
+        (void)hipGetLastError();
+        e->light_ow = false;
+    }
     if (hipGetLastError() != hipSuccess) { rr_destroy(e); *out = nullptr; return fail(RR_EDEVICE, "rr_create: device error during set-up"); }
     return RR_OK;
 }
@@ -4372,11 +4584,13 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         // the step's main chain; RR_NO_FUSED_SETUP: the separate k_render_setup launch -- same bits, tested)
         static const bool no_fused_setup = getenv("RR_NO_FUSED_SETUP") != nullptr;
         const RenderModel *fused_rm = no_fused_setup ? nullptr : e->RM_dev;
+        const bool light_ow = e->light_ow;
         if (e->timing) {
             // timing leg: the very same launches, one after the other on the main stream, each under its timer -- 2 / 3 / 4 / 6
             // what the main stream runs in an untimed step (the light envs), 7 / 8 what the side streams run beside it, 0 / 1 the
             // look-ahead of the next step, which an untimed step runs on the heavy stream behind the heavy envs' render
-            TIMED(2, hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, fused_rm));
+            if (light_ow) TIMED(2, hipLaunchKernelGGL(k_solve_light_ow, dim3((N + 15) / 16), dim3(LIGHT_OW_THREADS), 4 * lds64, e->stream, e->B, e->P, e->D, fused_rm));
+            else TIMED(2, hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, fused_rm));
             TIMED(7, { launch_solve_class(e, 2, e->stream); launch_solve_class(e, 3, e->stream); });
             launch_render(e, D, restore, 1, e->stream, true, fused_rm != nullptr);
             TIMED(8, { launch_render(e, D, restore, 2, e->stream, false); launch_render(e, D, restore, 3, e->stream, false); });
@@ -4415,7 +4629,8 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
             launch_render(e, D, restore, 3, e->aux, false);
         } else launch_render(e, D, restore, 3, e->aux2, false);
         hipEventRecord(e->ev_join, e->aux);
-        hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, fused_rm);
+        if (light_ow) hipLaunchKernelGGL(k_solve_light_ow, dim3((N + 15) / 16), dim3(LIGHT_OW_THREADS), 4 * lds64, e->stream, e->B, e->P, e->D, fused_rm);
+        else hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, fused_rm);
         if (ahead && la_on_vh) {
             hipEventRecord(e->ev_dyn, e->stream);             // the light envs' solve
             hipStreamWaitEvent(e->aux2, e->ev_dyn, 0);

@@ -219,3 +219,39 @@ def test_edited_eye_camera_reaches_the_retina():
     r2, d2, m2 = o2.render()
     assert (m2 == obs2['mask']).all()
     e.close()
+
+
+def test_object_wave_form_of_the_light_solve_is_bitwise_equivalent(monkeypatch):
+    """k_solve_light_ow (workgroups of five waves for sixteen envs: four waves of 16-lane env groups for the command part, the row
+    build and the robot's rows, the fifth wave one lane per (env, object) for the object chains, integration and the objects'
+    render instances) against k_solve_light (RR_NO_OBJECT_WAVE=1: everything of an env on its 16-lane group): states, joints,
+    touch sensors, object poses, contact forces, images bitwise equal over 200 steps of full-range commands with resets, a
+    teleport and a rejected (non-finite) command in between, at an env count that is not a multiple of 16 and with 1..3 objects."""
+    for n_obj, N in ((3, 130), (2, 49), (1, 16)):
+        a = BatchedREALRobotEnv(N, objects=n_obj, width=64, height=64)
+        b = _make(monkeypatch, {'RR_NO_OBJECT_WAVE': '1'}, N, objects=n_obj, width=64, height=64)
+        rng = np.random.default_rng(7 + n_obj)
+        ids = list(range(N))
+        for t in range(200):
+            cmd = synthetic_actions(ids, t, seed=5).astype(np.float32)
+            if t == 60:
+                m = (rng.random(N) < 0.3).astype(np.uint8)
+                a.reset(m); b.reset(m)
+            if t == 120:
+                pose = np.array([-0.1, 0.2, 0.5, 0, 0, 0, 1], np.float32)
+                a.set_object_pose(5, 0, pose); b.set_object_pose(5, 0, pose)
+            if t == 90:         # a rejected (non-finite) device-resident command: env 3 does not step
+                import torch
+                dc = torch.from_numpy(cmd).cuda()
+                dc[3, 2] = float('nan')
+                a.step(device_ptr=dc.data_ptr(), render=True); b.step(device_ptr=dc.data_ptr(), render=True)
+                torch.cuda.synchronize()
+                assert a.host(nat.F_ERRFLAGS)[3] == 2
+            else:
+                a.step(cmd, render=True); b.step(cmd, render=True)
+            if t % 10 == 9 or t in (90, 91):
+                assert _same(_snapshot(a), _snapshot(b)), (n_obj, t)
+                for i in (0, 5, N - 1):
+                    assert np.array_equal(a.contacts(i), b.contacts(i)), (n_obj, t, i)
+        assert (a.host(nat.F_ERRFLAGS)[3] & 2) == 0      # (the rejected command was one step only)
+        a.close(); b.close()
