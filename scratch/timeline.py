@@ -10,7 +10,7 @@ f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ev = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0], r.get('Queue_Id', '?')) for r in rows))
 names = set(e[2] for e in ev)
-mark = 'k_solve_light' if 'k_solve_light' in names else 'k_solve'
+mark = next(m for m in ('k_solve_light_ow', 'k_solve_light', 'k_solve') if m in names)
 starts = [i for i, e in enumerate(ev) if e[2] == mark]
 for which in (back, back - 1):
     i0, i1 = starts[-which], starts[-which + 1]

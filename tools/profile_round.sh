@@ -46,7 +46,7 @@ tr['_note']="HBM bytes per step from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (se
 json.dump(tr, open(O+'/traffic_latest.json','w'), indent=1)
 sv={'config': cfg, 'source': TAG+'_sq_counters.json', 'valu_wave_instr_per_launch': {k: round(v['SQ_INSTS_VALU']['mean']) for k,v in sq.items() if 'SQ_INSTS_VALU' in v}}
 json.dump(sv, open(O+'/sq_latest.json','w'), indent=1)
-for k in ('k_raster','k_shade','k_solve','k_collide','k_prep_a','k_prep_b','k_prep_ab','k_solve_light','k_render_setup','k_render_list'):
+for k in ('k_raster','k_shade','k_solve','k_collide','k_prep_a','k_prep_b','k_prep_ab','k_solve_light','k_solve_light_ow','k_render_setup','k_render_list'):
     r={c: x['mean'] for c,x in sq.get(k,{}).items()}
     if not r: continue
     wc=r.get('SQ_WAVE_CYCLES',0) or 1
