@@ -590,8 +590,8 @@ __device__ __forceinline__ Xf load_xf(const ShapeData *S, int s, const float *sc
 #ifdef RR_RASTER_STATS
 // development build only: cycle stamps of kernel phases (lane 0 of every block), see scratch/sprof.py
 __device__ unsigned long long g_sprof[16];
-#define SPROF(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && (!(P.ablate & 0x4000) || (int)blockIdx.x == (P.ablate >> 16))) atomicAdd(&g_sprof[i], now_ - sp_t0); sp_t0 = now_; } while (0)   /* RR_ABLATE = block << 16 | 0x4000: one block only */
-#define SPROF_INIT unsigned long long sp_t0 = __builtin_readcyclecounter();
+#define SPROF(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == (LIGHT_OW_THREADS == 384 ? 1 : 0) && (!(P.ablate & 0x4000) || (int)blockIdx.x == (P.ablate >> 16))) atomicAdd(&g_sprof[i], now_ - sp_t0); sp_t0 = now_; } while (0)   /* RR_ABLATE = block << 16 | 0x4000: one block only */
+#define SPROF_INIT unsigned long long sp_t0 = __builtin_amdgcn_s_memrealtime();
 // per solver workgroup: {total cycles, cycles up to the end of the row build, cycles of the PGS loop, -, then per env
 // nc | generic contacts << 8 | leading object-vs-static contacts << 16 | last F-list length << 24}
 __device__ unsigned g_sblk[4096 * 8];
@@ -1547,7 +1547,9 @@ __device__ __forceinline__ void instance_setup(const BodyParams &B, const SimPar
 // (env, object) (light_object_wave below).  In a light env the robot's rows and each object's rows are separate problems;
 // with the object rows on lanes 11..13 of every group 62 % of a sweep's instructions ran with 3 of 16 lanes live.
 __device__ void light_object_wave(const BodyParams &B, const SimParams &P, const DevPtrs &D, const RenderModel *RMp);
-#define LIGHT_OW_THREADS 320
+#ifndef LIGHT_OW_THREADS
+#define LIGHT_OW_THREADS 384
+#endif
 #define OW_FLAGS 0       // L_GSC words of an env that its group publishes for the object wave: flags (1 light env of this launch, 2 does not step)
 #define OW_MASK 1        // .. +3: the contacts (bit = list index) of object 0 / 1 / 2
 #define OW_QUAT 4        // .. +12: the objects' orientations at the start of the step (after the out-of-bounds rule)
@@ -1555,16 +1557,29 @@ template <bool GEN, bool OW = false>
 __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams &P, const DevPtrs &D, int sel, int coop_launch, const RenderModel *RMp = nullptr) {
     static_assert(!(GEN && OW), "the object wave belongs to the light form");
     const int N = P.N;
-    // (OW wave roles: J J J J O.  Eight waves O J J J - J - - with the three spare ones exiting at once -- the object wave alone
-    // on its SIMD -- was tried: wrong results, 1.7 ms; a workgroup whose waves end before its barrier is not something to build on.)
-    if (OW && (threadIdx.x >> 6) == 4) { light_object_wave(B, P, D, RMp); return; }
-    const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
     if (sel <= 1 && blockIdx.x == 0 && threadIdx.x == 0) {
         // (once per step, by the launch every step has: the bookkeeping of the contact frame this step's look-ahead will fill;
         // the number of heavy / very heavy envs of this step goes to pinned host memory on the way -- a posted write)
         if (D.hcount_host) { D.hcount_host[0] = D.hcount[0]; D.hcount_host[1] = D.hcount2[0]; }
         D.hcount_next[0] = 0; D.hcount_next[1] = 0; D.hcount2_next[0] = 0; D.hcount2_next[1] = 0;
     }
+#if LIGHT_OW_THREADS == 384
+    // wave roles O J J J - J: waves w and w + 4 of a workgroup land on the same SIMD (scratch/ubench/simd_map.hip), so the object
+    // wave has its SIMD to itself -- wave 4 only keeps the workgroup's barrier company and ends -- and two of the four group
+    // waves share one (together as many issue slots as the object wave).  Object wave 53 -> 37 us (scratch/sprof_light.py), the
+    // kernel 56.7 -> 54.3 us, the step 0.691 -> 0.685 ms.  (LIGHT_OW_THREADS 320: J J J J O, the object wave shares with a group wave.)
+    int jwave = 0;
+    if (OW) {
+        const int wv = threadIdx.x >> 6;
+        if (wv == 0) { light_object_wave(B, P, D, RMp); return; }
+        if (wv == 4) { __syncthreads(); return; }
+        jwave = wv < 4 ? wv - 1 : 3;
+    }
+    const int grp = OW ? 4 * jwave + ((threadIdx.x >> 4) & 3) : threadIdx.x >> 4, l = threadIdx.x & 15;
+#else
+    if (OW && (threadIdx.x >> 6) == 4) { light_object_wave(B, P, D, RMp); return; }
+    const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+#endif
     const int unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // the wave's index in the launch
     // coop (a heavy / very heavy list of at most COOP_MAX envs -- the host's lagged count decides, any actual count is handled):
     // ONE env per wave -- its four 16-lane groups build the rows of four contacts at a time (the row build of an env at the
@@ -2428,7 +2443,29 @@ __device__ __forceinline__ void light_object_wave(const BodyParams &B, const Sim
               L_GSC = fix + LF_GSC, L_OBJ = fix + LF_OBJ;
     float *state = D.state;
     const float dt = P.dt;
+#ifdef RR_RASTER_STATS
+    unsigned long long ow_t0 = __builtin_amdgcn_s_memrealtime();      // (100 MHz: the shader clock counter runs with the DVFS state)
+#define OWPROF(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); if (t == 0 && (!(P.ablate & 0x4000) || (int)blockIdx.x == (P.ablate >> 16))) atomicAdd(&g_sprof[i], now_ - ow_t0); ow_t0 = now_; } while (0)
+#else
+#define OWPROF(i)
+#endif
+    // (while the env groups stage in and build rows: which render instance is this object's -- uniform loads, one round trip)
+    int my_inst = -1, my_inst2 = -1;
+    if (RMp) {
+        const RenderModel &RM = *RMp;
+        const int ni = RM.ni;
+#pragma unroll
+        for (int i = 0; i < MAXINST; i++) {
+            const bool m_ = i < ni && RM.in_otype[i] == 2 && RM.in_oidx[i] == o;
+            my_inst2 = (m_ && my_inst >= 0 && my_inst2 < 0) ? i : my_inst2;
+            my_inst = (m_ && my_inst < 0) ? i : my_inst;
+        }
+    }
+#ifdef RR_RASTER_STATS
+    if (t == 0 && blockIdx.x < 4096) g_sblk[(2048 + blockIdx.x) * 8] = (unsigned)ow_t0;       // (scratch/ow_blocks.py: when did this workgroup start / end?)
+#endif
     __syncthreads();
+    OWPROF(8);           // waiting for the env groups (stage-in, command part, row build)
     const int flags = *(const int *)&LD(L_GSC + OW_FLAGS);
     if (!lane_on || !(flags & 1)) return;          // (per lane: nothing below crosses lanes)
     const bool dead = (flags & 2) != 0;
@@ -2475,6 +2512,7 @@ __device__ __forceinline__ void light_object_wave(const BodyParams &B, const Sim
             ot_l[i][k] = 0.0f;
         }
     }
+    OWPROF(9);           // rows from LDS to registers
     v2f V01 = P2(0.0f, 0.0f), V23 = P2(0.0f, 0.0f), V45 = P2(0.0f, 0.0f);
     // warm start: the inherited normal impulses
 #pragma unroll
@@ -2511,6 +2549,7 @@ __device__ __forceinline__ void light_object_wave(const BodyParams &B, const Sim
         OST_STEP(0) OST_STEP(1) OST_STEP(2) OST_STEP(3)
     }
 #pragma pop_macro("REG_ROW_STEP")
+    OWPROF(10);          // sweeps
     // ---- contact forces of this object's contacts (robot.py:131-150 reads them)
 #pragma unroll
     for (int i = 0; i < KOS; i++) {
@@ -2569,21 +2608,31 @@ __device__ __forceinline__ void light_object_wave(const BodyParams &B, const Sim
         o_fin[3] = r0 * inv; o_fin[4] = r1 * inv; o_fin[5] = r2 * inv; o_fin[6] = r3 * inv;
     }
     if (!finite) atomicOr(&D.errflags[env], 1u);
+    OWPROF(11);          // forces, integration
     }       // (!dead)
     // ---- the render instances of this object
     if (RMp) {
         const RenderModel &RM = *RMp;
         const float qj[NB] = {0};
+        if (my_inst >= 0) instance_setup_core(B, RM, D, env, my_inst, 2, o, qj, o_fin);
+        if (my_inst2 >= 0) {          // (an object drawn as more than two instances: the rest in a loop)
+            instance_setup_core(B, RM, D, env, my_inst2, 2, o, qj, o_fin);
 #pragma unroll 1
-        for (int i = 0; i < RM.ni; i++)
-            if (RM.in_otype[i] == 2 && RM.in_oidx[i] == o) instance_setup_core(B, RM, D, env, i, 2, o, qj, o_fin);
+            for (int i = my_inst2 + 1; i < RM.ni; i++)
+                if (RM.in_otype[i] == 2 && RM.in_oidx[i] == o) instance_setup_core(B, RM, D, env, i, 2, o, qj, o_fin);
+        }
     }
+    OWPROF(12);          // render instances
+#ifdef RR_RASTER_STATS
+    if (t == 0 && blockIdx.x < 4096) g_sblk[(2048 + blockIdx.x) * 8 + 1] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 __global__ void __launch_bounds__(256) k_solve(BodyParams B, SimParams P, DevPtrs D, int sel, int coop_launch) { solve_body<true>(B, P, D, sel, coop_launch); }
 // the light envs of a split step (sel 1), 64-thread workgroups
 // (RMp: the render model when the step draws -- the kernel then sets up the render instances of its envs; else nullptr)
 __global__ void __launch_bounds__(64) k_solve_light(BodyParams B, SimParams P, DevPtrs D, const RenderModel *RMp) { solve_body<false>(B, P, D, 1, 0, RMp); }
-// ... in workgroups for sixteen envs with one wave running the object chains (OW)
+// ... in workgroups for sixteen envs with one wave running the object chains (OW); the bookkeeping of solve_body's first lines
+// is thread 0's whatever its wave's role
 __global__ void __launch_bounds__(LIGHT_OW_THREADS) k_solve_light_ow(BodyParams B, SimParams P, DevPtrs D, const RenderModel *RMp) { solve_body<false, true>(B, P, D, 1, 0, RMp); }
 
 // obs pack without stepping (after reset / set_state)

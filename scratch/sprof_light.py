@@ -8,7 +8,7 @@ import sys
 
 if len(sys.argv) > 1 and sys.argv[1] == 'child':
     sys.path.insert(0, '/root/repo')
-    os.environ['RR_LIB'] = os.path.join(os.path.dirname(__file__), '..', 'real_robots_amd', 'csrc', 'librealrobot_hip_stats.so')
+    os.environ['RR_LIB'] = os.environ.get('RR_STATS_LIB', os.path.join(os.path.dirname(__file__), '..', 'real_robots_amd', 'csrc', 'librealrobot_hip_stats.so'))
     import numpy as np
     import torch
     from real_robots_amd import _native as nat
@@ -36,12 +36,13 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     torch.cuda.synchronize()
     lib.rr_debug_solver_prof(out, 0)
     v = np.array(list(out), dtype=np.float64) / K
-    print(' '.join('%.0f' % x for x in v[:8]))
+    print(' '.join('%.0f' % x for x in v[:13]))
 else:
-    names = ['stage-in + command', 'row build', 'motor + limit rows', 'register rows', 'PGS sweeps', 'integrate', 'forces/touch', '-']
+    names = ['stage-in + command', 'row build', 'motor + limit rows', 'register rows', 'PGS sweeps', 'integrate', 'forces/touch', '-',
+             'OW: wait for groups', 'OW: load rows', 'OW: sweeps', 'OW: forces+integr.', 'OW: instances']
     print('%-8s' % 'block' + ''.join('%20s' % n for n in names) + '%10s' % 'total')
-    for b in (300, 522, 744, 966):
+    for b in (70, 130, 190, 250):
         env = dict(os.environ, RR_ABLATE=str((b << 16) | 0x4000))
         r = subprocess.run([sys.executable, __file__, 'child'], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
         v = [float(x) for x in r.stdout.strip().split('\n')[-1].split()]
-        print('%-8d' % b + ''.join('%20.0f' % x for x in v) + '%10.0f' % sum(v))
+        print('%-8d' % b + ''.join('%20.0f' % x for x in v) + '   groups %.0f  object wave %.0f' % (sum(v[:8]), sum(v[8:])))
