@@ -538,6 +538,7 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
         vs.z -= P.dt * P.gravity;
         v3 alo = mulv(Iinv, cross(om, mulv(Iw, om)));
         v3 ws = om + (alo * -1.0f - om * (P.ang_damp + P.ang_damp * wn)) * P.dt;
+#pragma unroll
         for (int k = 0; k < 9; k++) { SCR(S_OR + 9 * i + k) = R.m[k]; SCR(S_OIINV + 9 * i + k) = Iinv.m[k]; }
         SCR(S_OVS + 3 * i) = vs.x; SCR(S_OVS + 3 * i + 1) = vs.y; SCR(S_OVS + 3 * i + 2) = vs.z;
         SCR(S_OWS + 3 * i) = ws.x; SCR(S_OWS + 3 * i + 1) = ws.y; SCR(S_OWS + 3 * i + 2) = ws.z;
