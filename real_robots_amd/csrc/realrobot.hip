@@ -139,6 +139,7 @@ struct DevPtrs {
     int *hlist;        // [N] the heavy envs of this step (in arrival order: placement only, never a result)
     int *hcount;       // [0] their number, [1] work counter of k_raster_list / k_render_list
     float4 *clist_next; int *ccount_next; float *cwarm_next; int *hgflag_next, *hlist2_next, *hcount2_next, *hlist_next, *hcount_next;
+    int *hpos, *hpos_next;     // [N] place of a heavy / very heavy env in its list (k_collide's launch order, collide_launch_env)
     float *cforce;     // [N][MAXC] normal force of every contact of the last solved step (rr_get_contacts, touch sensors, warm start)
     int *hcount_host;  // device address of the pinned host word that receives the current number of heavy envs (or nullptr)
     int *timestep;     // [N]
@@ -1229,17 +1230,32 @@ __device__ __forceinline__ void collide_env(const SimParams &P, const DevPtrs &D
         bool vh = heavy && ngen > P.heavy2_min;
         if (vh) {
             const int sl = atomicAdd(D.hcount2_next, 1);
-            if (sl < VH_MAX) { D.hgflag_next[env] = 2; D.hlist2_next[sl] = env; }
+            if (sl < VH_MAX) { D.hgflag_next[env] = 2; D.hlist2_next[sl] = env; D.hpos_next[env] = sl; }
             else { atomicSub(D.hcount2_next, 1); vh = false; }
         }
-        if (heavy && !vh) { D.hgflag_next[env] = 1; D.hlist_next[atomicAdd(D.hcount_next, 1)] = env; }
+        if (heavy && !vh) { const int sl = atomicAdd(D.hcount_next, 1); D.hgflag_next[env] = 1; D.hlist_next[sl] = env; D.hpos_next[env] = sl; }
         else if (!heavy) D.hgflag_next[env] = 0;
     }
 }
 // One workgroup per env of the class `sel` (pick_env): N workgroups whatever the class (a heavy list's length is known on the
 // device only; workgroups past its end, or whose env is not of the class, exit before touching anything).
-__global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, DevPtrs D, int ns, int sel) {
-    const int env = pick_env(D, sel, blockIdx.x, P.N);
+// All envs (sel 0) in the order "longest first": the kernel lasts four rounds of workgroups and an env pressed on the table
+// takes four times the mean (scratch/cprof.py), so the envs that were very heavy / heavy in the step just solved -- the lists of
+// the CURRENT contact frame -- take the first h_first workgroups (a lagged host count + a margin; list entries beyond it and
+// everybody else follow in env order: an env's place in its list, hpos, says on which side it is).  Every env exactly once.
+__device__ __forceinline__ int collide_launch_env(const DevPtrs &D, int idx, int N, int h_first) {
+    if (idx < h_first) {
+        const int n2 = D.hcount2[0], n1 = D.hcount[0];
+        return idx < n2 ? D.hlist2[idx] : (idx - n2 < n1 ? D.hlist[idx - n2] : -1);
+    }
+    const int env = idx - h_first;
+    if (env >= N) return -1;
+    const int g = D.hgflag[env];
+    if (g != 0 && (g == 2 ? D.hpos[env] : D.hcount2[0] + D.hpos[env]) < h_first) return -1;      // (it was among the first)
+    return env;
+}
+__global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, DevPtrs D, int ns, int sel, int h_first) {
+    const int env = (sel == 0 && h_first > 0) ? collide_launch_env(D, blockIdx.x, P.N, h_first) : pick_env(D, sel, blockIdx.x, P.N);
     if (env < 0) return;
     collide_env(P, D, ns, env);
 }
@@ -3930,7 +3946,7 @@ struct rr_env {
     hipStream_t aux2;              // the very heavy envs' solve + render (RR_HEAVY2_MIN)
     // Look-ahead: the state part of step t+1 (k_prep_ab, k_collide) runs on the side streams behind the render
     // of the heavy / very heavy envs of step t, beside the main stream's shading.
-    struct Frame { float4 *clist; int *ccount; float *cwarm; int *hgflag, *hlist, *hcount, *hlist2, *hcount2; } fr[2];
+    struct Frame { float4 *clist; int *ccount; float *cwarm; int *hgflag, *hlist, *hcount, *hlist2, *hcount2, *hpos; } fr[2];
     int cur;                       // fr[cur]: the frame of the last solved step (rr_get_contacts, contact history); fr[cur ^ 1]: the look-ahead's
     bool la_valid;                 // fr[cur ^ 1] and the scratch slab hold the collision pass / dynamics of the next step for the present state
     bool lookahead;                // RR_NO_LOOKAHEAD=1: never ahead, every step prepares itself in line (A/B, tests)
@@ -4027,6 +4043,7 @@ static void bind_frames(rr_env *e) {
     D.clist = C.clist; D.ccount = C.ccount; D.cwarm = C.cwarm; D.hgflag = C.hgflag; D.hlist = C.hlist; D.hcount = C.hcount; D.hlist2 = C.hlist2; D.hcount2 = C.hcount2;
     D.clist_next = X.clist; D.ccount_next = X.ccount; D.cwarm_next = X.cwarm; D.hgflag_next = X.hgflag; D.hlist_next = X.hlist; D.hcount_next = X.hcount;
     D.hlist2_next = X.hlist2; D.hcount2_next = X.hcount2;
+    D.hpos = C.hpos; D.hpos_next = X.hpos;
 }
 
 // the contact count and the class of every env belong to the contact frame of the last solved step, which changes place every step
@@ -4236,7 +4253,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     for (int f = 0; f < 2; f++) {
         rr_env::Frame &F = e->fr[f];
         ALLOC(F.clist, (size_t)N * MAXC * 3); ALLOC(F.ccount, (size_t)N); ALLOC(F.cwarm, (size_t)N * MAXC);
-        ALLOC(F.hgflag, (size_t)N); ALLOC(F.hlist, (size_t)N); ALLOC(F.hcount, (size_t)4); ALLOC(F.hlist2, (size_t)N); ALLOC(F.hcount2, (size_t)4);
+        ALLOC(F.hgflag, (size_t)N); ALLOC(F.hpos, (size_t)N); ALLOC(F.hlist, (size_t)N); ALLOC(F.hcount, (size_t)4); ALLOC(F.hlist2, (size_t)N); ALLOC(F.hcount2, (size_t)4);
     }
     e->cur = 0; e->la_valid = false;
     bind_frames(e);
@@ -4536,7 +4553,14 @@ static void launch_prep_b(rr_env *e, int sel, hipStream_t st) {
     hipLaunchKernelGGL(k_prep_b, env_grid(e), dim3(e->epb), 0, st, e->B, e->P, e->D, sel);
 }
 static void launch_collide(rr_env *e, int sel, hipStream_t st) {
-    hipLaunchKernelGGL(k_collide, dim3(e->P.N), dim3(COLLIDE_THREADS), 0, st, e->P, e->D, e->n_shapes, sel);
+    // (h_first: the lagged host copy of the two list lengths + a margin; RR_COLLIDE_ORDER=0: env order)
+    static const bool ordered = !(getenv("RR_COLLIDE_ORDER") && atoi(getenv("RR_COLLIDE_ORDER")) == 0);
+    int h_first = 0;
+    if (sel == 0 && ordered && e->h_hcount) {
+        const int lag = ((volatile int *)e->h_hcount)[0] + ((volatile int *)e->h_hcount)[1];
+        if (lag > 0) h_first = std::min(e->P.N, lag + 64);
+    }
+    hipLaunchKernelGGL(k_collide, dim3(e->P.N + h_first), dim3(COLLIDE_THREADS), 0, st, e->P, e->D, e->n_shapes, sel, h_first);
 }
 static void launch_prep_ab(rr_env *e, int sel, hipStream_t st) {
     hipLaunchKernelGGL(k_prep_ab, env_grid(e), dim3(e->epb), 0, st, e->B, e->P, e->D, sel);
