@@ -390,11 +390,38 @@ __device__ __forceinline__ void prep_body(const BodyParams &B, const SimParams &
     float q[NB], qd[NB];
 #pragma unroll
     for (int i = 0; i < NB; i++) { q[i] = STT(ST_Q + i); qd[i] = STT(ST_QD + i); }
+    if (PHASE == 1) {
+        // ---- kinematics only, streamed: a body's frame goes to the scratch record as soon as it exists and only the frame at hand
+        // and the one the chain forks from are kept (fk_all's operations in fk_all's order: same bits).  The kernel then needs a
+        // third of the registers (69 instead of 194 VGPRs).
+        m3 Rc = {{1, 0, 0, 0, 1, 0, 0, 0, 1}}, Rf = Rc;
+        v3 pc = mk(B.robot_pos[0], B.robot_pos[1], B.robot_pos[2]), pf = pc;
+        constexpr int FORK = 6;                    // PARENT: a chain 0..8 with the second finger pair 9, 10 hanging off body 6
+        static_assert(PARENT[9] == FORK && PARENT[10] == 9 && PARENT[8] == 7 && PARENT[7] == 6, "streamed forward kinematics");
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if (b == 9) { Rc = Rf; pc = pf; }      // (bodies 0..8: the parent is the previous body; 9: body 6; 10: body 9)
+            m3 jr;
+#pragma unroll
+            for (int k = 0; k < 9; k++) jr.m[k] = B.jrot[b][k];
+            const m3 Rj = nc::mul(Rc, jr);
+            const v3 ax = mk(B.axis[b][0], B.axis[b][1], B.axis[b][2]);
+            const v3 pb = nc::add(pc, nc::mulv(Rc, mk(B.jpos[b][0], B.jpos[b][1], B.jpos[b][2])));
+            const m3 Rb = nc::mul(Rj, nc::axis_angle(ax, q[b]));
+            const v3 axw = nc::mulv(Rj, ax);
+#pragma unroll
+            for (int k = 0; k < 9; k++) SCR(S_BR + 9 * b + k) = Rb.m[k];
+            SCR(S_BP + 3 * b) = pb.x; SCR(S_BP + 3 * b + 1) = pb.y; SCR(S_BP + 3 * b + 2) = pb.z;
+            SCR(S_BAX + 3 * b) = axw.x; SCR(S_BAX + 3 * b + 1) = axw.y; SCR(S_BAX + 3 * b + 2) = axw.z;
+            Rc = Rb; pc = pb;
+            if (b == FORK) { Rf = Rb; pf = pb; }
+        }
+    }
     // ---- kinematics
     m3 bR[NB]; v3 bp[NB], bax[NB], bcom[NB]; m3 bI[NB];
-    fk_all(B, q, bR, bp, bax);
+    if (PHASE != 1) fk_all(B, q, bR, bp, bax);
 #pragma unroll
-    for (int b = 0; b < NB; b++) {
+    for (int b = 0; b < (PHASE == 1 ? 0 : NB); b++) {
         bcom[b] = bp[b] + mulv(bR[b], mk(B.com[b][0], B.com[b][1], B.com[b][2]));
         bI[b] = inertia_world(bR[b], B.inertia[b]);
         if (PHASE != 2) {
@@ -4709,6 +4736,11 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
             hipEventRecord(e->ev_dyn, e->stream);             // the light envs' solve
             hipStreamWaitEvent(e->aux2, e->ev_dyn, 0);
             hipStreamWaitEvent(e->aux2, e->ev_hsolved, 0);    // the heavy envs' solve
+            // (k_prep_ab needs a whole free SIMD for each of its 64 waves -- 256 VGPRs + AGPRs -- and sits in its queue until the
+            // shading's grid is exhausted: 55-100 us between the last solve and the collision pass.  Measured against it: the
+            // kinematics half alone (69 VGPRs: it moves into the holes retiring render workgroups leave, 21 us) in front of the
+            // collision pass and the dynamics half behind it (0.685 ms) or on the main stream behind the shading (0.671)
+            // instead of 0.672 -- the collision pass then runs beside the shading and takes as much longer.)
             hipLaunchKernelGGL(k_prep_ab, env_grid(e), dim3(e->epb), 0, e->aux2, e->B, e->P, e->D, 0);
             launch_collide(e, 0, e->aux2);
         }
