@@ -255,3 +255,26 @@ def test_object_wave_form_of_the_light_solve_is_bitwise_equivalent(monkeypatch):
                     assert np.array_equal(a.contacts(i), b.contacts(i)), (n_obj, t, i)
         assert (a.host(nat.F_ERRFLAGS)[3] & 2) == 0      # (the rejected command was one step only)
         a.close(); b.close()
+
+
+def test_collide_launch_order_does_not_change_results(monkeypatch):
+    """k_collide launches last step's very heavy / heavy envs first (collide_launch_env); RR_COLLIDE_ORDER=0 keeps env order.  The
+    order only decides which workgroup handles which env and in which order the envs are appended to the heavy lists: states,
+    contacts, classes and images are bitwise the same over 240 full-range steps with resets in between (envs that are on a list
+    and light again, lists longer and shorter than the lagged count the launch is sized with)."""
+    N = 384
+    a = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    b = _make(monkeypatch, {'RR_COLLIDE_ORDER': '0'}, N, objects=3, width=64, height=64)
+    rng = np.random.default_rng(21)
+    ids = list(range(N))
+    for t in range(240):
+        cmd = synthetic_actions(ids, t, seed=9).astype(np.float32)
+        if t in (80, 160):
+            m = (rng.random(N) < 0.4).astype(np.uint8)
+            a.reset(m); b.reset(m)
+        a.step(cmd, render=True); b.step(cmd, render=True)
+        if t % 20 == 19:
+            assert _same(_snapshot(a), _snapshot(b)), t
+            assert np.array_equal(a.host(nat.F_ENV_CLASS), b.host(nat.F_ENV_CLASS)), t
+    assert (a.host(nat.F_ENV_CLASS) > 0).sum() >= 3      # (heavy envs exist: the first workgroups had list entries to take)
+    a.close(); b.close()
