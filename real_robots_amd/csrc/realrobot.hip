@@ -4761,8 +4761,22 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 0, 0));
     HIPCHK(hipGetLastError());
     int rc = RR_OK;
+    // (one class.  With a camera the state part of the next step runs on the side stream beside the render of this one;
+    // RR_UNSPLIT_LA_INLINE=1: behind it on the main stream.)
+    static const bool la_inline = getenv("RR_UNSPLIT_LA_INLINE") != nullptr;
+    const bool la_beside = ahead && render_mode && overlap && !la_inline;
+    if (la_beside) {
+        hipEventRecord(e->ev_fork, e->stream);
+        hipStreamWaitEvent(e->aux, e->ev_fork, 0);
+        launch_prep_ab(e, 0, e->aux);
+        launch_collide(e, 0, e->aux);
+        hipEventRecord(e->ev_join, e->aux);
+    }
     if (render_mode) rc = do_render(e, render_mode == 2);
-    if (ahead) {                // (one class: nothing to run beside -- the state part of the next step follows in line)
+    if (la_beside) {
+        hipStreamWaitEvent(e->stream, e->ev_join, 0);
+        e->la_valid = true;
+    } else if (ahead) {
         state_part_all(e, overlap);
         e->la_valid = true;
     }
