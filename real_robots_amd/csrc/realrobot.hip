@@ -4715,7 +4715,8 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         // for the very heavy envs' solve.)
         // (per-class look-aheads beside the visibility pass only queue up behind the LDS-filling raster workgroups; a fourth
         // stream for it slows every kernel of the step down -- one more hardware queue: 1.19 instead of 0.81 ms)
-        const bool la_on_vh = !e->h_hcount || ((volatile int *)e->h_hcount)[1] <= 64;
+        static const int la_vh_max = getenv("RR_LA_VH_MAX") ? atoi(getenv("RR_LA_VH_MAX")) : 64;       // (tests: -1 forces the other placement)
+        const bool la_on_vh = la_vh_max >= 0 && (!e->h_hcount || ((volatile int *)e->h_hcount)[1] <= la_vh_max);
         const bool vh_render_on_h = ahead && la_on_vh;
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
@@ -4729,7 +4730,10 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
             hipStreamWaitEvent(e->aux, e->ev_vsolved, 0);
             launch_render(e, D, restore, 3, e->aux, false);
         } else launch_render(e, D, restore, 3, e->aux2, false);
-        hipEventRecord(e->ev_join, e->aux);
+        // (hundreds of very heavy envs -- macro actions: RR_MACRO_LA=0 keeps the look-ahead at the tail of the main stream)
+        static const bool macro_la_side = !(getenv("RR_MACRO_LA") && atoi(getenv("RR_MACRO_LA")) == 0);
+        const bool la_split_side = ahead && !la_on_vh && macro_la_side;
+        if (!la_split_side) hipEventRecord(e->ev_join, e->aux);
         if (light_ow) hipLaunchKernelGGL(k_solve_light_ow, dim3((N + 15) / 16), dim3(LIGHT_OW_THREADS), 4 * lds64, e->stream, e->B, e->P, e->D, fused_rm);
         else hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, fused_rm);
         if (ahead && la_on_vh) {
@@ -4744,9 +4748,24 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
             hipLaunchKernelGGL(k_prep_ab, env_grid(e), dim3(e->epb), 0, e->aux2, e->B, e->P, e->D, 0);
             launch_collide(e, 0, e->aux2);
         }
+        if (la_split_side) {
+            // the heavy stream is done with its envs' render long before the very heavy envs' is (their solve lasts twice as long):
+            // the kinematics half of the next step's preparation (69 VGPRs: it gets onto the machine beside the renders) and the
+            // collision pass go there, once every solve is done; the dynamics half (a whole SIMD per wave) behind the very heavy
+            // envs' render
+            hipEventRecord(e->ev_dyn, e->stream);             // the light envs' solve
+            hipStreamWaitEvent(e->aux, e->ev_dyn, 0);
+            hipStreamWaitEvent(e->aux, e->ev_vsolved, 0);
+            launch_prep_a(e, 0, 0, e->aux);
+            launch_collide(e, 0, e->aux);
+            hipEventRecord(e->ev_join, e->aux);
+            hipStreamWaitEvent(e->aux2, e->ev_dyn, 0);
+            hipStreamWaitEvent(e->aux2, e->ev_hsolved, 0);
+            launch_prep_b(e, 0, e->aux2);
+        }
         hipEventRecord(e->ev_join2, e->aux2);
         launch_render(e, D, restore, 1, e->stream, false, fused_rm != nullptr);
-        if (ahead && !la_on_vh) {
+        if (ahead && !la_on_vh && !la_split_side) {
             hipStreamWaitEvent(e->stream, e->ev_hsolved, 0);
             hipStreamWaitEvent(e->stream, e->ev_vsolved, 0);
             hipLaunchKernelGGL(k_prep_ab, env_grid(e), dim3(e->epb), 0, e->stream, e->B, e->P, e->D, 0);
