@@ -4726,10 +4726,16 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         hipStreamWaitEvent(e->aux2, e->ev_fork, 0);
         launch_solve_class(e, 3, e->aux2);
         if (ahead) hipEventRecord(e->ev_vsolved, e->aux2);
-        if (vh_render_on_h) {          // (at the tail of the main stream, behind the shading, instead: 0.733 ms)
+        // (the very heavy envs' render: behind the heavy envs' on their stream -- unless that list is a long one (three launches, the
+        // longest chain of the step in the late window of the benchmark workload): then at the tail of the main stream, which is
+        // done with the shading by then.  With a short heavy list the main stream's tail measured 0.733 instead of 0.727 ms.)
+        static const int vh_main = getenv("RR_VH_ON_MAIN") ? atoi(getenv("RR_VH_ON_MAIN")) : -1;      // -1 by the list's length, 0 never, 1 always
+        const bool h_long = e->h_hcount && (long long)*(volatile int *)e->h_hcount * e->RM.ntiles > RENDER_LIST_WGS;
+        const bool vh_render_on_main = vh_render_on_h && (vh_main < 0 ? h_long : vh_main == 1);
+        if (vh_render_on_h && !vh_render_on_main) {
             hipStreamWaitEvent(e->aux, e->ev_vsolved, 0);
             launch_render(e, D, restore, 3, e->aux, false);
-        } else launch_render(e, D, restore, 3, e->aux2, false);
+        } else if (!vh_render_on_h) launch_render(e, D, restore, 3, e->aux2, false);
         // (hundreds of very heavy envs -- macro actions: RR_MACRO_LA=0 keeps the look-ahead at the tail of the main stream)
         static const bool macro_la_side = !(getenv("RR_MACRO_LA") && atoi(getenv("RR_MACRO_LA")) == 0);
         const bool la_split_side = ahead && !la_on_vh && macro_la_side;
@@ -4765,6 +4771,10 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         }
         hipEventRecord(e->ev_join2, e->aux2);
         launch_render(e, D, restore, 1, e->stream, false, fused_rm != nullptr);
+        if (vh_render_on_main) {
+            hipStreamWaitEvent(e->stream, e->ev_vsolved, 0);
+            launch_render(e, D, restore, 3, e->stream, false);
+        }
         if (ahead && !la_on_vh && !la_split_side) {
             hipStreamWaitEvent(e->stream, e->ev_hsolved, 0);
             hipStreamWaitEvent(e->stream, e->ev_vsolved, 0);
