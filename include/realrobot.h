@@ -43,11 +43,17 @@ enum {
     RR_F_MASK = 5,      /* i32 [N, H, W]     body unique id, -1 background  env.py:552-558 */
     RR_F_TIMESTEP = 6,  /* i32 [N]           env.timestep                 env.py:217,346 */
     RR_F_ERRFLAGS = 7,  /* u32 [N]           1: non-finite state detected (env frozen until reset / set_state); 2: this step's command was
-                                             not finite (env not stepped, robot.py:189); 4: internal consistency (never expected) */
+                                             not finite (env not stepped, robot.py:189: its state, clock and observations stay as they
+                                             are; its contact list is dropped -- RR_F_CONTACT_COUNT 0, rr_get_contacts empty -- and the
+                                             next accepted step starts its contact solve cold, like a step after rr_set_state);
+                                             4: internal consistency (never expected) */
     RR_F_STATE = 8,     /* f32 [N, 61]       q[11] qd[11] 3x(pos3 quat4 lin3 ang3)  (checkpoint / parity) */
     RR_F_FRAG_COUNT = 9,/* u32 [N, tiles]    diagnostic: entries of k_shade's work list in the last render (pixels won by moving geometry + pixels vacated since the frame before) */
-    RR_F_CONTACT_COUNT = 10, /* i32 [N]      contacts of the last solved step (rr_get_contacts returns them one env at a time) */
-    RR_F_ENV_CLASS = 11,     /* i32 [N]      diagnostic: 0 light, 1 heavy, 2 very heavy -- which launch solved / rendered the env in the last step */
+    RR_F_CONTACT_COUNT = 10, /* i32 [N]      contacts of the last solved step (rr_get_contacts returns them one env at a time); 0 after
+                                             rr_reset / rr_set_state of that env */
+    RR_F_ENV_CLASS = 11,     /* i32 [N]      diagnostic: 0 light, 1 heavy, 2 very heavy -- which launch solved / rendered the env in the last
+                                             step.  Both fields live in fixed buffers written by the solve kernels: a pointer
+                                             from rr_get_buffer stays valid over steps like every other field's */
     RR_F_COUNT = 12
 };
 

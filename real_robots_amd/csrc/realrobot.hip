@@ -132,6 +132,8 @@ struct DevPtrs {
                        // spinning}; meta = bodyA | bodyB << 8 | linkA << 16 (bytes; -1 static, 0..15 robot body, 16+i object i).
                        // Written by the env's k_collide workgroup (as clist_next), read by its k_solve group in one round trip.
     int *ccount;       // [N] number of contacts in clist
+    int *ccount_pub, *class_pub;   // [N] RR_F_CONTACT_COUNT / RR_F_ENV_CLASS: the count and class of the last SOLVED step in fixed storage (the
+                                   // frames change roles every step; a pointer handed out by rr_get_buffer must not) -- written by the solve kernels
     float *cwarm;      // [N][MAXC] initial normal impulse of every contact of clist (k_collide: 0.85 x the matched previous one)
     int *hgflag;       // [N] 0: light; 1: this env has generic contact rows this step -- "heavy"; 2: more than P.heavy2_min of them -- "very heavy"
     int *hlist2;       // [N] the very heavy envs of this step (a handful: an arm crushed onto the table at the contact cap)
@@ -1666,6 +1668,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     const v3 pk_l = mk(SCR(S_BP + 3 * lj), SCR(S_BP + 3 * lj + 1), SCR(S_BP + 3 * lj + 2));
     const v3 ak_l = mk(SCR(S_BAX + 3 * lj), SCR(S_BAX + 3 * lj + 1), SCR(S_BAX + 3 * lj + 2));
     const int ccount_in = D.ccount[env];
+    const int cls_in = sel == 0 ? D.hgflag[env] : sel - 1;           // (sel 1 / 2 / 3: the launch's class)
     float cw0, cw1, cw2;              // warm-start impulses of contacts l, 16 + l, 32 + l
     float4 cr0, cr1, cr2, cr3, cr4, cr5, cr6, cr7, cr8;   // lane l's float4 #(l + 16 i) of the list: cr0..2 = the first 16 records
     {
@@ -1721,6 +1724,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     // an env whose command was rejected does not step; the list the look-ahead made for this step is dropped with it, so that
     // the normal forces of the last solved step (cforce) are never matched against a list they do not belong to
     if (!frozen && rejected && l == 0) D.ccount[env] = 0;
+    if (l == 0 && mine && env_raw < N) { D.ccount_pub[env] = (!frozen && rejected) ? 0 : ccount_in; D.class_pub[env] = cls_in; }
     if (!dead) {
         if (l < NB) STT(ST_TGT + l) = tgt_l;
         if (lo_ >= 0 && lo_ < P.nobj && object_out_of_bounds(raw_x, raw_z, B.table_z)) {       // env.py:257-264
@@ -2711,6 +2715,7 @@ __global__ void k_reset(BodyParams B, SimParams P, DevPtrs D, const unsigned cha
     D.errflags[env] = 0;
     for (int k = 0; k < 4; k++) D.touch[(size_t)env * 4 + k] = 0;
     D.ccount[env] = 0;
+    D.ccount_pub[env] = 0; D.class_pub[env] = 0;
 }
 
 __global__ void k_state_io(SimParams P, DevPtrs D, float *aos /*[N][61]*/, int to_aos) {
@@ -2739,6 +2744,7 @@ __global__ void k_state_io(SimParams P, DevPtrs D, float *aos /*[N][61]*/, int t
         D.errflags[env] = 0;
         for (int k = 0; k < 4; k++) D.touch[(size_t)env * 4 + k] = 0;
         D.ccount[env] = 0;
+        D.ccount_pub[env] = 0; D.class_pub[env] = 0;
     }
 }
 
@@ -3977,6 +3983,15 @@ struct rr_env {
     int cur;                       // fr[cur]: the frame of the last solved step (rr_get_contacts, contact history); fr[cur ^ 1]: the look-ahead's
     bool la_valid;                 // fr[cur ^ 1] and the scratch slab hold the collision pass / dynamics of the next step for the present state
     bool lookahead;                // RR_NO_LOOKAHEAD=1: never ahead, every step prepares itself in line (A/B, tests)
+    // Placement knobs of rr_step's schedule, read from the environment at rr_create so that a test can force every
+    // branch the lagged heavy counters would pick (tests/test_gpu_round4.py): none of them may change a result.
+    int la_vh_max;                 // RR_LA_VH_MAX (64): look-ahead behind the very heavy envs' solve while their lagged count is <= this; -1: never
+    int vh_main;                   // RR_VH_ON_MAIN (-1: by the heavy list's length; 0 never; 1 always): very heavy envs' render at the main stream's tail
+    bool macro_la_side;            // RR_MACRO_LA=0: with many very heavy envs the look-ahead stays at the tail of the main stream
+    bool la_inline;                // RR_UNSPLIT_LA_INLINE: the unsplit step's look-ahead behind its render instead of beside it
+    bool no_fused_setup;           // RR_NO_FUSED_SETUP: separate k_render_setup launch for the light envs
+    bool collide_ordered;          // RR_COLLIDE_ORDER=0: k_collide in env order (default: last step's heavy envs first)
+    int force_hcount[2];           // RR_FORCE_HCOUNT="h,vh": what the host-side decisions read instead of the lagged counters (tests; -1: the counters)
     int n_shapes;
     float table_pos[3];            // target of the default eye camera (env.py:253-255)
     float t_ms[RR_NUM_KERNELS];
@@ -3987,6 +4002,14 @@ struct rr_env {
     // recorded behind its copy has completed
     char *pin_buf[4]; hipEvent_t pin_ev[4]; bool pin_used[4]; int pin_next; size_t pin_bytes;
 };
+
+// The lagged host copy of the heavy (which 0) / very heavy (which 1) list length: written to mapped pinned memory by a recent
+// step's kernels, read here without any synchronisation -- it only ever selects a launch shape or a placement, never a result
+// (every placement is forced and compared bitwise in tests/test_gpu_round4.py; RR_FORCE_HCOUNT pins what is read).
+static inline int lagged_count(const rr_env *e, int which, int fallback) {
+    if (e->force_hcount[which] >= 0) return e->force_hcount[which];
+    return e->h_hcount ? ((volatile int *)e->h_hcount)[which] : fallback;
+}
 
 template <typename T>
 static int dev_alloc(rr_env *e, T **p, size_t count, bool zero = true) {
@@ -4073,10 +4096,11 @@ static void bind_frames(rr_env *e) {
     D.hpos = C.hpos; D.hpos_next = X.hpos;
 }
 
-// the contact count and the class of every env belong to the contact frame of the last solved step, which changes place every step
+// The contact count and the class of every env belong to the contact frame of the last solved step, which changes place every
+// step: the solve kernels publish both into fixed [N] buffers, so that a pointer from rr_get_buffer stays valid (realrobot.h).
 static void refresh_frame_fields(rr_env *e) {
-    e->field_ptr[RR_F_CONTACT_COUNT] = e->D.ccount;
-    e->field_ptr[RR_F_ENV_CLASS] = e->D.hgflag;
+    e->field_ptr[RR_F_CONTACT_COUNT] = e->D.ccount_pub;
+    e->field_ptr[RR_F_ENV_CLASS] = e->D.class_pub;
 }
 
 static ImageOut env_images(const rr_env *e) {
@@ -4137,6 +4161,14 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->sep_restore = getenv("RR_SEPARATE_RESTORE") != nullptr;
     e->split_heavy = getenv("RR_NO_SPLIT") == nullptr;
     e->lookahead = getenv("RR_NO_LOOKAHEAD") == nullptr;
+    e->la_vh_max = getenv("RR_LA_VH_MAX") ? atoi(getenv("RR_LA_VH_MAX")) : 64;
+    e->vh_main = getenv("RR_VH_ON_MAIN") ? atoi(getenv("RR_VH_ON_MAIN")) : -1;
+    e->macro_la_side = !(getenv("RR_MACRO_LA") && atoi(getenv("RR_MACRO_LA")) == 0);
+    e->la_inline = getenv("RR_UNSPLIT_LA_INLINE") != nullptr;
+    e->no_fused_setup = getenv("RR_NO_FUSED_SETUP") != nullptr;
+    e->collide_ordered = !(getenv("RR_COLLIDE_ORDER") && atoi(getenv("RR_COLLIDE_ORDER")) == 0);
+    e->force_hcount[0] = e->force_hcount[1] = -1;
+    if (getenv("RR_FORCE_HCOUNT")) sscanf(getenv("RR_FORCE_HCOUNT"), "%d,%d", &e->force_hcount[0], &e->force_hcount[1]);
 
     e->h_hcount = nullptr;
     e->split_max_pct = getenv("RR_SPLIT_MAX_PCT") ? atoi(getenv("RR_SPLIT_MAX_PCT")) : 60;
@@ -4285,6 +4317,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->cur = 0; e->la_valid = false;
     bind_frames(e);
     ALLOC(D.cforce, (size_t)N * MAXC);
+    ALLOC(D.ccount_pub, (size_t)N); ALLOC(D.class_pub, (size_t)N);
     e->D.hcount_host = nullptr;
     if (e->h_hcount && hipHostGetDevicePointer((void **)&e->D.hcount_host, e->h_hcount, 0) != hipSuccess) e->D.hcount_host = nullptr;
     ALLOC(D.timestep, (size_t)N);
@@ -4551,7 +4584,7 @@ static void launch_render(rr_env *e, const DevPtrs &D, int restore, int sel, hip
         // the heavy envs, a few (lagged host copy of their number: at most one item per workgroup): one list-walking launch for
         // set-up, visibility and shading -- the tail of the step's longest chain; many: the three kernels (the fused one needs
         // 128 VGPRs: two workgroups per CU, which a long list pays for)
-        if (sel == 3 || (sel == 2 && e->h_hcount && (long long)*(volatile int *)e->h_hcount * e->RM.ntiles <= RENDER_LIST_WGS)) {
+        if (sel == 3 || (sel == 2 && (long long)lagged_count(e, 0, e->P.N) * e->RM.ntiles <= RENDER_LIST_WGS)) {
             hipLaunchKernelGGL(k_render_list, dim3(std::min(N * e->RM.ntiles, sel == 3 ? 256 : RENDER_LIST_WGS)), dim3(RASTER_THREADS), 0, st, e->B, e->P, e->RM_dev, D, io, e->n_inst_used, restore, sel == 3 ? 1 : 0);
             return;
         }
@@ -4581,10 +4614,9 @@ static void launch_prep_b(rr_env *e, int sel, hipStream_t st) {
 }
 static void launch_collide(rr_env *e, int sel, hipStream_t st) {
     // (h_first: the lagged host copy of the two list lengths + a margin; RR_COLLIDE_ORDER=0: env order)
-    static const bool ordered = !(getenv("RR_COLLIDE_ORDER") && atoi(getenv("RR_COLLIDE_ORDER")) == 0);
     int h_first = 0;
-    if (sel == 0 && ordered && e->h_hcount) {
-        const int lag = ((volatile int *)e->h_hcount)[0] + ((volatile int *)e->h_hcount)[1];
+    if (sel == 0 && e->collide_ordered && e->h_hcount) {
+        const int lag = lagged_count(e, 0, 0) + lagged_count(e, 1, 0);
         if (lag > 0) h_first = std::min(e->P.N, lag + 64);
     }
     hipLaunchKernelGGL(k_collide, dim3(e->P.N + h_first), dim3(COLLIDE_THREADS), 0, st, e->P, e->D, e->n_shapes, sel, h_first);
@@ -4604,7 +4636,7 @@ static void launch_solve_class(rr_env *e, int sel, hipStream_t st) {
     const int N = e->P.N;
     const int ngroups = (N + SGRP - 1) / SGRP;
     const size_t lds64 = (size_t)SGRP * LF_TOTAL * sizeof(float);
-    const int lagged = e->h_hcount ? ((volatile int *)e->h_hcount)[sel == 2 ? 0 : 1] : N;
+    const int lagged = lagged_count(e, sel == 2 ? 0 : 1, N);
     const bool coop = e->P.coop_build && lagged <= COOP_MAX;
     if (coop) hipLaunchKernelGGL(k_solve, dim3((N + 3) / 4), dim3(256), lds64, st, e->B, e->P, e->D, sel, 1);
     else hipLaunchKernelGGL(k_solve, dim3((ngroups + 3) / 4), dim3(256), 4 * lds64, st, e->B, e->P, e->D, sel, 0);
@@ -4670,7 +4702,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     const size_t lds64 = (size_t)SGRP * LF_TOTAL * sizeof(float);
     // (the number of heavy envs of a recent step, written to pinned host memory by the solve kernel without anybody waiting for it: when most are
     // heavy -- macro actions, every gripper pushing -- there is nothing to gain from the split)
-    const bool mostly_heavy = e->h_hcount && (long long)*(volatile int *)e->h_hcount * 100 > (long long)N * e->split_max_pct;
+    const bool mostly_heavy = (long long)lagged_count(e, 0, 0) * 100 > (long long)N * e->split_max_pct;
     const bool ahead = e->lookahead;            // this step ends with the state part of the next one
     // (a step without camera runs all envs in one launch: its classes side by side were measured -- config 2: 0.525 instead of 0.452 ms)
     if (e->aux && !g_skip && render_mode && e->split_heavy && !mostly_heavy) {
@@ -4683,8 +4715,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         const int restore = ensure_images(e, D);
         // (the light solve sets up the render instances of its envs itself: one launch and a 20 us kernel less at the head of
         // the step's main chain; RR_NO_FUSED_SETUP: the separate k_render_setup launch -- same bits, tested)
-        static const bool no_fused_setup = getenv("RR_NO_FUSED_SETUP") != nullptr;
-        const RenderModel *fused_rm = no_fused_setup ? nullptr : e->RM_dev;
+        const RenderModel *fused_rm = e->no_fused_setup ? nullptr : e->RM_dev;
         const bool light_ow = e->light_ow;
         if (e->timing) {
             // timing leg: the very same launches, one after the other on the main stream, each under its timer -- 2 / 3 / 4 / 6
@@ -4715,8 +4746,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         // for the very heavy envs' solve.)
         // (per-class look-aheads beside the visibility pass only queue up behind the LDS-filling raster workgroups; a fourth
         // stream for it slows every kernel of the step down -- one more hardware queue: 1.19 instead of 0.81 ms)
-        static const int la_vh_max = getenv("RR_LA_VH_MAX") ? atoi(getenv("RR_LA_VH_MAX")) : 64;       // (tests: -1 forces the other placement)
-        const bool la_on_vh = la_vh_max >= 0 && (!e->h_hcount || ((volatile int *)e->h_hcount)[1] <= la_vh_max);
+        const bool la_on_vh = e->la_vh_max >= 0 && lagged_count(e, 1, 0) <= e->la_vh_max;       // (RR_LA_VH_MAX=-1 forces the other placement)
         const bool vh_render_on_h = ahead && la_on_vh;
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
@@ -4729,16 +4759,14 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         // (the very heavy envs' render: behind the heavy envs' on their stream -- unless that list is a long one (three launches, the
         // longest chain of the step in the late window of the benchmark workload): then at the tail of the main stream, which is
         // done with the shading by then.  With a short heavy list the main stream's tail measured 0.733 instead of 0.727 ms.)
-        static const int vh_main = getenv("RR_VH_ON_MAIN") ? atoi(getenv("RR_VH_ON_MAIN")) : -1;      // -1 by the list's length, 0 never, 1 always
-        const bool h_long = e->h_hcount && (long long)*(volatile int *)e->h_hcount * e->RM.ntiles > RENDER_LIST_WGS;
-        const bool vh_render_on_main = vh_render_on_h && (vh_main < 0 ? h_long : vh_main == 1);
+        const bool h_long = (long long)lagged_count(e, 0, 0) * e->RM.ntiles > RENDER_LIST_WGS;
+        const bool vh_render_on_main = vh_render_on_h && (e->vh_main < 0 ? h_long : e->vh_main == 1);     // RR_VH_ON_MAIN: -1 by the list's length, 0 never, 1 always
         if (vh_render_on_h && !vh_render_on_main) {
             hipStreamWaitEvent(e->aux, e->ev_vsolved, 0);
             launch_render(e, D, restore, 3, e->aux, false);
         } else if (!vh_render_on_h) launch_render(e, D, restore, 3, e->aux2, false);
         // (hundreds of very heavy envs -- macro actions: RR_MACRO_LA=0 keeps the look-ahead at the tail of the main stream)
-        static const bool macro_la_side = !(getenv("RR_MACRO_LA") && atoi(getenv("RR_MACRO_LA")) == 0);
-        const bool la_split_side = ahead && !la_on_vh && macro_la_side;
+        const bool la_split_side = ahead && !la_on_vh && e->macro_la_side;
         if (!la_split_side) hipEventRecord(e->ev_join, e->aux);
         if (light_ow) hipLaunchKernelGGL(k_solve_light_ow, dim3((N + 15) / 16), dim3(LIGHT_OW_THREADS), 4 * lds64, e->stream, e->B, e->P, e->D, fused_rm);
         else hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, fused_rm);
@@ -4792,8 +4820,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     int rc = RR_OK;
     // (one class.  With a camera the state part of the next step runs on the side stream beside the render of this one;
     // RR_UNSPLIT_LA_INLINE=1: behind it on the main stream.)
-    static const bool la_inline = getenv("RR_UNSPLIT_LA_INLINE") != nullptr;
-    const bool la_beside = ahead && render_mode && overlap && !la_inline;
+    const bool la_beside = ahead && render_mode && overlap && !e->la_inline;
     if (la_beside) {
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
@@ -4854,7 +4881,18 @@ int rr_set_state(rr_env *e, const float *state_host) {
 // {header, state slab [72][N] (incl. motor targets), contact count [N], contact list [N][48][3] float4, normal forces [N][48],
 //  timestep [N], errflags [N], touch [N][4], object home poses [21][N]}: the 61-float state of RR_F_STATE plus the contact
 // history of the warm start (Bullet: the persistent manifolds with their cached impulses) and the episode clocks.
-struct CkptHeader { char magic[8]; int32_t version, N, nobj, reserved; };
+// The header also carries every parameter the continuation depends on: a blob restored into a handle that steps differently
+// (other dt / ERP / margin / sweeps / warm-start factor / object-lane capacity / inertia source / edge contacts) is rejected
+// instead of silently diverging.
+struct CkptHeader { char magic[8]; int32_t version, N, nobj, iters; float dt, erp, margin, warmstart; int32_t os_cap, edge_contacts, urdf_inertia, reserved; };
+static CkptHeader ckpt_header(const rr_env *e) {
+    CkptHeader hd;
+    memset(&hd, 0, sizeof hd);
+    memcpy(hd.magic, "RRCKPT02", 8); hd.version = 2; hd.N = e->P.N; hd.nobj = e->P.nobj; hd.iters = e->P.iters;
+    hd.dt = e->P.dt; hd.erp = e->P.erp; hd.margin = e->P.margin; hd.warmstart = e->P.warmstart;
+    hd.os_cap = e->P.os_cap; hd.edge_contacts = e->P.edge_contacts; hd.urdf_inertia = e->cfg.use_urdf_inertia;
+    return hd;
+}
 static size_t ckpt_bytes(const rr_env *e) {
     const size_t N = e->P.N;
     return sizeof(CkptHeader) + 4 * (ST_TOTAL * N + N + N * MAXC * 12 + N * MAXC + N + N + N * 4 + NOBJ * 7 * N);
@@ -4881,8 +4919,7 @@ int rr_checkpoint_save(rr_env *e, void *dst_host, size_t bytes) {
     if (!e || !dst_host) return fail(RR_EINVAL, "null argument");
     if (bytes != ckpt_bytes(e)) return fail(RR_EINVAL, "rr_checkpoint_save: size mismatch (rr_checkpoint_bytes)");
     HIPCHK(hipSetDevice(e->cfg.device));
-    CkptHeader hd;
-    memcpy(hd.magic, "RRCKPT01", 8); hd.version = 1; hd.N = e->P.N; hd.nobj = e->P.nobj; hd.reserved = 0;
+    const CkptHeader hd = ckpt_header(e);
     memcpy(dst_host, &hd, sizeof hd);
     const int rc = ckpt_copy(e, (char *)dst_host, true);
     if (rc != RR_OK) return rc;
@@ -4894,12 +4931,22 @@ int rr_checkpoint_restore(rr_env *e, const void *src_host, size_t bytes) {
     if (bytes != ckpt_bytes(e)) return fail(RR_EINVAL, "rr_checkpoint_restore: size mismatch (rr_checkpoint_bytes)");
     CkptHeader hd;
     memcpy(&hd, src_host, sizeof hd);
-    if (memcmp(hd.magic, "RRCKPT01", 8) != 0 || hd.version != 1 || hd.N != e->P.N || hd.nobj != e->P.nobj)
+    const CkptHeader mine = ckpt_header(e);
+    if (memcmp(hd.magic, mine.magic, 8) != 0 || hd.version != mine.version || hd.N != mine.N || hd.nobj != mine.nobj)
         return fail(RR_EINVAL, "rr_checkpoint_restore: not a checkpoint of an env handle of this shape");
+    if (memcmp(&hd, &mine, sizeof hd) != 0)
+        return fail(RR_EINVAL, "rr_checkpoint_restore: the checkpoint was taken with other step parameters (dt / erp / margin / solver_iters / warm start / object-lane capacity / inertia source / edge contacts)");
     HIPCHK(hipSetDevice(e->cfg.device));
     e->la_valid = false;
     const int rc = ckpt_copy(e, (char *)const_cast<void *>(src_host), false);
     if (rc != RR_OK) return rc;
+    // the published count follows the restored list; the class diagnostic and k_collide's launch order start clean (the lists of
+    // the handle's own run say nothing about the restored one)
+    const size_t N = e->P.N;
+    HIPCHK(hipMemcpyAsync(e->D.ccount_pub, e->D.ccount, 4 * N, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->D.class_pub, 0, 4 * N, e->stream));
+    HIPCHK(hipMemsetAsync(e->D.hgflag, 0, 4 * N, e->stream));
+    HIPCHK(hipMemsetAsync(e->D.hcount, 0, 16, e->stream)); HIPCHK(hipMemsetAsync(e->D.hcount2, 0, 16, e->stream));
     hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
     HIPCHK(hipStreamSynchronize(e->stream));   // the source is host memory
     return RR_OK;

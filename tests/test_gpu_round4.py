@@ -1,0 +1,266 @@
+"""GPU tests (-m gpu) of round 4, through the C ABI:
+* every placement rr_step's host side picks from the lagged heavy counters (csrc/realrobot.hip, "Look-ahead" block of rr_step)
+  is FORCED through the knobs the library reads at rr_create and compared bitwise with the unsplit, in-line step
+  (RR_NO_SPLIT=1 RR_NO_LOOKAHEAD=1): the schedule may never change a result (env.py:326-356 is one sequential step);
+* the macro workload and the late window of the headline workload exactly as bench.secondary_workloads runs them (4096 envs,
+  render every step) are followed by the float oracle at size, the way tests/test_gpu_round3.py follows the headline window;
+* RR_F_CONTACT_COUNT / RR_F_ENV_CLASS have stable storage: a pointer obtained once stays valid over steps (realrobot.h).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from real_robots_amd import _native as nat
+from real_robots_amd.batched import BatchedREALRobotEnv
+from real_robots_amd.distributed import synthetic_actions
+
+pytestmark = pytest.mark.gpu
+
+PLAIN = {'RR_NO_SPLIT': '1', 'RR_NO_LOOKAHEAD': '1'}
+
+
+def _make(monkeypatch, env_vars, *args, **kw):
+    for k, v in env_vars.items():
+        monkeypatch.setenv(k, v)
+    try:
+        return BatchedREALRobotEnv(*args, **kw)
+    finally:
+        for k in env_vars:
+            monkeypatch.delenv(k, raising=False)
+
+
+def _snapshot(env):
+    return (env.state, env.host(nat.F_TOUCH), env.host(nat.F_CONTACT_COUNT), env.host(nat.F_RGB), env.host(nat.F_DEPTH),
+            env.host(nat.F_MASK), env.host(nat.F_JOINTS), env.host(nat.F_OBJ_POSE), env.host(nat.F_ERRFLAGS),
+            env.host(nat.F_ENV_CLASS))
+
+
+def _first_difference(a, b):
+    names = ('state', 'touch', 'contact_count', 'rgb', 'depth', 'mask', 'joints', 'obj_pose', 'errflags', 'env_class')
+    for n, x, y in zip(names, a, b):
+        if not np.array_equal(x, y, equal_nan=True):
+            bad = np.argwhere(np.asarray(x != y).reshape(len(x), -1).any(1)).ravel()
+            return '%s differs in envs %s' % (n, bad[:8].tolist())
+    return None
+
+
+# Every placement of realrobot.hip's rr_step, by the knob that forces it.  RR_FORCE_HCOUNT pins what the host-side decisions
+# read instead of the lagged counters ("heavy,very heavy"): launch shapes (coop form <= 256, list-walking render <= 768 items,
+# k_collide's h_first) and placements then differ from what the device-side lists actually hold -- which is exactly the
+# situation of a lagged counter, and must not matter.
+PLACEMENTS = [
+    ('default', {}),
+    ('look-ahead never on the very heavy stream: kinematics + collide on the heavy stream, dynamics on the very heavy one',
+     {'RR_LA_VH_MAX': '-1'}),
+    ('look-ahead at the tail of the main stream', {'RR_LA_VH_MAX': '-1', 'RR_MACRO_LA': '0'}),
+    ('look-ahead on the very heavy stream only while there is no very heavy env: the placement changes mid-run',
+     {'RR_LA_VH_MAX': '0'}),
+    ('very heavy render always at the tail of the main stream', {'RR_VH_ON_MAIN': '1'}),
+    ('very heavy render never on the main stream, long heavy list assumed', {'RR_VH_ON_MAIN': '0', 'RR_FORCE_HCOUNT': '2000,10'}),
+    ('long lists assumed: packed solves, three-kernel render of the heavy list, very heavy render on main, look-ahead on the side',
+     {'RR_FORCE_HCOUNT': '2000,300'}),
+    ('long lists assumed, look-ahead on the main stream', {'RR_FORCE_HCOUNT': '2000,300', 'RR_MACRO_LA': '0'}),
+    ('empty lists assumed: coop solves, list-walking renders, k_collide in env order', {'RR_FORCE_HCOUNT': '0,0'}),
+    ('split off (mostly heavy): one k_solve for all, look-ahead beside the render', {'RR_SPLIT_MAX_PCT': '0', 'RR_FORCE_HCOUNT': '1,0'}),
+    ('split off, look-ahead behind the render on the main stream', {'RR_SPLIT_MAX_PCT': '0', 'RR_FORCE_HCOUNT': '1,0', 'RR_UNSPLIT_LA_INLINE': '1'}),
+    ('split switches off mid-run (more than 2 % heavy envs)', {'RR_SPLIT_MAX_PCT': '2'}),
+    ('separate k_render_setup for the light envs, k_collide in env order', {'RR_NO_FUSED_SETUP': '1', 'RR_COLLIDE_ORDER': '0'}),
+    ('look-ahead without the split', {'RR_NO_SPLIT': '1'}),
+    ('split without the look-ahead', {'RR_NO_LOOKAHEAD': '1'}),
+]
+
+
+@pytest.mark.parametrize('group', [0, 1, 2])
+def test_every_schedule_placement_is_bitwise_the_inline_step(monkeypatch, group):
+    """448 envs, 250 full-range steps (heavy and very heavy envs appear: arms pressed on the table), per-env render flags,
+    resets, teleports, home-pose edits and state restores in between; states, touch, contact counts and lists with forces,
+    images, classes and error flags of every forced placement are bitwise those of the unsplit in-line step."""
+    N, T = 448, 250
+    names = [p for k, p in enumerate(PLACEMENTS) if k % 3 == group]
+    envs = [_make(monkeypatch, PLAIN, N, objects=3, width=128, height=128)]
+    envs += [_make(monkeypatch, v, N, objects=3, width=128, height=128) for _, v in names]
+    rng = np.random.default_rng(41 + group)
+    for t in range(T):
+        cmd = synthetic_actions(range(N), t, seed=3).astype(np.float32)
+        ev = rng.random()
+        mask = (rng.random(N) < 0.15).astype(np.uint8)
+        pose = np.array([rng.uniform(-0.2, 0.0), rng.uniform(-0.3, 0.3), rng.uniform(0.3, 0.6), 0, 0, 0, 1], np.float32)
+        i, o = int(rng.integers(0, N)), int(rng.integers(0, 3))
+        mode = int(rng.integers(0, 4))
+        flags = (rng.random(N) < 0.6).astype(np.uint8)
+        for e in envs:
+            if ev < 0.02:
+                e.reset(mask)
+            elif ev < 0.04:
+                e.set_object_pose(i, o, pose)
+            elif ev < 0.05:
+                e.set_object_home(i, o, pose)
+            elif ev < 0.06:
+                e.state = e.state
+            e.step(cmd, render=[False, True, True, flags][mode])
+        if t % 25 == 24 or t < 2:
+            ref = _snapshot(envs[0])
+            cref = [envs[0].contacts(k) for k in range(0, N, 31)]
+            for (name, _), e in zip(names, envs[1:]):
+                d = _first_difference(ref, _snapshot(e))
+                assert d is None, (name, t, d)
+                assert all(np.array_equal(c, e.contacts(k)) for c, k in zip(cref, range(0, N, 31))), (name, t)
+    cls = envs[0].host(nat.F_ENV_CLASS)
+    assert (cls == 1).sum() >= 3 and (cls == 2).sum() >= 1, ((cls == 1).sum(), (cls == 2).sum())     # both side streams had work
+    assert (envs[0].host(nat.F_ERRFLAGS) == 0).all()
+    for e in envs:
+        e.close()
+
+
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def _oracle_check(env, o, sel, st0, cache, st1, cmd_of, rgb, dep, t):
+    """One oracle step for each env of `sel` from the device state st0 + contact history: lists bit-identical, states within the
+    force-scaled one-step bounds, image mask exact, depth 1e-5, RGB <= 1 except <= 2 texel-boundary pixels."""
+    from tests.test_gpu_contacts_fuzz import _lists_identical, state_bounds
+    worst = 0.0
+    for i in sel:
+        i = int(i)
+        o.state = st0[i].astype(np.float64)
+        o.set_contact_cache(cache[i])
+        o.step(cmd_of(i).astype(np.float64))
+        cd, co = env.contacts(i), o.contacts()
+        assert _lists_identical(cd, co), (t, i, len(cd), len(co))
+        fmax = float(cd[:, 10].max()) if len(cd) else 0.0
+        dj = float(np.abs(st1[i][:22] - o.state[:22]).max())
+        dobj = np.abs((st1[i][22:] - o.state[22:]).reshape(3, 13))
+        bj, bo, bv = state_bounds(fmax)
+        assert dj <= bj and dobj[:, :7].max() <= bo and dobj[:, 7:].max() <= bv, (t, i, fmax, dj, dobj[:, :7].max(), dobj[:, 7:].max())
+        worst = max(worst, dj / bj, dobj[:, :7].max() / bo, dobj[:, 7:].max() / bv)
+        o.state = st1[i].astype(np.float64)
+        r, d, m = o.render()
+        diff = np.abs(r.astype(int) - rgb[i].astype(int)).max(-1)
+        assert (diff > 1).sum() <= 2 and np.abs(d - dep[i]).max() <= 1e-5, (t, i, int((diff > 1).sum()))
+        assert ((d < 1.0) == (dep[i] < 1.0)).all()
+    return worst
+
+
+def test_macro_workload_at_size_against_the_oracle(monkeypatch):
+    """BASELINE config 5's shape exactly as bench.secondary_workloads runs it: 4096 envs, macro actions drawn with seed 0 from
+    macro_space (env.py:49-52) and planned on the device, one plan row per step (env.py:388-412), render every step, steps
+    0..340 -- by then 1 500-2 000 envs are heavy and hundreds very heavy, the split switches itself off and on around 60 % and
+    the look-ahead moves between the streams.  Every 50 steps the 8 envs with the most contacts are stepped by the float oracle
+    from the device state and contact history with the plan row the device consumed; every 50 steps the whole batch is
+    compared bitwise with the unsplit in-line run."""
+    import torch
+    bench = _bench_module()
+    N, T = bench.ENVS_PER_GPU, 340
+    assert N == 4096
+    macro = np.random.default_rng(0).uniform([-0.25, -0.5], [0.05, 0.5], size=(N, 2, 2))
+    env = BatchedREALRobotEnv(N, objects=3, width=128, height=128, want_mask=False)
+    plain = _make(monkeypatch, PLAIN, N, objects=3, width=128, height=128, want_mask=False)
+    env.plan_macro(macro)
+    plain.plan_macro(macro)
+    o = Oracle(3, 128, 128, f32=True)
+    checks, heavy_seen, vheavy_seen = 0, 0, 0
+    for t in range(T):
+        chk = t % 50 == 49
+        if chk:
+            torch.cuda.synchronize()
+            st0 = env.state
+            nc = env.host(nat.F_CONTACT_COUNT)
+            sel = np.argsort(-nc, kind='stable')[:8]
+            cache = {int(i): env.contacts(int(i)) for i in sel}
+            rows = {int(i): env.get_plan(int(i))[t] for i in sel}
+        env.step_plan(render=True)
+        plain.step_plan(render=True)
+        if not chk:
+            continue
+        st1 = env.state
+        cls = env.host(nat.F_ENV_CLASS)
+        rgb, dep = env.host(nat.F_RGB), env.host(nat.F_DEPTH)
+        _oracle_check(env, o, sel, st0, cache, st1, lambda i: rows[i], rgb, dep, t)
+        checks += len(sel)
+        heavy_seen, vheavy_seen = max(heavy_seen, int((cls == 1).sum())), max(vheavy_seen, int((cls == 2).sum()))
+        assert np.array_equal(st1, plain.state, equal_nan=True), t
+        assert np.array_equal(rgb, plain.host(nat.F_RGB)) and np.array_equal(dep, plain.host(nat.F_DEPTH)), t
+        assert np.array_equal(env.host(nat.F_CONTACT_COUNT), plain.host(nat.F_CONTACT_COUNT)), t
+    assert checks == 8 * (T // 50)
+    assert heavy_seen > 500 and vheavy_seen > 64, (heavy_seen, vheavy_seen)      # the macro placements were in play
+    assert (env.host(nat.F_ERRFLAGS) == 0).all()
+    env.close()
+    plain.close()
+
+
+def test_late_window_of_the_headline_workload_against_the_oracle(monkeypatch):
+    """The headline workload (bench.make_commands, 4096 envs, render every step) in its LATE window, as bench.py's first secondary
+    entry times it: the first 2000 steps run without camera (the state does not depend on it; the images persist from frame to
+    frame, so a first rendered frame is a full frame), then steps 2000..2100 with a render every step -- ~650 heavy envs, three
+    render launches for their list, the very heavy envs' render at the tail of the main stream.  Oracle steps for the 8 envs
+    with the most contacts every 25 steps, whole batch bitwise against the unsplit in-line run at the same points."""
+    import torch
+    bench = _bench_module()
+    N, T0, T = bench.ENVS_PER_GPU, 2000, 100
+    cmds = bench.make_commands(torch, np, np.arange(N), T0 + T, 1.0, 'cuda:0')
+    env = BatchedREALRobotEnv(N, objects=3, width=128, height=128, want_mask=False)
+    plain = _make(monkeypatch, PLAIN, N, objects=3, width=128, height=128, want_mask=False)
+    for t in range(T0):
+        env.step(device_ptr=cmds[t].data_ptr(), render=False)
+        plain.step(device_ptr=cmds[t].data_ptr(), render=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(env.state, plain.state, equal_nan=True)
+    o = Oracle(3, 128, 128, f32=True)
+    checks, heavy_seen = 0, 0
+    for t in range(T0, T0 + T):
+        chk = t % 25 == 24
+        if chk:
+            torch.cuda.synchronize()
+            st0 = env.state
+            nc = env.host(nat.F_CONTACT_COUNT)
+            sel = np.argsort(-nc, kind='stable')[:8]
+            cache = {int(i): env.contacts(int(i)) for i in sel}
+        env.step(device_ptr=cmds[t].data_ptr(), render=True)
+        plain.step(device_ptr=cmds[t].data_ptr(), render=True)
+        if not chk:
+            continue
+        st1 = env.state
+        cls = env.host(nat.F_ENV_CLASS)
+        rgb, dep = env.host(nat.F_RGB), env.host(nat.F_DEPTH)
+        cmd_h = cmds[t].cpu().numpy()
+        _oracle_check(env, o, sel, st0, cache, st1, lambda i: cmd_h[i], rgb, dep, t)
+        checks += len(sel)
+        heavy_seen = max(heavy_seen, int((cls == 1).sum()))
+        assert np.array_equal(st1, plain.state, equal_nan=True), t
+        assert np.array_equal(rgb, plain.host(nat.F_RGB)) and np.array_equal(dep, plain.host(nat.F_DEPTH)), t
+    assert checks == 8 * (T // 25)
+    assert heavy_seen * 4 > 768, heavy_seen             # the long-list placement (h_long) was in play
+    assert (env.host(nat.F_ERRFLAGS) == 0).all()
+    env.close()
+    plain.close()
+
+
+def test_contact_count_and_env_class_pointers_are_stable_over_steps():
+    """realrobot.h: a pointer from rr_get_buffer stays valid until rr_destroy.  RR_F_CONTACT_COUNT and RR_F_ENV_CLASS used to
+    point into the double-buffered contact frame, which changes roles every step: a DLPack view taken once
+    must show, after every step, what rr_copy_to_host returns."""
+    import torch
+    N = 256
+    env = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    cc = torch.from_dlpack(env.device_buffer(nat.F_CONTACT_COUNT))
+    cl = torch.from_dlpack(env.device_buffer(nat.F_ENV_CLASS))
+    seen_heavy = False
+    for t in range(200):
+        env.step(synthetic_actions(range(N), t, seed=3).astype(np.float32), render=(t % 3 == 0))
+        env.sync()
+        a, b = cc.cpu().numpy().reshape(-1), env.host(nat.F_CONTACT_COUNT)
+        assert np.array_equal(a, b), t
+        c, d = cl.cpu().numpy().reshape(-1), env.host(nat.F_ENV_CLASS)
+        assert np.array_equal(c, d), t
+        assert all(len(env.contacts(i)) == b[i] for i in (0, 17, N - 1)), t
+        seen_heavy = seen_heavy or bool((d > 0).any())
+    assert seen_heavy
+    env.close()
