@@ -42,8 +42,14 @@ ENVS_PER_GPU = 4096
 N_OBJECTS = 3
 W = H = 128
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
-# VALU issue peak in wave64 instructions / s: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
-VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4
+# VALU issue peak in wave64 instructions / s.  Neither of the two textbook figures holds on this part (profiles/r04_valu_issue.txt,
+# tools/ubench/valu_issue.hip: independent chains of one instruction kind at 1..8 waves per SIMD on every SIMD of the chip):
+# one wave alone issues a VALU instruction every 6.6-8 cycles; at eight waves per SIMD single-kind streams (v_fma_f32, v_cmp,
+# v_min3, v_cvt, DPP moves) saturate at 505-553 G wave-instr/s (~4.3 cycles per instruction and SIMD at the 2.15-2.4 GHz the
+# part sustains), a sample-test-like mix (sub, mul, fma, cmp, cndmask) at 806 G (2.8 cycles) -- not the 614 G of "4 cycles at
+# 2.4 GHz" round 3 assumed, and not the 1 229 G of "2 cycles".  The run measures the mix rate itself (rr_device_microbench kind 2,
+# the same kernel) and prices the dominant kernel against it; this constant is only the fallback when that call fails.
+VALU_PEAK_WAVE_INSTR = 806e9
 RENDER_KERNELS = ('k_image_setup', 'k_raster', 'k_shade')                      # together they produce the observation image
 SIDE_STREAM_KERNELS = ('k_solve_heavy', 'render_heavy')                        # the heavy envs' share, beside the main stream
 
@@ -240,6 +246,21 @@ def secondary_workloads(torch, np, nat, BatchedREALRobotEnv, device, steps):
     timed(env, n2, lambda t: env.step(device_ptr=cmds2[t].data_ptr(), render=False), 150, 4 * steps,
           "config 2: REALRobot2020-R2J1, 1024 envs, 1 object, full-range joint commands, no render (dynamics-only)", 1, 64, 64, False)
     env.close()
+    # (3b) the reference's DEFAULT camera (robot.py:30-31: 320x240) at 4096 envs, and R1 (mask observation, robot.py:99-112) at the
+    # headline's 128x128: 7 B x 76 800 = 538 KB resp. 11 B x 16 384 = 180 KB of image per env-step (SURVEY 8d accounting)
+    for (w_, h_, mask_, label) in ((320, 240, False, "config 3 at the reference's default camera: 4096 envs, 3 objects, full-range commands, 320x240 RGB+depth "
+                                                        "every step (538 KB of image per env-step)"),
+                                   (W, H, True, "REALRobot2020-R1J3 shape: 4096 envs, 3 objects, full-range commands, 128x128 RGB+depth+MASK every step "
+                                                "(180 KB of image per env-step)")):
+        try:
+            env = BatchedREALRobotEnv(ENVS_PER_GPU, objects=3, width=w_, height=h_, device=device, want_mask=mask_)
+            cmds = make_commands(torch, np, ids, 150 + steps + 10, 1.0, dev)
+            timed(env, ENVS_PER_GPU, lambda t: env.step(device_ptr=cmds[t].data_ptr(), render=True), 150, steps, label, 3, w_, h_, True)
+            out[-1]["image_algorithmic_GBs"] = round((w_ * h_ * (11 if mask_ else 7)) * ENVS_PER_GPU / (out[-1]["ms_per_step"] * 1e-3) / 1e9, 1)
+            env.close()
+            del cmds
+        except Exception as ex:            # the headline must not depend on it
+            out.append({"workload": label, "error": repr(ex)})
     # (4) BASELINE config 5 at size: batched evaluate() -- 4096 envs, macro actions, intrinsic phase + extrinsic trials with
     # goals of a seeded synthetic dataset, a device-side batched policy, scores computed on the device
     try:
@@ -270,6 +291,25 @@ def secondary_workloads(torch, np, nat, BatchedREALRobotEnv, device, steps):
                 "note": "single-env drop-in latency, host-bound (ctypes + D2H per step); the CPU oracle's single-core rate on the "
                         "same shape is cpu_baseline.config1_single_core"})
     return out
+
+
+def check_plan(rows, world, total, distinct_devices=True):
+    """rows[r] = [1, device ordinal, first env id, end env id, rank] as gathered from rank r.  Returns None when the plan holds,
+    else the reason: wrong rank count, a rank out of place, two ranks on one device, env-id blocks that do not tile [0, total)."""
+    if len(rows) != world or sum(r[0] for r in rows) != world:
+        return "the collective saw %d ranks, the launch promised %d" % (sum(r[0] for r in rows), world)
+    if [r[4] for r in rows] != list(range(world)):
+        return "ranks out of order in the gather: %s" % [r[4] for r in rows]
+    if distinct_devices and len({r[1] for r in rows}) != world:
+        return "two ranks share a device ordinal: %s" % [r[1] for r in rows]
+    pos = 0
+    for r in rows:
+        if r[2] != pos or r[3] < r[2]:
+            return "env-id blocks do not tile [0, %d): rank %d holds [%d, %d), expected to start at %d" % (total, r[4], r[2], r[3], pos)
+        pos = r[3]
+    if pos != total:
+        return "env-id blocks end at %d, not at %d" % (pos, total)
+    return None
 
 
 class _StubEnv:
@@ -384,6 +424,22 @@ def main():
         total = n_local * world
         start, stop = shard_range(total, rank, world)
     ids = np.arange(start, stop)
+    # N > 1: the collective backend itself has to confirm the plan -- every rank contributes {1, its device ordinal, its env-id
+    # range} to one all-gather (RCCL on GPUs): the number of ranks seen, distinct devices, and env-id blocks that tile
+    # [0, total) without gap or overlap.  Anything else ends the run with a one-line reason and a non-zero exit code.
+    ranks_seen, plan_rows = 1, None
+    if world > 1:
+        mine = torch.tensor([1, local_rank, start, stop, rank], dtype=torch.int64, device=dev)
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        plan_rows = [[int(x) for x in r.cpu().tolist()] for r in rows]
+        ranks_seen = sum(r[0] for r in plan_rows)
+        why = check_plan(plan_rows, world, total, distinct_devices=not stub)
+        if why:
+            if rank == 0:
+                print("bench.py: multi-GPU plan violated: " + why, file=sys.stderr)
+            dist.destroy_process_group()
+            raise SystemExit(3)
     n_obj = args.objects
     # An explicit stream for the library AND for torch's work of this process (the observation gather): the collectives are
     # ordered after the step that produced their buffers because both sit on this one stream, not because both happen to use
@@ -458,7 +514,8 @@ def main():
                               "vs_baseline": None, "dtype": "f32", "data": "STUB ENV -- plumbing test, nothing was simulated",
                               "config": {"workload": "stub", "envs_total": total, "envs_per_gpu": n_local, "world": world,
                                          "gather": args.gather, "gathered_bytes_per_step_per_rank": gathered_bytes,
-                                         "rank_env_ids": [int(start), int(stop)], "parallelism": "env-shard x%d" % world},
+                                         "rank_env_ids": [int(start), int(stop)], "parallelism": "env-shard x%d" % world,
+                                         "ranks_seen": ranks_seen, "plan": plan_rows},
                               "timed_steps": timed_steps, "roofline": None}))
         if world > 1:
             # every rank reports its shard for the test that launched it
@@ -496,16 +553,27 @@ def main():
         traffic_src = "profiles/traffic_latest.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this configuration, not of this run" % prof.get('source', '?')
     else:
         traffic_src = "null: " + why
+    # what this box achieves, measured in this run by the library (rr_device_microbench): HBM copy / triad bandwidth and the VALU
+    # issue rate of a sample-test-like mix at the raster kernel's occupancy ("measure achievable ... in the same run")
+    ubench, ubench_err = None, None
+    try:
+        ubench = nat.device_microbench(local_rank)
+    except Exception as ex:            # the headline must not depend on it
+        ubench_err = repr(ex)
+    valu_peak = (ubench['valu_mix_G_wave_instr_s'] * 1e9) if ubench else VALU_PEAK_WAVE_INSTR
     valu = None
     sq, why_sq = load_profile('sq_latest.json', run_cfg)
     if sq is not None and dom_kernel in sq.get('valu_wave_instr_per_launch', {}):
         wi = float(sq['valu_wave_instr_per_launch'][dom_kernel])
         dur = kernels[dom_kernel]["avg_ms"] * 1e-3
         valu = {"kernel": dom_kernel, "wave_instr_per_launch": round(wi), "wave_instr_per_env_step": round(wi / n_local, 1),
-                "achieved": round(wi / dur / 1e9, 2), "peak": round(VALU_PEAK_WAVE_INSTR / 1e9, 1), "unit": "G wave64-instr/s",
-                "frac": round(wi / dur / VALU_PEAK_WAVE_INSTR, 4),
-                "source": "SQ_INSTS_VALU of profiles/sq_latest.json (%s, same configuration) / this run's HIP-event duration; "
-                          "peak = 256 CU x 4 SIMD x 2.4 GHz / 4 cycles" % sq.get('source', '?')}
+                "achieved": round(wi / dur / 1e9, 2), "peak": round(valu_peak / 1e9, 1), "unit": "G wave64-instr/s",
+                "frac": round(wi / dur / valu_peak, 4),
+                "peak_is": ("measured in this run: rr_device_microbench kind 2, a sample-test-like mix (sub, mul, fma, cmp, cndmask) at "
+                            "eight waves per SIMD on every SIMD" if ubench else "fallback constant (the in-run measurement failed: %s)" % ubench_err) +
+                           "; the sweep over instruction kinds and 1..8 waves per SIMD is profiles/r04_valu_issue.txt: single-kind "
+                           "streams saturate at 505-553 G, the mix at 806 G; neither 614 G (4 cycles at 2.4 GHz) nor 1229 G (2 cycles) holds",
+                "source": "SQ_INSTS_VALU of profiles/sq_latest.json (%s, same configuration) / this run's HIP-event duration" % sq.get('source', '?')}
     else:
         valu = {"kernel": dom_kernel, "frac": None, "note": "null: " + (why_sq or "kernel not in the profile")}
     ach = kernels[dom]["algorithmic_GBs"]
@@ -518,6 +586,11 @@ def main():
     roofline = {"bound": bound, "kernel": dom if dom != 'render_stage' else "+".join(kernels['render_stage']['members']),
                 "dominant_single_kernel": dom_kernel,
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
+                "hbm_achievable_GBs": ({"copy": ubench['hbm_copy_GBs'], "triad": ubench['hbm_triad_GBs'],
+                                        "frac_of_copy": round(ach / ubench['hbm_copy_GBs'], 6),
+                                        "note": "device copy / triad of 256 MiB arrays measured in this run (rr_device_microbench); "
+                                                "`peak` stays the 8 TB/s spec figure the contract prescribes"}
+                                       if ubench else {"error": ubench_err}),
                 "achieved_is": "ALGORITHMIC bytes per launch / HIP-event duration (full images, although a frame rewrites only "
                                "the pixels that changed) -- the contract's accounting, not a measured HBM rate; `traffic` is the measured one",
                 "traffic": traffic, "traffic_lower_bound": traffic_lo, "achieved_traffic_frac": traffic_frac,
@@ -568,7 +641,9 @@ def main():
                        "envs_total": total, "envs_per_gpu": n_local, "command_scale": args.command_scale,
                        "solver_iters": args.solver_iters, "dt": 0.005, "parallelism": "env-shard x%d" % world,
                        "gather": args.gather, "gathered_bytes_per_step_per_rank": gathered_bytes,
-                       "world": world, "rccl_version": rccl if world > 1 else None,
+                       "world": world, "ranks_seen": ranks_seen, "rccl_version": rccl if world > 1 else None,
+                       "ranks_seen_note": "sum over an RCCL all_gather of ones (with every rank's device ordinal and env-id block, checked "
+                                          "against the plan before the first step; a violation exits non-zero)" if world > 1 else None,
                        "device": torch.cuda.get_device_name(local_rank),
                        "multi_gpu_note": None if world > 1 else "N>1 is unmeasured until the driver's SCALE run exists; "
                                                                 "the step path has no collective (DESIGN.md 6)"},

@@ -192,6 +192,11 @@ int rr_step_plan_masked(rr_env *env, const uint8_t *idle_mask_host, int32_t rend
 int rr_set_timing(rr_env *env, int32_t enable);
 int rr_get_timing(rr_env *env, float *ms_out /*[RR_NUM_KERNELS]*/, int32_t *launches_out /*[RR_NUM_KERNELS]*/);
 
+/* Device micro-benchmarks for the roofline of bench.py (the achievable figure is measured in the same run, not quoted):
+ * kind 0: HBM copy bandwidth, 1: HBM triad bandwidth (GB/s; 256 MiB arrays); 2: VALU issue rate of a sample-test-like instruction
+ * mix at eight waves per SIMD (G wave64-instructions/s).  No env handle needed; fails with RR_EDEVICE without a GPU. */
+int rr_device_microbench(int32_t device, int32_t kind, double *result);
+
 const char *rr_last_error(void);
 int rr_abi_version(void);
 

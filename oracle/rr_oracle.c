@@ -1418,6 +1418,12 @@ static inline int bary(const stri_t *s, float px, float py, float *b) {
 
 int32_t *rro_debug_tri = NULL;   /* optional [H*W] buffer receiving the winning triangle id (tests/debug) */
 void rro_set_debug_tri(int32_t *p) { rro_debug_tri = p; }
+/* optional work histogram of the visibility pass (sizing of the rasteriser, scratch/raster_hist.py): for triangles of moving
+ * instances, by the number n of sample points in the clipped bounding box -- bucket 0: n = 0, 1: 1, 2: 2, 3: 3..4, 4: 5..8,
+ * 5: 9..16, 6: 17..64, 7: > 64 -- h[b] triangles, h[8 + b] sample points tested, h[16 + b] sample points covered */
+int64_t *rro_debug_hist = NULL;
+void rro_set_debug_hist(int64_t *p) { rro_debug_hist = p; }
+static int hist_bucket(int n) { return n <= 0 ? 0 : n == 1 ? 1 : n == 2 ? 2 : n <= 4 ? 3 : n <= 8 ? 4 : n <= 16 ? 5 : n <= 64 ? 6 : 7; }
 void rro_render(rr_oracle *o, uint8_t *rgb, float *depth, int32_t *mask) {
     const model_t *m = &o->m;
     int W = o->W, H = o->H;
@@ -1459,10 +1465,17 @@ void rro_render(rr_oracle *o, uint8_t *rgb, float *depth, int32_t *mask) {
             if (xmax < 0 || ymax < 0 || xmin > (float)(W - 1) || ymin > (float)(H - 1)) continue;
             int x0 = (int)ceilf(fmaxf(xmin, 0.0f)), x1 = (int)floorf(fminf(xmax, (float)(W - 1)));
             int y0 = (int)ceilf(fmaxf(ymin, 0.0f)), y1 = (int)floorf(fminf(ymax, (float)(H - 1)));
+            int hb = -1;
+            if (rro_debug_hist && inst >= 3) {
+                int n = (x1 >= x0 && y1 >= y0) ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
+                hb = hist_bucket(n);
+                rro_debug_hist[hb]++; rro_debug_hist[8 + hb] += n;
+            }
             for (int py = y0; py <= y1; py++)
                 for (int px = x0; px <= x1; px++) {
                     float b[3];
                     if (!bary(&s, (float)px, (float)py, b)) continue;
+                    if (hb >= 0) rro_debug_hist[16 + hb]++;
                     float z = fmaf(b[0], s.sz[0], fmaf(b[1], s.sz[1], b[2] * s.sz[2]));
                     float d = fmaf(0.5f, z, 0.5f);
                     if (!(d >= 0.0f && d <= 1.0f)) continue;

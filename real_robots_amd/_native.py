@@ -29,7 +29,7 @@ SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_objec
            'rr_get_buffer', 'rr_copy_to_host', 'rr_set_state', 'rr_sync', 'rr_link_poses', 'rr_get_contacts',
            'rr_set_timing', 'rr_get_timing', 'rr_last_error', 'rr_abi_version', 'rr_ik', 'rr_plan_macro', 'rr_get_plan',
            'rr_step_plan', 'rr_set_camera', 'rr_set_object_poses', 'rr_step_plan_masked', 'rr_checkpoint_bytes',
-           'rr_checkpoint_save', 'rr_checkpoint_restore', 'rr_evaluate_goals')
+           'rr_checkpoint_save', 'rr_checkpoint_restore', 'rr_evaluate_goals', 'rr_device_microbench')
 
 
 class Config(C.Structure):
@@ -98,6 +98,7 @@ def load_library():
     L.rr_set_object_poses.argtypes = [vp, vp, vp]
     L.rr_step_plan_masked.argtypes = [vp, vp, i32, vp]
     L.rr_evaluate_goals.argtypes = [vp, vp, vp, vp]
+    L.rr_device_microbench.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     L.rr_checkpoint_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.rr_checkpoint_save.argtypes = [vp, vp, C.c_size_t]
     L.rr_checkpoint_restore.argtypes = [vp, vp, C.c_size_t]
@@ -203,3 +204,15 @@ def _dlpack(self, stream=None, **kwargs):
 
 DeviceBuffer.__dlpack__ = _dlpack
 DeviceBuffer.__dlpack_device__ = lambda self: (KDL_ROCM, getattr(self._owner, 'device', 0))
+
+
+def device_microbench(device=0):
+    """HBM copy / triad bandwidth (GB/s) and the VALU issue rate of a sample-test-like mix at eight waves per SIMD
+    (G wave64-instructions/s), measured on `device` by the library (rr_device_microbench)."""
+    L = load_library()
+    out = {}
+    for kind, name in ((0, 'hbm_copy_GBs'), (1, 'hbm_triad_GBs'), (2, 'valu_mix_G_wave_instr_s')):
+        r = C.c_double()
+        check(L.rr_device_microbench(int(device), kind, C.byref(r)))
+        out[name] = round(r.value, 1)
+    return out

@@ -3226,20 +3226,25 @@ __device__ __forceinline__ bool block_may_overlap(const STri &s, float ia, int p
 // {R[9], colour[3], tex_off, tex_w (0: untextured), tex_h, uid}, which keeps the chain of dependent global loads of a
 // shaded pixel at two (triangle record, texel).
 struct ShadeCtx { const DevPtrs *D; const float *mvp; const float *sinst; int W, H; };
-__device__ __forceinline__ void shade_pixel(const ShadeCtx &c, int t, int px, int row, unsigned char *rgb3, int &mask) {
+// one 128-byte record per triangle: 7 x 16-byte loads from a single cache line instead of 26 scattered dwords
+// (every lane shades a different triangle, so the cost of a load is its number of distinct lines)
+struct TriRec { float4 v[7]; };
+__device__ __forceinline__ TriRec load_tri_rec(const DevPtrs &D, int t) {
+    TriRec r;
+    const float4 *rp = D.tri_rec + (size_t)8 * t;
+#pragma unroll
+    for (int k = 0; k < 7; k++) r.v[k] = rp[k];
+    return r;
+}
+__device__ __forceinline__ void shade_pixel(const ShadeCtx &c, const TriRec &tr, int px, int row, unsigned char *rgb3, int &mask) {
     const DevPtrs &D = *c.D;
     const int W = c.W, H = c.H;
     const float Lx = -50.0f, Ly = 30.0f, Lz = 100.0f;
     const float linv = 1.0f / sqrtf(Lx * Lx + Ly * Ly + Lz * Lz);
     const float L0 = Lx * linv, L1 = Ly * linv, L2 = Lz * linv;
-    // one 128-byte record per triangle: 7 x 16-byte loads from a single cache line instead of 26 scattered dwords
-    // (every lane shades a different triangle, so the cost of a load is its number of distinct lines)
     float rec[28];
-    {
-        const float4 *rp = D.tri_rec + (size_t)8 * t;
 #pragma unroll
-        for (int k = 0; k < 7; k++) { const float4 v = rp[k]; rec[4 * k] = v.x; rec[4 * k + 1] = v.y; rec[4 * k + 2] = v.z; rec[4 * k + 3] = v.w; }
-    }
+    for (int k = 0; k < 7; k++) { rec[4 * k] = tr.v[k].x; rec[4 * k + 1] = tr.v[k].y; rec[4 * k + 2] = tr.v[k].z; rec[4 * k + 3] = tr.v[k].w; }
     const float *tp = rec, *nn = rec + 9, *uv = rec + 18;
     const int inst = __float_as_int(rec[24]);
     STri s;
@@ -3435,6 +3440,24 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
                 s.sx[k] = lane_gather(psx, src); s.sy[k] = lane_gather(psy, src); s.sz[k] = lane_gather(psz, src);
                 s.w[k] = 1.0f;
             }
+#if defined(RR_PROBE_BPERM) || defined(RR_PROBE_VALU) || defined(RR_PROBE_DSMIN)
+            // (sensitivity probes, development variants only: extra LDS permutes / VALU work / LDS atomics per window -- which pipe
+            // does the kernel's duration follow?  scratch/variants)
+            {
+                float pv0 = psx, pv1 = psy, pv2 = psz, pv3 = psx + psy;
+#ifdef RR_PROBE_BPERM
+                for (int i_ = 0; i_ < RR_PROBE_BPERM / 4; i_++) { pv0 = lane_gather(pv0, (lane + 1) & 63); pv1 = lane_gather(pv1, (lane + 3) & 63); pv2 = lane_gather(pv2, (lane + 5) & 63); pv3 = lane_gather(pv3, (lane + 7) & 63); }
+#endif
+#ifdef RR_PROBE_VALU
+#pragma unroll
+                for (int i_ = 0; i_ < RR_PROBE_VALU / 4; i_++) { pv0 = __builtin_fmaf(pv0, 1.0001f, 0.5f); pv1 = __builtin_fmaf(pv1, 1.0001f, 0.5f); pv2 = __builtin_fmaf(pv2, 1.0001f, 0.5f); pv3 = __builtin_fmaf(pv3, 1.0001f, 0.5f); }
+#endif
+#ifdef RR_PROBE_DSMIN
+                for (int i_ = 0; i_ < RR_PROBE_DSMIN; i_++) atomicMin(&vis[(lane * 61 + i_ * 7) & (TILE_PIX - 1)], ~0ull);      // (never changes a key)
+#endif
+                if (pv0 + pv1 + pv2 + pv3 == 12345.678f) s.sz[0] = pv0;
+            }
+#endif
             // corners nearer than the near plane (sx = NaN): none -> the ordinary paths below; all -> nothing to draw;
             // one or two -> the triangle is clipped against the plane by the whole wave (rare, see the end of the loop body)
             const int nnear = (s.sx[0] != s.sx[0] ? 1 : 0) + (s.sx[1] != s.sx[1] ? 1 : 0) + (s.sx[2] != s.sx[2] ? 1 : 0);
@@ -3818,26 +3841,53 @@ __global__ void k_background(const RenderModel *RMp, DevPtrs D) {
 #define SHADE_SPLIT 2       // with four tiles per env a list holds ~300 entries: 256 x 8 0.113 ms, x 4 0.101, x 2 0.098, 512 x 1 0.106, 128 x 3 0.100
 #endif
 // chunk z of nz of the fragment list of (env, tile); mvp / sinst: the workgroup's staging arrays
-template <int NTHREADS>
+template <int NTHREADS, bool PREFETCH = true>
 __device__ __forceinline__ void shade_block(const RenderModel &RM, const DevPtrs &D, const ImageOut &out, int env, int tile, int z, int nz,
                                             float (*mvp)[16], float (*sinst)[16]) {
+    // The kernel is a chain of dependent global round trips at full occupancy (VALU active 3 % of a wave's cycles, waiting 79 %,
+    // profiles/r03_g): count -> instance constants -> barrier -> list entry -> triangle record -> texel -> stores were five in a
+    // row.  Here the first list entry is requested together with the count (its address never depends on the count: the list's
+    // allocation holds TILE_PIX entries), the instance constants and the first triangle record together right behind it -- three
+    // round trips: {count, entry} -> {instance constants, record, static key} -> texel.
+    static_assert(MAXINST * 8 <= NTHREADS, "the instance constants are staged by one 16-byte load per thread");
+    const uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
+    const unsigned i0 = (unsigned)z * NTHREADS + threadIdx.x;
     const unsigned n = D.frag_count[(size_t)env * RM.ntiles + tile];
+    const uint2 f0 = lst[i0 < TILE_PIX ? i0 : 0u];
     if ((unsigned)z * NTHREADS >= n) return;                    // (workgroup-uniform)
-    stage_instances(RM, D, env, threadIdx.x, NTHREADS, mvp, sinst);
+    const float4 *isrc = (const float4 *)(D.inst_xf + (size_t)env * MAXINST * 32);
+    const int si = (int)threadIdx.x < RM.ni * 8 ? (int)threadIdx.x : 0;
+    const float4 stg = isrc[si];
+    const int row0 = tile * RM.tile_h;
+    const unsigned long long *sv = D.static_vis ? D.static_vis + (size_t)row0 * RM.W : nullptr;   // null while the static layer itself is built
+    const bool v0 = i0 < n;
+    const int t0 = (v0 && (f0.y & 0x3ffffu) != FRAG_VACATED) ? (int)(f0.y & 0x3ffffu) : 0;          // (always a valid record address)
+    // (PREFETCH false -- the list-walking render kernel, whose body also holds the visibility pass: the record is fetched behind
+    // the barrier, where its 28 registers do not overlap the staging)
+    TriRec rec;
+    unsigned long long svk = 0ull;
+    if (PREFETCH) { rec = load_tri_rec(D, t0); svk = sv ? sv[v0 ? (f0.y >> 18) : 0u] : 0ull; }
+    if ((int)threadIdx.x < RM.ni * 8) {
+        const int inst = threadIdx.x >> 3, q = threadIdx.x & 7;
+        if (q < 4) *(float4 *)&mvp[inst][4 * q] = stg; else *(float4 *)&sinst[inst][4 * (q - 4)] = stg;
+    }
     __syncthreads();
     ShadeCtx ctx;
     ctx.D = &D; ctx.mvp = &mvp[0][0]; ctx.sinst = &sinst[0][0]; ctx.W = RM.W; ctx.H = RM.H;
-    const uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
-    const int row0 = tile * RM.tile_h;
     const size_t base = (size_t)env * out.env_stride + (size_t)row0 * RM.W;
-    const unsigned long long *sv = D.static_vis ? D.static_vis + (size_t)row0 * RM.W : nullptr;   // null while the static layer itself is built
-    for (unsigned i = z * NTHREADS + threadIdx.x; i < n; i += nz * NTHREADS) {
-        const uint2 f = lst[i];
+    uint2 f = f0;
+    for (unsigned i = i0; i < n; i += nz * NTHREADS) {
+        if (!PREFETCH || i != i0) {                             // (PREFETCH: lists longer than one trip of the launch, rare)
+            f = lst[i];
+            const int t_ = (f.y & 0x3ffffu) != FRAG_VACATED ? (int)(f.y & 0x3ffffu) : 0;
+            rec = load_tri_rec(D, t_);
+            svk = sv ? sv[f.y >> 18] : 0ull;
+        }
         const int pi = (int)(f.y >> 18), t = (int)(f.y & 0x3ffffu);
         // a moving triangle only shows where it beats the static layer (depth, then triangle id; static ids are lower);
         // where it does not, and where the previous frame's fragment has gone, the pixel goes back to the static layer
         // (the image persists in HBM from frame to frame, do_render)
-        if (t == (int)FRAG_VACATED || (sv && !((((unsigned long long)f.x << 32) | (unsigned)t) < sv[pi]))) {
+        if (t == (int)FRAG_VACATED || (sv && !((((unsigned long long)f.x << 32) | (unsigned)t) < svk))) {
             // (vacated entries only exist in env frames; with RR_NO_STATIC_LAYER the static buffers hold the background)
             const size_t so = (size_t)row0 * RM.W + (size_t)pi, o = base + (size_t)pi;
             out.rgb[o * 3] = D.static_rgb[so * 3]; out.rgb[o * 3 + 1] = D.static_rgb[so * 3 + 1]; out.rgb[o * 3 + 2] = D.static_rgb[so * 3 + 2];
@@ -3847,7 +3897,7 @@ __device__ __forceinline__ void shade_block(const RenderModel &RM, const DevPtrs
         }
         const int lrow = pi / RM.W, px = pi - lrow * RM.W;
         unsigned char c3[3]; int m;
-        shade_pixel(ctx, t, px, row0 + lrow, c3, m);
+        shade_pixel(ctx, rec, px, row0 + lrow, c3, m);
         const size_t o = base + (size_t)pi;
         out.rgb[o * 3] = c3[0]; out.rgb[o * 3 + 1] = c3[1]; out.rgb[o * 3 + 2] = c3[2];
         out.depth[o] = __uint_as_float(f.x);
@@ -3894,7 +3944,7 @@ __device__ __forceinline__ void render_list_body(const BodyParams &B, const SimP
             raster_tile<NT_>(P, RM, D, n_inst_used, 0, env, tile, restore);
             __threadfence_block();      // the fragment list and its count, written by this workgroup, are read back below
             __syncthreads();
-            shade_block<NT_>(RM, D, out, env, tile, 0, 1, smvp, sinst);
+            shade_block<NT_, false>(RM, D, out, env, tile, 0, 1, smvp, sinst);
         }
         __syncthreads();        // the LDS of the tile and the staging arrays are reused
     }
@@ -4949,6 +4999,81 @@ int rr_checkpoint_restore(rr_env *e, const void *src_host, size_t bytes) {
     HIPCHK(hipMemsetAsync(e->D.hcount, 0, 16, e->stream)); HIPCHK(hipMemsetAsync(e->D.hcount2, 0, 16, e->stream));
     hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
     HIPCHK(hipStreamSynchronize(e->stream));   // the source is host memory
+    return RR_OK;
+}
+
+
+// ---- device micro-benchmarks for bench.py's roofline ("achievable" measured in the same run) -------------------
+// kind 0: HBM copy (read + write), 1: HBM triad a = b + s c (2 reads + 1 write), 256 MiB per array, float4 per lane, grid-stride;
+// kind 2: VALU issue rate of a sample-test-like mix (sub, mul, fma, cmp, cndmask with real dependencies) at the raster kernel's
+// shape -- 512-thread workgroups, 39 KB of LDS each, four per CU = eight waves per SIMD (tools/ubench/valu_issue.hip sweeps
+// waves per SIMD and instruction kinds; profiles/r04_valu_issue.txt).  Result: GB/s (0, 1) or G wave64-instructions/s (2).
+__global__ void __launch_bounds__(256) k_ub_copy(const float4 *__restrict__ a, float4 *__restrict__ b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
+}
+__global__ void __launch_bounds__(256) k_ub_triad(float4 *__restrict__ a, const float4 *__restrict__ b, const float4 *__restrict__ c, float s, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float4 x = b[i], y = c[i];
+        a[i] = make_float4(fmaf(s, y.x, x.x), fmaf(s, y.y, x.y), fmaf(s, y.z, x.z), fmaf(s, y.w, x.w));
+    }
+}
+#define UB_S8(x) x x x x x x x x
+__global__ void __launch_bounds__(512) k_ub_valu(float *out, int iters, float a, float b) {
+    extern __shared__ float ub_lds[];
+    float x0 = threadIdx.x * a, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    for (int it = 0; it < iters; it++) {
+        asm volatile(UB_S8("v_sub_f32 %0, %1, %8\n v_mul_f32 %2, %0, %9\n v_fma_f32 %3, %2, %8, %0\n v_cmp_lt_f32 vcc, %3, %9\n"
+                           "v_cndmask_b32 %4, %5, %6, vcc\n v_sub_f32 %5, %7, %9\n v_fma_f32 %6, %4, %8, %5\n v_mul_f32 %7, %6, %8\n")
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc");
+    }
+    const float r = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+    if (r == 12345.678f) ub_lds[threadIdx.x] = r;
+    out[(size_t)blockIdx.x * 512 + threadIdx.x] = r;
+}
+int rr_device_microbench(int32_t device, int32_t kind, double *result) {
+    if (!result || kind < 0 || kind > 2) return fail(RR_EINVAL, "rr_device_microbench: bad argument");
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return fail(RR_EDEVICE, "rr_device_microbench: no such HIP device (no CPU fallback)"); }
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    const int ncu = prop.multiProcessorCount;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    float best_ms = 1e30f;
+    double units = 0.0;
+    if (kind <= 1) {
+        const size_t bytes = (size_t)256 << 20, n4 = bytes / 16;
+        float4 *buf[3] = {nullptr, nullptr, nullptr};
+        for (int i = 0; i < (kind == 0 ? 2 : 3); i++) { HIPCHK(hipMalloc((void **)&buf[i], bytes)); HIPCHK(hipMemset(buf[i], 0, bytes)); }
+        for (int rep = 0; rep < 6; rep++) {
+            hipEventRecord(e0, 0);
+            if (kind == 0) hipLaunchKernelGGL(k_ub_copy, dim3(ncu * 16), dim3(256), 0, 0, buf[0], buf[1], n4);
+            else hipLaunchKernelGGL(k_ub_triad, dim3(ncu * 16), dim3(256), 0, 0, buf[0], buf[1], buf[2], 0.5f, n4);
+            hipEventRecord(e1, 0);
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0) best_ms = std::min(best_ms, ms);
+        }
+        for (int i = 0; i < 3; i++) if (buf[i]) hipFree(buf[i]);
+        units = (double)bytes * (kind == 0 ? 2 : 3) / 1e9;                 // GB moved per launch
+    } else {
+        const int iters = 800, blocks = 4 * ncu;
+        float *out = nullptr;
+        HIPCHK(hipMalloc((void **)&out, (size_t)blocks * 512 * 4));
+        HIPCHK(hipFuncSetAttribute((const void *)k_ub_valu, hipFuncAttributeMaxDynamicSharedMemorySize, 39 * 1024));
+        for (int rep = 0; rep < 4; rep++) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k_ub_valu, dim3(blocks), dim3(512), 39 * 1024, 0, out, iters, 1.0001f, 0.5f);
+            hipEventRecord(e1, 0);
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0) best_ms = std::min(best_ms, ms);
+        }
+        hipFree(out);
+        units = (double)iters * 64 * blocks * 8 / 1e9;                     // G wave-instructions per launch
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    HIPCHK(hipGetLastError());
+    *result = units / (best_ms * 1e-3);
     return RR_OK;
 }
 

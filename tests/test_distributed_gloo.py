@@ -75,3 +75,45 @@ def test_bench_plumbing_two_ranks_stub_env(scaling):
     ranks = sorted(ln for ln in r.stderr.splitlines() if ln.startswith('RANK '))
     half = total // 2
     assert ranks == ["RANK 0 ids 0 %d steps 10" % half, "RANK 1 ids %d %d steps 10" % (half, total)], ranks
+
+
+def test_bench_plumbing_four_ranks_gather_images_and_plan_check():
+    """Four ranks on CPU (gloo), `--gather images`: every rank's env-id block, the image slabs' byte count, `ranks_seen` from the
+    collective itself (an all_gather of ones with every rank's device ordinal and env-id block) and the plan the ranks reported."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 27000 + (os.getpid() * 13) % 4000
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '4', '--steps', '4', '--warmup', '1',
+           '--presettle', '2', '--envs-per-gpu', '6', '--image', '16x8', '--gather', 'images', '--stub-env']
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 4 and cfg["world"] == 4 and cfg["ranks_seen"] == 4 and cfg["envs_total"] == 24
+    assert [row[2:4] for row in cfg["plan"]] == [[0, 6], [6, 12], [12, 18], [18, 24]] and [row[4] for row in cfg["plan"]] == [0, 1, 2, 3]
+    assert cfg["gathered_bytes_per_step_per_rank"] == 24 * (9 + 4 + 21) * 4 + 24 * 16 * 8 * (3 + 4)
+    ranks = sorted(ln for ln in r.stderr.splitlines() if ln.startswith('RANK '))
+    assert ranks == ["RANK %d ids %d %d steps 7" % (k, 6 * k, 6 * k + 6) for k in range(4)], ranks
+
+
+def test_plan_check_names_every_violation():
+    """bench.check_plan: what makes `bench.py --gpus N` exit non-zero before the first step."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    good = [[1, 0, 0, 8, 0], [1, 1, 8, 16, 1]]
+    assert bench.check_plan(good, 2, 16) is None
+    assert 'saw 1 ranks' in bench.check_plan(good[:1], 2, 16)
+    assert 'share a device' in bench.check_plan([[1, 0, 0, 8, 0], [1, 0, 8, 16, 1]], 2, 16)
+    assert bench.check_plan([[1, 0, 0, 8, 0], [1, 0, 8, 16, 1]], 2, 16, distinct_devices=False) is None
+    assert 'do not tile' in bench.check_plan([[1, 0, 0, 8, 0], [1, 1, 9, 16, 1]], 2, 16)
+    assert 'end at 15' in bench.check_plan([[1, 0, 0, 8, 0], [1, 1, 8, 15, 1]], 2, 16)
+    assert 'out of order' in bench.check_plan([[1, 1, 8, 16, 1], [1, 0, 0, 8, 0]], 2, 16)
