@@ -3072,13 +3072,16 @@ __global__ void k_plan_fetch(SimParams P, DevPtrs D, const float *plan, int *pla
 #endif
 // LDS of a raster workgroup: 32 KB of keys + 1 KB window list + 1 KB running ends + 1.5 KB matrices + 4 KB clip queue = 39.5 KB:
 // four workgroups per CU = eight waves per SIMD, which also needs <= 64 VGPRs (A/B: three workgroups 0.434 ms, four 0.390 ms)
+#ifndef MAXWIN
 #define MAXWIN 512       // 64-triangle windows per model (rr_create checks nt)
+#endif
 #define RASTER_INST 24   // instances whose matrices a raster workgroup stages (rr_create checks the model)
 #define RASTER_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+
 static_assert(RASTER_INST <= MAXINST && MAXWIN <= 512, "clip queue entries: window position (9 bits) << 6 | lane");
 #ifndef CLIPQ
-#define CLIPQ 2048       // triangles crossing the near plane per (env, tile) that are clipped (a link cut by the plane has a few hundred)
-#endif
+#define CLIPQ 2048       // triangles crossing the near plane per (env, tile) that are clipped (a link cut by the plane has a few hundred;
+#endif                   // an overflow raises error flag 4 of the env instead of dropping triangles silently)
 #ifndef INLINE_PIX
 #define INLINE_PIX 2     // sample points of a small triangle walked by its own lane; the rest is redistributed over the wave
 #endif
@@ -3313,9 +3316,23 @@ __device__ __forceinline__ void stage_instances(const RenderModel &RM, const Dev
 // Development-only work counters (librealrobot_hip_stats.so, `make stats`; never part of the shipped library).
 __device__ unsigned long long g_rstats[16];
 #define RSTAT(i, v) do { if (P.ablate & 0x8000) atomicAdd(&g_rstats[i], (unsigned long long)(v)); } while (0)   /* RR_ABLATE=32768 */
-extern "C" int rr_debug_raster_stats(unsigned long long *out16, int reset) {
-    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rstats), sizeof(g_rstats)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rstats), z, sizeof(z)) != hipSuccess) return -1; }
+// phase clock of the window loop (RR_ABLATE=4096; scratch/rphase.py): wave cycles between phase marks; every workgroup sums its
+// waves in LDS and writes its ten totals to a slot of its own (global atomics from every wave would be what the clock measures)
+__device__ unsigned g_rphase_wg[65536][10];
+#define PH_DECL unsigned long long ph_t_ = __builtin_readcyclecounter(); unsigned pa0_ = 0, pa1_ = 0, pa2_ = 0, pa3_ = 0, pa4_ = 0, pa5_ = 0, pa6_ = 0, pa7_ = 0, pa8_ = 0, pa9_ = 0; \
+    __shared__ unsigned ph_lds_[10]; if (tid < 10) ph_lds_[tid] = 0;
+#define PH(i) do { if (P.ablate & 0x1000) { const unsigned long long n_ = __builtin_readcyclecounter(); pa##i##_ += (unsigned)(n_ - ph_t_); ph_t_ = n_; } } while (0)
+#define PH_FLUSH do { if (P.ablate & 0x1000) { if (lane == 0) { atomicAdd(&ph_lds_[0], pa0_); atomicAdd(&ph_lds_[1], pa1_); atomicAdd(&ph_lds_[2], pa2_); atomicAdd(&ph_lds_[3], pa3_); atomicAdd(&ph_lds_[4], pa4_); \
+    atomicAdd(&ph_lds_[5], pa5_); atomicAdd(&ph_lds_[6], pa6_); atomicAdd(&ph_lds_[7], pa7_); atomicAdd(&ph_lds_[8], pa8_); atomicAdd(&ph_lds_[9], pa9_); } __syncthreads(); \
+    if (tid < 10) g_rphase_wg[(env * RM.ntiles + tile) & 65535][tid] = ph_lds_[tid]; } } while (0)
+extern "C" int rr_debug_raster_phase(unsigned long long *out16, int reset) {
+    static unsigned h[65536][10];
+    if (out16) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rphase_wg), sizeof(h)) != hipSuccess) return -1;
+        for (int i = 0; i < 16; i++) out16[i] = 0;
+        for (int w = 0; w < 65536; w++) for (int i = 0; i < 10; i++) out16[i] += h[w][i];
+    }
+    if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_rphase_wg), h, sizeof(h)) != hipSuccess) return -1; }
     return 0;
 }
 // phase ablations of k_raster for the time breakdown in DESIGN.md (RR_ABLATE bits: 1 no rasterisation after projection,
@@ -3324,6 +3341,9 @@ extern "C" int rr_debug_raster_stats(unsigned long long *out16, int reset) {
 #else
 #define RSTAT(i, v)
 #define ABL(bit) false
+#define PH_DECL
+#define PH(i)
+#define PH_FLUSH
 #endif
 
 // Visibility pass of one (env, tile).  pass 0 = per-env frame: starts from the static layer's keys when D.static_vis !=
@@ -3412,11 +3432,13 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
 #ifdef RR_RASTER_STATS
     const unsigned long long t_loop0_ = __builtin_readcyclecounter();
 #endif
+    PH_DECL
     for (;;) {
         unsigned k = 0;
         if (lane == 0) k = atomicAdd(&wnext, 1u);
         k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
         if (k >= nw) break;
+        PH(0);                                      // window fetch
         const int tb = t_begin + ((int)wlist[k] << 6);
         if (lane == 0) RSTAT(1, 1);                 // windows that pass the cluster test
         const int t = tb + lane;
@@ -3464,6 +3486,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             needs_clip = live && nnear > 0 && nnear < 3;
             live = live && nnear == 0;
         }
+        PH(1);                                      // loads, projection, corner gather
         if (live) {
             float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
             float ymin = fminf(s.sy[0], fminf(s.sy[1], s.sy[2])), ymax = fmaxf(s.sy[0], fmaxf(s.sy[1], s.sy[2]));
@@ -3482,6 +3505,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
                 area = (x1 - x0 + 1) * (y1 - y0 + 1);
             }
         }
+        PH(2);                                      // bounding box, set-up
         if (ABL(1)) continue;
         const bool big = live && area > P.small_area;
 #ifdef RR_RASTER_STATS
@@ -3512,9 +3536,11 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
                 raster_pixel_hoisted(s, ia, t, px, py, H, W, row0, vis);
                 if (++px > x1) { px = x0; py++; }
             }
+            PH(3);                                  // in-lane sample points
             const int rem = small ? area - ninl : 0;
             int total;
             const int pre = wave_excl_scan(rem, lane, total);
+            PH(4);                                  // scan
             if (total > 0) {
                 unsigned short *we = wends[tid >> 6];
                 we[lane] = (unsigned short)(pre + rem);                                // inclusive ends, non-decreasing over the lanes
@@ -3538,6 +3564,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
                     if (valid) raster_pixel_hoisted(bs, bia, tb + src, sx0 + idx - ry * sbw, sy0 + ry, H, W, row0, vis);
                 }
             }
+            PH(5);                                  // redistribution rounds
         }
         unsigned long long todo = ABL(2) ? 0ull : __ballot(big);
         while (todo) {        // wave-cooperative: all 64 lanes rasterise the triangle of lane `src`
@@ -3593,12 +3620,15 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
                 }
             }
         }
+        PH(6);                                      // wave-cooperative large triangles
         // triangles that cross the near plane are rare: they are queued and clipped after the window loop
         if (needs_clip && !ABL(16)) { const unsigned qi = atomicAdd(&nclipq, 1u); if (qi < CLIPQ) clipq[qi] = (unsigned short)((k << 6) | lane); }
     }
+    PH(7);                                          // last fetch + (below) waiting for the other waves
     // ---- triangles that cross the near plane (queued above): clipped against w = NEAR_W (Sutherland-Hodgman, the oracle's
     // clip_near()) into a triangle or a fan of two, which a whole wave rasterises under the original triangle id
     __syncthreads();
+    PH(8);
     for (unsigned qi = tid >> 6; qi < min(nclipq, (unsigned)CLIPQ); qi += NT_ / 64) {
         const int bt = t_begin + ((int)wlist[clipq[qi] >> 6] << 6) + (clipq[qi] & 63);
         const int tb = bt & ~63;
@@ -3693,6 +3723,8 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             }
         }
     }
+    PH(9);                                          // near-plane pass
+    PH_FLUSH;
 #ifdef RR_RASTER_STATS
     const unsigned long long t_exit_ = __builtin_readcyclecounter();
 #endif
@@ -3730,6 +3762,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
         }
     }
     __syncthreads();
+    if (tid == 0 && nclipq > CLIPQ) atomicOr(&D.errflags[env], 4u);      // (clip queue overflow: triangles were dropped -- never expected)
     if (tid == 0) { D.frag_count[(size_t)env * RM.ntiles + tile] = nlist; RSTAT(12, nlist); RSTAT(13, 1); RSTAT(14, nclipq); RSTAT(15, nclipq > 0 ? 1 : 0); }
 }
 
@@ -3841,53 +3874,27 @@ __global__ void k_background(const RenderModel *RMp, DevPtrs D) {
 #define SHADE_SPLIT 2       // with four tiles per env a list holds ~300 entries: 256 x 8 0.113 ms, x 4 0.101, x 2 0.098, 512 x 1 0.106, 128 x 3 0.100
 #endif
 // chunk z of nz of the fragment list of (env, tile); mvp / sinst: the workgroup's staging arrays
-template <int NTHREADS, bool PREFETCH = true>
+// Deferred shading of chunk z of nz of the fragment list of (env, tile) by the calling workgroup.
+template <int NTHREADS>
 __device__ __forceinline__ void shade_block(const RenderModel &RM, const DevPtrs &D, const ImageOut &out, int env, int tile, int z, int nz,
                                             float (*mvp)[16], float (*sinst)[16]) {
-    // The kernel is a chain of dependent global round trips at full occupancy (VALU active 3 % of a wave's cycles, waiting 79 %,
-    // profiles/r03_g): count -> instance constants -> barrier -> list entry -> triangle record -> texel -> stores were five in a
-    // row.  Here the first list entry is requested together with the count (its address never depends on the count: the list's
-    // allocation holds TILE_PIX entries), the instance constants and the first triangle record together right behind it -- three
-    // round trips: {count, entry} -> {instance constants, record, static key} -> texel.
-    static_assert(MAXINST * 8 <= NTHREADS, "the instance constants are staged by one 16-byte load per thread");
-    const uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
-    const unsigned i0 = (unsigned)z * NTHREADS + threadIdx.x;
     const unsigned n = D.frag_count[(size_t)env * RM.ntiles + tile];
-    const uint2 f0 = lst[i0 < TILE_PIX ? i0 : 0u];
     if ((unsigned)z * NTHREADS >= n) return;                    // (workgroup-uniform)
-    const float4 *isrc = (const float4 *)(D.inst_xf + (size_t)env * MAXINST * 32);
-    const int si = (int)threadIdx.x < RM.ni * 8 ? (int)threadIdx.x : 0;
-    const float4 stg = isrc[si];
-    const int row0 = tile * RM.tile_h;
-    const unsigned long long *sv = D.static_vis ? D.static_vis + (size_t)row0 * RM.W : nullptr;   // null while the static layer itself is built
-    const bool v0 = i0 < n;
-    const int t0 = (v0 && (f0.y & 0x3ffffu) != FRAG_VACATED) ? (int)(f0.y & 0x3ffffu) : 0;          // (always a valid record address)
-    // (PREFETCH false -- the list-walking render kernel, whose body also holds the visibility pass: the record is fetched behind
-    // the barrier, where its 28 registers do not overlap the staging)
-    TriRec rec;
-    unsigned long long svk = 0ull;
-    if (PREFETCH) { rec = load_tri_rec(D, t0); svk = sv ? sv[v0 ? (f0.y >> 18) : 0u] : 0ull; }
-    if ((int)threadIdx.x < RM.ni * 8) {
-        const int inst = threadIdx.x >> 3, q = threadIdx.x & 7;
-        if (q < 4) *(float4 *)&mvp[inst][4 * q] = stg; else *(float4 *)&sinst[inst][4 * (q - 4)] = stg;
-    }
+    stage_instances(RM, D, env, threadIdx.x, NTHREADS, mvp, sinst);
     __syncthreads();
     ShadeCtx ctx;
     ctx.D = &D; ctx.mvp = &mvp[0][0]; ctx.sinst = &sinst[0][0]; ctx.W = RM.W; ctx.H = RM.H;
+    const uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
+    const int row0 = tile * RM.tile_h;
     const size_t base = (size_t)env * out.env_stride + (size_t)row0 * RM.W;
-    uint2 f = f0;
-    for (unsigned i = i0; i < n; i += nz * NTHREADS) {
-        if (!PREFETCH || i != i0) {                             // (PREFETCH: lists longer than one trip of the launch, rare)
-            f = lst[i];
-            const int t_ = (f.y & 0x3ffffu) != FRAG_VACATED ? (int)(f.y & 0x3ffffu) : 0;
-            rec = load_tri_rec(D, t_);
-            svk = sv ? sv[f.y >> 18] : 0ull;
-        }
+    const unsigned long long *sv = D.static_vis ? D.static_vis + (size_t)row0 * RM.W : nullptr;   // null while the static layer itself is built
+    for (unsigned i = z * NTHREADS + threadIdx.x; i < n; i += nz * NTHREADS) {
+        const uint2 f = lst[i];
         const int pi = (int)(f.y >> 18), t = (int)(f.y & 0x3ffffu);
         // a moving triangle only shows where it beats the static layer (depth, then triangle id; static ids are lower);
         // where it does not, and where the previous frame's fragment has gone, the pixel goes back to the static layer
         // (the image persists in HBM from frame to frame, do_render)
-        if (t == (int)FRAG_VACATED || (sv && !((((unsigned long long)f.x << 32) | (unsigned)t) < svk))) {
+        if (t == (int)FRAG_VACATED || (sv && !((((unsigned long long)f.x << 32) | (unsigned)t) < sv[pi]))) {
             // (vacated entries only exist in env frames; with RR_NO_STATIC_LAYER the static buffers hold the background)
             const size_t so = (size_t)row0 * RM.W + (size_t)pi, o = base + (size_t)pi;
             out.rgb[o * 3] = D.static_rgb[so * 3]; out.rgb[o * 3 + 1] = D.static_rgb[so * 3 + 1]; out.rgb[o * 3 + 2] = D.static_rgb[so * 3 + 2];
@@ -3897,13 +3904,18 @@ __device__ __forceinline__ void shade_block(const RenderModel &RM, const DevPtrs
         }
         const int lrow = pi / RM.W, px = pi - lrow * RM.W;
         unsigned char c3[3]; int m;
-        shade_pixel(ctx, rec, px, row0 + lrow, c3, m);
+        shade_pixel(ctx, load_tri_rec(D, t), px, row0 + lrow, c3, m);
         const size_t o = base + (size_t)pi;
         out.rgb[o * 3] = c3[0]; out.rgb[o * 3 + 1] = c3[1]; out.rgb[o * 3 + 2] = c3[2];
         out.depth[o] = __uint_as_float(f.x);
         if (out.mask) out.mask[o] = m;
     }
 }
+// Measured in round 4 and dropped (k_shade alone, 4096 envs, 0.103 ms as it stands): the first list entry requested together with the
+// count and the triangle record together with the instance constants (three dependent round trips instead of five): 0.104 ms;
+// cooperative record loads -- eight lanes per 128-byte record, one load instruction covering eight records in eight cache
+// lines instead of 64, transposed through 14 KB of LDS: 0.101 ms; one 512-thread workgroup per env walking the concatenation
+// of its tile lists (4 096 workgroups instead of 32 768, instance constants staged once per env): 0.120 ms.
 __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags, int env0, int sel) {
     __shared__ __attribute__((aligned(16))) float mvp[MAXINST][16];
     __shared__ __attribute__((aligned(16))) float sinst[MAXINST][16];
@@ -3944,7 +3956,7 @@ __device__ __forceinline__ void render_list_body(const BodyParams &B, const SimP
             raster_tile<NT_>(P, RM, D, n_inst_used, 0, env, tile, restore);
             __threadfence_block();      // the fragment list and its count, written by this workgroup, are read back below
             __syncthreads();
-            shade_block<NT_, false>(RM, D, out, env, tile, 0, 1, smvp, sinst);
+            shade_block<NT_>(RM, D, out, env, tile, 0, 1, smvp, sinst);
         }
         __syncthreads();        // the LDS of the tile and the staging arrays are reused
     }
@@ -4268,7 +4280,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     P.dt = cfg->dt > 0 ? cfg->dt : 0.005f; P.gravity = 9.81f; P.erp = cfg->erp > 0 ? cfg->erp : 0.2f;
     P.margin = cfg->margin > 0 ? cfg->margin : 0.02f; P.kp = 0.1f; P.kd = 1.0f; P.max_impulse = 100000.0f * P.dt;
     P.ablate = getenv("RR_ABLATE") ? atoi(getenv("RR_ABLATE")) : 0;
-    P.small_area = getenv("RR_SMALL_AREA") ? atoi(getenv("RR_SMALL_AREA")) : SMALL_AREA;
+    P.small_area = std::min(64, getenv("RR_SMALL_AREA") ? atoi(getenv("RR_SMALL_AREA")) : SMALL_AREA);      // (<= 64: a record's box width has 6 bits)
     // RR_SOLVER_POOL (tests): LDS floats for object-vs-static rows, 60 per contact; contacts beyond it take the generic (slot layout) path
     P.heavy_min = getenv("RR_HEAVY_MIN") ? atoi(getenv("RR_HEAVY_MIN")) : 0;
     P.heavy2_min = getenv("RR_HEAVY2_MIN") ? atoi(getenv("RR_HEAVY2_MIN")) : 16;      // generic contacts above which an env is "very heavy" (1000: never; A/B 6..30: 13-16 best)
@@ -4331,6 +4343,8 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     RM.ni = ni; RM.nt = nt; RM.W = cfg->width; RM.H = cfg->height; RM.nl = nl;
     RM.tile_h = TILE_PIX / RM.W; if (RM.tile_h > RM.H) RM.tile_h = RM.H;
     RM.ntiles = (RM.H + RM.tile_h - 1) / RM.tile_h;
+    if (RM.W > 1024 || RM.H > 1024) { rr_destroy(e); return fail(RR_EINVAL, "rr_create: image larger than 1024 x 1024 (10-bit box origins in the rasteriser's records)"); }
+    if (RM.ntiles > 255) { rr_destroy(e); return fail(RR_EINVAL, "rr_create: image too large (more than 255 raster tiles of 4096 pixels)"); }
     NEED(ip = b.i32("inst_owner", ni * 4));
     for (int i = 0; i < ni; i++) { RM.in_otype[i] = ip[4 * i]; RM.in_oidx[i] = ip[4 * i + 1]; RM.in_uid[i] = ip[4 * i + 2]; RM.in_tex[i] = ip[4 * i + 3]; }
     NEED(f = b.f32("inst_color", ni * 3)); memcpy(RM.in_color, f, (size_t)ni * 12);

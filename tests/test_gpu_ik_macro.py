@@ -129,16 +129,32 @@ def test_all_36_perimeter_pairs_of_the_reference_script():
             assert np.abs(env.host(nat.F_JOINTS) - q_pred).max() < 0.03
             far = np.linalg.norm(env.link_poses()[:, base, :3] - np.array([-0.419, 0.0, 1.14]), axis=1)
             assert np.median(far) < 0.01 and far.max() < 0.12       # a joint with more than 2 rad to go is still on its way
-        if t in (199, 249, 999):
+        if t in (199, 249, 749, 999):
             lp = env.link_poses()[:, base, :3]
             for i, (p1, p2) in enumerate(pairs):
-                tgt = {199: [p1[0], p1[1], 0.6], 249: [p1[0], p1[1], 0.46], 999: home}[t]
+                tgt = {199: [p1[0], p1[1], 0.6], 249: [p1[0], p1[1], 0.46], 749: [p2[0], p2[1], 0.46], 999: home}[t]
                 dist[(t, i)] = float(np.linalg.norm(lp[i] - tgt))
-    for i, (p1, p2) in enumerate(pairs):
-        assert dist[(999, i)] < 0.01, (999, pairs[i], dist[(999, i)])
-        assert dist[(249, i)] < 0.012, (249, pairs[i], dist[(249, i)])
-        bound = 0.08 if p1 in ((0.05, -0.5), (0.05, 0.5)) else (0.012 if p1 == (-0.25, 0.0) else 0.01)
-        assert dist[(199, i)] < bound, (199, pairs[i], dist[(199, i)])
+    # Pair by pair against the oracle's run of the same script under the documented motor model (tests/golden/macro_sensitivity.json,
+    # asserted on the oracle in tests/test_oracle_pins.py): the device plans with its own IK (rr_plan_macro, 1e-3 rad from the
+    # checker's plans) and steps in fp32 -- its way-point distances follow the oracle's to DEV_TOL -- and the reference script's
+    # own 0.01 m (tests/test_actions.py:147-152) holds wherever the documented model reaches it with that margin to spare:
+    # all 36 pairs at t = 999, the 35 reachable ones at t = 749, the 18 at t = 199; at t = 249 the model itself ends 9.75 mm
+    # from (p1, 0.46) for the slowest pair, so the device is held to the oracle's residual + DEV_TOL there (<= 0.0102 m).
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'macro_sensitivity.json')))
+    assert [tuple(map(tuple, p)) for p in fx['pairs']] == pairs
+    fixture = np.array(fx['distance_m']['kp=0.1,rate_limit=on'])
+    DEV_TOL = 4e-4
+    worst = {}
+    for col, t in ((0, 199), (1, 249), (2, 749), (4, 999)):
+        for i in range(N):
+            d, f = dist[(t, i)], fixture[i, col]
+            worst[t] = max(worst.get(t, 0.0), abs(d - f))
+            assert abs(d - f) < DEV_TOL, (t, pairs[i], d, f)
+            if f < 0.01 - DEV_TOL:
+                assert d < 0.01, (t, pairs[i], d)
+    print("device vs oracle way-point distances, worst difference per check point [m]:", {k: round(v, 6) for k, v in worst.items()})
+    assert sum(dist[(249, i)] < 0.01 for i in range(N)) >= 30 and max(dist[(249, i)] for i in range(N)) < 0.0102
     assert (env.host(nat.F_TIMESTEP) == 1000).all() and (env.host(nat.F_ERRFLAGS) == 0).all()
     env.close()
 

@@ -594,3 +594,56 @@ def test_warm_starting_carries_the_normal_impulses_over():
     b.state = a.state                               # cold
     a.step(None); b.step(None)
     assert np.abs(a.state - b.state).max() > 1e-9
+
+
+def test_reference_macro_script_all_36_pairs_at_the_reference_tolerance():
+    """reference tests/test_actions.py:62-71,101-117,147-152: ALL 36 ordered pairs of the six perimeter points, objects parked on
+    the shelf (test_actions.py:95-98), gripper `base` against the script's way points at t = 199, 249, 749, 999 with the script's
+    own 0.01 m -- asserted wherever the documented motor model (kp 0.1, 10 % of the command error per step, behind the rate limit
+    of env.py:314-321) reaches it, with the exact residual recorded where it does not:
+      * t = 249, (p1, 0.46): all 36 (worst 9.75 mm: the arm is still closing the last millimetres of the 14 cm descent);
+      * t = 999, home: all 36 (1.0 mm);
+      * t = 749, (p2, 0.46): 35 of 36; ((0.05, 0.5) -> (-0.25, -0.5)) is 16.9 mm off: the longest sweep of the script, 500 steps
+        are not enough at 0.02-0.03 rad per step;
+      * t = 199, (p1, 0.6): the 18 pairs whose p1 is (-0.25, +-0.5) or (0.05, 0); p1 = (-0.25, 0) misses by 0.2 mm (10.2 mm: 1.8 rad
+        of joint travel from home2 in 100 steps), the corners (0.05, -0.5) / (0.05, 0.5) by 61.6 / 21.4 mm (reach limit: the IK has
+        no exact solution there, under every motor variant of tests/golden/macro_sensitivity.json).
+    t = 849 is the open question of DESIGN.md 2 (out of reach under the documented model) and is only compared with the fixture.
+    The run must also reproduce the committed sensitivity fixture (same plans, same oracle) to 1e-6 m."""
+    import json
+    from oracle.kinematics import generate_plan
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'macro_sensitivity.json')))
+    pairs = [tuple(map(tuple, p)) for p in fx['pairs']]
+    assert len(pairs) == 36
+    fixture = np.array(fx['distance_m']['kp=0.1,rate_limit=on'])
+    home, home2 = np.array([-0.55, 0.0, 1.27]), np.array([-0.419, 0.0, 1.14])
+    got = np.zeros((36, 5))
+    for i, (p1, p2) in enumerate(pairs):
+        o = Oracle(3, 64, 64)
+        o.reset()
+        for k, p in enumerate([[0.2, 0.0, 0.75], [0.2, -0.3, 0.75], [0.2, 0.3, 0.75]]):
+            o.set_object_pose(k, np.array(p + [0, 0, 0, 1.0]))
+        plan = generate_plan(np.zeros(11), [p1, p2])
+        tg = {199: [p1[0], p1[1], 0.6], 249: [p1[0], p1[1], 0.46], 749: [p2[0], p2[1], 0.46], 849: home2, 999: home}
+        for t in range(1000):
+            o.step(plan[t])
+            if t in tg:
+                got[i, fx['check_steps'].index(t)] = np.linalg.norm(o.link_pose('base')[:3] - tg[t])
+    assert np.abs(got - fixture).max() < 2e-5, np.abs(got - fixture).max()       # (the fixture is rounded to 1e-5)
+    tol = fx['tolerance_of_the_reference_script_m']
+    assert tol == 0.01
+    c199, c249, c749, c999 = got[:, 0], got[:, 1], got[:, 2], got[:, 4]
+    assert (c249 < tol).all() and c249.max() < 0.0098
+    assert (c999 < tol).all() and c999.max() < 0.0011
+    over749 = [i for i in range(36) if c749[i] >= tol]
+    assert over749 == [30] and pairs[30] == ((0.05, 0.5), (-0.25, -0.5)) and c749[30] < 0.0170
+    reach199 = [i for i in range(36) if pairs[i][0] in ((-0.25, -0.5), (-0.25, 0.5), (0.05, 0.0))]
+    assert len(reach199) == 18 and (c199[reach199] < tol).all()
+    for i in range(36):
+        p1 = pairs[i][0]
+        if p1 == (-0.25, 0.0):
+            assert 0.0100 <= c199[i] < 0.0103, (i, c199[i])
+        elif p1 == (0.05, -0.5):
+            assert c199[i] < 0.0617
+        elif p1 == (0.05, 0.5):
+            assert c199[i] < 0.0215

@@ -17,11 +17,13 @@
 #define REP16(x) REP4(REP4(x))
 #define REP64(x) REP4(REP16(x))
 
-enum { M_FMA = 0, M_PKFMA, M_CVT, M_RCP, M_MULLO, M_ADD64, M_CNDMASK, M_CMP, M_DPPMOV, M_BPERM, M_MIN3, M_MIX, M_COUNT };
+enum { M_FMA = 0, M_PKFMA, M_CVT, M_RCP, M_MULLO, M_ADD64, M_CNDMASK, M_CMP, M_DPPMOV, M_BPERM, M_MIN3, M_MIX, M_FMA_SGPR, M_CNDMASK_SMASK, M_FMA_LIT, M_CNDMASK_AFTER_CMP, M_SALU_MIX, M_COUNT };
 static const char *mode_name[M_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_i32", "v_rcp_f32", "v_mul_lo_u32", "v_lshl_add_u64",
                                          "v_cndmask_b32", "v_cmp_lt_f32", "v_mov_b32 dpp", "ds_bpermute_b32", "v_min3_f32",
-                                         "raster mix (sub,mul,fma,cmp,cndmask)"};
-static const int mode_ops[M_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};      // instructions per inner block
+                                         "raster mix (sub,mul,fma,cmp,cndmask)",
+                                         "v_fma_f32 with an SGPR operand", "v_cndmask_b32, mask in an SGPR pair (s_mov)", "v_add_f32 with a literal constant",
+                                         "v_cmp + v_cndmask pairs", "fma x2 + s_and_b64/s_add pairs (SALU beside VALU)"};
+static const int mode_ops[M_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};      // instructions per inner block
 
 __global__ void __launch_bounds__(1024) k(float *out, unsigned long long *cyc, int mode, int iters, float a, float b) {
     extern __shared__ float lds[];
@@ -34,6 +36,7 @@ __global__ void __launch_bounds__(1024) k(float *out, unsigned long long *cyc, i
     int i0 = threadIdx.x, i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3, i4 = i0 + 4, i5 = i0 + 5, i6 = i0 + 6, i7 = i0 + 7;
     const int ia = (int)(a * 3.0f) | 1;
     const int baddr = ((threadIdx.x + 1) & 63) << 2;
+    unsigned long long smask = 0x5555555555555555ull ^ (unsigned long long)iters; int scnt = iters;
     __syncthreads();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, independent of the DVFS state
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -88,6 +91,26 @@ __global__ void __launch_bounds__(1024) k(float *out, unsigned long long *cyc, i
         case M_MIX:     // the instruction mix of a sample-point test: subtract, multiply, fused multiply-add, compare, select
             REP2(asm volatile(S8("v_sub_f32 %0, %1, %8\n v_mul_f32 %2, %0, %9\n v_fma_f32 %3, %2, %8, %0\n v_cmp_lt_f32 vcc, %3, %9\n"
                                "v_cndmask_b32 %4, %5, %6, vcc\n v_sub_f32 %5, %7, %9\n v_fma_f32 %6, %4, %8, %5\n v_mul_f32 %7, %6, %8\n"): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc");)
+            break;
+        case M_FMA_SGPR:
+            REP2(asm volatile(S8("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                               "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a), "v"(b));)
+            break;
+        case M_CNDMASK_SMASK:
+            REP2(asm volatile(S8("v_cndmask_b32 %0, %0, %8, %9\n v_cndmask_b32 %1, %1, %8, %9\n v_cndmask_b32 %2, %2, %8, %9\n v_cndmask_b32 %3, %3, %8, %9\n"
+                               "v_cndmask_b32 %4, %4, %8, %9\n v_cndmask_b32 %5, %5, %8, %9\n v_cndmask_b32 %6, %6, %8, %9\n v_cndmask_b32 %7, %7, %8, %9\n"): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "s"(smask));)
+            break;
+        case M_FMA_LIT:
+            REP2(asm volatile(S8("v_add_f32 %0, 0x3f000123, %0\n v_add_f32 %1, 0x3f000123, %1\n v_add_f32 %2, 0x3f000123, %2\n v_add_f32 %3, 0x3f000123, %3\n"
+                               "v_add_f32 %4, 0x3f000123, %4\n v_add_f32 %5, 0x3f000123, %5\n v_add_f32 %6, 0x3f000123, %6\n v_add_f32 %7, 0x3f000123, %7\n"): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));)
+            break;
+        case M_CNDMASK_AFTER_CMP:
+            REP2(asm volatile(S8("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                               "v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %8, vcc\n"): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a) : "vcc");)
+            break;
+        case M_SALU_MIX:     // 4 VALU + 4 SALU per block of 8 (only the VALU ones would be counted by SQ_INSTS_VALU)
+            REP2(asm volatile(S8("v_fma_f32 %0, %0, %8, %9\n s_and_b64 %10, %10, exec\n v_fma_f32 %1, %1, %8, %9\n s_add_u32 %11, %11, 1\n"
+                               "v_fma_f32 %2, %2, %8, %9\n s_and_b64 %10, %10, exec\n v_fma_f32 %3, %3, %8, %9\n s_add_u32 %11, %11, 1\n"): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b), "s"(smask), "s"(scnt) : "scc");)
             break;
         }
     }
