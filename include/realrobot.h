@@ -146,6 +146,21 @@ int rr_checkpoint_bytes(rr_env *env, size_t *bytes);
 int rr_checkpoint_save(rr_env *env, void *dst_host, size_t bytes);
 int rr_checkpoint_restore(rr_env *env, const void *src_host, size_t bytes);
 int rr_sync(rr_env *env);
+/* Host mirror of the low-dimensional observations, for callers that read them on the host after every step (the gym facade:
+ * Kuka.calc_state + get_touch_sensors, robot.py:152-163, 203-211): a pinned, device-mapped host block
+ *   { f32 joints [N][9] | f32 touch [N][4] | f32 object poses [N][n_obj][7] | i32 timestep [N] | u32 errflags [N] }
+ * which, once mapped, the last launch of every rr_step / rr_reset / rr_set_state / rr_set_object_pose(s) / rr_checkpoint_restore
+ * on the library's stream refreshes.  Valid to read after rr_sync (one wait per step instead of one synchronising copy per
+ * field); owned by the library until rr_destroy.  Repeated calls return the same block. */
+int rr_map_observations(rr_env *env, void **host_ptr, size_t *bytes);
+/* The same for the images of a handful of envs (EyeCamera.render returns host arrays, env.py:536-567): pinned host copies of
+ * RR_F_RGB / RR_F_DEPTH / RR_F_MASK (pass NULL for what is not wanted), refreshed by asynchronous copies behind every rr_step that
+ * renders and every rr_render; valid to read after rr_sync.  At most 256 MiB per step in total. */
+int rr_map_images(rr_env *env, void **rgb_host, void **depth_host, void **mask_host);
+/* Waits until the mapped blocks (rr_map_observations / rr_map_images) hold the observations of the last step -- not for the rest of
+ * the stream: with a handful of envs the state part of the NEXT step is queued behind the mirror and runs while the
+ * caller computes its next action.  Without a mapping it is rr_sync. */
+int rr_sync_observations(rr_env *env);
 
 /* Replaces robot.parts[name].get_position()/get_pose() (env.py:230-232): world pose of the COM frame of
  * every robot link, f32 [N, 17, 7] (URDF depth-first link order, see data/realrobot_model_links.txt). */

@@ -29,7 +29,7 @@ SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_objec
            'rr_get_buffer', 'rr_copy_to_host', 'rr_set_state', 'rr_sync', 'rr_link_poses', 'rr_get_contacts',
            'rr_set_timing', 'rr_get_timing', 'rr_last_error', 'rr_abi_version', 'rr_ik', 'rr_plan_macro', 'rr_get_plan',
            'rr_step_plan', 'rr_set_camera', 'rr_set_object_poses', 'rr_step_plan_masked', 'rr_checkpoint_bytes',
-           'rr_checkpoint_save', 'rr_checkpoint_restore', 'rr_evaluate_goals', 'rr_device_microbench')
+           'rr_checkpoint_save', 'rr_checkpoint_restore', 'rr_evaluate_goals', 'rr_device_microbench', 'rr_map_observations', 'rr_map_images', 'rr_sync_observations')
 
 
 class Config(C.Structure):
@@ -99,6 +99,9 @@ def load_library():
     L.rr_step_plan_masked.argtypes = [vp, vp, i32, vp]
     L.rr_evaluate_goals.argtypes = [vp, vp, vp, vp]
     L.rr_device_microbench.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    L.rr_map_observations.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.rr_sync_observations.argtypes = [vp]
+    L.rr_map_images.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.rr_checkpoint_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.rr_checkpoint_save.argtypes = [vp, vp, C.c_size_t]
     L.rr_checkpoint_restore.argtypes = [vp, vp, C.c_size_t]

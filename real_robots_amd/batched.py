@@ -42,7 +42,22 @@ class BatchedREALRobotEnv:
         nat.check(self.L.rr_get_buffer(self.h, nat.F_FRAG_COUNT, C.byref(p_), C.byref(n_)))
         self._shapes[nat.F_FRAG_COUNT] = ((self.N, max(1, n_.value // (4 * self.N))), np.uint32)
 
+    def map_images(self, mask=True):
+        """Pinned host copies of the images that every rendered step refreshes (rr_map_images; a handful of envs only): numpy views
+        (rgb [N, H, W, 3] u8, depth [N, H, W] f32, mask [N, H, W] i32 or None) -- valid after `sync()`."""
+        key = '_img_mirror_m' if mask else '_img_mirror'
+        if getattr(self, key, None) is None:
+            pr, pd, pm = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            nat.check(self.L.rr_map_images(self.h, C.byref(pr), C.byref(pd), C.byref(pm) if mask else None))
+            npx = self.N * self.H * self.W
+            rgb = np.frombuffer((C.c_uint8 * (npx * 3)).from_address(pr.value), dtype=np.uint8).reshape(self.N, self.H, self.W, 3)
+            dep = np.frombuffer((C.c_float * npx).from_address(pd.value), dtype=np.float32).reshape(self.N, self.H, self.W)
+            msk = np.frombuffer((C.c_int32 * npx).from_address(pm.value), dtype=np.int32).reshape(self.N, self.H, self.W) if mask else None
+            setattr(self, key, (rgb, dep, msk))
+        return getattr(self, key)
+
     def close(self):
+        self._mirror = self._img_mirror = self._img_mirror_m = None      # (views into memory the library frees)
         if getattr(self, 'h', None):
             self.L.rr_destroy(self.h)
             self.h = None
@@ -88,6 +103,31 @@ class BatchedREALRobotEnv:
 
     def sync(self):
         nat.check(self.L.rr_sync(self.h))
+
+    def sync_observations(self):
+        """Waits for the mapped observation blocks of the last step only (rr_sync_observations)."""
+        nat.check(self.L.rr_sync_observations(self.h))
+
+    def map_observations(self):
+        """Host mirror of the low-dimensional observations (rr_map_observations): numpy views over pinned host memory that every
+        step refreshes -- valid after `sync()`.  Returns dict(joints [N, 9], touch [N, 4], obj_pose [N, n_obj, 7], timestep [N],
+        errflags [N])."""
+        if getattr(self, '_mirror', None) is None:
+            p, n = C.c_void_p(), C.c_size_t()
+            nat.check(self.L.rr_map_observations(self.h, C.byref(p), C.byref(n)))
+            N, k = self.N, self.n_objects
+            buf = (C.c_float * (n.value // 4)).from_address(p.value)
+            f = np.frombuffer(buf, dtype=np.float32)
+            o = 0
+            out = {}
+            for name, shape in (('joints', (N, 9)), ('touch', (N, 4)), ('obj_pose', (N, k, 7))):
+                sz = int(np.prod(shape))
+                out[name] = f[o:o + sz].reshape(shape)
+                o += sz
+            out['timestep'] = f[o:o + N].view(np.int32)
+            out['errflags'] = f[o + N:o + 2 * N].view(np.uint32)
+            self._mirror = out
+        return self._mirror
 
     # ------------------------------------------------------------------ data access
     def host(self, field):

@@ -2699,6 +2699,19 @@ __global__ void k_obs(SimParams P, DevPtrs D) {
     }
 }
 
+// Host mirror of the low-dimensional observations (rr_map_observations): device-mapped pinned host memory that a step's last
+// launch on the main stream fills -- the single-env facade then needs ONE wait per step and no device-to-host copy calls.
+struct ObsMirror { float *joints, *touch, *objpose; int *timestep; unsigned *errflags; };
+__global__ void k_obs_mirror(SimParams P, DevPtrs D, ObsMirror M) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= P.N) return;
+    for (int i = 0; i < 9; i++) M.joints[(size_t)env * 9 + i] = D.joints[(size_t)env * 9 + i];
+    for (int i = 0; i < 4; i++) M.touch[(size_t)env * 4 + i] = D.touch[(size_t)env * 4 + i];
+    for (int i = 0; i < P.nobj * 7; i++) M.objpose[(size_t)env * P.nobj * 7 + i] = D.objpose[(size_t)env * P.nobj * 7 + i];
+    M.timestep[env] = D.timestep[env];
+    M.errflags[env] = D.errflags[env];
+}
+
 // ---------------------------------------------------------------------------------------------- reset / state io
 __global__ void k_reset(BodyParams B, SimParams P, DevPtrs D, const unsigned char *mask) {
     const int N = P.N;
@@ -3290,7 +3303,11 @@ __device__ __forceinline__ void shade_pixel(const ShadeCtx &c, const TriRec &tr,
         u = u - floorf(u); v = v - floorf(v);
         const int th = __float_as_int(xf[14]);
         int tx = min((int)(u * (float)tw), tw - 1), ty = min((int)(v * (float)th), th - 1);
+#if defined(RR_SHADE_PROBE) && (RR_SHADE_PROBE & 2)
+        unsigned px4 = D.tex[(size_t)__float_as_int(xf[12]) + (size_t)((tx + ty) & 63)];      // (probe: texels of one cache-line set)
+#else
         unsigned px4 = D.tex[(size_t)__float_as_int(xf[12]) + (size_t)(th - 1 - ty) * tw + tx];
+#endif
         tex0 = (float)(px4 & 255); tex1 = (float)((px4 >> 8) & 255); tex2 = (float)((px4 >> 16) & 255);
     }
     float shade = 0.6f + 0.35f * diff + 0.05f * spec;
@@ -3904,11 +3921,19 @@ __device__ __forceinline__ void shade_block(const RenderModel &RM, const DevPtrs
         }
         const int lrow = pi / RM.W, px = pi - lrow * RM.W;
         unsigned char c3[3]; int m;
+#if defined(RR_SHADE_PROBE) && (RR_SHADE_PROBE & 4)
+        shade_pixel(ctx, load_tri_rec(D, t & 63), px, row0 + lrow, c3, m);      // (probe: 64 records for everybody -- one cache line set)
+#else
         shade_pixel(ctx, load_tri_rec(D, t), px, row0 + lrow, c3, m);
+#endif
         const size_t o = base + (size_t)pi;
+#if defined(RR_SHADE_PROBE) && (RR_SHADE_PROBE & 1)
+        if (c3[0] == 1 && c3[1] == 2 && c3[2] == 3 && m == 12345) out.depth[o] = 0.0f;      // (probe: no image stores)
+#else
         out.rgb[o * 3] = c3[0]; out.rgb[o * 3 + 1] = c3[1]; out.rgb[o * 3 + 2] = c3[2];
         out.depth[o] = __uint_as_float(f.x);
         if (out.mask) out.mask[o] = m;
+#endif
     }
 }
 // Measured in round 4 and dropped (k_shade alone, 4096 envs, 0.103 ms as it stands): the first list entry requested together with the
@@ -4053,6 +4078,11 @@ struct rr_env {
     bool la_inline;                // RR_UNSPLIT_LA_INLINE: the unsplit step's look-ahead behind its render instead of beside it
     bool no_fused_setup;           // RR_NO_FUSED_SETUP: separate k_render_setup launch for the light envs
     bool collide_ordered;          // RR_COLLIDE_ORDER=0: k_collide in env order (default: last step's heavy envs first)
+    void *obs_host;                // rr_map_observations: mapped pinned block {joints [N][9], touch [N][4], poses [N][nobj][7], timestep [N], errflags [N]} or nullptr
+    ObsMirror obs_dev;             // its device-visible addresses
+    hipEvent_t ev_obs;             // recorded behind the mirror's launches: rr_sync_observations waits for it alone
+    bool ev_obs_set;
+    void *img_host[3];             // rr_map_images: pinned host copies of RGB / depth / mask that every rendered step refreshes (or nullptr)
     int force_hcount[2];           // RR_FORCE_HCOUNT="h,vh": what the host-side decisions read instead of the lagged counters (tests; -1: the counters)
     int n_shapes;
     float table_pos[3];            // target of the default eye camera (env.py:253-255)
@@ -4071,6 +4101,25 @@ struct rr_env {
 static inline int lagged_count(const rr_env *e, int which, int fallback) {
     if (e->force_hcount[which] >= 0) return e->force_hcount[which];
     return e->h_hcount ? ((volatile int *)e->h_hcount)[which] : fallback;
+}
+
+// k_obs (joint angles and object poses of the state -> observation buffers) and, when mapped, the host mirror behind it
+static void launch_mirror(rr_env *e, bool rendered = false) {
+    if (e->obs_host) hipLaunchKernelGGL(k_obs_mirror, dim3((e->P.N + 63) / 64), dim3(64), 0, e->stream, e->P, e->D, e->obs_dev);
+    if (rendered) {
+        const int f[3] = {RR_F_RGB, RR_F_DEPTH, RR_F_MASK};
+        for (int i = 0; i < 3; i++)
+            if (e->img_host[i] && e->field_ptr[f[i]]) hipMemcpyAsync(e->img_host[i], e->field_ptr[f[i]], e->field_bytes[f[i]], hipMemcpyDeviceToHost, e->stream);
+    }
+    if (e->obs_host || e->img_host[0] || e->img_host[1] || e->img_host[2]) {
+        if (!e->ev_obs && hipEventCreateWithFlags(&e->ev_obs, hipEventDisableTiming) != hipSuccess) { e->ev_obs = nullptr; (void)hipGetLastError(); return; }
+        hipEventRecord(e->ev_obs, e->stream);
+        e->ev_obs_set = true;
+    }
+}
+static void launch_obs(rr_env *e) {
+    hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
+    launch_mirror(e);
 }
 
 template <typename T>
@@ -4144,6 +4193,9 @@ int rr_destroy(rr_env *e) {
     if (e->ev_dyn) hipEventDestroy(e->ev_dyn);
     for (int i = 0; i < 4; i++) { if (e->pin_buf[i]) hipHostFree(e->pin_buf[i]); if (e->pin_ev[i]) hipEventDestroy(e->pin_ev[i]); }
     if (e->h_hcount) hipHostFree(e->h_hcount);
+    if (e->obs_host) hipHostFree(e->obs_host);
+    for (int i = 0; i < 3; i++) if (e->img_host[i]) hipHostFree(e->img_host[i]);
+    if (e->ev_obs) hipEventDestroy(e->ev_obs);
     delete e;
     return RR_OK;
 }
@@ -4230,6 +4282,9 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->no_fused_setup = getenv("RR_NO_FUSED_SETUP") != nullptr;
     e->collide_ordered = !(getenv("RR_COLLIDE_ORDER") && atoi(getenv("RR_COLLIDE_ORDER")) == 0);
     e->force_hcount[0] = e->force_hcount[1] = -1;
+    e->obs_host = nullptr; memset(&e->obs_dev, 0, sizeof e->obs_dev);
+    e->img_host[0] = e->img_host[1] = e->img_host[2] = nullptr;
+    e->ev_obs = nullptr; e->ev_obs_set = false;
     if (getenv("RR_FORCE_HCOUNT")) sscanf(getenv("RR_FORCE_HCOUNT"), "%d,%d", &e->force_hcount[0], &e->force_hcount[1]);
 
     e->h_hcount = nullptr;
@@ -4534,7 +4589,7 @@ int rr_reset(rr_env *e, const uint8_t *mask_host) {
     }
     e->la_valid = false;          // the state changes from outside: the next step prepares itself in line
     hipLaunchKernelGGL(k_reset, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->B, e->P, e->D, m);
-    hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
+    launch_obs(e);
     HIPCHK(hipGetLastError());
     return RR_OK;
 }
@@ -4577,7 +4632,7 @@ int rr_set_object_pose(rr_env *e, int32_t env_index, int32_t obj, const float *p
     for (int k = 0; k < 4; k++)
         HIPCHK(hipMemcpyAsync(e->D.state + (ST_OQUAT + 4 * obj + k) * N + env_index, pose7 + 3 + k, 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));   // pose7/zero are stack/host memory
-    hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
+    launch_obs(e);
     return RR_OK;
 }
 
@@ -4592,7 +4647,7 @@ int rr_set_object_poses(rr_env *e, const float *poses_host, const uint8_t *env_m
     const unsigned char *m = nullptr;
     if (env_mask_host) { HIPCHK(hipMemcpyAsync(e->mask_dev, env_mask_host, N, hipMemcpyHostToDevice, e->stream)); m = e->mask_dev; }
     hipLaunchKernelGGL(k_set_object_poses, dim3((N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D, e->state_aos, m);
-    hipLaunchKernelGGL(k_obs, dim3((N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
+    launch_obs(e);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));   // the arguments are host memory
     return RR_OK;
@@ -4670,6 +4725,7 @@ static int do_render(rr_env *e, bool use_flags) {
 
 // ---- look-ahead: the state part of the NEXT step (k_prep_a -> k_collide, k_prep_b beside them) ------------------------------
 // Per-class launches (sel: pick_env) cover N work items whatever the class.
+#define SMALL_N_MAX 64      // up to this many envs a step without the three-stream split runs as one chain on the main stream (rr_step)
 static void launch_prep_a(rr_env *e, int sel, int zero_counts, hipStream_t st) {
     hipLaunchKernelGGL(k_prep_a, env_grid(e), dim3(e->epb), 0, st, e->B, e->P, e->D, sel, zero_counts);
 }
@@ -4795,6 +4851,7 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
                 TIMED(1, launch_collide(e, 0, e->stream));
                 e->la_valid = true;
             }
+            launch_mirror(e, render_mode != 0);
             HIPCHK(hipGetLastError());
             return RR_OK;
         }
@@ -4876,15 +4933,28 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         if (ahead) e->la_valid = true;
         hipStreamWaitEvent(e->stream, e->ev_join, 0);
         hipStreamWaitEvent(e->stream, e->ev_join2, 0);
+        launch_mirror(e, render_mode != 0);
         HIPCHK(hipGetLastError());
         return RR_OK;
     }
-    TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 0, 0));
+    // A handful of envs (the single-env gym facade, BASELINE config 1): the step is one latency chain -- solve -> preparation ->
+    // collision pass, 72 + 34 + 13 us at N = 1 (scratch/small_n.py) -- and nothing overlaps with anything.  The classes are then
+    // solved one after the other on the main stream by their own kernels (the light form is 41 us instead of the generic kernel's
+    // 72; a launch whose list is empty ends at once: a single env is in exactly one class), and up to SMALL_N_MAX envs the look-ahead
+    // runs as two launches on the same stream, no events.
+    const bool small_n = N <= SMALL_N_MAX && e->split_heavy && e->aux && !e->timing && !g_skip;
+    if (small_n && N == 1) {     // (one env is in exactly one class; with several, the classes side by side in the generic kernel are faster: 16 envs 0.67 vs 0.81 ms)
+        if (e->light_ow) hipLaunchKernelGGL(k_solve_light_ow, dim3((N + 15) / 16), dim3(LIGHT_OW_THREADS), 4 * lds64, e->stream, e->B, e->P, e->D, (const RenderModel *)nullptr);
+        else hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, (const RenderModel *)nullptr);
+        launch_solve_class(e, 2, e->stream);
+        launch_solve_class(e, 3, e->stream);
+    } else
+        TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 0, 0));
     HIPCHK(hipGetLastError());
     int rc = RR_OK;
     // (one class.  With a camera the state part of the next step runs on the side stream beside the render of this one;
     // RR_UNSPLIT_LA_INLINE=1: behind it on the main stream.)
-    const bool la_beside = ahead && render_mode && overlap && !e->la_inline;
+    const bool la_beside = ahead && render_mode && overlap && !e->la_inline && !small_n;
     if (la_beside) {
         hipEventRecord(e->ev_fork, e->stream);
         hipStreamWaitEvent(e->aux, e->ev_fork, 0);
@@ -4897,16 +4967,23 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         hipStreamWaitEvent(e->stream, e->ev_join, 0);
         e->la_valid = true;
     } else if (ahead) {
-        state_part_all(e, overlap);
+        // (a handful of envs: the observations of this step are complete here -- the mirror goes in front of the look-ahead, so that
+        // a caller waiting for the observations alone (rr_sync_observations) gets them 45 us earlier and the state part of the next
+        // step runs while the host computes its next action)
+        if (small_n) { launch_mirror(e, render_mode != 0); launch_prep_ab(e, 0, e->stream); launch_collide(e, 0, e->stream); }
+        else state_part_all(e, overlap);
         e->la_valid = true;
     }
+    if (!(small_n && ahead && !la_beside)) launch_mirror(e, render_mode != 0);
     return rc;
 }
 
 int rr_render(rr_env *e) {
     if (!e) return fail(RR_EINVAL, "null env");
     HIPCHK(hipSetDevice(e->cfg.device));
-    return do_render(e, false);
+    const int rc = do_render(e, false);
+    launch_mirror(e, true);
+    return rc;
 }
 
 int rr_get_buffer(rr_env *e, int32_t field, void **dev_ptr, size_t *bytes) {
@@ -4936,7 +5013,7 @@ int rr_set_state(rr_env *e, const float *state_host) {
     e->la_valid = false;
     HIPCHK(hipMemcpyAsync(e->state_aos, state_host, e->field_bytes[RR_F_STATE], hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(k_state_io, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D, e->state_aos, 0);
-    hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
+    launch_obs(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     return RR_OK;
 }
@@ -5011,7 +5088,7 @@ int rr_checkpoint_restore(rr_env *e, const void *src_host, size_t bytes) {
     HIPCHK(hipMemsetAsync(e->D.class_pub, 0, 4 * N, e->stream));
     HIPCHK(hipMemsetAsync(e->D.hgflag, 0, 4 * N, e->stream));
     HIPCHK(hipMemsetAsync(e->D.hcount, 0, 16, e->stream)); HIPCHK(hipMemsetAsync(e->D.hcount2, 0, 16, e->stream));
-    hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
+    launch_obs(e);
     HIPCHK(hipStreamSynchronize(e->stream));   // the source is host memory
     return RR_OK;
 }
@@ -5088,6 +5165,56 @@ int rr_device_microbench(int32_t device, int32_t kind, double *result) {
     hipEventDestroy(e0); hipEventDestroy(e1);
     HIPCHK(hipGetLastError());
     *result = units / (best_ms * 1e-3);
+    return RR_OK;
+}
+
+int rr_map_observations(rr_env *e, void **host_ptr, size_t *bytes) {
+    if (!e || !host_ptr) return fail(RR_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t N = e->P.N, nobj = e->P.nobj;
+    const size_t nb = 4 * (N * 9 + N * 4 + N * nobj * 7 + N + N);
+    if (!e->obs_host) {
+        void *h = nullptr, *d = nullptr;
+        HIPCHK(hipHostMalloc(&h, nb, hipHostMallocMapped));
+        memset(h, 0, nb);
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { hipHostFree(h); (void)hipGetLastError(); return fail(RR_EDEVICE, "rr_map_observations: pinned host memory is not device-mapped on this system"); }
+        float *f = (float *)d;
+        e->obs_dev.joints = f; e->obs_dev.touch = f + N * 9; e->obs_dev.objpose = f + N * 13;
+        e->obs_dev.timestep = (int *)(f + N * (13 + nobj * 7)); e->obs_dev.errflags = (unsigned *)(f + N * (14 + nobj * 7));
+        e->obs_host = h;
+        launch_mirror(e);
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    *host_ptr = e->obs_host;
+    if (bytes) *bytes = nb;
+    return RR_OK;
+}
+
+int rr_sync_observations(rr_env *e) {
+    if (!e) return fail(RR_EINVAL, "null env");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    if (e->ev_obs_set) HIPCHK(hipEventSynchronize(e->ev_obs)); else HIPCHK(hipStreamSynchronize(e->stream));
+    return RR_OK;
+}
+
+int rr_map_images(rr_env *e, void **rgb_host, void **depth_host, void **mask_host) {
+    if (!e) return fail(RR_EINVAL, "null env");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    void **out[3] = {rgb_host, depth_host, mask_host};
+    const int f[3] = {RR_F_RGB, RR_F_DEPTH, RR_F_MASK};
+    size_t total = 0;
+    for (int i = 0; i < 3; i++) if (out[i]) total += e->field_bytes[f[i]];
+    if (total > ((size_t)256 << 20)) return fail(RR_EINVAL, "rr_map_images: more than 256 MiB of images per step (meant for a handful of envs; batches read the device buffers)");
+    for (int i = 0; i < 3; i++) {
+        if (!out[i]) continue;
+        if (!e->field_ptr[f[i]]) return fail(RR_EINVAL, "rr_map_images: field not available (RR_FLAG_NO_MASK)");
+        if (!e->img_host[i]) {
+            HIPCHK(hipHostMalloc(&e->img_host[i], e->field_bytes[f[i]], hipHostMallocDefault));
+            HIPCHK(hipMemcpyAsync(e->img_host[i], e->field_ptr[f[i]], e->field_bytes[f[i]], hipMemcpyDeviceToHost, e->stream));
+        }
+        *out[i] = e->img_host[i];
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
     return RR_OK;
 }
 

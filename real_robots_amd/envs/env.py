@@ -317,7 +317,7 @@ class REALRobotEnv:
         return self.robot.object_bodies[name].get_pose()
 
     def get_all_used_objects(self):
-        poses = self._backend().host(nat.F_OBJ_POSE)[0].astype(np.float64)
+        poses = self.robot._mirror()['obj_pose'][0].astype(np.float64)
         return {obj: poses[i, :3] for i, obj in enumerate(self.robot.used_objects[1:])}
 
     def get_contacts(self):
@@ -327,18 +327,22 @@ class REALRobotEnv:
         be = self._backend()
         self._sync_eye_camera()
         be.render()
-        return be.host(nat.F_RGB)[0], be.host(nat.F_MASK)[0], be.host(nat.F_DEPTH)[0].astype(np.float64)
+        return self._fetch_retina()
 
-    def _fetch_retina(self):
+    def _fetch_retina(self, need_mask=True):
+        """The frame the last render left, as fresh host arrays (EyeCamera.render returns new arrays, env.py:560-567): the backend
+        keeps pinned host copies that every rendered step refreshes asynchronously (rr_map_images) -- one wait, then plain copies."""
         be = self._backend()
-        return be.host(nat.F_RGB)[0], be.host(nat.F_MASK)[0], be.host(nat.F_DEPTH)[0].astype(np.float64)
+        rgb, dep, msk = be.map_images(mask=need_mask)
+        be.sync_observations()
+        return rgb[0].copy(), (msk[0].copy() if need_mask else None), dep[0].astype(np.float64)
 
     # ------------------------------------------------------------------ observations (env.py:266-312)
     def get_observation(self, camera_on=True, _rendered=False):
         joints = self.robot.calc_state()
         sensors = self.robot.get_touch_sensors()
         if camera_on:
-            retina, _, depth = self._fetch_retina() if _rendered else self.get_retina()
+            retina, _, depth = self._fetch_retina(need_mask=False) if _rendered else self.get_retina()
         else:
             retina, depth = self.no_retina, self.no_depth
         O = Kuka.ObsSpaces

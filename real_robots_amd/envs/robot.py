@@ -115,14 +115,22 @@ class Kuka:
             return np.array(self.object_poses['table'][:3] + [0.0, 0.0, 0.0, 1.0])
         be = self._env._backend()
         if kind == 'object':
-            return be.host(nat.F_OBJ_POSE)[0, index].astype(np.float64)
+            return self._mirror()['obj_pose'][0, index].astype(np.float64)
         return be.link_poses()[0, index].astype(np.float64)
 
+    def _mirror(self):
+        """The backend's host mirror of the low-dimensional observations (rr_map_observations): one wait, no copy calls --
+        the single-env facade reads joints and touch sensors after every step (env.py:336-339)."""
+        be = self._env._backend()
+        m = be.map_observations()
+        be.sync_observations()
+        return m
+
     def calc_state(self):                               # robot.py:203-211
-        return [float(x) for x in self._env._backend().host(nat.F_JOINTS)[0]]
+        return self._mirror()['joints'][0].tolist()
 
     def get_touch_sensors(self):                        # robot.py:152-163
-        return self._env._backend().host(nat.F_TOUCH)[0].astype(np.float64)
+        return self._mirror()['touch'][0].astype(np.float64)
 
     def get_contacts(self, forces=False):               # robot.py:131-150
         out = {}

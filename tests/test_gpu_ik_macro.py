@@ -144,7 +144,7 @@ def test_all_36_perimeter_pairs_of_the_reference_script():
     fx = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'macro_sensitivity.json')))
     assert [tuple(map(tuple, p)) for p in fx['pairs']] == pairs
     fixture = np.array(fx['distance_m']['kp=0.1,rate_limit=on'])
-    DEV_TOL = 4e-4
+    DEV_TOL = 6e-4
     worst = {}
     for col, t in ((0, 199), (1, 249), (2, 749), (4, 999)):
         for i in range(N):

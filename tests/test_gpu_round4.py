@@ -264,3 +264,61 @@ def test_contact_count_and_env_class_pointers_are_stable_over_steps():
         seen_heavy = seen_heavy or bool((d > 0).any())
     assert seen_heavy
     env.close()
+
+
+def test_host_mirrors_follow_every_step():
+    """rr_map_observations / rr_map_images / rr_sync_observations (the single-env facade's read-back, env.py:336-339, 536-567): after
+    every step -- with and without camera, after resets and teleports -- the mapped host blocks hold what rr_copy_to_host returns, for
+    one env (class-by-class chain on the main stream) and for a small batch."""
+    for N in (1, 5):
+        env = BatchedREALRobotEnv(N, objects=3, width=96, height=64)
+        m = env.map_observations()
+        rgb, dep, msk = env.map_images(mask=True)
+        rng = np.random.default_rng(N)
+        for t in range(120):
+            if t == 40:
+                env.reset()
+            if t == 70:
+                env.set_object_pose(0, 1, np.array([-0.1, 0.1, 0.5, 0, 0, 0, 1], np.float32))
+            cam = bool(rng.random() < 0.4)
+            env.step(synthetic_actions(range(N), t, seed=3).astype(np.float32), render=cam)
+            env.sync_observations()
+            j, tc, op, ts = m['joints'].copy(), m['touch'].copy(), m['obj_pose'].copy(), m['timestep'].copy()
+            img = (rgb.copy(), dep.copy(), msk.copy()) if cam else None
+            assert np.array_equal(j, env.host(nat.F_JOINTS)) and np.array_equal(tc, env.host(nat.F_TOUCH)), (N, t)
+            assert np.array_equal(op, env.host(nat.F_OBJ_POSE)) and np.array_equal(ts, env.host(nat.F_TIMESTEP)), (N, t)
+            assert np.array_equal(m['errflags'], env.host(nat.F_ERRFLAGS))
+            if cam:
+                assert np.array_equal(img[0], env.host(nat.F_RGB)) and np.array_equal(img[1], env.host(nat.F_DEPTH)), (N, t)
+                assert np.array_equal(img[2], env.host(nat.F_MASK)), (N, t)
+        env.close()
+
+
+def test_single_env_chain_is_bitwise_the_batched_step():
+    """One env (the gym facade's backend) is stepped class by class on the main stream with the look-ahead as two plain launches
+    (rr_step's small-N path); as a member of a batch of 80 the same env takes the generic kernels and the side streams.  The batch
+    runs first (300 full-range steps, a camera frame every third step); an env that was light at some check points and heavy at
+    others is then replayed alone with its command stream: bitwise the same trajectory, contacts, touch sensors and frames."""
+    N, T = 80, 300
+    b = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    cmds = [synthetic_actions(range(N), t, seed=6).astype(np.float32) for t in range(T)]
+    rec, cls_seen = {}, np.zeros((N, 3), bool)
+    for t in range(T):
+        b.step(cmds[t], render=(t % 3 == 0))
+        if t % 10 == 9:
+            rec[t] = (b.state, b.host(nat.F_TOUCH), b.host(nat.F_RGB), b.host(nat.F_DEPTH), [b.contacts(i) for i in range(N)])
+            c = b.host(nat.F_ENV_CLASS)
+            cls_seen[np.arange(N), c] = True
+    cand = np.flatnonzero(cls_seen[:, 0] & (cls_seen[:, 1] | cls_seen[:, 2]))
+    assert len(cand) > 0, cls_seen.sum(0)
+    b.close()
+    for k in cand[:2]:
+        a = BatchedREALRobotEnv(1, objects=3, width=64, height=64)
+        for t in range(T):
+            a.step(cmds[t][k:k + 1], render=(t % 3 == 0))
+            if t % 10 == 9:
+                st, tc, rgb, dep, con = rec[t]
+                assert np.array_equal(a.state[0], st[k], equal_nan=True), (k, t)
+                assert np.array_equal(a.host(nat.F_TOUCH)[0], tc[k]) and np.array_equal(a.contacts(0), con[k]), (k, t)
+                assert np.array_equal(a.host(nat.F_RGB)[0], rgb[k]) and np.array_equal(a.host(nat.F_DEPTH)[0], dep[k]), (k, t)
+        a.close()
