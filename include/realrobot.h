@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 3   /* 3: RR_F_CONTACT_COUNT, RR_F_ENV_CLASS, rr_checkpoint_*, rr_evaluate_goals */
+#define RR_ABI_VERSION 4   /* 3: RR_F_CONTACT_COUNT, RR_F_ENV_CLASS, rr_checkpoint_*, rr_evaluate_goals; 4: rr_map_observations, rr_map_images,
+                              rr_sync_observations, rr_device_microbench; checkpoint blobs carry the step parameters (version 2 header) */
 
 enum {
     RR_OK = 0,

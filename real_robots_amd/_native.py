@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('RR_LIB', os.path.join(_HERE, 'csrc', 'librealrobot_hi
 BLOB_GZ = os.path.join(_HERE, 'data', 'realrobot_model.bin.gz')
 LINK_NAMES = open(os.path.join(_HERE, 'data', 'realrobot_model_links.txt')).read().split()
 
-RR_ABI_VERSION = 3
+RR_ABI_VERSION = 4
 (F_JOINTS, F_TOUCH, F_OBJ_POSE, F_RGB, F_DEPTH, F_MASK, F_TIMESTEP, F_ERRFLAGS, F_STATE, F_FRAG_COUNT, F_CONTACT_COUNT,
  F_ENV_CLASS) = range(12)
 NUM_KERNELS = 9

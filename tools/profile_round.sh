@@ -3,7 +3,7 @@
 # rocprofv3 kernel stats, PMC HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes, never combined with other trace
 # domains), SQ VALU counters.  Output: gpurun_out/round/ ; traffic_latest.json and sq_latest.json carry the run
 # configuration so that bench.py only attaches them to runs of that configuration.  Usage: tools/profile_round.sh [tag]
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; mkdir -p $O
 cd $R && python bench.py --steps 200 --warmup 20 > $O/${TAG}_bench.json 2> $O/bench.err; tail -c 600 $O/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
