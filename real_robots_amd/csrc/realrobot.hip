@@ -3333,6 +3333,11 @@ __device__ __forceinline__ void stage_instances(const RenderModel &RM, const Dev
 // Development-only work counters (librealrobot_hip_stats.so, `make stats`; never part of the shipped library).
 __device__ unsigned long long g_rstats[16];
 #define RSTAT(i, v) do { if (P.ablate & 0x8000) atomicAdd(&g_rstats[i], (unsigned long long)(v)); } while (0)   /* RR_ABLATE=32768 */
+extern "C" int rr_debug_raster_stats(unsigned long long *out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rstats), sizeof(g_rstats)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rstats), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
 // phase clock of the window loop (RR_ABLATE=4096; scratch/rphase.py): wave cycles between phase marks; every workgroup sums its
 // waves in LDS and writes its ten totals to a slot of its own (global atomics from every wave would be what the clock measures)
 __device__ unsigned g_rphase_wg[65536][10];

@@ -203,7 +203,9 @@ class REALRobotEnv:
 
     def _eye_key(self):
         cam = self.eyes["eye"]
-        return (tuple(float(x) for x in cam.eyePosition), tuple(float(x) for x in cam.upVector), float(cam.fov))
+        table = tuple(float(x) for x in self.robot.object_poses['table'][:3])       # the target of the retina (env.py:253-255)
+        aspect = float(getattr(cam, 'render_width', self.robot.eye_width)) / float(getattr(cam, 'render_height', self.robot.eye_height))
+        return (tuple(float(x) for x in cam.eyePosition), tuple(float(x) for x in cam.upVector), float(cam.fov), table, aspect)
 
     def _sync_eye_camera(self):
         """get_retina is `self.eyes["eye"].render(table position)` in the reference (env.py:249-255): replacing that camera
@@ -214,11 +216,12 @@ class REALRobotEnv:
         if key != self._eye_pushed:
             from ..mathutil import look_at, perspective
             cam = self.eyes["eye"]
-            if key == ((0.01, 0.0, 1.2), (0.0, 0.0, 1.0), 80.0):          # the reference's default eye: the library's own matrices
+            default_aspect = float(self.robot.eye_width) / float(self.robot.eye_height)
+            if key == ((0.01, 0.0, 1.2), (0.0, 0.0, 1.0), 80.0, (0.0, 0.0, 0.08), default_aspect):     # the reference's default eye: the library's own matrices
                 self._backend().set_camera(None, None)
             else:
-                self._backend().set_camera(look_at(cam.eyePosition, [0.0, 0.0, 0.08], cam.upVector),         # table position, robot.py:20
-                                           perspective(cam.fov, float(self.robot.eye_width) / self.robot.eye_height, 0.1, 100.0))
+                # (the look-at target is the table body's position, the aspect the camera's own render size: env.py:249-255, 536-551)
+                self._backend().set_camera(look_at(cam.eyePosition, list(key[3]), cam.upVector), perspective(cam.fov, key[4], 0.1, 100.0))
             self._eye_pushed = key
 
     def extrinsicFormula(self, p_goal, p, a_goal, a, w=1):

@@ -7,8 +7,8 @@ the same methods and attributes (`num_envs`, `single_action_space`, `single_obse
 `observation_space`).  Episodes end like the reference's (env.py:345-352): `truncated` once `timestep >=
 max_episode_steps`.  Autoreset is gymnasium's SAME-STEP mode (`metadata["autoreset_mode"] = "same_step"`): a truncated env
 is reset inside the step() that truncated it, the returned observation is the first one of its next episode and the last
-observation of the finished episode is in `infos["final_obs"]` (low-dim entries; `infos["_final_obs"]` is the mask of the envs
-it applies to) -- every action acts on the episode its observation came from, no action is dropped.
+observation of the finished episode is in `infos["final_obs"]` (an object array: a dict of the low-dim entries for every finished
+env, None elsewhere; `infos["_final_obs"]` is the mask of the envs it applies to) -- every action acts on the episode its observation came from, no action is dropped.
 Observations are batched numpy arrays; with `device_obs=True` the image / low-dim entries are the library's device
 buffers instead (DLPack / __cuda_array_interface__, zero copy into torch on ROCm).
 """
@@ -48,14 +48,16 @@ class REALRobotVectorEnv(_Base):
         self.action_space = spaces.Dict({
             "joint_command": spaces.Box(low=np.tile(self._robot.min_joints, (self.num_envs, 1)),
                                         high=np.tile(self._robot.max_joints, (self.num_envs, 1)), dtype=float),
-            "render": spaces.MultiBinary(1)})
+            "render": spaces.MultiBinary(self.num_envs)})
         self.observation_space = _batch_dict_space(self.single_observation_space, self.num_envs)
         self.metadata = {"autoreset_mode": "same_step"}
         self.max_episode_steps = int(max_episode_steps)
         self.render_every_step, self.device_obs, self.additional_obs = bool(render_every_step), bool(device_obs), bool(additional_obs)
         self._be = BatchedREALRobotEnv(self.num_envs, objects=objects, width=eye_width, height=eye_height, device=device,
                                        want_mask=additional_obs)
-        self._steps = np.zeros(self.num_envs, np.int64)      # host-side episode clocks (no device read-back per step)
+        # host-side episode clocks (no device read-back per step): the batched env behind this adapter is private to it, every
+        # path that resets an env goes through reset() / step() below and resets its clock with it
+        self._steps = np.zeros(self.num_envs, np.int64)
 
     # ------------------------------------------------------------------ observations
     def _obs(self, rendered):
@@ -90,7 +92,15 @@ class REALRobotVectorEnv(_Base):
         infos = {}
         if truncated.any():
             # same-step autoreset: keep the finished episodes' last low-dim observation, reset those envs, re-render them
-            infos["final_obs"] = {"joint_positions": self._be.host(nat.F_JOINTS), "touch_sensors": self._be.host(nat.F_TOUCH)}
+            # (gymnasium's layout: an object array with one dict per finished env and None elsewhere, plus the boolean mask)
+            j, tc = self._be.host(nat.F_JOINTS), self._be.host(nat.F_TOUCH)
+            op = self._be.host(nat.F_OBJ_POSE) if self.additional_obs else None
+            fin = np.full(n, None, dtype=object)
+            for i in np.flatnonzero(truncated):
+                fin[i] = {"joint_positions": j[i], "touch_sensors": tc[i]}
+                if op is not None:
+                    fin[i]["object_positions"] = op[i]
+            infos["final_obs"] = fin
             infos["_final_obs"] = truncated.copy()
             self._be.reset(truncated.astype(np.uint8))
             self._steps[truncated] = 0

@@ -236,7 +236,7 @@ def test_dlpack_and_vector_env_adapter():
     assert np.allclose(j.cpu().numpy(), venv._be.host(nat.F_JOINTS))
     assert (rgb.cpu().numpy() == venv._be.host(nat.F_RGB)).all()
     # same-step autoreset: the step that truncated the episodes returned their final low-dim observation in infos and reset them
-    assert info["_final_obs"].all() and float(info["final_obs"]["joint_positions"][0, 1]) > 0.05
+    assert info["_final_obs"].all() and float(info["final_obs"][0]["joint_positions"][1]) > 0.05
     assert (venv._be.host(nat.F_TIMESTEP) == 0).all() and abs(float(j[0, 1])) < 1e-6
     obs, rew, term, trunc, info = venv.step(act)
     assert (venv._be.host(nat.F_TIMESTEP) == 1).all() and not trunc.any() and info == {}
