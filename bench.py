@@ -17,15 +17,18 @@ no collective on the stepping path; `--gather lowdim|images` adds the optional p
                 beside them for the few heavy ones) and, for the unit that dominates the step's critical path, ALGORITHMIC
                 bytes per launch / duration against the 8 TB/s HBM peak (`achieved` is that ratio, not a measured HBM rate; the
                 measured HBM bytes of the same configuration, when a committed PMC profile matches it, are `traffic`).
-                `roofline.valu` prices the dominant kernel against the VALU issue peak, which is what actually bounds it.
+                `roofline.hbm_achievable_GBs`: device copy / triad bandwidth measured in this run (rr_device_microbench).
+                `roofline.valu` prices the dominant kernel against the VALU issue rate a sample-test-like instruction mix reaches
+                in this run on the same device (rr_device_microbench kind 2), which is what actually bounds it; the sweep over
+                instruction kinds and occupancies behind that choice is profiles/r04_valu_issue.txt.
   timed_steps / heavy_envs   which steps of the workload the timed region covered and how many envs were heavy / very heavy
                 (solved and rendered on the side streams) at its start and end: full-range random commands
                 press more and more arms onto the table, so the rate depends on the window
   secondary     (N=1 only) the same library on the other workloads a reader needs to judge the headline: the LATE window
                 (steps 2000-2200, SURVEY 8(d) config 3's horizon), half-range commands (round 1's headline), macro-action
                 pushing and a batched evaluate() (BASELINE config 5), BASELINE config 2 (1024 envs, 1 object, no render),
-                BASELINE config 1 (one env through real_robots.make(...).step, camera off / on, with the CPU oracle's
-                single-core rate beside it)
+                the reference's default 320x240 camera and the R1 shape (with mask) at 4096 envs, BASELINE config 1 (one env
+                through real_robots.make(...).step, camera off / on, with the CPU oracle's single-core rate beside it)
   cpu_baseline  PyBullet ("reference") when importable on this box, else the CPU oracle ("port"; oracle/ is the checker,
                 never the product), timed on the host cores on a bounded sample of the same workload
 """
@@ -288,7 +291,9 @@ def secondary_workloads(torch, np, nat, BatchedREALRobotEnv, device, steps):
     e1.close()
     out.append({"workload": "config 1: REALRobot2020-R2J1-v0, ONE env through real_robots.make(...).step (gym facade: rr_step + "
                             "observation read-back every step, 320x240 eye when the action asks for it)", **res,
-                "note": "single-env drop-in latency, host-bound (ctypes + D2H per step); the CPU oracle's single-core rate on the "
+                "note": "single-env drop-in latency: the step is one device-side latency chain (solve -> preparation -> collision pass, "
+                        "~85 us) plus the facade's host time; observations come back through mapped host mirrors with one wait per step "
+                        "(rr_map_observations / rr_sync_observations, DESIGN.md 5.3); the CPU oracle's single-core rate on the "
                         "same shape is cpu_baseline.config1_single_core"})
     return out
 

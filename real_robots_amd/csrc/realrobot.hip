@@ -1632,7 +1632,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     // contact cap is a fifth of its chain with 16 lanes); group 0 then sweeps, groups 1..3 run along as no-ops.  The wave has
     // one LDS region (the launch asks for a quarter of the LDS of the packed form: the same sixteen envs per CU).  Same
     // arithmetic per row whichever group builds it: results do not depend on the mode (tested bitwise).
-    const bool coop = GEN && sel >= 2 && coop_launch;
+    const bool coop = GEN && coop_launch && (sel >= 2 || sel == 0);    // (sel 0: every env its own wave -- batches of at most one wave per SIMD, rr_step)
     const int cg = coop ? (grp & 3) : 0;                              // this group's place among the builders of its env
     int env_raw = OW ? 16 * (int)blockIdx.x + grp : (coop ? unit : 4 * unit + (grp & 3));
     bool mine = true;                                                 // this 16-lane group has an env to solve in this launch
@@ -4088,6 +4088,7 @@ struct rr_env {
     hipEvent_t ev_obs;             // recorded behind the mirror's launches: rr_sync_observations waits for it alone
     bool ev_obs_set;
     void *img_host[3];             // rr_map_images: pinned host copies of RGB / depth / mask that every rendered step refreshes (or nullptr)
+    bool coop_all;                 // RR_COOP_ALL=0: the one-launch solve of a small batch four envs to a wave (A/B, tests)
     int force_hcount[2];           // RR_FORCE_HCOUNT="h,vh": what the host-side decisions read instead of the lagged counters (tests; -1: the counters)
     int n_shapes;
     float table_pos[3];            // target of the default eye camera (env.py:253-255)
@@ -4287,6 +4288,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->no_fused_setup = getenv("RR_NO_FUSED_SETUP") != nullptr;
     e->collide_ordered = !(getenv("RR_COLLIDE_ORDER") && atoi(getenv("RR_COLLIDE_ORDER")) == 0);
     e->force_hcount[0] = e->force_hcount[1] = -1;
+    e->coop_all = !(getenv("RR_COOP_ALL") && atoi(getenv("RR_COOP_ALL")) == 0) && getenv("RR_NO_COOP") == nullptr;
     e->obs_host = nullptr; memset(&e->obs_dev, 0, sizeof e->obs_dev);
     e->img_host[0] = e->img_host[1] = e->img_host[2] = nullptr;
     e->ev_obs = nullptr; e->ev_obs_set = false;
@@ -4730,6 +4732,7 @@ static int do_render(rr_env *e, bool use_flags) {
 
 // ---- look-ahead: the state part of the NEXT step (k_prep_a -> k_collide, k_prep_b beside them) ------------------------------
 // Per-class launches (sel: pick_env) cover N work items whatever the class.
+#define COOP_ALL_MAX 1024   // up to this many envs a step that solves all envs in one launch gives every env its own wave (RR_COOP_ALL=0: four to a wave)
 #define SMALL_N_MAX 64      // up to this many envs a step without the three-stream split runs as one chain on the main stream (rr_step)
 static void launch_prep_a(rr_env *e, int sel, int zero_counts, hipStream_t st) {
     hipLaunchKernelGGL(k_prep_a, env_grid(e), dim3(e->epb), 0, st, e->B, e->P, e->D, sel, zero_counts);
@@ -4953,7 +4956,11 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
         else hipLaunchKernelGGL(k_solve_light, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, (const RenderModel *)nullptr);
         launch_solve_class(e, 2, e->stream);
         launch_solve_class(e, 3, e->stream);
-    } else
+    } else if (e->coop_all && N <= COOP_ALL_MAX && e->split_heavy)
+        // (up to one wave per SIMD of the chip -- BASELINE config 2's 1024 envs: every env gets a wave of its own, whose four groups
+        // build its rows side by side; four envs to a wave is the form for batches that would not fit the machine otherwise)
+        TIMED(2, hipLaunchKernelGGL(k_solve, dim3((N + 3) / 4), dim3(256), lds64, e->stream, e->B, e->P, e->D, 0, 1));
+    else
         TIMED(2, hipLaunchKernelGGL(k_solve, dim3(ngroups), dim3(SGRP * 16), lds64, e->stream, e->B, e->P, e->D, 0, 0));
     HIPCHK(hipGetLastError());
     int rc = RR_OK;

@@ -322,3 +322,61 @@ def test_single_env_chain_is_bitwise_the_batched_step():
                 assert np.array_equal(a.host(nat.F_TOUCH)[0], tc[k]) and np.array_equal(a.contacts(0), con[k]), (k, t)
                 assert np.array_equal(a.host(nat.F_RGB)[0], rgb[k]) and np.array_equal(a.host(nat.F_DEPTH)[0], dep[k]), (k, t)
         a.close()
+
+
+def test_checkpoint_of_other_step_parameters_is_rejected(monkeypatch):
+    """A checkpoint continues bit for bit only in a handle that steps the same way: the header carries dt / ERP / margin / sweeps /
+    warm-start factor / object-lane capacity / inertia source / edge contacts, and a blob taken with other values is refused
+    (round 3 accepted it and diverged silently).  After a restore the published contact count follows the restored list and the
+    class diagnostic starts clean."""
+    a = BatchedREALRobotEnv(32, objects=3, width=64, height=64)
+    for t in range(80):
+        a.step(synthetic_actions(range(32), t, seed=3).astype(np.float32), render=False)
+    ck = a.checkpoint()
+    nc = a.host(nat.F_CONTACT_COUNT)
+    for kw, env_vars in (({'solver_iters': 20}, {}), ({'dt': 0.004}, {}), ({}, {'RR_NO_WARMSTART': '1'}), ({}, {'RR_SOLVER_POOL': '600'})):
+        b = _make(monkeypatch, env_vars, 32, objects=3, width=64, height=64, **kw)
+        with pytest.raises(nat.NativeError, match='other step parameters'):
+            b.restore(ck)
+        b.close()
+    c = BatchedREALRobotEnv(32, objects=3, width=64, height=64)
+    c.restore(ck)
+    assert np.array_equal(c.host(nat.F_CONTACT_COUNT), nc) and (c.host(nat.F_ENV_CLASS) == 0).all()
+    a.step(synthetic_actions(range(32), 80, seed=3).astype(np.float32), render=True)
+    c.step(synthetic_actions(range(32), 80, seed=3).astype(np.float32), render=True)
+    assert np.array_equal(a.state, c.state, equal_nan=True) and np.array_equal(a.host(nat.F_RGB), c.host(nat.F_RGB))
+    a.close()
+    c.close()
+
+
+def test_device_microbench_reports_plausible_ceilings():
+    """rr_device_microbench (bench.py's roofline): HBM copy / triad bandwidth and the VALU issue rate of a sample-test-like mix,
+    measured on the device.  Plausibility only: between a tenth of and the full spec figure (8 TB/s; 256 CU x 4 SIMD x 2.4 GHz / 2
+    cycles = 1 229 G wave-instr/s is the most any reading of the hardware allows)."""
+    r = nat.device_microbench(0)
+    assert 800.0 < r['hbm_copy_GBs'] < 8000.0 and 800.0 < r['hbm_triad_GBs'] < 8000.0, r
+    assert 300.0 < r['valu_mix_G_wave_instr_s'] < 1229.0, r
+
+
+def test_one_wave_per_env_solve_of_small_batches_is_bitwise_the_packed_form(monkeypatch):
+    """A step that solves all envs in one launch (no camera; config 2) gives every env a wave of its own up to 1024 envs -- its four
+    16-lane groups build the rows side by side (the coop form, until now only for the heavy lists) -- instead of four envs to a
+    wave (RR_COOP_ALL=0): bitwise the same states, contacts, touch sensors and classes over 260 full-range steps with resets, at a
+    batch size that is not a multiple of four; config 2 2.39 -> 2.61 M env-steps/s."""
+    N = 203
+    a = BatchedREALRobotEnv(N, objects=1, width=64, height=64)
+    b = _make(monkeypatch, {'RR_COOP_ALL': '0'}, N, objects=1, width=64, height=64)
+    rng = np.random.default_rng(5)
+    for t in range(260):
+        cmd = synthetic_actions(range(N), t, seed=8).astype(np.float32)
+        if t in (90, 180):
+            m = (rng.random(N) < 0.3).astype(np.uint8)
+            a.reset(m); b.reset(m)
+        a.step(cmd, render=False); b.step(cmd, render=False)
+        if t % 20 == 19:
+            assert np.array_equal(a.state, b.state, equal_nan=True), t
+            assert np.array_equal(a.host(nat.F_TOUCH), b.host(nat.F_TOUCH)) and np.array_equal(a.host(nat.F_CONTACT_COUNT), b.host(nat.F_CONTACT_COUNT)), t
+            assert np.array_equal(a.host(nat.F_ENV_CLASS), b.host(nat.F_ENV_CLASS)), t
+            assert all(np.array_equal(a.contacts(i), b.contacts(i)) for i in range(0, N, 17)), t
+    assert (a.host(nat.F_ENV_CLASS) > 0).any() and (a.host(nat.F_ERRFLAGS) == 0).all()
+    a.close(); b.close()
