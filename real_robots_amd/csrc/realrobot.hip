@@ -4833,7 +4833,9 @@ int rr_step(rr_env *e, const float *joint_cmd, int32_t cmd_on_device, int32_t re
     const bool mostly_heavy = (long long)lagged_count(e, 0, 0) * 100 > (long long)N * e->split_max_pct;
     const bool ahead = e->lookahead;            // this step ends with the state part of the next one
     // (a step without camera runs all envs in one launch: its classes side by side were measured -- config 2: 0.525 instead of 0.452 ms)
-    if (e->aux && !g_skip && render_mode && e->split_heavy && !mostly_heavy) {
+    // (ONE env -- the gym facade -- renders in its chain on the main stream too: solve -> set-up, visibility, shading -> mirror and
+    // image copies -> look-ahead; the three-stream split has nothing to overlap there and costs six events: 119 -> 95 us per step)
+    if (e->aux && !g_skip && render_mode && e->split_heavy && !mostly_heavy && !(N == 1 && !e->timing)) {
         // The few envs with generic contact rows take several times as long as the others (the kernel lasts as long
         // as its longest Gauss-Seidel chain).  They are solved and rendered on the side streams -- four groups per 256-thread
         // workgroup, so that they fill the LDS of a few CUs and leave the rest to the raster workgroups of the light envs --
