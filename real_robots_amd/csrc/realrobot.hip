@@ -1610,7 +1610,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         D.hcount_next[0] = 0; D.hcount_next[1] = 0; D.hcount2_next[0] = 0; D.hcount2_next[1] = 0;
     }
 #if LIGHT_OW_THREADS == 384
-    // wave roles O J J J - J: waves w and w + 4 of a workgroup land on the same SIMD (scratch/ubench/simd_map.hip), so the object
+    // wave roles O J J J - J: waves w and w + 4 of a workgroup land on the same SIMD (tools/ubench/simd_map.hip), so the object
     // wave has its SIMD to itself -- wave 4 only keeps the workgroup's barrier company and ends -- and two of the four group
     // waves share one (together as many issue slots as the object wave).  Object wave 53 -> 37 us (scratch/sprof_light.py), the
     // kernel 56.7 -> 54.3 us, the step 0.691 -> 0.685 ms.  (LIGHT_OW_THREADS 320: J J J J O, the object wave shares with a group wave.)
