@@ -3108,6 +3108,20 @@ struct STri { float sx[3], sy[3], sz[3], w[3]; };
 // v_fma_f32 round identically), everything else is compiled contraction-free.
 #define FMA3(a0, x0, a1, x1, a2, x2, c) __builtin_fmaf((a0), (x0), __builtin_fmaf((a1), (x1), __builtin_fmaf((a2), (x2), (c))))   // a0 x0 + (a1 x1 + (a2 x2 + c))
 #define PDIFF(a, b, c, d) __builtin_fmaf((a), (b), -((c) * (d)))                                                                  // a b - c d: one product, one fused step
+// Correctly rounded 1 / x for a normal x whose reciprocal is normal too (|x| within 2^-96 .. 2^96: clip w >= 0.1, signed areas
+// 1e-12 .. 1e12): the compiler's IEEE division expands to v_div_scale x 2, v_rcp, a Newton step, two residual corrections,
+// v_div_fmas, v_div_fixup -- eleven instructions; inside that range the scaling and the fix-up are the identity and what remains is
+// this sequence, operation for operation (so the bits are those of `1.0f / x` and of the oracle's division): eight instructions.
+__device__ __forceinline__ float recip_exact(float x) {
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e0 = __builtin_fmaf(-x, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float q0 = r1;                                   // numerator 1
+    const float e1 = __builtin_fmaf(-x, q0, 1.0f);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-x, q1, 1.0f);
+    return __builtin_fmaf(e2, r1, q1);
+}
 __device__ __forceinline__ bool project_tri(const float *mvp, const float *tp /*9 floats*/, int W, int H, STri &s) {
 #pragma clang fp contract(off)
 #pragma unroll
@@ -3118,7 +3132,7 @@ __device__ __forceinline__ bool project_tri(const float *mvp, const float *tp /*
         float cz = FMA3(mvp[8], vx, mvp[9], vy, mvp[10], vz, mvp[11]);
         float cw = FMA3(mvp[12], vx, mvp[13], vy, mvp[14], vz, mvp[15]);
         if (cw < 0.1f) return false;
-        float iw = 1.0f / cw;
+        float iw = recip_exact(cw);
         s.sx[k] = __builtin_fmaf(cx * iw, 0.5f * (float)W, 0.5f * (float)W);
         s.sy[k] = __builtin_fmaf(cy * iw, 0.5f * (float)H, 0.5f * (float)H);
         s.sz[k] = cz * iw;
@@ -3134,7 +3148,7 @@ __device__ __forceinline__ void project_vertex(const float *mvp, float vx, float
     const float cy = FMA3(mvp[4], vx, mvp[5], vy, mvp[6], vz, mvp[7]);
     const float cz = FMA3(mvp[8], vx, mvp[9], vy, mvp[10], vz, mvp[11]);
     const float cw = FMA3(mvp[12], vx, mvp[13], vy, mvp[14], vz, mvp[15]);
-    const float iw = 1.0f / cw;
+    const float iw = recip_exact(cw);                         // (a vertex behind the near plane is flagged below; its values are never used)
     sx = (cw < 0.1f) ? __int_as_float(0x7fc00000) : __builtin_fmaf(cx * iw, 0.5f * (float)W, 0.5f * (float)W);
     sy = __builtin_fmaf(cy * iw, 0.5f * (float)H, 0.5f * (float)H);
     sz = cz * iw;
@@ -3171,7 +3185,7 @@ __device__ __forceinline__ bool bary(const STri &s, float px, float py, float *b
     float x0 = s.sx[0], y0 = s.sy[0], x1 = s.sx[1], y1 = s.sy[1], x2 = s.sx[2], y2 = s.sy[2];
     float area = PDIFF(x1 - x0, y2 - y0, x2 - x0, y1 - y0);
     if (fabsf(area) < 1e-12f) return false;
-    float ia = 1.0f / area;
+    float ia = recip_exact(area);
     b[0] = PDIFF(x1 - px, y2 - py, x2 - px, y1 - py) * ia;
     b[1] = PDIFF(x2 - px, y0 - py, x0 - px, y2 - py) * ia;
     b[2] = 1.0f - b[0] - b[1];
@@ -3200,7 +3214,7 @@ __device__ __forceinline__ TriEdge tri_edge(const STri &s) {
     float area = PDIFF(s.sx[1] - s.sx[0], s.sy[2] - s.sy[0], s.sx[2] - s.sx[0], s.sy[1] - s.sy[0]);
     TriEdge e;
     e.ok = !(fabsf(area) < 1e-12f);
-    e.ia = 1.0f / area;
+    e.ia = recip_exact(area);                               // (|area| >= 1e-12 when ok; a degenerate triangle is not drawn and its value never used)
     return e;
 }
 __device__ __forceinline__ void raster_pixel_hoisted(const STri &s, float ia, int t, int px, int py, int H, int W, int row0,
@@ -3582,7 +3596,9 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
                     const float bia = lane_gather(ia, src);
                     const int sx0 = lane_gather_i(x0, src), sy0 = lane_gather_i(y0, src), sbw = lane_gather_i(bw, src);
                     const int idx = INLINE_PIX + w - lane_gather_i(pre, src);
-                    const int ry = (int)(((float)idx + 0.5f) / (float)sbw);      // exact for these small integers
+                    // row of point idx in a box sbw wide: (idx + 0.5) / sbw lies at least 0.5 / 64 from an integer, far more than the
+                    // error of the approximate reciprocal on these small integers (idx < 64 + INLINE_PIX, sbw <= 64)
+                    const int ry = (int)(((float)idx + 0.5f) * __builtin_amdgcn_rcpf((float)sbw));
                     if (valid) raster_pixel_hoisted(bs, bia, tb + src, sx0 + idx - ry * sbw, sy0 + ry, H, W, row0, vis);
                 }
             }
@@ -3775,11 +3791,20 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     __syncthreads();
     if (tid < MAXWIN / 32) RSTAT(11, __popc(win_bits[tid]));      // (slot 11 reused: clusters with at least one winning pixel)
 #endif
-    for (int i = tid; i < npix; i += NT_) {
-        const unsigned long long key = vis[i];
+    // (one LDS atomic per wave and trip -- ballot, popcount, v_mbcnt -- instead of one per listed pixel: ~300 same-address atomics
+    // per tile serialise in the LDS; the order of the list is immaterial)
+    for (int i0 = 0; i0 < npix; i0 += NT_) {
+        const int i = i0 + tid;
+        const unsigned long long key = i < npix ? vis[i] : ~0ull;
         const unsigned tri = key == VIS_WAS_DYNAMIC ? FRAG_VACATED : (unsigned)(key & 0xffffffffu);
-        if (key != ~0ull) {
-            const unsigned slot = atomicAdd(&nlist, 1u);
+        const bool has = key != ~0ull;
+        const unsigned long long hm = __ballot(has);
+        if (hm == 0ull) continue;                       // (wave-uniform)
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&nlist, (unsigned)__popcll(hm));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (has) {
+            const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
             lst[slot] = make_uint2((unsigned)(key >> 32), ((unsigned)i << 18) | tri);
         }
     }
