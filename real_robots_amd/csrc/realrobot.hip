@@ -3523,23 +3523,24 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             live = live && nnear == 0;
         }
         PH(1);                                      // loads, projection, corner gather
-        if (live) {
-            float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
-            float ymin = fminf(s.sy[0], fminf(s.sy[1], s.sy[2])), ymax = fmaxf(s.sy[0], fmaxf(s.sy[1], s.sy[2]));
-            live = !(xmax < 0 || ymax < ty0 || xmin > (float)(W - 1) || ymin > ty1);
-            // back faces of closed, consistently wound meshes can never win the depth test (opt-in, RR_CULL)
-            if (live && RM.in_cull[inst] && PDIFF(s.sx[1] - s.sx[0], s.sy[2] - s.sy[0], s.sx[2] - s.sx[0], s.sy[1] - s.sy[0]) <= 0.0f) live = false;
-            if (live) {
-                x0 = (int)ceilf(fmaxf(xmin, 0.0f)); x1 = (int)floorf(fminf(xmax, (float)(W - 1)));
-                y0 = (int)ceilf(fmaxf(ymin, ty0)); y1 = (int)floorf(fminf(ymax, ty1));
-                live = !(x1 < x0 || y1 < y0);
-            }
-            if (live) {
-                const TriEdge te = tri_edge(s);
-                live = te.ok;
-                ia = te.ia;
-                area = (x1 - x0 + 1) * (y1 - y0 + 1);
-            }
+        {
+            // Straight-line set-up for all 64 lanes (nested `if (live)` blocks save nothing in lock-step and cost exec-mask bookkeeping
+            // and re-initialisation on every path): box, clamps as one v_med3 each -- the visibility test in front of them
+            // guarantees xmax >= 0, xmin <= W - 1, ... so med3(x, lo, hi) is max(x, lo) resp. min(x, hi), the oracle's values --,
+            // signed area and its reciprocal; a lane that is not live ends with area 0.
+            const float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
+            const float ymin = fminf(s.sy[0], fminf(s.sy[1], s.sy[2])), ymax = fmaxf(s.sy[0], fmaxf(s.sy[1], s.sy[2]));
+            const float wm1 = (float)(W - 1);
+            bool on = live && !(xmax < 0 || ymax < ty0 || xmin > wm1 || ymin > ty1);
+            const TriEdge te = tri_edge(s);
+            // back faces of closed, consistently wound meshes can never win the depth test (opt-in, RR_CULL; wave-uniform per window)
+            if (RM.in_cull[inst]) on = on && !(PDIFF(s.sx[1] - s.sx[0], s.sy[2] - s.sy[0], s.sx[2] - s.sx[0], s.sy[1] - s.sy[0]) <= 0.0f);
+            x0 = (int)ceilf(__builtin_amdgcn_fmed3f(xmin, 0.0f, wm1)); x1 = (int)floorf(__builtin_amdgcn_fmed3f(xmax, 0.0f, wm1));
+            y0 = (int)ceilf(__builtin_amdgcn_fmed3f(ymin, ty0, ty1)); y1 = (int)floorf(__builtin_amdgcn_fmed3f(ymax, ty0, ty1));
+            on = on && !(x1 < x0 || y1 < y0) && te.ok;
+            ia = te.ia;
+            area = on ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
+            live = on;
         }
         PH(2);                                      // bounding box, set-up
         if (ABL(1)) continue;
@@ -3567,11 +3568,18 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             const bool small = live && !big;
             const int bw = x1 - x0 + 1;
             const int ninl = small ? min(area, INLINE_PIX) : 0;
+#if INLINE_PIX == 2
+            // (written out: the first point of the box, then its right neighbour -- or the point below it when the box is one
+            // column wide; a loop with a per-lane trip count pays for its bookkeeping in every iteration)
+            if (ninl > 0) raster_pixel_hoisted(s, ia, t, x0, y0, H, W, row0, vis);
+            if (ninl > 1) raster_pixel_hoisted(s, ia, t, bw > 1 ? x0 + 1 : x0, bw > 1 ? y0 : y0 + 1, H, W, row0, vis);
+#else
             int px = x0, py = y0;
             for (int i = 0; i < ninl; i++) {
                 raster_pixel_hoisted(s, ia, t, px, py, H, W, row0, vis);
                 if (++px > x1) { px = x0; py++; }
             }
+#endif
             PH(3);                                  // in-lane sample points
             const int rem = small ? area - ninl : 0;
             int total;
