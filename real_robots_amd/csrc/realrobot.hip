@@ -93,6 +93,7 @@ struct ShapeData {    // global memory, read uniformly
 struct RenderModel {
     int ni, nt, W, H, tile_h, ntiles, first_dynamic_tri;
     int in_otype[MAXINST], in_oidx[MAXINST], in_uid[MAXINST], in_tex[MAXINST], in_cull[MAXINST];
+    int any_cull;            // some in_cull is set (RR_CULL): the window loop looks the flag of its instance up only then
     float in_color[MAXINST][3];
     int tex_off[16], tex_w[16], tex_h[16];
     int link_body[NLINK_MAX];
@@ -3534,7 +3535,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             bool on = live && !(xmax < 0 || ymax < ty0 || xmin > wm1 || ymin > ty1);
             const TriEdge te = tri_edge(s);
             // back faces of closed, consistently wound meshes can never win the depth test (opt-in, RR_CULL; wave-uniform per window)
-            if (RM.in_cull[inst]) on = on && !(PDIFF(s.sx[1] - s.sx[0], s.sy[2] - s.sy[0], s.sx[2] - s.sx[0], s.sy[1] - s.sy[0]) <= 0.0f);
+            if (RM.any_cull && RM.in_cull[inst]) on = on && !(PDIFF(s.sx[1] - s.sx[0], s.sy[2] - s.sy[0], s.sx[2] - s.sx[0], s.sy[1] - s.sy[0]) <= 0.0f);
             x0 = (int)ceilf(__builtin_amdgcn_fmed3f(xmin, 0.0f, wm1)); x1 = (int)floorf(__builtin_amdgcn_fmed3f(xmax, 0.0f, wm1));
             y0 = (int)ceilf(__builtin_amdgcn_fmed3f(ymin, ty0, ty1)); y1 = (int)floorf(__builtin_amdgcn_fmed3f(ymax, ty0, ty1));
             on = on && !(x1 < x0 || y1 < y0) && te.ok;
@@ -4445,7 +4446,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     NEED(f = b.f32("inst_color", ni * 3)); memcpy(RM.in_color, f, (size_t)ni * 12);
     // Back-face culling of closed meshes is opt-in (RR_CULL=1): it is invisible unless the near plane cuts through a
     // mesh (then TinyRenderer shows the inside faces), so the default keeps exact parity with the two-sided oracle.
-    if (getenv("RR_CULL")) { NEED(ip = b.i32("inst_cull", ni)); memcpy(RM.in_cull, ip, (size_t)ni * 4); }
+    if (getenv("RR_CULL")) { NEED(ip = b.i32("inst_cull", ni)); memcpy(RM.in_cull, ip, (size_t)ni * 4); for (int i = 0; i < ni; i++) RM.any_cull |= ip[i] != 0; }
     NEED(ip = b.i32("tex_info", ntex * 3));
     for (int t = 0; t < ntex; t++) { RM.tex_off[t] = ip[3 * t]; RM.tex_w[t] = ip[3 * t + 1]; RM.tex_h[t] = ip[3 * t + 2]; }
     NEED(ip = b.i32("link_body", nl)); memcpy(RM.link_body, ip, nl * 4);
