@@ -93,6 +93,7 @@ struct ShapeData {    // global memory, read uniformly
 struct RenderModel {
     int ni, nt, W, H, tile_h, ntiles, first_dynamic_tri;
     int in_otype[MAXINST], in_oidx[MAXINST], in_uid[MAXINST], in_tex[MAXINST], in_cull[MAXINST];
+    unsigned w_magic;        // ceil(2^32 / W): row of a pixel-in-tile index = __umulhi(index, w_magic), exact for index < 2^20 and W <= 1024
     int any_cull;            // some in_cull is set (RR_CULL): the window loop looks the flag of its instance up only then
     float in_color[MAXINST][3];
     int tex_off[16], tex_w[16], tex_h[16];
@@ -3298,13 +3299,13 @@ __device__ __forceinline__ void shade_pixel(const ShadeCtx &c, const TriRec &tr,
         const float v0 = k0[1] - yn * k0[3], v1 = k1[1] - yn * k1[3], v2 = k2[1] - yn * k2[3];
         c0 = u1 * v2 - u2 * v1; c1 = u2 * v0 - u0 * v2; c2 = u0 * v1 - u1 * v0;
     }
-    float cs = 1.0f / (c0 + c1 + c2);
+    float cs = recip_exact(c0 + c1 + c2);              // (sum of the perspective weights: of the order of 1 / w, far inside the range)
     c0 *= cs; c1 *= cs; c2 *= cs;
     float n0 = c0 * nn[0] + c1 * nn[3] + c2 * nn[6], n1 = c0 * nn[1] + c1 * nn[4] + c2 * nn[7], n2 = c0 * nn[2] + c1 * nn[5] + c2 * nn[8];
     const float *xf = c.sinst + inst * 16;
     float w0 = xf[0] * n0 + xf[1] * n1 + xf[2] * n2, w1 = xf[3] * n0 + xf[4] * n1 + xf[5] * n2, w2 = xf[6] * n0 + xf[7] * n1 + xf[8] * n2;
     float nlen = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
-    if (nlen > 0) { const float inl = 1.0f / nlen; w0 *= inl; w1 *= inl; w2 *= inl; }
+    if (nlen > 0) { const float inl = recip_exact(nlen); w0 *= inl; w1 *= inl; w2 *= inl; }      // (a rotated unit normal: length ~1)
     float ndl = w0 * L0 + w1 * L1 + w2 * L2;
     float diff = fmaxf(ndl, 0.0f);
     float r0 = w0 * (2 * ndl) - L0, r1 = w1 * (2 * ndl) - L1, r2 = w2 * (2 * ndl) - L2;
@@ -3938,6 +3939,9 @@ __device__ __forceinline__ void shade_block(const RenderModel &RM, const DevPtrs
     if ((unsigned)z * NTHREADS >= n) return;                    // (workgroup-uniform)
     stage_instances(RM, D, env, threadIdx.x, NTHREADS, mvp, sinst);
     __syncthreads();
+#if defined(RR_SHADE_PROBE) && (RR_SHADE_PROBE & 8)
+    if (mvp[0][0] != 12345.678f) return;           // (probe: the prologue only -- count, instance constants, barrier)
+#endif
     ShadeCtx ctx;
     ctx.D = &D; ctx.mvp = &mvp[0][0]; ctx.sinst = &sinst[0][0]; ctx.W = RM.W; ctx.H = RM.H;
     const uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
@@ -3958,7 +3962,7 @@ __device__ __forceinline__ void shade_block(const RenderModel &RM, const DevPtrs
             if (out.mask) out.mask[o] = D.static_mask[so];
             continue;
         }
-        const int lrow = pi / RM.W, px = pi - lrow * RM.W;
+        const int lrow = (int)__umulhi((unsigned)pi, RM.w_magic), px = pi - lrow * RM.W;      // pi / W without the 20-instruction integer division
         unsigned char c3[3]; int m;
 #if defined(RR_SHADE_PROBE) && (RR_SHADE_PROBE & 4)
         shade_pixel(ctx, load_tri_rec(D, t & 63), px, row0 + lrow, c3, m);      // (probe: 64 records for everybody -- one cache line set)
@@ -4439,6 +4443,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     RM.ni = ni; RM.nt = nt; RM.W = cfg->width; RM.H = cfg->height; RM.nl = nl;
     RM.tile_h = TILE_PIX / RM.W; if (RM.tile_h > RM.H) RM.tile_h = RM.H;
     RM.ntiles = (RM.H + RM.tile_h - 1) / RM.tile_h;
+    RM.w_magic = (unsigned)((0x100000000ull + (unsigned long long)RM.W - 1) / (unsigned long long)RM.W);
     if (RM.W > 1024 || RM.H > 1024) { rr_destroy(e); return fail(RR_EINVAL, "rr_create: image larger than 1024 x 1024 (10-bit box origins in the rasteriser's records)"); }
     if (RM.ntiles > 255) { rr_destroy(e); return fail(RR_EINVAL, "rr_create: image too large (more than 255 raster tiles of 4096 pixels)"); }
     NEED(ip = b.i32("inst_owner", ni * 4));
