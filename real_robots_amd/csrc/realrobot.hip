@@ -163,7 +163,7 @@ struct DevPtrs {
     const int *tri_inst;    // [NT]
     const float4 *cluster_sphere; // [NT/64] bounding sphere (instance frame) of each 64-triangle raster cluster
     const float *cluster_verts;   // [NT/64][3][64] the cluster's distinct vertex positions (x row, y row, z row)
-    const int *tri_vidx;          // [NT] cluster-local vertex indices of the triangle's corners, v0 | v1 << 8 | v2 << 16
+    const int *tri_vidx;          // [NT] cluster-local vertex indices of the triangle's corners as ds_bpermute byte addresses: 4 v0 | 4 v1 << 8 | 4 v2 << 16
     const unsigned *tex;    // RGBX texels
     const ShapeData *shapes;
     const unsigned long long *static_vis;   // [H*W] visibility keys of the never-moving instances (or nullptr)
@@ -3234,6 +3234,20 @@ __device__ __forceinline__ void raster_pixel_hoisted(const STri &s, float ia, in
     atomicMin(&vis[(H - 1 - py - row0) * W + px], key);
 }
 
+// The same for a sample point given as floats (integer valued: exact) with its index in the tile's visibility buffer already known.
+__device__ __forceinline__ void raster_pixel_at(const STri &s, float ia, int t, float fx, float fy, int vidx, unsigned long long *vis) {
+#pragma clang fp contract(off)
+    const float b0 = PDIFF(s.sx[1] - fx, s.sy[2] - fy, s.sx[2] - fx, s.sy[1] - fy) * ia;
+    const float b1 = PDIFF(s.sx[2] - fx, s.sy[0] - fy, s.sx[0] - fx, s.sy[2] - fy) * ia;
+    const float b2 = 1.0f - b0 - b1;
+    if (!(b0 >= 0 && b1 >= 0 && b2 >= 0)) return;
+    const float z = __builtin_fmaf(b0, s.sz[0], __builtin_fmaf(b1, s.sz[1], b2 * s.sz[2]));
+    const float d = __builtin_fmaf(0.5f, z, 0.5f);
+    if (!(d >= 0.0f && d <= 1.0f)) return;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
+    atomicMin(&vis[vidx], key);
+}
+
 // Conservative test "can any sample point of the pixel rectangle [px0,px1]x[py0,py1] pass raster_pixel_hoisted's
 // inside test?".  Exact barycentrics are affine in (px, py), so their maximum over the rectangle is at a corner; the
 // float evaluation of raster_pixel_hoisted differs from the exact value by at most delta (see the caller), hence a
@@ -3393,7 +3407,7 @@ struct ImageOut { unsigned char *rgb; float *depth; int *mask; size_t env_stride
 // the tile's visibility buffer (file scope: the list-walking render kernels stage their shading constants in it once the
 // fragment list is out -- their workgroups then need no more LDS than a raster workgroup)
 __shared__ __attribute__((aligned(16))) unsigned long long g_vis[TILE_PIX];
-template <int NT_>
+template <int NT_, bool CARRY = true>
 __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderModel &RM, const DevPtrs &D, int n_inst_used, int pass, int env, int tile, int restore) {
     unsigned long long *vis = g_vis;
     __shared__ __attribute__((aligned(16))) float mvp[RASTER_INST][16];
@@ -3496,8 +3510,10 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             const int vi = D.tri_vidx[t];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const int src = (vi >> (8 * k)) & 63;
-                s.sx[k] = lane_gather(psx, src); s.sy[k] = lane_gather(psy, src); s.sz[k] = lane_gather(psz, src);
+                const int adr = (vi >> (8 * k)) & 255;               // (byte address of the owning lane: v_bfe_u32)
+                s.sx[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(adr, __float_as_int(psx)));
+                s.sy[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(adr, __float_as_int(psy)));
+                s.sz[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(adr, __float_as_int(psz)));
                 s.w[k] = 1.0f;
             }
 #if defined(RR_PROBE_BPERM) || defined(RR_PROBE_VALU) || defined(RR_PROBE_DSMIN)
@@ -3520,9 +3536,11 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
 #endif
             // corners nearer than the near plane (sx = NaN): none -> the ordinary paths below; all -> nothing to draw;
             // one or two -> the triangle is clipped against the plane by the whole wave (rare, see the end of the loop body)
-            const int nnear = (s.sx[0] != s.sx[0] ? 1 : 0) + (s.sx[1] != s.sx[1] ? 1 : 0) + (s.sx[2] != s.sx[2] ? 1 : 0);
-            needs_clip = live && nnear > 0 && nnear < 3;
-            live = live && nnear == 0;
+            // (a NaN among the three sx: their sum is NaN; all three: their minimum is NaN too -- v_min3 returns a number when it has one)
+            const float sxsum = s.sx[0] + s.sx[1] + s.sx[2], sxmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2]));
+            const bool any_near = sxsum != sxsum, all_near = sxmin != sxmin;
+            needs_clip = live && any_near && !all_near;
+            live = live && !any_near;
         }
         PH(1);                                      // loads, projection, corner gather
         {
@@ -3573,8 +3591,18 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
 #if INLINE_PIX == 2
             // (written out: the first point of the box, then its right neighbour -- or the point below it when the box is one
             // column wide; a loop with a per-lane trip count pays for its bookkeeping in every iteration)
-            if (ninl > 0) raster_pixel_hoisted(s, ia, t, x0, y0, H, W, row0, vis);
-            if (ninl > 1) raster_pixel_hoisted(s, ia, t, bw > 1 ? x0 + 1 : x0, bw > 1 ? y0 : y0 + 1, H, W, row0, vis);
+            if (!CARRY) {        // (the list-walking kernels: three registers fewer around their item loop)
+                if (ninl > 0) raster_pixel_hoisted(s, ia, t, x0, y0, H, W, row0, vis);
+                if (ninl > 1) raster_pixel_hoisted(s, ia, t, bw > 1 ? x0 + 1 : x0, bw > 1 ? y0 : y0 + 1, H, W, row0, vis);
+            } else {
+                // (coordinates as floats and the buffer index carried from the first point to the second: one conversion pair and
+                // one integer multiply per triangle instead of per point)
+                const float fx0 = (float)x0, fy0 = (float)y0;
+                const int vi0 = (H - 1 - y0 - row0) * W + x0;
+                const bool wide = bw > 1;
+                if (ninl > 0) raster_pixel_at(s, ia, t, fx0, fy0, vi0, vis);
+                if (ninl > 1) raster_pixel_at(s, ia, t, wide ? fx0 + 1.0f : fx0, wide ? fy0 : fy0 + 1.0f, wide ? vi0 + 1 : vi0 - W, vis);
+            }
 #else
             int px = x0, py = y0;
             for (int i = 0; i < ninl; i++) {
@@ -3687,7 +3715,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             const int cvi = D.tri_vidx[bt];
                 const float *cv = D.cluster_verts + (size_t)(tb >> 6) * 192;
             float c0[4], c1[4], c2[4];
-            { const int i0 = cvi & 63, i1 = (cvi >> 8) & 63, i2 = (cvi >> 16) & 63;
+            { const int i0 = (cvi & 255) >> 2, i1 = ((cvi >> 8) & 255) >> 2, i2 = ((cvi >> 16) & 255) >> 2;
               clip_vertex(mvp[inst], cv[i0], cv[64 + i0], cv[128 + i0], c0);
               clip_vertex(mvp[inst], cv[i1], cv[64 + i1], cv[128 + i1], c1);
               clip_vertex(mvp[inst], cv[i2], cv[64 + i2], cv[128 + i2], c2); }
@@ -3848,7 +3876,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_pe
         if (it >= nitems) break;
         const int tile = it % RM.ntiles, ge = it / RM.ntiles;
         const int env = hlist[ge];
-        if (env < P.N && !(D.render_flags && !D.render_flags[env])) raster_tile<RASTER_THREADS>(P, RM, D, n_inst_used, 0, env, tile, restore);
+        if (env < P.N && !(D.render_flags && !D.render_flags[env])) raster_tile<RASTER_THREADS, false>(P, RM, D, n_inst_used, 0, env, tile, restore);
         __syncthreads();        // the LDS of the tile is reused
     }
 }
@@ -4543,7 +4571,14 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
                 float *dcv; int *dtv;
                 ALLOC(dcv, (size_t)nt * 3); ALLOC(dtv, (size_t)nt);
                 hipMemcpy(dcv, cvs.data(), (size_t)nt * 12, hipMemcpyHostToDevice);
-                hipMemcpy(dtv, tv, (size_t)nt * 4, hipMemcpyHostToDevice);
+                // (the corner indices go to the device as ds_bpermute byte addresses, index x 4 in each byte: one bit-field extract per
+                // corner in the window loop instead of a shift and a mask)
+                std::vector<int32_t> tv4((size_t)nt);
+                for (int t_ = 0; t_ < nt; t_++) {
+                    const int a0 = tv[t_] & 63, a1 = (tv[t_] >> 8) & 63, a2 = (tv[t_] >> 16) & 63;
+                    tv4[t_] = (a0 << 2) | (a1 << 10) | (a2 << 18);
+                }
+                hipMemcpy(dtv, tv4.data(), (size_t)nt * 4, hipMemcpyHostToDevice);
                 D.cluster_verts = dcv; D.tri_vidx = dtv;
             }
             float4 *dcs;
