@@ -102,6 +102,8 @@ struct RenderModel {
     int nl;
     float VP[16];
     float plane_norm[5];     // |xyz| of the frustum planes w+x, w-x, w+y, w-y, w (near) -- invariant under the rigid model matrices
+    float tile_plane[256][4];  // per raster tile: NDC y of its first / last sample row and |xyz| of those two planes {ndc_a, nrm_a, ndc_b, nrm_b}
+                             // (host side, frustum_plane_norms: two square roots and twenty multiply-adds per WAVE of the visibility pass otherwise)
 };
 
 // scratch slots (floats per env), one record per env [N][S_TOTAL]
@@ -3445,11 +3447,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     const int lane = tid & 63, lx = lane & 7, ly = lane >> 3;
     const int nwin = (t_stop - t_begin + 63) >> 6;
     // tile bounds as two more planes of the cull (multi-tile images): NDC y of the tile's first and last sample rows
-    const float ndc_a = 2.0f * ty0 / (float)H - 1.0f, ndc_b = 2.0f * ty1 / (float)H - 1.0f;
-    const float nrm_a = sqrtf((RM.VP[4] - ndc_a * RM.VP[12]) * (RM.VP[4] - ndc_a * RM.VP[12]) + (RM.VP[5] - ndc_a * RM.VP[13]) * (RM.VP[5] - ndc_a * RM.VP[13]) +
-                              (RM.VP[6] - ndc_a * RM.VP[14]) * (RM.VP[6] - ndc_a * RM.VP[14]));
-    const float nrm_b = sqrtf((RM.VP[4] - ndc_b * RM.VP[12]) * (RM.VP[4] - ndc_b * RM.VP[12]) + (RM.VP[5] - ndc_b * RM.VP[13]) * (RM.VP[5] - ndc_b * RM.VP[13]) +
-                              (RM.VP[6] - ndc_b * RM.VP[14]) * (RM.VP[6] - ndc_b * RM.VP[14]));
+    const float ndc_a = RM.tile_plane[tile][0], nrm_a = RM.tile_plane[tile][1], ndc_b = RM.tile_plane[tile][2], nrm_b = RM.tile_plane[tile][3];
     const bool tiled = RM.ntiles > 1;
     // Incremental image update (do_render): the env's image in HBM still holds its previous frame.  The pixels of that
     // frame's fragment list are marked in the (still empty) visibility buffer with a key above every real one; those that
@@ -4241,6 +4239,16 @@ static void frustum_plane_norms(RenderModel &RM) {
         RM.plane_norm[k] = sqrtf(a * a + b * b + c * c);
     }
     RM.plane_norm[4] = sqrtf(V[12] * V[12] + V[13] * V[13] + V[14] * V[14]);
+    // the two tile-boundary planes of every raster tile (conservative cull of a cluster against the tile's sample rows)
+    for (int tile = 0; tile < RM.ntiles && tile < 256; tile++) {
+        const int row0 = tile * RM.tile_h, rows = std::min(RM.tile_h, RM.H - row0);
+        const float ty0 = (float)(RM.H - 1 - (row0 + rows - 1)), ty1 = (float)(RM.H - 1 - row0);
+        for (int k = 0; k < 2; k++) {
+            const float ndc = 2.0f * (k ? ty1 : ty0) / (float)RM.H - 1.0f;
+            const float a = V[4] - ndc * V[12], b = V[5] - ndc * V[13], c = V[6] - ndc * V[14];
+            RM.tile_plane[tile][2 * k] = ndc; RM.tile_plane[tile][2 * k + 1] = sqrtf(a * a + b * b + c * c);
+        }
+    }
 }
 
 extern "C" {
