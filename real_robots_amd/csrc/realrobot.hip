@@ -92,8 +92,9 @@ struct ShapeData {    // global memory, read uniformly
 
 struct RenderModel {
     int ni, nt, W, H, tile_h, ntiles, first_dynamic_tri;
+    int tile_w, ntx;         // raster tiles are tile_w x tile_h pixels, ntx of them across: full-width strips up to 128 columns, 64 x 64 squares above (rr_create)
     int in_otype[MAXINST], in_oidx[MAXINST], in_uid[MAXINST], in_tex[MAXINST], in_cull[MAXINST];
-    unsigned w_magic;        // ceil(2^32 / W): row of a pixel-in-tile index = __umulhi(index, w_magic), exact for index < 2^20 and W <= 1024
+    unsigned w_magic;        // ceil(2^32 / tile_w): row of a pixel-in-tile index = __umulhi(index, w_magic), exact for index < 2^20 and tile_w <= 1024
     int any_cull;            // some in_cull is set (RR_CULL): the window loop looks the flag of its instance up only then
     float in_color[MAXINST][3];
     int tex_off[16], tex_w[16], tex_h[16];
@@ -102,7 +103,7 @@ struct RenderModel {
     int nl;
     float VP[16];
     float plane_norm[5];     // |xyz| of the frustum planes w+x, w-x, w+y, w-y, w (near) -- invariant under the rigid model matrices
-    float tile_plane[256][4];  // per raster tile: NDC y of its first / last sample row and |xyz| of those two planes {ndc_a, nrm_a, ndc_b, nrm_b}
+    float tile_plane[256][8];  // per raster tile: NDC y of its first / last sample row and |xyz| of those two planes {ndc_a, nrm_a, ndc_b, nrm_b}, then the same for its first / last sample column
                              // (host side, frustum_plane_norms: two square roots and twenty multiply-adds per WAVE of the visibility pass otherwise)
 };
 
@@ -3221,8 +3222,8 @@ __device__ __forceinline__ TriEdge tri_edge(const STri &s) {
     e.ia = recip_exact(area);                               // (|area| >= 1e-12 when ok; a degenerate triangle is not drawn and its value never used)
     return e;
 }
-__device__ __forceinline__ void raster_pixel_hoisted(const STri &s, float ia, int t, int px, int py, int H, int W, int row0,
-                                                     unsigned long long *vis) {
+__device__ __forceinline__ void raster_pixel_hoisted(const STri &s, float ia, int t, int px, int py, int H, int W /* row stride of the tile's buffer */, int row0,
+                                                     unsigned long long *vis, int xoff = 0 /* first column of the tile */) {
 #pragma clang fp contract(off)
     const float fx = (float)px, fy = (float)py;
     const float b0 = PDIFF(s.sx[1] - fx, s.sy[2] - fy, s.sx[2] - fx, s.sy[1] - fy) * ia;
@@ -3233,7 +3234,7 @@ __device__ __forceinline__ void raster_pixel_hoisted(const STri &s, float ia, in
     const float d = __builtin_fmaf(0.5f, z, 0.5f);
     if (!(d >= 0.0f && d <= 1.0f)) return;
     const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
-    atomicMin(&vis[(H - 1 - py - row0) * W + px], key);
+    atomicMin(&vis[(H - 1 - py - row0) * W + px - xoff], key);
 }
 
 // The same for a sample point given as floats (integer valued: exact) with its index in the tile's visibility buffer already known.
@@ -3419,9 +3420,11 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     __shared__ unsigned short clipq[CLIPQ];             // triangles that cross the near plane (rare), clipped after the window loop: position in wlist << 6 | lane
     __shared__ unsigned nclipq;
     const int W = RM.W, H = RM.H;
-    const int row0 = tile * RM.tile_h;
-    const int rows = min(RM.tile_h, H - row0);
-    const int npix = rows * W;
+    // the tile: rows [row0, row0 + rows) x columns [tx0i, tx0i + cols); its visibility buffer has TW pixels per row
+    const int TW = RM.tile_w, tyi = tile / RM.ntx, tx0i = (tile - tyi * RM.ntx) * TW;
+    const int row0 = tyi * RM.tile_h;
+    const int rows = min(RM.tile_h, H - row0), cols = min(TW, W - tx0i);
+    const int npix = rows * TW;
     const int tid = threadIdx.x;
     const bool layered = (pass == 0) && (D.static_vis != nullptr);
     // (incremental image update, see below: this thread's entry of the previous frame's list is fetched first -- its
@@ -3437,6 +3440,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     __syncthreads();
     // tile bounds in screen y (py = H-1-row)
     const float ty0 = (float)(H - 1 - (row0 + rows - 1)), ty1 = (float)(H - 1 - row0);
+    const float txlo = (float)tx0i, txhi = (float)(tx0i + cols - 1);      // ... and in screen x
     const int NT = RM.nt;
     const int t_begin = layered ? RM.first_dynamic_tri : 0;
     const int t_end = (pass == 1) ? RM.first_dynamic_tri : NT;
@@ -3448,6 +3452,8 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     const int nwin = (t_stop - t_begin + 63) >> 6;
     // tile bounds as two more planes of the cull (multi-tile images): NDC y of the tile's first and last sample rows
     const float ndc_a = RM.tile_plane[tile][0], nrm_a = RM.tile_plane[tile][1], ndc_b = RM.tile_plane[tile][2], nrm_b = RM.tile_plane[tile][3];
+    const float ndx_a = RM.tile_plane[tile][4], nrx_a = RM.tile_plane[tile][5], ndx_b = RM.tile_plane[tile][6], nrx_b = RM.tile_plane[tile][7];
+    const bool xtiled = RM.ntx > 1;
     const bool tiled = RM.ntiles > 1;
     // Incremental image update (do_render): the env's image in HBM still holds its previous frame.  The pixels of that
     // frame's fragment list are marked in the (still empty) visibility buffer with a key above every real one; those that
@@ -3469,7 +3475,8 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
         const float r = cs.w * 1.001f + 1e-4f;      // conservative
         const bool out = (cw + cx) < -r * RM.plane_norm[0] || (cw - cx) < -r * RM.plane_norm[1] || (cw + cy) < -r * RM.plane_norm[2] ||
                          (cw - cy) < -r * RM.plane_norm[3] || (cw - 0.1f) < -r * RM.plane_norm[4] ||
-                         (tiled && ((ndc_a * cw - cy) > r * nrm_a * 1.001f + 1e-4f * cw || (cy - ndc_b * cw) > r * nrm_b * 1.001f + 1e-4f * cw));
+                         (tiled && ((ndc_a * cw - cy) > r * nrm_a * 1.001f + 1e-4f * cw || (cy - ndc_b * cw) > r * nrm_b * 1.001f + 1e-4f * cw)) ||
+                         (xtiled && ((ndx_a * cw - cx) > r * nrx_a * 1.001f + 1e-4f * cw || (cx - ndx_b * cw) > r * nrx_b * 1.001f + 1e-4f * cw));
         RSTAT(0, 1);                                // windows
         if (!out && inst < n_inst_used) wlist[atomicAdd(&wcount, 1u)] = (unsigned short)wi;
     }
@@ -3544,16 +3551,16 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
         {
             // Straight-line set-up for all 64 lanes (nested `if (live)` blocks save nothing in lock-step and cost exec-mask bookkeeping
             // and re-initialisation on every path): box, clamps as one v_med3 each -- the visibility test in front of them
-            // guarantees xmax >= 0, xmin <= W - 1, ... so med3(x, lo, hi) is max(x, lo) resp. min(x, hi), the oracle's values --,
+            // guarantees xmax >= the tile's first column, xmin <= its last, ... so med3(x, lo, hi) is max(x, lo) resp. min(x, hi): the
+            // oracle's box clipped to the tile --,
             // signed area and its reciprocal; a lane that is not live ends with area 0.
             const float xmin = fminf(s.sx[0], fminf(s.sx[1], s.sx[2])), xmax = fmaxf(s.sx[0], fmaxf(s.sx[1], s.sx[2]));
             const float ymin = fminf(s.sy[0], fminf(s.sy[1], s.sy[2])), ymax = fmaxf(s.sy[0], fmaxf(s.sy[1], s.sy[2]));
-            const float wm1 = (float)(W - 1);
-            bool on = live && !(xmax < 0 || ymax < ty0 || xmin > wm1 || ymin > ty1);
+            bool on = live && !(xmax < txlo || ymax < ty0 || xmin > txhi || ymin > ty1);
             const TriEdge te = tri_edge(s);
             // back faces of closed, consistently wound meshes can never win the depth test (opt-in, RR_CULL; wave-uniform per window)
             if (RM.any_cull && RM.in_cull[inst]) on = on && !(PDIFF(s.sx[1] - s.sx[0], s.sy[2] - s.sy[0], s.sx[2] - s.sx[0], s.sy[1] - s.sy[0]) <= 0.0f);
-            x0 = (int)ceilf(__builtin_amdgcn_fmed3f(xmin, 0.0f, wm1)); x1 = (int)floorf(__builtin_amdgcn_fmed3f(xmax, 0.0f, wm1));
+            x0 = (int)ceilf(__builtin_amdgcn_fmed3f(xmin, txlo, txhi)); x1 = (int)floorf(__builtin_amdgcn_fmed3f(xmax, txlo, txhi));
             y0 = (int)ceilf(__builtin_amdgcn_fmed3f(ymin, ty0, ty1)); y1 = (int)floorf(__builtin_amdgcn_fmed3f(ymax, ty0, ty1));
             on = on && !(x1 < x0 || y1 < y0) && te.ok;
             ia = te.ia;
@@ -3590,21 +3597,21 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             // (written out: the first point of the box, then its right neighbour -- or the point below it when the box is one
             // column wide; a loop with a per-lane trip count pays for its bookkeeping in every iteration)
             if (!CARRY) {        // (the list-walking kernels: three registers fewer around their item loop)
-                if (ninl > 0) raster_pixel_hoisted(s, ia, t, x0, y0, H, W, row0, vis);
-                if (ninl > 1) raster_pixel_hoisted(s, ia, t, bw > 1 ? x0 + 1 : x0, bw > 1 ? y0 : y0 + 1, H, W, row0, vis);
+                if (ninl > 0) raster_pixel_hoisted(s, ia, t, x0, y0, H, TW, row0, vis, tx0i);
+                if (ninl > 1) raster_pixel_hoisted(s, ia, t, bw > 1 ? x0 + 1 : x0, bw > 1 ? y0 : y0 + 1, H, TW, row0, vis, tx0i);
             } else {
                 // (coordinates as floats and the buffer index carried from the first point to the second: one conversion pair and
                 // one integer multiply per triangle instead of per point)
                 const float fx0 = (float)x0, fy0 = (float)y0;
-                const int vi0 = (H - 1 - y0 - row0) * W + x0;
+                const int vi0 = (H - 1 - y0 - row0) * TW + x0 - tx0i;
                 const bool wide = bw > 1;
                 if (ninl > 0) raster_pixel_at(s, ia, t, fx0, fy0, vi0, vis);
-                if (ninl > 1) raster_pixel_at(s, ia, t, wide ? fx0 + 1.0f : fx0, wide ? fy0 : fy0 + 1.0f, wide ? vi0 + 1 : vi0 - W, vis);
+                if (ninl > 1) raster_pixel_at(s, ia, t, wide ? fx0 + 1.0f : fx0, wide ? fy0 : fy0 + 1.0f, wide ? vi0 + 1 : vi0 - TW, vis);
             }
 #else
             int px = x0, py = y0;
             for (int i = 0; i < ninl; i++) {
-                raster_pixel_hoisted(s, ia, t, px, py, H, W, row0, vis);
+                raster_pixel_hoisted(s, ia, t, px, py, H, TW, row0, vis, tx0i);
                 if (++px > x1) { px = x0; py++; }
             }
 #endif
@@ -3635,7 +3642,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
                     // row of point idx in a box sbw wide: (idx + 0.5) / sbw lies at least 0.5 / 64 from an integer, far more than the
                     // error of the approximate reciprocal on these small integers (idx < 64 + INLINE_PIX, sbw <= 64)
                     const int ry = (int)(((float)idx + 0.5f) * __builtin_amdgcn_rcpf((float)sbw));
-                    if (valid) raster_pixel_hoisted(bs, bia, tb + src, sx0 + idx - ry * sbw, sy0 + ry, H, W, row0, vis);
+                    if (valid) raster_pixel_hoisted(bs, bia, tb + src, sx0 + idx - ry * sbw, sy0 + ry, H, TW, row0, vis, tx0i);
                 }
             }
             PH(5);                                  // redistribution rounds
@@ -3661,7 +3668,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
                 for (int by = 0; by < bh; by += 8)
                     for (int bx = 0; bx < bw; bx += 8) {
                         const int ox = bx + lx, oy = by + ly;
-                        if (ox < bw && oy < bh) raster_pixel_hoisted(bs, bia, bt, bx0 + ox, by0 + oy, H, W, row0, vis);
+                        if (ox < bw && oy < bh) raster_pixel_hoisted(bs, bia, bt, bx0 + ox, by0 + oy, H, TW, row0, vis, tx0i);
                     }
                 continue;
             }
@@ -3690,7 +3697,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
                     const int byi = (int)(((float)j + 0.5f) * inbx), bxi = j - byi * nbx;
                     const int ox = 8 * bxi + lx, oy = 8 * byi + ly;
                     if (lane == 0) RSTAT(9, 1);     // 8x8 blocks rasterised by the hierarchical path
-                    if (ox < bw && oy < bh) raster_pixel_hoisted(bs, bia, bt, bx0 + ox, by0 + oy, H, W, row0, vis);
+                    if (ox < bw && oy < bh) raster_pixel_hoisted(bs, bia, bt, bx0 + ox, by0 + oy, H, TW, row0, vis, tx0i);
                 }
             }
         }
@@ -3750,8 +3757,8 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             // clipped bounding box and reciprocal area: the same arithmetic as the per-lane set-up above
             const float xmin = fminf(bs.sx[0], fminf(bs.sx[1], bs.sx[2])), xmax = fmaxf(bs.sx[0], fmaxf(bs.sx[1], bs.sx[2]));
             const float ymin = fminf(bs.sy[0], fminf(bs.sy[1], bs.sy[2])), ymax = fmaxf(bs.sy[0], fmaxf(bs.sy[1], bs.sy[2]));
-            if (xmax < 0 || ymax < ty0 || xmin > (float)(W - 1) || ymin > ty1) continue;
-            const int bx0 = (int)ceilf(fmaxf(xmin, 0.0f)), bx1 = (int)floorf(fminf(xmax, (float)(W - 1)));
+            if (xmax < txlo || ymax < ty0 || xmin > txhi || ymin > ty1) continue;
+            const int bx0 = (int)ceilf(fmaxf(xmin, txlo)), bx1 = (int)floorf(fminf(xmax, txhi));
             const int by0 = (int)ceilf(fmaxf(ymin, ty0)), by1 = (int)floorf(fminf(ymax, ty1));
             if (bx1 < bx0 || by1 < by0) continue;
             const TriEdge te = tri_edge(bs);
@@ -3763,7 +3770,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
                 for (int by = 0; by < bh; by += 8)
                     for (int bx = 0; bx < bw; bx += 8) {
                         const int ox = bx + lx, oy = by + ly;
-                        if (ox < bw && oy < bh) raster_pixel_hoisted(bs, bia, bt, bx0 + ox, by0 + oy, H, W, row0, vis);
+                        if (ox < bw && oy < bh) raster_pixel_hoisted(bs, bia, bt, bx0 + ox, by0 + oy, H, TW, row0, vis, tx0i);
                     }
                 continue;
             }
@@ -3792,7 +3799,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
                     const int byi = (int)(((float)j + 0.5f) * inbx), bxi = j - byi * nbx;
                     const int ox = 8 * bxi + lx, oy = 8 * byi + ly;
                     if (lane == 0) RSTAT(9, 1);     // 8x8 blocks rasterised by the hierarchical path
-                    if (ox < bw && oy < bh) raster_pixel_hoisted(bs, bia, bt, bx0 + ox, by0 + oy, H, W, row0, vis);
+                    if (ox < bw && oy < bh) raster_pixel_hoisted(bs, bia, bt, bx0 + ox, by0 + oy, H, TW, row0, vis, tx0i);
                 }
             }
         }
@@ -3809,8 +3816,8 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     }
 #endif
     if (pass == 1) {   // publish the static layer's keys
-        unsigned long long *sv = D.static_vis_out + (size_t)row0 * W;
-        for (int i = tid; i < npix; i += NT_) sv[i] = vis[i];
+        unsigned long long *sv = D.static_vis_out + (size_t)row0 * W + tx0i;
+        for (int i = tid; i < npix; i += NT_) { const int lr = i / TW, lx = i - lr * TW; if (lx < cols) sv[(size_t)lr * W + lx] = vis[i]; }
     }
     // ---- compaction: pixels owned by a triangle rasterised in this pass go to the fragment list of this (env, tile)
     // (the comparison with the static layer's key is left to k_shade: a dependent global read at the tail of this
@@ -3857,11 +3864,14 @@ __global__ void __launch_bounds__(RASTER_THREADS) RASTER_ATTR k_raster(SimParams
     raster_tile<RASTER_THREADS>(P, *RMp, D, n_inst_used, pass, env, tile, restore);
 }
 
+#ifndef LIST_WAVES
+#define LIST_WAVES 5         // (6: 80 VGPRs, three workgroups per CU, but 12 bytes of scratch since the tiles have a column range; 5: 96 VGPRs, two per CU)
+#endif
 #define RASTER_LIST_WGS 768      // three per CU: the item loop around the tile needs more than the 64 VGPRs of four (a long list of heavy
                                  // envs must not be rendered at a fraction of the occupancy)
 // The heavy envs (D.hlist, D.hcount -- known on the device only): a fixed number of workgroups walk the
 // list, so that no LDS-filling workgroup is launched just to find that its env is not on it.
-__global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) k_raster_list(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int restore, int which) {
+__global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_per_eu(LIST_WAVES, 8))) k_raster_list(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int restore, int which) {
     const RenderModel &RM = *RMp;
     int *hcount = which ? D.hcount2 : D.hcount;
     const int *hlist = which ? D.hlist2 : D.hlist;
@@ -3912,7 +3922,10 @@ __global__ void __launch_bounds__(RESTORE_THREADS) k_restore(const RenderModel *
     if (use_flags && D.render_flags && !D.render_flags[env]) return;
     const unsigned n = D.frag_count[(size_t)env * RM.ntiles + tile];          // still the previous frame's count
     const uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
-    const size_t sbase = (size_t)tile * RM.tile_h * RM.W, base = (size_t)env * out.env_stride + sbase;
+    const int tyi_ = tile / RM.ntx, row0_ = tyi_ * RM.tile_h, tx0_ = (tile - tyi_ * RM.ntx) * RM.tile_w;
+    const size_t ebase = (size_t)env * out.env_stride;
+    // (pixel-in-tile index -> pixel of the image)
+#define RESTORE_GP(PI) ((size_t)(row0_ + (int)__umulhi((unsigned)(PI), RM.w_magic)) * RM.W + (size_t)(tx0_ + (int)(PI) - (int)__umulhi((unsigned)(PI), RM.w_magic) * RM.tile_w))
     // four fragments per thread and trip, every load of the trip issued before the first store (the kernel is a chain of
     // dependent round trips: list entry -> static pixel -> store)
     for (unsigned i0 = 0; i0 < n; i0 += 4 * RESTORE_THREADS) {
@@ -3922,7 +3935,7 @@ __global__ void __launch_bounds__(RESTORE_THREADS) k_restore(const RenderModel *
         unsigned char r[4][3]; float d[4]; int m[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const size_t so = sbase + (pi[k] != 0xffffffffu ? pi[k] : 0u);
+            const size_t so = RESTORE_GP(pi[k] != 0xffffffffu ? pi[k] : 0u);
             r[k][0] = D.static_rgb[so * 3]; r[k][1] = D.static_rgb[so * 3 + 1]; r[k][2] = D.static_rgb[so * 3 + 2];
             d[k] = D.static_depth[so];
             m[k] = out.mask ? D.static_mask[so] : 0;
@@ -3930,12 +3943,13 @@ __global__ void __launch_bounds__(RESTORE_THREADS) k_restore(const RenderModel *
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (pi[k] == 0xffffffffu) continue;
-            const size_t o = base + pi[k];
+            const size_t o = ebase + RESTORE_GP(pi[k]);
             out.rgb[o * 3] = r[k][0]; out.rgb[o * 3 + 1] = r[k][1]; out.rgb[o * 3 + 2] = r[k][2];
             out.depth[o] = d[k];
             if (out.mask) out.mask[o] = m[k];
         }
     }
+#undef RESTORE_GP
 }
 
 __global__ void k_background(const RenderModel *RMp, DevPtrs D) {
@@ -3971,31 +3985,33 @@ __device__ __forceinline__ void shade_block(const RenderModel &RM, const DevPtrs
     ShadeCtx ctx;
     ctx.D = &D; ctx.mvp = &mvp[0][0]; ctx.sinst = &sinst[0][0]; ctx.W = RM.W; ctx.H = RM.H;
     const uint2 *lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
-    const int row0 = tile * RM.tile_h;
-    const size_t base = (size_t)env * out.env_stride + (size_t)row0 * RM.W;
-    const unsigned long long *sv = D.static_vis ? D.static_vis + (size_t)row0 * RM.W : nullptr;   // null while the static layer itself is built
+    const int tyi = tile / RM.ntx, row0 = tyi * RM.tile_h, tx0i = (tile - tyi * RM.ntx) * RM.tile_w;
+    const size_t ebase = (size_t)env * out.env_stride;
+    const unsigned long long *sv = D.static_vis;                 // null while the static layer itself is built
     for (unsigned i = z * NTHREADS + threadIdx.x; i < n; i += nz * NTHREADS) {
         const uint2 f = lst[i];
         const int pi = (int)(f.y >> 18), t = (int)(f.y & 0x3ffffu);
+        // pixel-in-tile index -> row and column of the image (tile_w pixels per buffer row; multiply-high instead of a division)
+        const int lrow = (int)__umulhi((unsigned)pi, RM.w_magic), px = tx0i + pi - lrow * RM.tile_w;
+        const size_t gp = (size_t)(row0 + lrow) * RM.W + (size_t)px;        // pixel of the image / of the static layer
         // a moving triangle only shows where it beats the static layer (depth, then triangle id; static ids are lower);
         // where it does not, and where the previous frame's fragment has gone, the pixel goes back to the static layer
         // (the image persists in HBM from frame to frame, do_render)
-        if (t == (int)FRAG_VACATED || (sv && !((((unsigned long long)f.x << 32) | (unsigned)t) < sv[pi]))) {
+        if (t == (int)FRAG_VACATED || (sv && !((((unsigned long long)f.x << 32) | (unsigned)t) < sv[gp]))) {
             // (vacated entries only exist in env frames; with RR_NO_STATIC_LAYER the static buffers hold the background)
-            const size_t so = (size_t)row0 * RM.W + (size_t)pi, o = base + (size_t)pi;
+            const size_t so = gp, o = ebase + gp;
             out.rgb[o * 3] = D.static_rgb[so * 3]; out.rgb[o * 3 + 1] = D.static_rgb[so * 3 + 1]; out.rgb[o * 3 + 2] = D.static_rgb[so * 3 + 2];
             out.depth[o] = D.static_depth[so];
             if (out.mask) out.mask[o] = D.static_mask[so];
             continue;
         }
-        const int lrow = (int)__umulhi((unsigned)pi, RM.w_magic), px = pi - lrow * RM.W;      // pi / W without the 20-instruction integer division
         unsigned char c3[3]; int m;
 #if defined(RR_SHADE_PROBE) && (RR_SHADE_PROBE & 4)
         shade_pixel(ctx, load_tri_rec(D, t & 63), px, row0 + lrow, c3, m);      // (probe: 64 records for everybody -- one cache line set)
 #else
         shade_pixel(ctx, load_tri_rec(D, t), px, row0 + lrow, c3, m);
 #endif
-        const size_t o = base + (size_t)pi;
+        const size_t o = ebase + gp;
 #if defined(RR_SHADE_PROBE) && (RR_SHADE_PROBE & 1)
         if (c3[0] == 1 && c3[1] == 2 && c3[2] == 3 && m == 12345) out.depth[o] = 0.0f;      // (probe: no image stores)
 #else
@@ -4241,12 +4257,17 @@ static void frustum_plane_norms(RenderModel &RM) {
     RM.plane_norm[4] = sqrtf(V[12] * V[12] + V[13] * V[13] + V[14] * V[14]);
     // the two tile-boundary planes of every raster tile (conservative cull of a cluster against the tile's sample rows)
     for (int tile = 0; tile < RM.ntiles && tile < 256; tile++) {
-        const int row0 = tile * RM.tile_h, rows = std::min(RM.tile_h, RM.H - row0);
+        const int tyi = tile / RM.ntx, tx0 = (tile - tyi * RM.ntx) * RM.tile_w, cols = std::min(RM.tile_w, RM.W - tx0);
+        const int row0 = tyi * RM.tile_h, rows = std::min(RM.tile_h, RM.H - row0);
         const float ty0 = (float)(RM.H - 1 - (row0 + rows - 1)), ty1 = (float)(RM.H - 1 - row0);
         for (int k = 0; k < 2; k++) {
             const float ndc = 2.0f * (k ? ty1 : ty0) / (float)RM.H - 1.0f;
             const float a = V[4] - ndc * V[12], b = V[5] - ndc * V[13], c = V[6] - ndc * V[14];
             RM.tile_plane[tile][2 * k] = ndc; RM.tile_plane[tile][2 * k + 1] = sqrtf(a * a + b * b + c * c);
+            // (sample column px sits at NDC x = 2 px / W - 1: the viewport maps (x + 1) W / 2)
+            const float ndx = 2.0f * (float)(k ? tx0 + cols - 1 : tx0) / (float)RM.W - 1.0f;
+            const float ax = V[0] - ndx * V[12], bx = V[1] - ndx * V[13], cx = V[2] - ndx * V[14];
+            RM.tile_plane[tile][4 + 2 * k] = ndx; RM.tile_plane[tile][5 + 2 * k] = sqrtf(ax * ax + bx * bx + cx * cx);
         }
     }
 }
@@ -4477,9 +4498,15 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     // render model
     RenderModel &RM = e->RM;
     RM.ni = ni; RM.nt = nt; RM.W = cfg->width; RM.H = cfg->height; RM.nl = nl;
-    RM.tile_h = TILE_PIX / RM.W; if (RM.tile_h > RM.H) RM.tile_h = RM.H;
-    RM.ntiles = (RM.H + RM.tile_h - 1) / RM.tile_h;
-    RM.w_magic = (unsigned)((0x100000000ull + (unsigned long long)RM.W - 1) / (unsigned long long)RM.W);
+    // Raster tiles of <= TILE_PIX pixels: full-width strips up to 128 columns (the 128 x 128 benchmark camera: four strips of 32
+    // rows); 64 x 64 squares for wider images -- a cluster of the arm is ~25 pixels across at 320 x 240 and met three of the
+    // 12-row strips a full-width tile would be there (set-up work x 3.1; squares: x 1.9).  RR_TILE_W overrides (A/B, tests).
+    RM.tile_w = RM.W <= 128 ? RM.W : 64;
+    if (getenv("RR_TILE_W")) { const int tw_ = atoi(getenv("RR_TILE_W")); if (tw_ >= 4 && tw_ <= RM.W && tw_ <= TILE_PIX) RM.tile_w = tw_; }
+    RM.ntx = (RM.W + RM.tile_w - 1) / RM.tile_w;
+    RM.tile_h = TILE_PIX / RM.tile_w; if (RM.tile_h > RM.H) RM.tile_h = RM.H;
+    RM.ntiles = RM.ntx * ((RM.H + RM.tile_h - 1) / RM.tile_h);
+    RM.w_magic = (unsigned)((0x100000000ull + (unsigned long long)RM.tile_w - 1) / (unsigned long long)RM.tile_w);
     if (RM.W > 1024 || RM.H > 1024) { rr_destroy(e); return fail(RR_EINVAL, "rr_create: image larger than 1024 x 1024 (10-bit box origins in the rasteriser's records)"); }
     if (RM.ntiles > 255) { rr_destroy(e); return fail(RR_EINVAL, "rr_create: image too large (more than 255 raster tiles of 4096 pixels)"); }
     NEED(ip = b.i32("inst_owner", ni * 4));
