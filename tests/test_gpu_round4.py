@@ -380,3 +380,27 @@ def test_one_wave_per_env_solve_of_small_batches_is_bitwise_the_packed_form(monk
             assert all(np.array_equal(a.contacts(i), b.contacts(i)) for i in range(0, N, 17)), t
     assert (a.host(nat.F_ENV_CLASS) > 0).any() and (a.host(nat.F_ERRFLAGS) == 0).all()
     a.close(); b.close()
+
+
+def test_raster_tile_shape_does_not_change_an_image(monkeypatch):
+    """Images wider than 128 columns are rasterised in 64 x 64 tiles (a cluster met three of the 12-row strips a full-width tile is
+    at 320 x 240), narrower ones in full-width strips; RR_TILE_W forces a shape.  The tile shape decides which workgroup owns a
+    pixel, never its value: RGB, depth and mask bitwise equal for squares, strips and two odd shapes at 320 x 240 (a partial last
+    column of tiles at 48 and 100) and at 128 x 128, over 40 steps with per-env render flags (incremental image update)."""
+    for (w, h, shapes) in ((320, 240, ('320', '48', '100')), (128, 128, ('64', '32'))):
+        ref = BatchedREALRobotEnv(24, objects=3, width=w, height=h)
+        others = [_make(monkeypatch, {'RR_TILE_W': tw}, 24, objects=3, width=w, height=h) for tw in shapes]
+        rng = np.random.default_rng(w)
+        for t in range(40):
+            cmd = synthetic_actions(range(24), t, seed=2).astype(np.float32)
+            flags = (rng.random(24) < 0.7).astype(np.uint8)
+            for e in [ref] + others:
+                e.step(cmd, render=(flags if t % 3 else True))
+            if t % 5 == 4:
+                a = (ref.host(nat.F_RGB), ref.host(nat.F_DEPTH), ref.host(nat.F_MASK))
+                for tw, e in zip(shapes, others):
+                    b = (e.host(nat.F_RGB), e.host(nat.F_DEPTH), e.host(nat.F_MASK))
+                    assert all(np.array_equal(x, y) for x, y in zip(a, b)), (w, tw, t)
+        assert (ref.host(nat.F_ERRFLAGS) == 0).all()
+        for e in [ref] + others:
+            e.close()
