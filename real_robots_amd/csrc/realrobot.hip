@@ -94,6 +94,7 @@ struct RenderModel {
     int ni, nt, W, H, tile_h, ntiles, first_dynamic_tri;
     int tile_w, ntx;         // raster tiles are tile_w x tile_h pixels, ntx of them across: full-width strips up to 128 columns, 64 x 64 squares above (rr_create)
     int in_otype[MAXINST], in_oidx[MAXINST], in_uid[MAXINST], in_tex[MAXINST], in_cull[MAXINST];
+    int tile_xbits;          // bits of a column within a tile (2^tile_xbits >= tile_w); a row within a tile then fits 14 - tile_xbits bits (tile_w * tile_h <= 4096)
     unsigned w_magic;        // ceil(2^32 / tile_w): row of a pixel-in-tile index = __umulhi(index, w_magic), exact for index < 2^20 and tile_w <= 1024
     int any_cull;            // some in_cull is set (RR_CULL): the window loop looks the flag of its instance up only then
     float in_color[MAXINST][3];
@@ -174,6 +175,9 @@ struct DevPtrs {
     unsigned char *static_rgb; float *static_depth; int *static_mask;   // [H*W] shaded static layer (shared by all envs)
     uint2 *frag_list;       // [N*ntiles][TILE_PIX] pixels won by moving triangles: {depth bits, pixel-in-tile << 18 | triangle}
     unsigned *frag_count;   // [N*ntiles]
+    // dispatch order of k_raster's workgroups (raster_order_class): the (env, tile) items by falling cost of the previous frame
+    unsigned *item_cost;        // [N*ntiles] duration of the item's workgroup in the last frame that rasterised it (100 MHz ticks)
+    const unsigned *item_perm;  // [N*ntiles] env << 8 | tile, costly items first; nullptr: env-major grid (envs, tiles)
 };
 
 // Which envs a launch handles: 0 all; 1 the light envs; 2 the heavy ones; 3 the very heavy ones (rr_step runs the few heavy
@@ -3390,16 +3394,47 @@ extern "C" int rr_debug_raster_phase(unsigned long long *out16, int reset) {
     if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_rphase_wg), h, sizeof(h)) != hipSuccess) return -1; }
     return 0;
 }
+// workgroup timeline of k_raster (RR_ABLATE=16384; scratch/rwgtime.py): start / end on the 100 MHz clock and the hardware slot
+// (HW_ID, XCC_ID) of every workgroup of the last launch -- how full the four workgroup slots of a CU are kept
+__device__ unsigned long long g_rwg_time[65536][3];
+extern "C" int rr_debug_raster_wgtime(unsigned long long *out /*[65536][3]*/, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rwg_time), sizeof(g_rwg_time)) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[65536][3]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rwg_time), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+// ... and marks inside a workgroup (thread 0, 100 MHz clock): 0 kernel entry, 1 selection flags there, 2 LDS filled + instances staged,
+// 3 clusters culled, 4 window loop done, 5 near-plane pass done, 6 list written
+__device__ unsigned long long g_rwg_marks[65536][8];
+#define WGM(i) do { if ((P.ablate & 0x4000) && threadIdx.x == 0) g_rwg_marks[(env * RM.ntiles + tile) & 65535][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int rr_debug_raster_wgmarks(unsigned long long *out /*[65536][8]*/) {
+    return (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rwg_marks), sizeof(g_rwg_marks)) == hipSuccess) ? 0 : -1;
+}
 // phase ablations of k_raster for the time breakdown in DESIGN.md (RR_ABLATE bits: 1 no rasterisation after projection,
 // 2 no wave-cooperative path, 8 no triangles at all); compiled out of the shipped library
 #define ABL(bit) (P.ablate & (bit))
 #else
 #define RSTAT(i, v)
+#define WGM(i)
 #define ABL(bit) false
 #define PH_DECL
 #define PH(i)
 #define PH_FLUSH
 #endif
+
+// The cluster cull (k_cull and raster_tile, same arithmetic): clip-space centre of the cluster's bounding sphere against the five
+// frustum planes, then against the planes of a tile's first / last sample row and column (RM.tile_plane), radius enlarged -- conservative.
+struct ClusterClip { float cx, cy, cw, r; };
+__device__ __forceinline__ bool cluster_outside_frustum(const RenderModel &RM, const float *m, const float4 cs, ClusterClip &c) {
+    c.cx = m[0] * cs.x + m[1] * cs.y + m[2] * cs.z + m[3]; c.cy = m[4] * cs.x + m[5] * cs.y + m[6] * cs.z + m[7];
+    c.cw = m[12] * cs.x + m[13] * cs.y + m[14] * cs.z + m[15];
+    c.r = cs.w * 1.001f + 1e-4f;
+    return (c.cw + c.cx) < -c.r * RM.plane_norm[0] || (c.cw - c.cx) < -c.r * RM.plane_norm[1] || (c.cw + c.cy) < -c.r * RM.plane_norm[2] ||
+           (c.cw - c.cy) < -c.r * RM.plane_norm[3] || (c.cw - 0.1f) < -c.r * RM.plane_norm[4];
+}
+__device__ __forceinline__ bool cluster_outside_tile(const ClusterClip &c, const float *tp /*RM.tile_plane[tile]*/, bool tiled, bool xtiled) {
+    return (tiled && ((tp[0] * c.cw - c.cy) > c.r * tp[1] * 1.001f + 1e-4f * c.cw || (c.cy - tp[2] * c.cw) > c.r * tp[3] * 1.001f + 1e-4f * c.cw)) ||
+           (xtiled && ((tp[4] * c.cw - c.cx) > c.r * tp[5] * 1.001f + 1e-4f * c.cw || (c.cx - tp[6] * c.cw) > c.r * tp[7] * 1.001f + 1e-4f * c.cw));
+}
 
 // Visibility pass of one (env, tile).  pass 0 = per-env frame: starts from the static layer's keys when D.static_vis !=
 // nullptr and rasterises only the triangles of moving instances; pass 1 = static layer (instances that never move: table,
@@ -3410,8 +3445,10 @@ struct ImageOut { unsigned char *rgb; float *depth; int *mask; size_t env_stride
 // the tile's visibility buffer (file scope: the list-walking render kernels stage their shading constants in it once the
 // fragment list is out -- their workgroups then need no more LDS than a raster workgroup)
 __shared__ __attribute__((aligned(16))) unsigned long long g_vis[TILE_PIX];
-template <int NT_, bool CARRY = true>
-__device__ __forceinline__ void raster_tile(const SimParams &P, const RenderModel &RM, const DevPtrs &D, int n_inst_used, int pass, int env, int tile, int restore) {
+// PRE: the caller has fetched this thread's two words of the previous frame's list (count, first entry) beside its own loads.
+template <int NT_, bool CARRY = true, bool LOOPED = false, bool PRE = false>
+__device__ __forceinline__ void raster_tile(const SimParams &P, const RenderModel &RM, const DevPtrs &D, int n_inst_used, int pass, int env, int tile, int restore,
+                                            unsigned n_old_pre = 0u, unsigned en_first_pre = 0u) {
     unsigned long long *vis = g_vis;
     __shared__ __attribute__((aligned(16))) float mvp[RASTER_INST][16];
     __shared__ unsigned nlist, wcount, wnext;
@@ -3425,19 +3462,35 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     const int row0 = tyi * RM.tile_h;
     const int rows = min(RM.tile_h, H - row0), cols = min(TW, W - tx0i);
     const int npix = rows * TW;
-    const int tid = threadIdx.x;
+    // (k_raster's instance -- PRE -- leaves the duration of the workgroup for the next frame's dispatch order, raster_order_class; the
+    // start time waits in LDS: scalar registers held across the whole pass were spilled)
+    __shared__ unsigned s_tc0;
+    if (PRE && threadIdx.x == 0) s_tc0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+    int tid_ = threadIdx.x;
+    if (LOOPED) asm volatile("" : "+v"(tid_));      // (inside an item loop: nothing derived from the thread index is kept live across items)
+    const int tid = tid_;
     const bool layered = (pass == 0) && (D.static_vis != nullptr);
     // (incremental image update, see below: this thread's entry of the previous frame's list is fetched first -- its
     // round trip hides behind the LDS fill and the instance staging)
-    const unsigned n_old = restore ? D.frag_count[(size_t)env * RM.ntiles + tile] : 0u;
+    // (a workgroup of an empty tile is nothing but a chain of round trips to memory -- 5 us, and two thirds of the tiles of the
+    // benchmark camera are nearly empty, scratch/rwgtime.py: every load whose address is known is issued before the first wait)
+    const unsigned n_old = restore ? (PRE ? n_old_pre : D.frag_count[(size_t)env * RM.ntiles + tile]) : 0u;
     const uint2 *old_lst = D.frag_list + ((size_t)env * RM.ntiles + tile) * TILE_PIX;
-    const unsigned en_first = (unsigned)tid < n_old ? old_lst[tid].y : 0xffffffffu;
+    const unsigned en_first = (unsigned)tid < n_old ? (PRE ? en_first_pre : old_lst[tid].y) : 0xffffffffu;
+    // the cull's inputs of this thread's cluster (one cluster per thread: MAXWIN <= NT_), fetched ahead of the LDS fill and the barrier
+    const int t_begin_ = ((pass == 0) && (D.static_vis != nullptr)) ? RM.first_dynamic_tri : 0;
+    const int nwin_ = ((ABL(8) ? 0 : ((pass == 1) ? RM.first_dynamic_tri : RM.nt)) - t_begin_ + 63) >> 6;
+    const bool cull_mine = tid < nwin_;
+    const int cull_tb = min(t_begin_ + (min(tid, max(nwin_ - 1, 0)) << 6), RM.nt - 64);      // (clamped: the loads are unconditional, straight-line code)
+    const int cull_inst = D.tri_inst[cull_tb];
+    const float4 cull_cs = D.cluster_sphere[cull_tb >> 6];
     // The tile starts empty (an LDS-only fill); the static layer's keys are compared at compaction time and only for the
     // few pixels a moving triangle reached (min is associative) -- no 128 KB read of the static keys per env.
     for (int i = tid; i < npix; i += NT_) vis[i] = ~0ull;
     if (tid == 0) { nlist = 0; wcount = 0; wnext = 0; nclipq = 0; }
     stage_instances(RM, D, env, tid, NT_, mvp, nullptr);
     __syncthreads();
+    WGM(2);
     // tile bounds in screen y (py = H-1-row)
     const float ty0 = (float)(H - 1 - (row0 + rows - 1)), ty1 = (float)(H - 1 - row0);
     const float txlo = (float)tx0i, txhi = (float)(tx0i + cols - 1);      // ... and in screen x
@@ -3465,27 +3518,31 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             if ((en & 0x3ffffu) != FRAG_VACATED) vis[en >> 18] = VIS_WAS_DYNAMIC;     // (a vacated entry was put back last time)
         }
     }
-    for (int wi = tid; wi < nwin; wi += NT_) {
-        const int tb = t_begin + (wi << 6);
-        const int inst = D.tri_inst[tb];
-        const float4 cs = D.cluster_sphere[tb >> 6];
-        const float *m = mvp[inst];
-        const float cx = m[0] * cs.x + m[1] * cs.y + m[2] * cs.z + m[3], cy = m[4] * cs.x + m[5] * cs.y + m[6] * cs.z + m[7];
-        const float cw = m[12] * cs.x + m[13] * cs.y + m[14] * cs.z + m[15];
-        const float r = cs.w * 1.001f + 1e-4f;      // conservative
-        const bool out = (cw + cx) < -r * RM.plane_norm[0] || (cw - cx) < -r * RM.plane_norm[1] || (cw + cy) < -r * RM.plane_norm[2] ||
-                         (cw - cy) < -r * RM.plane_norm[3] || (cw - 0.1f) < -r * RM.plane_norm[4] ||
-                         (tiled && ((ndc_a * cw - cy) > r * nrm_a * 1.001f + 1e-4f * cw || (cy - ndc_b * cw) > r * nrm_b * 1.001f + 1e-4f * cw)) ||
-                         (xtiled && ((ndx_a * cw - cx) > r * nrx_a * 1.001f + 1e-4f * cw || (cx - ndx_b * cw) > r * nrx_b * 1.001f + 1e-4f * cw));
+    static_assert(MAXWIN <= NT_, "one cluster per thread in the cull");
+    if (cull_mine) {
+        const int wi = tid;
+        int inst = cull_inst;
+        float4 cs = cull_cs;
+        asm("" : "+v"(inst), "+v"(cs.x), "+v"(cs.y), "+v"(cs.z), "+v"(cs.w));      // (nothing computed from them ahead of the barrier: the wait for the two loads stays down here)
+        ClusterClip cc;
+        const bool out = cluster_outside_frustum(RM, mvp[inst], cs, cc) || cluster_outside_tile(cc, RM.tile_plane[tile], tiled, xtiled);
         RSTAT(0, 1);                                // windows
         if (!out && inst < n_inst_used) wlist[atomicAdd(&wcount, 1u)] = (unsigned short)wi;
     }
     __syncthreads();
+    WGM(3);
     // Every wave takes 64 consecutive triangles per window.  A triangle whose clipped bounding box holds <= small_area
     // sample points is rasterised by its own lane; bigger ones are handed to the whole wave (ballot, v_readlane broadcast
     // of the projected triangle, 64 sample points per step in 8x8 blocks) so that one large triangle does not make 63
     // lanes wait.
     const unsigned nw = wcount;
+    // Nothing reaches this tile and nothing was drawn in it last time (more than half of the lower tiles of the benchmark camera):
+    // its list stays empty -- no window loop, no near-plane pass, no compaction of an untouched buffer (3 of the 6.6 us such a
+    // workgroup lasts, scratch/rwgtime.py)
+    if (pass == 0 && nw == 0 && n_old == 0) {
+        if (tid == 0) { D.frag_count[(size_t)env * RM.ntiles + tile] = 0; RSTAT(13, 1); if (PRE && D.item_cost) D.item_cost[(size_t)env * RM.ntiles + tile] = (unsigned)__builtin_amdgcn_s_memrealtime() - s_tc0 + 1u; }
+        return;
+    }
 #ifdef RR_RASTER_STATS
     const unsigned long long t_loop0_ = __builtin_readcyclecounter();
 #endif
@@ -3623,6 +3680,12 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
             if (total > 0) {
                 unsigned short *we = wends[tid >> 6];
                 we[lane] = (unsigned short)(pre + rem);                                // inclusive ends, non-decreasing over the lanes
+                // (box origin relative to the tile, box width and the lane's first point number in one word: one ds_bpermute per round
+                // instead of four -- an LDS permute costs the CU six cycles, three times a 4-byte LDS read (tools/ubench/valu_issue.hip).
+                // 14 bits of origin: column in tile_xbits, row above it -- a tile has <= 4096 pixels --; 6 of width - 1: a small box is at
+                // most 64 wide; 12 of point number: at most 64 x 62 left-over points)
+                const int ty0i = H - row0 - rows, xb = RM.tile_xbits;                  // (screen y of the tile's lowest row)
+                const int packed = (x0 - tx0i) | ((y0 - ty0i) << xb) | ((bw - 1) << 14) | (pre << 20);
                 for (int w0 = 0; w0 < total; w0 += 64) {             // wave-uniform trip count: ds_bpermute needs the owner lanes active
                     const int w = w0 + lane;
                     const bool valid = w < total;
@@ -3637,8 +3700,9 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
                         bs.w[k] = 1.0f;
                     }
                     const float bia = lane_gather(ia, src);
-                    const int sx0 = lane_gather_i(x0, src), sy0 = lane_gather_i(y0, src), sbw = lane_gather_i(bw, src);
-                    const int idx = INLINE_PIX + w - lane_gather_i(pre, src);
+                    const int pk = lane_gather_i(packed, src);
+                    const int sx0 = (pk & ((1 << xb) - 1)) + tx0i, sy0 = ((pk & 0x3fff) >> xb) + ty0i, sbw = ((pk >> 14) & 63) + 1;
+                    const int idx = INLINE_PIX + w - (int)((unsigned)pk >> 20);
                     // row of point idx in a box sbw wide: (idx + 0.5) / sbw lies at least 0.5 / 64 from an integer, far more than the
                     // error of the approximate reciprocal on these small integers (idx < 64 + INLINE_PIX, sbw <= 64)
                     const int ry = (int)(((float)idx + 0.5f) * __builtin_amdgcn_rcpf((float)sbw));
@@ -3710,6 +3774,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     // clip_near()) into a triangle or a fan of two, which a whole wave rasterises under the original triangle id
     __syncthreads();
     PH(8);
+    WGM(4);
     for (unsigned qi = tid >> 6; qi < min(nclipq, (unsigned)CLIPQ); qi += NT_ / 64) {
         const int bt = t_begin + ((int)wlist[clipq[qi] >> 6] << 6) + (clipq[qi] & 63);
         const int tb = bt & ~63;
@@ -3806,6 +3871,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     }
     PH(9);                                          // near-plane pass
     PH_FLUSH;
+    WGM(5);
 #ifdef RR_RASTER_STATS
     const unsigned long long t_exit_ = __builtin_readcyclecounter();
 #endif
@@ -3853,19 +3919,108 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     }
     __syncthreads();
     if (tid == 0 && nclipq > CLIPQ) atomicOr(&D.errflags[env], 4u);      // (clip queue overflow: triangles were dropped -- never expected)
+    WGM(6);
+    if (PRE && pass == 0 && tid == 0 && D.item_cost) D.item_cost[(size_t)env * RM.ntiles + tile] = (unsigned)__builtin_amdgcn_s_memrealtime() - s_tc0 + 1u;      // (100 MHz ticks)
     if (tid == 0) { D.frag_count[(size_t)env * RM.ntiles + tile] = nlist; RSTAT(12, nlist); RSTAT(13, 1); RSTAT(14, nclipq); RSTAT(15, nclipq > 0 ? 1 : 0); }
 }
 
 // One workgroup per (env, tile); sel (env_selected): all envs, or only those of light solver groups.
+// Grid (envs, tiles) -- or, with D.item_perm (pass 0), one dimension of envs * tiles workgroups that take the items in the order of
+// raster_order_class: the hardware deals workgroups out by their linear index -- XCD = index mod 8, shader engine = (index / 8) mod 4,
+// strictly in turn: a shader engine whose four slots per CU are taken holds up its XCD's queue -- so the index order decides how evenly
+// the 32 engines are loaded (scratch/rwgtime.py, scratch/rorder.py: env order 0.708 of the slots busy, cost order 0.842).
 __global__ void __launch_bounds__(RASTER_THREADS) RASTER_ATTR k_raster(SimParams P, const RenderModel *RMp, DevPtrs D, int n_inst_used, int pass, int env0, int restore, int sel) {
-    const int env = blockIdx.x + env0, tile = blockIdx.y;
-    if (pass == 0 && D.render_flags && !D.render_flags[env]) return;
-    if (!env_selected(D.hgflag, env, sel)) return;
-    raster_tile<RASTER_THREADS>(P, *RMp, D, n_inst_used, pass, env, tile, restore);
+    int env, tile;
+    if (pass == 0 && D.item_perm) { const unsigned it = D.item_perm[blockIdx.x]; if (it == 0xffffffffu) return; env = (int)(it >> 8); tile = (int)(it & 255u); }
+    else { env = blockIdx.x + env0; tile = blockIdx.y; }
+#ifdef RR_RASTER_STATS
+    { const RenderModel &RM = *RMp; WGM(0); }
+#endif
+    // (the two selection flags and this thread's words of the previous frame's list in ONE round trip, then the branches)
+    const size_t item = (size_t)env * RMp->ntiles + tile;
+    const bool flagged = pass == 0 && D.render_flags != nullptr;
+    const unsigned char rflag = (flagged ? D.render_flags : (const unsigned char *)D.hgflag)[env];
+    const int cls = D.hgflag[env];
+    const unsigned n_old_pre = D.frag_count[item];
+    const unsigned en_first_pre = D.frag_list[item * TILE_PIX + threadIdx.x].y;
+    // (one branch on all four: none of the loads can be moved behind it.  The last term is never true -- N > 0 --, whatever the
+    // two words hold)
+    const int selected = (int)(sel == 0) | ((int)(sel == 1) & (int)(cls == 0)) | ((int)(sel == 2) & (int)(cls == 1)) | ((int)(sel == 3) & (int)(cls == 2));
+    if (((int)flagged & (int)(rflag == 0)) | (selected ^ 1) | ((int)(P.N < 0) & ((int)(n_old_pre > 0x7fffffffu) | (int)((en_first_pre >> 30) == 2u)))) return;
+#ifdef RR_RASTER_STATS
+    unsigned long long wt0_ = 0;
+    if (P.ablate & 0x4000) wt0_ = __builtin_amdgcn_s_memrealtime();
+    { const RenderModel &RM = *RMp; WGM(1); }
+#endif
+    raster_tile<RASTER_THREADS, true, false, true>(P, *RMp, D, n_inst_used, pass, env, tile, restore, n_old_pre, en_first_pre);
+#ifdef RR_RASTER_STATS
+    if ((P.ablate & 0x4000) && threadIdx.x == 0) {
+        unsigned long long *g = g_rwg_time[(env * RMp->ntiles + tile) & 65535];
+        g[0] = wt0_; g[1] = __builtin_amdgcn_s_memrealtime();
+        g[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);
+    }
+#endif
 }
 
+// Dispatch order of the next frame's k_raster: the (env, tile) items by falling cost (counting sort over 1024 linear bins of the
+// durations k_raster has just measured), by a few extra workgroups of the k_shade launch that follows it (a stream of its own was
+// measured: a fifth stream shares a hardware queue with one of the step's four and serialises it, 0.67 -> 0.83 ms).  One class per
+// XCD: workgroup index mod 8 is the XCD, and an env stays on the XCD it has in the env-major grids (env mod 8) -- k_shade's
+// workgroups read the fragment lists from the L2 of the XCD that wrote them (dispatched without regard to that: k_shade 0.097 ->
+// 0.155 ms).  perm[8 * j + x] = the j-th costliest item of the envs = x (mod 8), env << 8 | tile, or ~0 behind the last one.
+// Costs change little from frame to frame (5 ms of motion); an order that is off only loads the shader engines less evenly, the
+// images do not depend on it.
+#define ORDER_BINS 1024
+template <int NT_>
+__device__ __forceinline__ void raster_order_class(int x, int N, int ntiles, int per_class, const unsigned *cost, unsigned *perm) {
+    static_assert(ORDER_BINS % NT_ == 0 && NT_ % 64 == 0 && NT_ <= 1024, "bins per thread");
+    constexpr int BPT = ORDER_BINS / NT_;
+    __shared__ unsigned hist[ORDER_BINS];
+    __shared__ unsigned s_max, wtot[NT_ / 64];
+    const int tid = threadIdx.x;
+    const int n_items = x < N ? ntiles * ((N - x + 7) >> 3) : 0;          // items of this class: envs x, x + 8, ...
+    __syncthreads();                                                       // (a workgroup may take several classes in turn)
+    if (tid == 0) s_max = 1u;
+    for (int b = tid; b < ORDER_BINS; b += NT_) hist[b] = 0u;
+    __syncthreads();
+#define ORDER_ITEM(k) ((size_t)(x + 8 * ((k) / ntiles)) * ntiles + (size_t)((k) % ntiles))
+#define ORDER_BIN(c) (ORDER_BINS - 1 - min((unsigned)((float)(c) * scale), (unsigned)(ORDER_BINS - 1)))      /* bin 0 = the costliest items */
+    unsigned mx = 0u;
+    for (int k = tid; k < n_items; k += NT_) mx = max(mx, cost[ORDER_ITEM(k)]);
+    for (int o = 32; o; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    if ((tid & 63) == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    const float scale = (float)(ORDER_BINS - 1) / (float)s_max;
+    for (int k = tid; k < n_items; k += NT_) atomicAdd(&hist[ORDER_BIN(cost[ORDER_ITEM(k)])], 1u);
+    __syncthreads();
+    // exclusive prefix over the bins: BPT consecutive bins per thread, wave scan of the threads' sums, the waves' totals
+    unsigned hb[BPT], sum = 0u;
+#pragma unroll
+    for (int j = 0; j < BPT; j++) { hb[j] = hist[tid * BPT + j]; sum += hb[j]; }
+    unsigned inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned v = (unsigned)__shfl_up((int)inc, o); if ((tid & 63) >= o) inc += v; }
+    if ((tid & 63) == 63) wtot[tid >> 6] = inc;
+    __syncthreads();
+    unsigned base = inc - sum;
+    for (int w = 0; w < (tid >> 6); w++) base += wtot[w];
+#pragma unroll
+    for (int j = 0; j < BPT; j++) { hist[tid * BPT + j] = base; base += hb[j]; }
+    __syncthreads();
+    for (int k = tid; k < n_items; k += NT_) {
+        const size_t i = ORDER_ITEM(k);
+        const unsigned pos = atomicAdd(&hist[ORDER_BIN(cost[i])], 1u);
+        perm[(size_t)8 * pos + x] = ((unsigned)(i / ntiles) << 8) | (unsigned)(i % ntiles);
+    }
+    for (int k = n_items + tid; k < per_class; k += NT_) perm[(size_t)8 * k + x] = 0xffffffffu;
+#undef ORDER_ITEM
+#undef ORDER_BIN
+}
+
+#ifndef LIST_CARRY
+#define LIST_CARRY false
+#endif
 #ifndef LIST_WAVES
-#define LIST_WAVES 5         // (6: 80 VGPRs, three workgroups per CU, but 12 bytes of scratch since the tiles have a column range; 5: 96 VGPRs, two per CU)
+#define LIST_WAVES 6         // (79 VGPRs: three workgroups per CU -- since nothing derived from the thread index stays live across the items of the loop)
 #endif
 #define RASTER_LIST_WGS 768      // three per CU: the item loop around the tile needs more than the 64 VGPRs of four (a long list of heavy
                                  // envs must not be rendered at a fraction of the occupancy)
@@ -3884,7 +4039,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_pe
         if (it >= nitems) break;
         const int tile = it % RM.ntiles, ge = it / RM.ntiles;
         const int env = hlist[ge];
-        if (env < P.N && !(D.render_flags && !D.render_flags[env])) raster_tile<RASTER_THREADS, false>(P, RM, D, n_inst_used, 0, env, tile, restore);
+        if (env < P.N && !(D.render_flags && !D.render_flags[env])) raster_tile<RASTER_THREADS, LIST_CARRY, true>(P, RM, D, n_inst_used, 0, env, tile, restore);
         __syncthreads();        // the LDS of the tile is reused
     }
 }
@@ -4026,9 +4181,16 @@ __device__ __forceinline__ void shade_block(const RenderModel &RM, const DevPtrs
 // cooperative record loads -- eight lanes per 128-byte record, one load instruction covering eight records in eight cache
 // lines instead of 64, transposed through 14 KB of LDS: 0.101 ms; one 512-thread workgroup per env walking the concatenation
 // of its tile lists (4 096 workgroups instead of 32 768, instance constants staged once per env): 0.120 ms.
-__global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags, int env0, int sel) {
+// order_n > 0: the launch has one more column of workgroups (blockIdx.x == order_n = the number of envs), which make the dispatch
+// order of the next frame's k_raster from the costs the last one has left (raster_order_class, eight classes).
+__global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp, DevPtrs D, ImageOut out, int use_flags, int env0, int sel, int order_n, unsigned *order_perm) {
     __shared__ __attribute__((aligned(16))) float mvp[MAXINST][16];
     __shared__ __attribute__((aligned(16))) float sinst[MAXINST][16];
+    if (order_n > 0 && (int)blockIdx.x == order_n) {
+        const int nt = RMp->ntiles, per_class = ((order_n + 7) >> 3) * nt;
+        for (int x = blockIdx.z * gridDim.y + blockIdx.y; x < 8; x += gridDim.y * gridDim.z) raster_order_class<SHADE_THREADS>(x, order_n, nt, per_class, D.item_cost, order_perm);
+        return;
+    }
     const int env = blockIdx.x + env0, tile = blockIdx.y;
     if (use_flags && D.render_flags && !D.render_flags[env]) return;
     if (!env_selected(D.hgflag, env, sel)) return;
@@ -4063,7 +4225,7 @@ __device__ __forceinline__ void render_list_body(const BodyParams &B, const SimP
             if ((int)threadIdx.x < RM.ni) instance_setup(B, P, RM, D, env, threadIdx.x);
             __threadfence_block();
             __syncthreads();
-            raster_tile<NT_>(P, RM, D, n_inst_used, 0, env, tile, restore);
+            raster_tile<NT_, true, true>(P, RM, D, n_inst_used, 0, env, tile, restore);
             __threadfence_block();      // the fragment list and its count, written by this workgroup, are read back below
             __syncthreads();
             shade_block<NT_>(RM, D, out, env, tile, 0, 1, smvp, sinst);
@@ -4071,7 +4233,10 @@ __device__ __forceinline__ void render_list_body(const BodyParams &B, const SimP
         __syncthreads();        // the LDS of the tile and the staging arrays are reused
     }
 }
-__global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
+#ifndef RENDER_LIST_WAVES
+#define RENDER_LIST_WAVES 4
+#endif
+__global__ void __launch_bounds__(RASTER_THREADS) __attribute__((amdgpu_waves_per_eu(RENDER_LIST_WAVES, 8)))
 k_render_list(BodyParams B, SimParams P, const RenderModel *RMp, DevPtrs D, ImageOut out, int n_inst_used, int restore, int which) {
     render_list_body<RASTER_THREADS>(B, P, RMp, D, out, n_inst_used, restore, which);
 }
@@ -4161,6 +4326,9 @@ struct rr_env {
     int vh_main;                   // RR_VH_ON_MAIN (-1: by the heavy list's length; 0 never; 1 always): very heavy envs' render at the main stream's tail
     bool macro_la_side;            // RR_MACRO_LA=0: with many very heavy envs the look-ahead stays at the tail of the main stream
     bool la_inline;                // RR_UNSPLIT_LA_INLINE: the unsplit step's look-ahead behind its render instead of beside it
+    // cost-ordered dispatch of k_raster (RR_NO_RASTER_ORDER=1: env-major grid)
+    unsigned *item_perm;           // [8 * ceil(N / 8) * ntiles] the order, written by the extra workgroups of k_shade
+    bool ord_valid, ord_pending;   // item_perm holds an order; a k_raster has left costs that the next k_shade launch turns into one
     bool no_fused_setup;           // RR_NO_FUSED_SETUP: separate k_render_setup launch for the light envs
     bool collide_ordered;          // RR_COLLIDE_ORDER=0: k_collide in env order (default: last step's heavy envs first)
     void *obs_host;                // rr_map_observations: mapped pinned block {joints [N][9], touch [N][4], poses [N][nobj][7], timestep [N], errflags [N]} or nullptr
@@ -4335,7 +4503,7 @@ static int build_static_layer(rr_env *e) {
         e->D.static_vis = nullptr;
         hipLaunchKernelGGL(k_render_setup, dim3((e->P.N * MAXINST + 63) / 64), dim3(64), 0, e->stream, e->B, e->P, e->RM_dev, e->D, 0);
         hipLaunchKernelGGL(k_raster, dim3(1, e->RM.ntiles), dim3(RASTER_THREADS), 0, e->stream, e->P, e->RM_dev, e->D, e->n_inst_used, 1, 0, 0, 0);
-        hipLaunchKernelGGL(k_shade, dim3(1, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, e->D, so, 0, 0, 0);
+        hipLaunchKernelGGL(k_shade, dim3(1, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, e->stream, e->RM_dev, e->D, so, 0, 0, 0, 0, (unsigned *)nullptr);
     }
     // the pass above used env 0's fragment list; from here on the lists describe what differs from the static layer
     if (hipMemsetAsync(e->D.frag_count, 0, (size_t)e->P.N * e->RM.ntiles * sizeof(unsigned), e->stream) != hipSuccess ||
@@ -4380,6 +4548,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->vh_main = getenv("RR_VH_ON_MAIN") ? atoi(getenv("RR_VH_ON_MAIN")) : -1;
     e->macro_la_side = !(getenv("RR_MACRO_LA") && atoi(getenv("RR_MACRO_LA")) == 0);
     e->la_inline = getenv("RR_UNSPLIT_LA_INLINE") != nullptr;
+    e->item_perm = nullptr; e->ord_valid = e->ord_pending = false;
     e->no_fused_setup = getenv("RR_NO_FUSED_SETUP") != nullptr;
     e->collide_ordered = !(getenv("RR_COLLIDE_ORDER") && atoi(getenv("RR_COLLIDE_ORDER")) == 0);
     e->force_hcount[0] = e->force_hcount[1] = -1;
@@ -4391,7 +4560,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
 
     e->h_hcount = nullptr;
     e->split_max_pct = getenv("RR_SPLIT_MAX_PCT") ? atoi(getenv("RR_SPLIT_MAX_PCT")) : 60;
-    if (hipHostMalloc((void **)&e->h_hcount, 2 * sizeof(int), hipHostMallocMapped) == hipSuccess) { e->h_hcount[0] = 0; e->h_hcount[1] = 0; } else e->h_hcount = nullptr;
+    if (hipHostMalloc((void **)&e->h_hcount, 4 * sizeof(int), hipHostMallocMapped) == hipSuccess) { e->h_hcount[0] = 0; e->h_hcount[1] = 0; e->h_hcount[2] = -1; e->h_hcount[3] = 0; } else e->h_hcount = nullptr;
     e->plan = nullptr; e->plan_step = nullptr; e->ik_in = nullptr; e->ik_out = nullptr; e->ik_err = nullptr;
     e->score_out = nullptr; e->score_mask = nullptr;
     e->cfg = *cfg;
@@ -4506,6 +4675,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     RM.ntx = (RM.W + RM.tile_w - 1) / RM.tile_w;
     RM.tile_h = TILE_PIX / RM.tile_w; if (RM.tile_h > RM.H) RM.tile_h = RM.H;
     RM.ntiles = RM.ntx * ((RM.H + RM.tile_h - 1) / RM.tile_h);
+    RM.tile_xbits = 0; while ((1 << RM.tile_xbits) < RM.tile_w) RM.tile_xbits++;
     RM.w_magic = (unsigned)((0x100000000ull + (unsigned long long)RM.tile_w - 1) / (unsigned long long)RM.tile_w);
     if (RM.W > 1024 || RM.H > 1024) { rr_destroy(e); return fail(RR_EINVAL, "rr_create: image larger than 1024 x 1024 (10-bit box origins in the rasteriser's records)"); }
     if (RM.ntiles > 255) { rr_destroy(e); return fail(RR_EINVAL, "rr_create: image too large (more than 255 raster tiles of 4096 pixels)"); }
@@ -4660,6 +4830,9 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
         if ((r = dev_alloc(e, &e->D.static_rgb, spx * 3)) != RR_OK || (r = dev_alloc(e, &e->D.static_depth, spx)) != RR_OK ||
             (r = dev_alloc(e, &e->D.static_mask, spx)) != RR_OK || (r = dev_alloc(e, &e->D.frag_count, (size_t)N * RM.ntiles)) != RR_OK ||
             (r = dev_alloc(e, &e->D.frag_list, (size_t)N * RM.ntiles * TILE_PIX, false)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
+        if (!getenv("RR_NO_RASTER_ORDER") && (long long)N * RM.ntiles >= 2048 && (long long)N * RM.ntiles <= (1 << 20) && N < (1 << 24)) {
+            if ((r = dev_alloc(e, &e->D.item_cost, (size_t)N * RM.ntiles)) != RR_OK || (r = dev_alloc(e, &e->item_perm, (size_t)8 * ((N + 7) / 8) * RM.ntiles)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
+        }
         if (!getenv("RR_NO_STATIC_LAYER")) {
             unsigned long long *sv = nullptr;
             if ((r = dev_alloc(e, &sv, spx)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
@@ -4808,13 +4981,28 @@ static int ensure_images(rr_env *e, DevPtrs &D) {
 // The three render kernels for the envs selected by `sel` (env_selected) on `st`.  The images persist in HBM from frame to
 // frame: only the pixels of the previous frame's fragment lists are put back to the static layer (`restore`), DESIGN.md 5.
 // `setup_done`: the instances of these envs are set up already (by the light solve).
+// Visibility pass of the envs selected by `sel` (all, or the light ones): one workgroup per (env, tile), dispatched in the order of the
+// last frame's costs when the batch is large enough to matter; the shading launch behind it makes the next order.
+static void launch_raster(rr_env *e, const DevPtrs &D, int restore, int sel, hipStream_t st) {
+    const int N = e->P.N, nt = e->RM.ntiles;
+    DevPtrs Do = D;
+    Do.item_perm = e->item_perm && e->ord_valid ? e->item_perm : nullptr;
+    hipLaunchKernelGGL(k_raster, Do.item_perm ? dim3((unsigned)(8 * ((N + 7) / 8) * nt)) : dim3(N, nt), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, Do, e->n_inst_used, 0, 0, restore, sel);
+    e->ord_pending = e->item_perm != nullptr;
+}
+static void launch_shade(rr_env *e, const DevPtrs &D, const ImageOut &io, int sel, hipStream_t st) {
+    const int N = e->P.N;
+    const bool ord = e->ord_pending && sel <= 1;       // (behind launch_raster on the same stream)
+    hipLaunchKernelGGL(k_shade, dim3(N + (ord ? 1 : 0), e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel, ord ? N : 0, e->item_perm);
+    if (ord) { e->ord_pending = false; e->ord_valid = true; }
+}
 static void launch_render(rr_env *e, const DevPtrs &D, int restore, int sel, hipStream_t st, bool timed, bool setup_done = false) {
     const int N = e->P.N;
     const ImageOut io = env_images(e);
     if (timed) {
         if (!setup_done) TIMED(3, hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, st, e->B, e->P, e->RM_dev, D, sel));
-        TIMED(4, hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, 0, 0, restore, sel));
-        TIMED(6, hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel));
+        TIMED(4, launch_raster(e, D, restore, sel, st));
+        TIMED(6, launch_shade(e, D, io, sel, st));
     } else {
         // the heavy envs, a few (lagged host copy of their number: at most one item per workgroup): one list-walking launch for
         // set-up, visibility and shading -- the tail of the step's longest chain; many: the three kernels (the fused one needs
@@ -4825,8 +5013,8 @@ static void launch_render(rr_env *e, const DevPtrs &D, int restore, int sel, hip
         }
         if (!setup_done) hipLaunchKernelGGL(k_render_setup, dim3((N * MAXINST + 63) / 64), dim3(64), 0, st, e->B, e->P, e->RM_dev, D, sel);
         if (sel == 2) hipLaunchKernelGGL(k_raster_list, dim3(std::min(N * e->RM.ntiles, RASTER_LIST_WGS)), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, restore, 0);
-        else hipLaunchKernelGGL(k_raster, dim3(N, e->RM.ntiles), dim3(RASTER_THREADS), 0, st, e->P, e->RM_dev, D, e->n_inst_used, 0, 0, restore, sel);
-        hipLaunchKernelGGL(k_shade, dim3(N, e->RM.ntiles, SHADE_SPLIT), dim3(SHADE_THREADS), 0, st, e->RM_dev, D, io, 1, 0, sel);
+        else launch_raster(e, D, restore, sel, st);
+        launch_shade(e, D, io, sel, st);
     }
 }
 
@@ -5500,3 +5688,4 @@ int rr_get_timing(rr_env *e, float *ms_out, int32_t *launches_out) {
 }
 
 }  // extern "C"
+

@@ -404,3 +404,30 @@ def test_raster_tile_shape_does_not_change_an_image(monkeypatch):
         assert (ref.host(nat.F_ERRFLAGS) == 0).all()
         for e in [ref] + others:
             e.close()
+
+
+def test_raster_dispatch_order_does_not_change_an_image(monkeypatch):
+    """From 2048 (env, tile) items on, k_raster's workgroups are dispatched in the order of the previous frame's costs (the extra
+    workgroups of k_shade sort the durations k_raster measured; env << 8 | tile per XCD class, ~0 padding when the batch is not a
+    multiple of eight).  The order decides where and when a tile is rasterised, never what is in it: states, contact lists, RGB,
+    depth, mask and error flags bitwise equal to the env-major grid (RR_NO_RASTER_ORDER=1) over 60 steps with resets, per-env
+    render flags and a render-less step in between -- at 515 envs (a partial last group of eight) and 128 x 128, and at 128 envs
+    with the 20 tiles of 320 x 240."""
+    for (n, w, h, steps) in ((515, 128, 128, 60), (128, 320, 240, 25)):
+        ref = _make(monkeypatch, {'RR_NO_RASTER_ORDER': '1'}, n, objects=3, width=w, height=h)
+        env = BatchedREALRobotEnv(n, objects=3, width=w, height=h)
+        rng = np.random.default_rng(n)
+        for t in range(steps):
+            cmd = synthetic_actions(range(n), t, seed=3).astype(np.float32)
+            flags = (rng.random(n) < 0.8).astype(np.uint8)
+            if t % 17 == 16:
+                mask = (rng.random(n) < 0.1).astype(np.uint8)
+                for e in (ref, env):
+                    e.reset(mask)
+            for e in (ref, env):
+                e.step(cmd, render=(False if t % 11 == 10 else (flags if t % 3 else True)))
+            if t % 6 == 5 or t == steps - 1:
+                for x, y in zip(_snapshot(ref), _snapshot(env)):
+                    assert np.array_equal(x, y), (n, w, t)
+        assert (env.host(nat.F_ERRFLAGS) == 0).all()
+        ref.close(); env.close()

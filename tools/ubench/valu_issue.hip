@@ -17,13 +17,15 @@
 #define REP16(x) REP4(REP4(x))
 #define REP64(x) REP4(REP16(x))
 
-enum { M_FMA = 0, M_PKFMA, M_CVT, M_RCP, M_MULLO, M_ADD64, M_CNDMASK, M_CMP, M_DPPMOV, M_BPERM, M_MIN3, M_MIX, M_FMA_SGPR, M_CNDMASK_SMASK, M_FMA_LIT, M_CNDMASK_AFTER_CMP, M_SALU_MIX, M_COUNT };
+enum { M_FMA = 0, M_PKFMA, M_CVT, M_RCP, M_MULLO, M_ADD64, M_CNDMASK, M_CMP, M_DPPMOV, M_BPERM, M_MIN3, M_MIX, M_FMA_SGPR, M_CNDMASK_SMASK, M_FMA_LIT, M_CNDMASK_AFTER_CMP, M_SALU_MIX, M_ADD_VV, M_MUL_VV, M_FMAC, M_MOV, M_ADD_E64, M_FMA_ADD_ALT, M_CMP_ADD_ALT, M_ADDU32, M_FMA_DISTINCT, M_CVT_ADD_ALT, M_CNDMASK_ADD_ALT, M_DS_READ_U16, M_DS_READ_B32, M_DS_READ_B64, M_DS_READ_B128, M_DS_READ_B32_RAND, M_DS_READ_B128_RAND, M_DS_WRITE_B32, M_DS_WRITE_B128, M_DS_MIN_U64_16, M_DS_ADD_RTN_1, M_DS_SWIZZLE, M_DS_READ_B32_BCAST, M_COUNT };
 static const char *mode_name[M_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_i32", "v_rcp_f32", "v_mul_lo_u32", "v_lshl_add_u64",
                                          "v_cndmask_b32", "v_cmp_lt_f32", "v_mov_b32 dpp", "ds_bpermute_b32", "v_min3_f32",
                                          "raster mix (sub,mul,fma,cmp,cndmask)",
                                          "v_fma_f32 with an SGPR operand", "v_cndmask_b32, mask in an SGPR pair (s_mov)", "v_add_f32 with a literal constant",
-                                         "v_cmp + v_cndmask pairs", "fma x2 + s_and_b64/s_add pairs (SALU beside VALU)"};
-static const int mode_ops[M_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};      // instructions per inner block
+                                         "v_cmp + v_cndmask pairs", "fma x2 + s_and_b64/s_add pairs (SALU beside VALU)",
+                                         "v_add_f32 e32, VGPR operands", "v_mul_f32 e32, VGPR operands", "v_fmac_f32 e32", "v_mov_b32 e32", "v_add_f32 e64", "v_fma_f32 / v_add_f32 alternating", "v_cmp_lt_f32 e32 / v_add_f32 alternating", "v_add_u32 e32", "v_fma_f32, four distinct registers", "v_cvt_f32_i32 / v_add_f32 alternating", "v_cndmask_b32 (SGPR mask) / v_add_f32 alternating",
+                                         "ds_read_u16, lane-linear", "ds_read_b32, lane-linear", "ds_read_b64, lane-linear", "ds_read_b128, lane-linear", "ds_read_b32, scattered", "ds_read_b128, scattered (16-byte aligned)", "ds_write_b32, lane-linear", "ds_write_b128, lane-linear", "ds_min_u64, 16 lanes, scattered", "ds_add_rtn_u32, one lane", "ds_swizzle_b32", "ds_read_b32, one address (broadcast)"};
+static const int mode_ops[M_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};      // instructions per inner block
 
 __global__ void __launch_bounds__(1024) k(float *out, unsigned long long *cyc, int mode, int iters, float a, float b) {
     extern __shared__ float lds[];
@@ -36,6 +38,10 @@ __global__ void __launch_bounds__(1024) k(float *out, unsigned long long *cyc, i
     int i0 = threadIdx.x, i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3, i4 = i0 + 4, i5 = i0 + 5, i6 = i0 + 6, i7 = i0 + 7;
     const int ia = (int)(a * 3.0f) | 1;
     const int baddr = ((threadIdx.x + 1) & 63) << 2;
+    const int lin2 = (threadIdx.x & 63) * 2 + (threadIdx.x >> 6) * 128, lin4 = lin2 * 2, lin8 = lin2 * 4, lin16 = lin2 * 8;
+    const int rnd4 = (int)(((threadIdx.x * 2654435761u) >> 8) & 0x1ffc), rnd16 = rnd4 & ~15, rnd8 = rnd4 & ~7;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f w0 = {x0, x1, x2, x3}, w1 = w0, w2 = w0, w3 = w0;
     unsigned long long smask = 0x5555555555555555ull ^ (unsigned long long)iters; int scnt = iters;
     __syncthreads();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, independent of the DVFS state
@@ -112,12 +118,81 @@ __global__ void __launch_bounds__(1024) k(float *out, unsigned long long *cyc, i
             REP2(asm volatile(S8("v_fma_f32 %0, %0, %8, %9\n s_and_b64 %10, %10, exec\n v_fma_f32 %1, %1, %8, %9\n s_add_u32 %11, %11, 1\n"
                                "v_fma_f32 %2, %2, %8, %9\n s_and_b64 %10, %10, exec\n v_fma_f32 %3, %3, %8, %9\n s_add_u32 %11, %11, 1\n"): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b), "s"(smask), "s"(scnt) : "scc");)
             break;
+        case M_ADD_VV:
+            REP2(asm volatile(S8("v_add_f32_e32 %0, %8, %0\n v_add_f32_e32 %1, %8, %1\n v_add_f32_e32 %2, %8, %2\n v_add_f32_e32 %3, %8, %3\n v_add_f32_e32 %4, %8, %4\n v_add_f32_e32 %5, %8, %5\n v_add_f32_e32 %6, %8, %6\n v_add_f32_e32 %7, %8, %7\n "): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));)
+            break;
+        case M_MUL_VV:
+            REP2(asm volatile(S8("v_mul_f32_e32 %0, %8, %0\n v_mul_f32_e32 %1, %8, %1\n v_mul_f32_e32 %2, %8, %2\n v_mul_f32_e32 %3, %8, %3\n v_mul_f32_e32 %4, %8, %4\n v_mul_f32_e32 %5, %8, %5\n v_mul_f32_e32 %6, %8, %6\n v_mul_f32_e32 %7, %8, %7\n "): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));)
+            break;
+        case M_FMAC:
+            REP2(asm volatile(S8("v_fmac_f32_e32 %0, %8, %9\n v_fmac_f32_e32 %1, %8, %9\n v_fmac_f32_e32 %2, %8, %9\n v_fmac_f32_e32 %3, %8, %9\n v_fmac_f32_e32 %4, %8, %9\n v_fmac_f32_e32 %5, %8, %9\n v_fmac_f32_e32 %6, %8, %9\n v_fmac_f32_e32 %7, %8, %9\n "): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));)
+            break;
+        case M_MOV:
+            REP2(asm volatile(S8("v_mov_b32_e32 %0, %1\n v_mov_b32_e32 %1, %2\n v_mov_b32_e32 %2, %3\n v_mov_b32_e32 %3, %4\n v_mov_b32_e32 %4, %5\n v_mov_b32_e32 %5, %6\n v_mov_b32_e32 %6, %7\n v_mov_b32_e32 %7, %0\n "): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));)
+            break;
+        case M_ADD_E64:
+            REP2(asm volatile(S8("v_add_f32_e64 %0, %8, %0\n v_add_f32_e64 %1, %8, %1\n v_add_f32_e64 %2, %8, %2\n v_add_f32_e64 %3, %8, %3\n v_add_f32_e64 %4, %8, %4\n v_add_f32_e64 %5, %8, %5\n v_add_f32_e64 %6, %8, %6\n v_add_f32_e64 %7, %8, %7\n "): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));)
+            break;
+        case M_FMA_ADD_ALT:
+            REP2(asm volatile(S8("v_fma_f32 %0, %0, %8, %9\n v_add_f32_e32 %1, %8, %1\n v_fma_f32 %2, %2, %8, %9\n v_add_f32_e32 %3, %8, %3\n v_fma_f32 %4, %4, %8, %9\n v_add_f32_e32 %5, %8, %5\n v_fma_f32 %6, %6, %8, %9\n v_add_f32_e32 %7, %8, %7\n "): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));)
+            break;
+        case M_CMP_ADD_ALT:
+            REP2(asm volatile(S8("v_cmp_lt_f32_e32 vcc, %0, %8\n v_add_f32_e32 %1, %8, %1\n v_cmp_lt_f32_e32 vcc, %2, %8\n v_add_f32_e32 %3, %8, %3\n v_cmp_lt_f32_e32 vcc, %4, %8\n v_add_f32_e32 %5, %8, %5\n v_cmp_lt_f32_e32 vcc, %6, %8\n v_add_f32_e32 %7, %8, %7\n "): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc");)
+            break;
+        case M_ADDU32:
+            REP2(asm volatile(S8("v_add_u32_e32 %0, %8, %0\n v_add_u32_e32 %1, %8, %1\n v_add_u32_e32 %2, %8, %2\n v_add_u32_e32 %3, %8, %3\n v_add_u32_e32 %4, %8, %4\n v_add_u32_e32 %5, %8, %5\n v_add_u32_e32 %6, %8, %6\n v_add_u32_e32 %7, %8, %7\n "): "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(ia), "v"(b));)
+            break;
+        case M_FMA_DISTINCT:
+            REP2(asm volatile(S8("v_fma_f32 %0, %1, %2, %3\n v_fma_f32 %1, %2, %3, %4\n v_fma_f32 %2, %3, %4, %5\n v_fma_f32 %3, %4, %5, %6\n v_fma_f32 %4, %5, %6, %7\n v_fma_f32 %5, %6, %7, %0\n v_fma_f32 %6, %7, %0, %1\n v_fma_f32 %7, %0, %1, %2\n "): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));)
+            break;
+        case M_CVT_ADD_ALT:
+            REP2(asm volatile(S8("v_cvt_f32_i32_e32 %0, %0\n v_add_f32_e32 %1, %8, %1\n v_cvt_f32_i32_e32 %2, %2\n v_add_f32_e32 %3, %8, %3\n v_cvt_f32_i32_e32 %4, %4\n v_add_f32_e32 %5, %8, %5\n v_cvt_f32_i32_e32 %6, %6\n v_add_f32_e32 %7, %8, %7\n "): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));)
+            break;
+        case M_CNDMASK_ADD_ALT:
+            REP2(asm volatile(S8("v_cndmask_b32_e64 %0, %0, %8, %9\n v_add_f32_e32 %1, %8, %1\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_add_f32_e32 %3, %8, %3\n v_cndmask_b32_e64 %4, %4, %8, %9\n v_add_f32_e32 %5, %8, %5\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_add_f32_e32 %7, %8, %7\n "): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "s"(smask));)
+            break;
+        case M_DS_READ_U16:
+            REP2(asm volatile(S8("ds_read_u16 %0, %8\n ds_read_u16 %1, %8\n ds_read_u16 %2, %8\n ds_read_u16 %3, %8\n ds_read_u16 %4, %8\n ds_read_u16 %5, %8\n ds_read_u16 %6, %8\n ds_read_u16 %7, %8\n  s_waitcnt lgkmcnt(0)\n"): "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7) : "v"(lin2));)
+            break;
+        case M_DS_READ_B32:
+            REP2(asm volatile(S8("ds_read_b32 %0, %8\n ds_read_b32 %1, %8\n ds_read_b32 %2, %8\n ds_read_b32 %3, %8\n ds_read_b32 %4, %8\n ds_read_b32 %5, %8\n ds_read_b32 %6, %8\n ds_read_b32 %7, %8\n  s_waitcnt lgkmcnt(0)\n"): "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7) : "v"(lin4));)
+            break;
+        case M_DS_READ_B64:
+            REP2(asm volatile(S8("ds_read_b64 %0, %8\n ds_read_b64 %1, %8\n ds_read_b64 %2, %8\n ds_read_b64 %3, %8\n ds_read_b64 %4, %8\n ds_read_b64 %5, %8\n ds_read_b64 %6, %8\n ds_read_b64 %7, %8\n  s_waitcnt lgkmcnt(0)\n"): "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3), "=v"(q4), "=v"(q5), "=v"(q6), "=v"(q7) : "v"(lin8));)
+            break;
+        case M_DS_READ_B128:
+            REP2(asm volatile(S8("ds_read_b128 %0, %4\n ds_read_b128 %1, %4\n ds_read_b128 %2, %4\n ds_read_b128 %3, %4\n ds_read_b128 %0, %4\n ds_read_b128 %1, %4\n ds_read_b128 %2, %4\n ds_read_b128 %3, %4\n  s_waitcnt lgkmcnt(0)\n"): "=v"(w0), "=v"(w1), "=v"(w2), "=v"(w3) : "v"(lin16));)
+            break;
+        case M_DS_READ_B32_RAND:
+            REP2(asm volatile(S8("ds_read_b32 %0, %8\n ds_read_b32 %1, %8\n ds_read_b32 %2, %8\n ds_read_b32 %3, %8\n ds_read_b32 %4, %8\n ds_read_b32 %5, %8\n ds_read_b32 %6, %8\n ds_read_b32 %7, %8\n  s_waitcnt lgkmcnt(0)\n"): "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7) : "v"(rnd4));)
+            break;
+        case M_DS_READ_B128_RAND:
+            REP2(asm volatile(S8("ds_read_b128 %0, %4\n ds_read_b128 %1, %4\n ds_read_b128 %2, %4\n ds_read_b128 %3, %4\n ds_read_b128 %0, %4\n ds_read_b128 %1, %4\n ds_read_b128 %2, %4\n ds_read_b128 %3, %4\n  s_waitcnt lgkmcnt(0)\n"): "=v"(w0), "=v"(w1), "=v"(w2), "=v"(w3) : "v"(rnd16));)
+            break;
+        case M_DS_WRITE_B32:
+            REP2(asm volatile(S8("ds_write_b32 %8, %0\n ds_write_b32 %8, %1\n ds_write_b32 %8, %2\n ds_write_b32 %8, %3\n ds_write_b32 %8, %4\n ds_write_b32 %8, %5\n ds_write_b32 %8, %6\n ds_write_b32 %8, %7\n  s_waitcnt lgkmcnt(0)\n"): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(lin4) : "memory");)
+            break;
+        case M_DS_WRITE_B128:
+            REP2(asm volatile(S8("ds_write_b128 %4, %0\n ds_write_b128 %4, %1\n ds_write_b128 %4, %2\n ds_write_b128 %4, %3\n ds_write_b128 %4, %0\n ds_write_b128 %4, %1\n ds_write_b128 %4, %2\n ds_write_b128 %4, %3\n  s_waitcnt lgkmcnt(0)\n"): "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(lin16) : "memory");)
+            break;
+        case M_DS_MIN_U64_16:
+            REP2(asm volatile("s_mov_b32 exec_lo, 0x11111111\n s_mov_b32 exec_hi, 0x11111111\n" S8("ds_min_u64 %8, %0\n ds_min_u64 %8, %1\n ds_min_u64 %8, %2\n ds_min_u64 %8, %3\n ds_min_u64 %8, %4\n ds_min_u64 %8, %5\n ds_min_u64 %8, %6\n ds_min_u64 %8, %7\n  s_waitcnt lgkmcnt(0)\n") "s_mov_b64 exec, -1\n": "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : "v"(rnd8) : "memory");)
+            break;
+        case M_DS_ADD_RTN_1:
+            REP2(asm volatile("s_mov_b64 exec, 1\n" S8("ds_add_rtn_u32 %0, %8, %9\n ds_add_rtn_u32 %1, %8, %9\n ds_add_rtn_u32 %2, %8, %9\n ds_add_rtn_u32 %3, %8, %9\n ds_add_rtn_u32 %4, %8, %9\n ds_add_rtn_u32 %5, %8, %9\n ds_add_rtn_u32 %6, %8, %9\n ds_add_rtn_u32 %7, %8, %9\n  s_waitcnt lgkmcnt(0)\n") "s_mov_b64 exec, -1\n": "=v"(i0), "=v"(i1), "=v"(i2), "=v"(i3), "=v"(i4), "=v"(i5), "=v"(i6), "=v"(i7) : "v"(lin4), "v"(ia) : "memory");)
+            break;
+        case M_DS_SWIZZLE:
+            REP2(asm volatile(S8("ds_swizzle_b32 %0, %0 offset:swizzle(SWAP,1)\n ds_swizzle_b32 %1, %1 offset:swizzle(SWAP,1)\n ds_swizzle_b32 %2, %2 offset:swizzle(SWAP,1)\n ds_swizzle_b32 %3, %3 offset:swizzle(SWAP,1)\n ds_swizzle_b32 %4, %4 offset:swizzle(SWAP,1)\n ds_swizzle_b32 %5, %5 offset:swizzle(SWAP,1)\n ds_swizzle_b32 %6, %6 offset:swizzle(SWAP,1)\n ds_swizzle_b32 %7, %7 offset:swizzle(SWAP,1)\n  s_waitcnt lgkmcnt(0)\n"): "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(lin4));)
+            break;
+        case M_DS_READ_B32_BCAST:
+            REP2(asm volatile(S8("ds_read_b32 %0, %8\n ds_read_b32 %1, %8\n ds_read_b32 %2, %8\n ds_read_b32 %3, %8\n ds_read_b32 %4, %8\n ds_read_b32 %5, %8\n ds_read_b32 %6, %8\n ds_read_b32 %7, %8\n  s_waitcnt lgkmcnt(0)\n"): "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3), "=v"(x4), "=v"(x5), "=v"(x6), "=v"(x7) : "v"(0));)
+            break;
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float r = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y +
-              (float)(q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7) + (float)(i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7);
+              (float)(q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7) + (float)(i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7) + w0.x + w1.y + w2.z + w3.w;
     if (r == 12345.678f) lds[threadIdx.x] = r;      // (keeps the LDS allocation and every chain alive)
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = r;
     if ((threadIdx.x & 63) == 0) {
@@ -141,7 +216,7 @@ int main(int argc, char **argv) {
     // (threads per workgroup, workgroups per CU, LDS per workgroup): W waves per SIMD; the LDS sizes keep one more workgroup off the CU
     struct Shape { int W, threads, per_cu, lds_kb; } shapes[] = {{1, 256, 1, 96}, {2, 512, 1, 96}, {4, 1024, 1, 96}, {6, 512, 3, 48}, {8, 512, 4, 39}};
     printf("%-40s %3s %14s %14s %14s %9s %10s\n", "instruction", "W", "cyc/instr/wave", "cyc/instr/SIMD", "G wave-instr/s", "clock GHz", "concurrent");
-    for (int m = 0; m < M_COUNT; m++)
+    for (int m = (argc > 1 ? atoi(argv[1]) : 0); m < M_COUNT; m++)
         for (const Shape &sh : shapes) {
             const int blocks = sh.per_cu * ncu, nw = blocks * (sh.threads / 64);
             float ms = 0;
