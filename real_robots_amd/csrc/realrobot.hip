@@ -3397,6 +3397,8 @@ extern "C" int rr_debug_raster_phase(unsigned long long *out16, int reset) {
 // workgroup timeline of k_raster (RR_ABLATE=16384; scratch/rwgtime.py): start / end on the 100 MHz clock and the hardware slot
 // (HW_ID, XCC_ID) of every workgroup of the last launch -- how full the four workgroup slots of a CU are kept
 __device__ unsigned long long g_rwg_time[65536][3];
+__device__ int g_shade_ablate;      // (k_shade has no SimParams: rr_debug_shade_ablate sets what it records)
+extern "C" int rr_debug_shade_ablate(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_shade_ablate), &v, sizeof(v)) == hipSuccess ? 0 : -1; }
 extern "C" int rr_debug_raster_wgtime(unsigned long long *out /*[65536][3]*/, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rwg_time), sizeof(g_rwg_time)) != hipSuccess) return -1;
     if (reset) { static unsigned long long z[65536][3]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rwg_time), z, sizeof(z)) != hipSuccess) return -1; }
@@ -4195,7 +4197,18 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp,
     const int env = blockIdx.x + env0, tile = blockIdx.y;
     if (use_flags && D.render_flags && !D.render_flags[env]) return;
     if (!env_selected(D.hgflag, env, sel)) return;
+#ifdef RR_RASTER_STATS
+    unsigned long long wt0_ = 0;      // (workgroup timeline of the shading: rr_debug_shade_ablate(0x10000), scratch/rwgtime.py shade)
+    if (g_shade_ablate & 0x10000) wt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
     shade_block<SHADE_THREADS>(*RMp, D, out, env, tile, blockIdx.z, gridDim.z, mvp, sinst);
+#ifdef RR_RASTER_STATS
+    if ((g_shade_ablate & 0x10000) && threadIdx.x == 0) {
+        unsigned long long *g = g_rwg_time[((env * RMp->ntiles + tile) * gridDim.z + blockIdx.z) & 65535];
+        g[0] = wt0_; g[1] = __builtin_amdgcn_s_memrealtime();
+        g[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);
+    }
+#endif
 }
 // (Visibility pass and shading of a tile in one workgroup -- k_render_list's body for every env, 64 VGPRs, same LDS -- was
 // measured: 0.470 ms instead of 0.383 + 0.097 alone, but 0.739 instead of 0.725 ms for the step: the heavy lists' render
