@@ -1281,6 +1281,10 @@ __device__ __forceinline__ void collide_env(const SimParams &P, const DevPtrs &D
 // takes four times the mean (scratch/cprof.py), so the envs that were very heavy / heavy in the step just solved -- the lists of
 // the CURRENT contact frame -- take the first h_first workgroups (a lagged host count + a margin; list entries beyond it and
 // everybody else follow in env order: an env's place in its list, hpos, says on which side it is).  Every env exactly once.
+#ifdef RR_RASTER_STATS
+__device__ unsigned long long g_cwg_time[65536][3];
+extern "C" int rr_debug_collide_wgtime(unsigned long long *out /*[65536][3]*/) { return (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cwg_time), sizeof(g_cwg_time)) == hipSuccess) ? 0 : -1; }
+#endif
 __device__ __forceinline__ int collide_launch_env(const DevPtrs &D, int idx, int N, int h_first) {
     if (idx < h_first) {
         const int n2 = D.hcount2[0], n1 = D.hcount[0];
@@ -1295,7 +1299,18 @@ __device__ __forceinline__ int collide_launch_env(const DevPtrs &D, int idx, int
 __global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, DevPtrs D, int ns, int sel, int h_first) {
     const int env = (sel == 0 && h_first > 0) ? collide_launch_env(D, blockIdx.x, P.N, h_first) : pick_env(D, sel, blockIdx.x, P.N);
     if (env < 0) return;
+#ifdef RR_RASTER_STATS
+    unsigned long long wt0_ = 0;      // (workgroup timeline of the collision pass: RR_ABLATE=131072, scratch/rwgtime.py collide)
+    if (P.ablate & 0x20000) wt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
     collide_env(P, D, ns, env);
+#ifdef RR_RASTER_STATS
+    if ((P.ablate & 0x20000) && threadIdx.x == 0) {
+        unsigned long long *g = g_cwg_time[env & 65535];
+        g[0] = wt0_; g[1] = __builtin_amdgcn_s_memrealtime();
+        g[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);
+    }
+#endif
 }
 #undef CAND_ARGMAX
 #pragma clang fp contract(fast)
