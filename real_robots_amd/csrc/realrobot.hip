@@ -3438,7 +3438,7 @@ extern "C" int rr_debug_raster_wgmarks(unsigned long long *out /*[65536][8]*/) {
 #define PH_FLUSH
 #endif
 
-// The cluster cull (k_cull and raster_tile, same arithmetic): clip-space centre of the cluster's bounding sphere against the five
+// The cluster cull of raster_tile: clip-space centre of the cluster's bounding sphere against the five
 // frustum planes, then against the planes of a tile's first / last sample row and column (RM.tile_plane), radius enlarged -- conservative.
 struct ClusterClip { float cx, cy, cw, r; };
 __device__ __forceinline__ bool cluster_outside_frustum(const RenderModel &RM, const float *m, const float4 cs, ClusterClip &c) {
@@ -3521,8 +3521,6 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
     const int lane = tid & 63, lx = lane & 7, ly = lane >> 3;
     const int nwin = (t_stop - t_begin + 63) >> 6;
     // tile bounds as two more planes of the cull (multi-tile images): NDC y of the tile's first and last sample rows
-    const float ndc_a = RM.tile_plane[tile][0], nrm_a = RM.tile_plane[tile][1], ndc_b = RM.tile_plane[tile][2], nrm_b = RM.tile_plane[tile][3];
-    const float ndx_a = RM.tile_plane[tile][4], nrx_a = RM.tile_plane[tile][5], ndx_b = RM.tile_plane[tile][6], nrx_b = RM.tile_plane[tile][7];
     const bool xtiled = RM.ntx > 1;
     const bool tiled = RM.ntiles > 1;
     // Incremental image update (do_render): the env's image in HBM still holds its previous frame.  The pixels of that
