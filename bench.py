@@ -608,7 +608,11 @@ def main():
                 "whole_step_algorithmic_GBs": round((algo['_state'] + (W * H * 7 if render else 0)) * n_local * args.steps / elapsed / 1e9, 2),
                 "bound_note": "`bound` comes from the counters: the dominant kernel's VALU issue fraction (roofline.valu) against its HBM "
                               "fractions. achieved / peak / frac stay in the contract's HBM terms (algorithmic bytes): at 116 KB and "
-                              "~0.3 M instructions per env-step the path is instruction-issue / latency bound (DESIGN.md 5)",
+                              "~0.3 M instructions per env-step the path is instruction-issue / latency bound (DESIGN.md 5): k_raster's "
+                              "own VALU stream alone issues at 780-810 G wave-instr/s, with its 26.8 M LDS instructions per launch (2-6 "
+                              "CU-cycles each) at 350-700 G -- VALU issue and LDS instruction issue load the CU about equally "
+                              "(profiles/r04_raster_stream_issue.txt, r04_valu_lds_issue.txt), and 0.86 of the workgroup slots are busy "
+                              "(profiles/r04_raster_wg_timeline.txt)",
                 "valu": valu,
                 "kernels": kernels,
                 "timing_note": "per-kernel durations: HIP events on the library's stream, the launches of a step one after the "
