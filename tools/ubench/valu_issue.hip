@@ -1,5 +1,6 @@
-// VALU issue-rate micro-benchmark for the `roofline.valu` peak of bench.py.
-// W waves per SIMD (W = 1, 2, 4, 8) on every SIMD of the chip run independent chains of one instruction; reported:
+// VALU and LDS instruction issue-rate micro-benchmark for the `roofline.valu` peak of bench.py and for
+// the LDS instruction costs of DESIGN.md 5 (profiles/r04_valu_issue.txt, r04_valu_lds_issue.txt).  `valu_issue [first mode]`.
+// W waves per SIMD (W = 1, 2, 4, 6, 8) on every SIMD of the chip run independent chains of one instruction (or a pattern of two); reported:
 //   * cycles per wave-instruction seen by one wave (s_memtime), and the same per SIMD (= wave cycles / W),
 //   * chip-wide wave-instructions per second from HIP-event wall time (what bench.py divides SQ_INSTS_VALU by).
 // Build: hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_issue.hip -o /tmp/valu_issue ; run on the GPU box.
