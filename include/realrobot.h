@@ -47,7 +47,10 @@ enum {
                                              not finite (env not stepped, robot.py:189: its state, clock and observations stay as they
                                              are; its contact list is dropped -- RR_F_CONTACT_COUNT 0, rr_get_contacts empty -- and the
                                              next accepted step starts its contact solve cold, like a step after rr_set_state);
-                                             4: internal consistency (never expected) */
+                                             4: internal consistency of the solver (never expected; the env stops stepping until reset / set_state);
+                                             8: RENDER status only -- more than 2048 near-plane-crossing triangles met one raster tile of the last
+                                             rendered frame and the surplus was dropped (a camera inside a mesh); the physics ignores this bit,
+                                             it stays set until rr_reset / rr_set_state of the env */
     RR_F_STATE = 8,     /* f32 [N, 61]       q[11] qd[11] 3x(pos3 quat4 lin3 ang3)  (checkpoint / parity) */
     RR_F_FRAG_COUNT = 9,/* u32 [N, tiles]    diagnostic: entries of k_shade's work list in the last render (pixels won by moving geometry + pixels vacated since the frame before) */
     RR_F_CONTACT_COUNT = 10, /* i32 [N]      contacts of the last solved step (rr_get_contacts returns them one env at a time); 0 after

@@ -68,6 +68,8 @@ def _lib(f32=False):
         L.rro_default_params.argtypes = [C.POINTER(Params)]
         L.rro_solution_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         L.rro_solution_residual.restype = C.c_int
+        L.rro_pair_contacts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.rro_pair_contacts.restype = C.c_int
         _libs[f32] = L
     return _libs[f32]
 
@@ -164,6 +166,13 @@ class Oracle:
         n = self.L.rro_solution_residual(self.h, s.ctypes.data, f.ctypes.data, len(f), float(active_thresh), out.ctypes.data, bits.ctypes.data)
         assert n == len(f), "contact count differs from the oracle's last step"
         return dict(res_sum=out[0], res_max=out[1], f_sum=out[2], f_max=out[3], n_active=int(out[4]), active=int(bits[0]))
+
+    def pair_contacts(self, shape_a, shape_b):
+        """Narrow phase of one shape pair at the present state -> (contact records [n, 12], (Ra, pa), (Rb, pb))."""
+        out, xf = np.empty((48, 12)), np.empty(24)
+        n = self.L.rro_pair_contacts(self.h, shape_a, shape_b, out.ctypes.data, 48, xf.ctypes.data)
+        assert n >= 0
+        return out[:n], (xf[:9].reshape(3, 3), xf[9:12]), (xf[12:21].reshape(3, 3), xf[21:24])
 
     def set_object_pose(self, obj, pose7):
         p = np.ascontiguousarray(pose7, dtype=np.float64)

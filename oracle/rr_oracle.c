@@ -761,6 +761,32 @@ static void collide(rr_oracle *o) {
         for (int i = 0; i < o->nobj; i++) collide_pair(o, m->n_static + r, s_obj0 + i, X);
 }
 
+/* Narrow phase of ONE shape pair at the present state (tests/test_narrowphase_exact.py: the contacts the oracle emits for a
+ * pair against the exact signed distance of the two full hulls).  Does not touch the env's contact list.  out: rro_contacts()
+ * records; xf24: the two shapes' world transforms {R (9, row major), p (3)} x 2.  Returns the number of contacts. */
+int rro_pair_contacts(rr_oracle *o, int sa, int sb, double *out, int maxc, double *xf24) {
+    const model_t *m = &o->m;
+    if (sa < 0 || sb < 0 || sa >= m->ns || sb >= m->ns) return -1;
+    static contact_t keep[MAXC];
+    const int nkeep = o->ncontacts;
+    memcpy(keep, o->contacts, sizeof(contact_t) * (size_t)nkeep);
+    forward_kinematics(o);
+    xform_t X[MAXSHAPES];
+    for (int s = 0; s < m->ns; s++) shape_xform(o, s, &X[s]);
+    o->ncontacts = 0;
+    collide_pair(o, sa, sb, X);
+    const int n = rro_contacts(o, out, maxc);
+    memcpy(o->contacts, keep, sizeof(contact_t) * (size_t)nkeep);
+    o->ncontacts = nkeep;
+    if (xf24)
+        for (int side = 0; side < 2; side++) {
+            const xform_t *x = &X[side == 0 ? sa : sb];
+            for (int k = 0; k < 9; k++) xf24[12 * side + k] = x->R[k];
+            for (int k = 0; k < 3; k++) xf24[12 * side + 9 + k] = x->p[k];
+        }
+    return n;
+}
+
 /* ------------------------------------------------------------------------------------------- solver */
 typedef struct {
     int bodyA, bodyB;

@@ -84,6 +84,8 @@ void rro_set_object_pose(rr_oracle *o, int obj, const double *pose7);
 int rro_solution_residual(const rr_oracle *o, const double *state_after61, const double *normal_force, int n,
                           double active_thresh, double *out5, uint64_t *active_bits);
 /* diagnostics */
+/* narrow phase of one shape pair (model shape indices) at the present state; xf24 (nullable): the shapes' world transforms */
+int rro_pair_contacts(rr_oracle *o, int shape_a, int shape_b, double *out, int max_contacts, double *xf24);
 void rro_mass_matrix(rr_oracle *o, double *M121, double *bias11);
 
 #ifdef __cplusplus

@@ -153,7 +153,7 @@ struct DevPtrs {
     int *timestep;     // [N]
     unsigned *errflags;// [N]
     float *obj_home;   // [NOBJ*7][N] per-env pose an object is put back to by reset / the out-of-bounds rule (robot.py:19-24, mutable there)
-    float4 *grows;     // [N * 6 MAXC + 1][16] generic solver rows in the slot layout {J_A, MJ_A, J_B, MJ_B} per lane; the last row is all zero
+    float4 *grows;     // [N * GP_RECS][16] generic solver rows in the slot layout, as canonical normal rows and as the blocks the sweeps stream (GP_*)
     float *cmd;        // [N][9]
     const float *cmd_in; // [N][9] the command buffer of this step: cmd, or the caller's device buffer (read in place)
     float *joints;     // [N][9]
@@ -630,8 +630,9 @@ __device__ __forceinline__ Xf load_xf(const ShapeData *S, int s, const float *sc
 #ifdef RR_RASTER_STATS
 // development build only: cycle stamps of kernel phases (lane 0 of every block), see scratch/sprof.py
 __device__ unsigned long long g_sprof[16];
-#define SPROF(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == (LIGHT_OW_THREADS == 384 ? 1 : 0) && (!(P.ablate & 0x4000) || (int)blockIdx.x == (P.ablate >> 16))) atomicAdd(&g_sprof[i], now_ - sp_t0); sp_t0 = now_; } while (0)   /* RR_ABLATE = block << 16 | 0x4000: one block only */
-#define SPROF_INIT unsigned long long sp_t0 = __builtin_amdgcn_s_memrealtime();
+#define SPROF(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); sp_acc[i] += (unsigned)(now_ - sp_t0); sp_t0 = now_; } while (0)   /* cheap phase clock: s_memtime into per-wave accumulators, flushed once (SBLK_END); RR_ABLATE = block << 16 | 0x4000: one block only */
+#define SPROF_INIT unsigned long long sp_t0 = __builtin_readcyclecounter(); unsigned sp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define SPROF_FLUSH do { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == ((OW && LIGHT_OW_THREADS == 384) ? 1 : 0) && (!(P.ablate & 0x4000) || (int)blockIdx.x == (P.ablate >> 16))) { _Pragma("unroll") for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_sprof[i_], (unsigned long long)sp_acc[i_]); } } while (0)
 // per solver workgroup: {total cycles, cycles up to the end of the row build, cycles of the PGS loop, -, then per env
 // nc | generic contacts << 8 | leading object-vs-static contacts << 16 | last F-list length << 24}
 __device__ unsigned g_sblk[4096 * 8];
@@ -650,6 +651,7 @@ extern "C" int rr_debug_solver_prof(unsigned long long *out16, int reset) {
 #else
 #define SPROF(i)
 #define SPROF_INIT
+#define SPROF_FLUSH
 #define SBLK_BEGIN
 #define SBLK_MARK(v)
 #define SBLK_END(ncv, gv, osv, nfv)
@@ -1362,9 +1364,23 @@ __device__ __forceinline__ void plane_space(v3 n, v3 &p, v3 &q) {   // btPlaneSp
 #define SGRP 4           // envs per workgroup (64 threads)
 #define OS_CAP 12        // object-vs-static contacts per env on the object lanes: KOS per object, rows staged in LDS
 #define GROWS (6 * MAXC) // generic row ids: 6 j + k for generic contact j; k = 0 normal, 1 2 lateral, 3 spinning, 4 5 rolling
+// LF_ZPAD: the scalars of the DUMMY generic contacts MAXC .. MAXC + 3 (all zero: a block step on them is a no-op) -- what a group
+// sweeps when another env of its wave has more blocks.  LF_LISTA / LF_LISTT: the active contacts of the friction / torsional
+// passes, one byte each, padded with MAXC.
+#define LIST_CAP (MAXC + 4)
 enum { LF_MINV = 0, LF_MOT = LF_MINV + 124, LF_LIM = LF_MOT + 36, LF_META = LF_LIM + 44, LF_MU = LF_META + MAXC, LF_SPIN = LF_MU + OS_CAP,
        LF_ROLL = LF_SPIN + OS_CAP, LF_OBJ = LF_ROLL + OS_CAP, LF_CST = LF_OBJ + NOBJ * 20, LF_OSL = LF_CST + 16 * 12, LF_OST = LF_OSL + OS_CAP * 36,
-       LF_GSC = LF_OST + OS_CAP * 24, LF_LISTF = LF_GSC + 4 * GROWS, LF_LISTT = LF_LISTF + MAXC, LF_TOTAL = LF_LISTT + (3 * MAXC) / 2 };
+       LF_GSC = LF_OST + OS_CAP * 24, LF_ZPAD = LF_GSC + 4 * GROWS, LF_LISTA = LF_ZPAD + 4 * 24, LF_LISTT = LF_LISTA + 16, LF_ENVW = LF_LISTT + 16, LF_TOTAL = LF_ENVW + 4 };
+static_assert(LIST_CAP <= 64, "a list of LIST_CAP bytes must fit its 16 floats");
+// Global store of the generic rows (D.grows), per env GP_RECS records of 16 lanes x float4:
+//   GP_C + j       the normal row of generic contact j in the canonical layout {J_A, MJ_A, J_B, MJ_B} (block repack, warm start)
+//   GP_N + 5 b     block of the normal rows of contacts 4 b .. 4 b + 3  {J pair, J pair, MJ pair, MJ pair, cross terms}
+//   GP_T + 5 j     block of the torsional rows of contact j (spinning, rolling, rolling, -)
+//   GP_F + 3 j     block of the lateral friction rows of contact j {J pair, MJ pair, cross term}
+// Block index NBLK4 / contact index MAXC are the dummies: all-zero records nobody writes.
+#define NBLK4 (MAXC / 4)
+enum { GP_C = 0, GP_N = GP_C + MAXC, GP_T = GP_N + 5 * (NBLK4 + 1), GP_F = GP_T + 5 * (MAXC + 1), GP_RECS = GP_F + 3 * (MAXC + 1) };
+#define GP_ENV_BYTES (GP_RECS * 256)
 #define SLDS_FLOATS (SGRP * LF_TOTAL)
 static_assert(SLDS_FLOATS * 4 * 4 <= 163840, "sixteen envs (four 64-thread workgroups or one 256-thread workgroup) must fit the 160 KiB LDS of a CU");
 static_assert(LF_TOTAL % 4 == 0 && LF_OSL % 4 == 0 && LF_OST % 4 == 0 && LF_GSC % 4 == 0 && LF_OBJ % 4 == 0 && LF_CST % 4 == 0, "row parts must be 16-byte aligned");
@@ -1664,7 +1680,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     else if (sel == 3) { mine = env_raw < *D.hcount2; env_raw = mine ? D.hlist2[env_raw] : N; }
     else if (sel == 1) mine = env_raw < N && D.hgflag[env_raw] == 0;
     if (!OW && __ballot(mine) == 0ull) return;                        // (wave-uniform; OW: every wave goes to the workgroup's barrier)
-    const int env = env_raw < N ? env_raw : N - 1;                    // groups without an env run along as no-ops
+    int env = env_raw < N ? env_raw : N - 1;                          // groups without an env run along as no-ops
     float *state = D.state, *scratch = D.scratch;
     const int lj = l < NB ? l : 0;               // joint owned by this lane (lanes >= 11 alias joint 0, masked)
     const int lo_ = (l >= NB && l < NB + NOBJ) ? l - NB : -1;   // object owned by this lane
@@ -1673,7 +1689,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     const int L_MINV = fix + LF_MINV, L_MOT = fix + LF_MOT, L_LIM = fix + LF_LIM, L_META = fix + LF_META, L_MU = fix + LF_MU,
               L_SPIN = fix + LF_SPIN, L_ROLL = fix + LF_ROLL, L_OSL = fix + LF_OSL, L_OST = fix + LF_OST, L_GSC = fix + LF_GSC,
               L_OBJ = fix + LF_OBJ, L_CST = fix + LF_CST;
-    unsigned short *listF = (unsigned short *)&LD(fix + LF_LISTF), *listT = (unsigned short *)&LD(fix + LF_LISTT);
+    unsigned char *listA = (unsigned char *)&LD(fix + LF_LISTA), *listT = (unsigned char *)&LD(fix + LF_LISTT);
     const float dt = P.dt, inv_dt = 1.0f / P.dt;
     SPROF_INIT
     SBLK_BEGIN
@@ -1740,7 +1756,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         rejected = ((unsigned)(__ballot(l < 9 && !isfinite(cmd_v)) >> (16 * (grp & 3))) & 0xffffu) != 0u;
     }
     const bool frozen = (ef0 & 1u) != 0u;
-    bool dead = frozen || (ef0 & ~3u) != 0u || rejected;
+    bool dead = frozen || (ef0 & ~11u) != 0u || rejected;      // (bit 8 is a render status: it never stops the physics)
     const int nct = dead ? 0 : min(ccount_in, MAXC);
     cw0 = l < nct ? cw0 : 0.0f; cw1 = 16 + l < nct ? cw1 : 0.0f; cw2 = 32 + l < nct ? cw2 : 0.0f;
     // ---- and only now the stores of the command part
@@ -1990,6 +2006,7 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
 #define MJA_STEP(J) { mja3[0] += minv_l[J] * row_bcast<J>(ja3[0]); mja3[1] += minv_l[J] * row_bcast<J>(ja3[1]); mja3[2] += minv_l[J] * row_bcast<J>(ja3[2]); }
                 MJA_STEP(0) MJA_STEP(1) MJA_STEP(2) MJA_STEP(3) MJA_STEP(4) MJA_STEP(5) MJA_STEP(6) MJA_STEP(7) MJA_STEP(8) MJA_STEP(9) MJA_STEP(10)
 #undef MJA_STEP
+                float mjf3[3], dinv3[3];          // M^-1 J^T of this lane's slot-A variable; 1 / diagonal (0: row absent)
 #pragma unroll
                 for (int ka = 0; ka < 3; ka++) {
                     const int kr = 3 * tq + ka;
@@ -1997,9 +2014,11 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
                     const bool present = !tors || (ka == 0 ? spin > 0 : roll > 0);
                     const float ja = ja3[ka], jb = jb3[ka], mjb = mjb3[ka];
                     const float mja = l < NB ? mja3[ka] : dot(d, hA_);
+                    mjf3[ka] = mja;
                     const float diag = group_sum(ja * mja + jb * mjb);
                     const float rel = group_sum(ja * ua + jb * ub);
-                    if (present) D.grows[((size_t)env * GROWS + r0 + kr) * 16 + l] = make_float4(ja, mja, jb, mjb);
+                    // (the normal row in the canonical layout: the block repack below and the coop warm start read it back)
+                    if (kr == 0) D.grows[((size_t)env * GP_RECS + GP_C + slot) * 16 + l] = make_float4(ja, mja, jb, mjb);
                     if (kr == 0 && !coop) { wsA = fmaf(mja, lam0, wsA); wsB = fmaf(mjb, lam0, wsB); }      // (coop: replayed in list order below)
                     float rhsn;
                     if (kr == 0) {
@@ -2010,10 +2029,38 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
                         else perr = -dist * P.erp * inv_dt;
                         rhsn = perr + verr;
                     } else rhsn = -rel;
-                    if (l == 0) {
-                        const float dinv = (present && diag > 0) ? 1.0f / diag : 0.0f;
+                    const float dinv = (present && diag > 0) ? 1.0f / diag : 0.0f;
+                    dinv3[ka] = dinv;
+                    if (l == 0)
                         *(float4 *)&LD(L_GSC + 4 * (r0 + kr)) = make_float4(rhsn * dinv, dinv, kr == 0 ? 0.0f : (kr < 3 ? mu : (kr == 3 ? spin : roll)), kr == 0 ? lam0 : 0.0f);
-                    }
+                }
+                // ---- the rows as the sweeps stream them (block Gauss-Seidel, see the sweep): lane (h, g) = (bit 3, bit 2) of the group
+                const bool hh_ = (l & 8) != 0, gg_ = (l & 4) != 0;
+                if (!tors) {
+                    // lateral friction pair (t1, t2): J pair in the lane's order (its own row first), M^-1 J^T pair, cross term of row t2
+                    const float c21 = group_sum(ja3[2] * mjf3[1] + jb3[2] * mjb3[1]);
+                    float4 *fp = D.grows + ((size_t)env * GP_RECS + GP_F + 3 * slot) * 16 + l;
+                    fp[0] = make_float4(hh_ ? ja3[2] : ja3[1], hh_ ? ja3[1] : ja3[2], hh_ ? jb3[2] : jb3[1], hh_ ? jb3[1] : jb3[2]);
+                    fp[16] = make_float4(mjf3[1], mjb3[1], mjf3[2], mjb3[2]);
+                    fp[32] = make_float4(hh_ ? -(dinv3[2] * c21) : 0.0f, 0.0f, 0.0f, 0.0f);
+                } else {
+                    // torsional triple (spinning about n, rolling about t1, t2) + an absent fourth row; absent rows are all zero
+                    const bool ps = spin > 0, pr = roll > 0;
+                    const float a0 = ps ? ja3[0] : 0.0f, b0 = ps ? jb3[0] : 0.0f, ma0 = ps ? mjf3[0] : 0.0f, mb0 = ps ? mjb3[0] : 0.0f;
+                    const float a1 = pr ? ja3[1] : 0.0f, b1 = pr ? jb3[1] : 0.0f, ma1 = pr ? mjf3[1] : 0.0f, mb1 = pr ? mjb3[1] : 0.0f;
+                    const float a2 = pr ? ja3[2] : 0.0f, b2 = pr ? jb3[2] : 0.0f, ma2 = pr ? mjf3[2] : 0.0f, mb2 = pr ? mjb3[2] : 0.0f;
+                    const float c10 = group_sum(a1 * ma0 + b1 * mb0), c20 = group_sum(a2 * ma0 + b2 * mb0), c21 = group_sum(a2 * ma1 + b2 * mb1);
+                    const float4 pa = make_float4(hh_ ? a1 : a0, hh_ ? a0 : a1, hh_ ? b1 : b0, hh_ ? b0 : b1);      // pair (row 0, row 1)
+                    const float4 pb = make_float4(hh_ ? 0.0f : a2, hh_ ? a2 : 0.0f, hh_ ? 0.0f : b2, hh_ ? b2 : 0.0f);  // pair (row 2, -)
+                    float4 *tp = D.grows + ((size_t)env * GP_RECS + GP_T + 5 * slot) * 16 + l;
+                    tp[0] = make_float4(gg_ ? pb.x : pa.x, gg_ ? pb.y : pa.y, gg_ ? pb.z : pa.z, gg_ ? pb.w : pa.w);     // (component selects: a
+                    tp[16] = make_float4(gg_ ? pa.x : pb.x, gg_ ? pa.y : pb.y, gg_ ? pa.z : pb.z, gg_ ? pa.w : pb.w);    //  select of structs goes through scratch)
+                    tp[32] = make_float4(ma0, mb0, ma1, mb1);
+                    tp[48] = make_float4(ma2, mb2, 0.0f, 0.0f);
+                    // (the lane's row: 2 g + h -- cross terms with the rows in front of it, times -1/diag)
+                    const float x0 = gg_ ? (hh_ ? 0.0f : -(dinv3[2] * c20)) : (hh_ ? -(dinv3[1] * c10) : 0.0f);
+                    const float x1 = (gg_ && !hh_) ? -(dinv3[2] * c21) : 0.0f;
+                    tp[64] = make_float4(x0, x1, 0.0f, 0.0f);
                 }
             }
         }
@@ -2024,12 +2071,62 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         const unsigned mm = (unsigned)(__ballot(class_mismatch) >> (16 * (grp & 3))) & 0xffffu;
         if (mm != 0u && l == 0 && !dead) atomicOr(&D.errflags[env], 4u);      // (internal consistency: never seen)
     }
+    if (GEN) {
+        // ---- block repack of the generic NORMAL rows: contacts 4 b .. 4 b + 3 as one block {J pair, J pair, M^-1 J^T pair, M^-1 J^T
+        // pair, cross terms} in the lanes' order (see the sweep), from the canonical rows the builders have just stored.  coop:
+        // group cg takes the blocks cg, cg + 4, ..  Also: the scalars of the dummy contacts and of the last block's absent rows.
+        const int ngw = max(max(__builtin_amdgcn_readlane(ng, 0), __builtin_amdgcn_readlane(ng, 16)),
+                            max(__builtin_amdgcn_readlane(ng, 32), __builtin_amdgcn_readlane(ng, 48)));
+        if (ngw > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            {
+                float4 *zp = (float4 *)&LD(fix + LF_ZPAD);
+                zp[l] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (l < 8) zp[16 + l] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            const bool hh_ = (l & 8) != 0, gg_ = (l & 4) != 0;
+            const int nbw = (ngw + 3) >> 2;
+#pragma unroll 1
+            for (int b = cg; b < nbw; b += coop ? 4 : 1) {
+                const int c0 = 4 * b;
+                const float4 *cp = D.grows + ((size_t)env * GP_RECS + GP_C) * 16 + l;
+                // (unconditional loads from always-valid addresses, values selected: DESIGN.md 7)
+                const float4 r0_ = sel4(c0 < ng, cp[16 * (c0 < ng ? c0 : 0)]), r1_ = sel4(c0 + 1 < ng, cp[16 * (c0 + 1 < ng ? c0 + 1 : 0)]),
+                             r2_ = sel4(c0 + 2 < ng, cp[16 * (c0 + 2 < ng ? c0 + 2 : 0)]), r3_ = sel4(c0 + 3 < ng, cp[16 * (c0 + 3 < ng ? c0 + 3 : 0)]);
+                const float d1 = c0 + 1 < ng ? LD(L_GSC + 24 * (c0 + 1 < ng ? c0 + 1 : 0) + 1) : 0.0f, d2 = c0 + 2 < ng ? LD(L_GSC + 24 * (c0 + 2 < ng ? c0 + 2 : 0) + 1) : 0.0f,
+                            d3 = c0 + 3 < ng ? LD(L_GSC + 24 * (c0 + 3 < ng ? c0 + 3 : 0) + 1) : 0.0f;
+                // cross terms J_k . M^-1 J_i^T (i < k): what row i's impulse change adds to row k's J . v
+                const float c10 = group_sum(r1_.x * r0_.y + r1_.z * r0_.w);
+                const float c20 = group_sum(r2_.x * r0_.y + r2_.z * r0_.w), c21 = group_sum(r2_.x * r1_.y + r2_.z * r1_.w);
+                const float c30 = group_sum(r3_.x * r0_.y + r3_.z * r0_.w), c31 = group_sum(r3_.x * r1_.y + r3_.z * r1_.w), c32 = group_sum(r3_.x * r2_.y + r3_.z * r2_.w);
+                const float4 pa = make_float4(hh_ ? r1_.x : r0_.x, hh_ ? r0_.x : r1_.x, hh_ ? r1_.z : r0_.z, hh_ ? r0_.z : r1_.z);
+                const float4 pb = make_float4(hh_ ? r3_.x : r2_.x, hh_ ? r2_.x : r3_.x, hh_ ? r3_.z : r2_.z, hh_ ? r2_.z : r3_.z);
+                const float dk = gg_ ? (hh_ ? d3 : d2) : d1;          // (the lane's row 2 g + h; row 0 has no cross term)
+                const float x0 = gg_ ? (hh_ ? c30 : c20) : (hh_ ? c10 : 0.0f), x1 = gg_ ? (hh_ ? c31 : c21) : 0.0f, x2 = (gg_ && hh_) ? c32 : 0.0f;
+                if (c0 < ng) {
+                    float4 *np = D.grows + ((size_t)env * GP_RECS + GP_N + 5 * b) * 16 + l;
+                    np[0] = make_float4(gg_ ? pb.x : pa.x, gg_ ? pb.y : pa.y, gg_ ? pb.z : pa.z, gg_ ? pb.w : pa.w);
+                    np[16] = make_float4(gg_ ? pa.x : pb.x, gg_ ? pa.y : pb.y, gg_ ? pa.z : pb.z, gg_ ? pa.w : pb.w);
+                    np[32] = make_float4(r0_.y, r0_.w, r1_.y, r1_.w);
+                    np[48] = make_float4(r2_.y, r2_.w, r3_.y, r3_.w);
+                    np[64] = make_float4(-(dk * x0), -(dk * x1), -(dk * x2), 0.0f);
+                    if (l >= 1 && l <= 3 && c0 + l >= ng) *(float4 *)&LD(L_GSC + 24 * (c0 + l)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                } else if (!coop) {
+                    // (four envs to a wave: this env has fewer blocks than another one of its wave -- it sweeps all-zero blocks meanwhile)
+                    float4 *np = D.grows + ((size_t)env * GP_RECS + GP_N + 5 * b) * 16 + l;
+                    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    np[0] = z4; np[16] = z4; np[32] = z4; np[48] = z4; np[64] = z4;
+                    if (l < 4) *(float4 *)&LD(L_GSC + 24 * (c0 + l)) = z4;
+                }
+            }
+        }
+    }
     if (coop) {
         // the warm-start velocity change of the generic normal rows, in list order, from the stored rows: the very fma sequence
         // a single builder runs in line (each of the four builders holds only its own contacts' share)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         for (int j = 0; j < ng; j++) {
-            const float4 rw = D.grows[((size_t)env * GROWS + 6 * j) * 16 + l];
+            const float4 rw = D.grows[((size_t)env * GP_RECS + GP_C + j) * 16 + l];
             const float l0 = LD(L_GSC + 24 * j + 3);
             wsA = fmaf(rw.y, l0, wsA); wsB = fmaf(rw.w, l0, wsB);
         }
@@ -2168,6 +2265,22 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
             const float hs_ = os_sp[i] * os_ln[i], hr_ = os_ro[i] * os_ln[i];                         \
             REG_TORS_STEP(os_n0[i], i, 0, hs_) REG_TORS_STEP(os_a0[i], i, 1, hr_) REG_TORS_STEP(os_b0[i], i, 2, hr_) \
         }
+    // joint limits beyond the register rows (GEN: all of them), existing rows only; the expressions of LIMIT_STEP
+#define LIMIT_LOOP                                                                                    \
+        _Pragma("unroll 1")                                                                           \
+        for (unsigned rem = limmask; rem; rem &= rem - 1) {                                           \
+            const int js = __ffs(rem) - 1;                                                            \
+            const int j = js >> 1;                                                                    \
+            const float lr = LD(L_LIM + 2 * js), ll = LD(L_LIM + 2 * js + 1), di = LD(L_MOT + 3 * j + 1); \
+            const float col = l < NB ? LD(L_MINV + lj * NB + j) : 0.0f;                               \
+            const float sg = (js & 1) == 0 ? 1.0f : -1.0f;                                            \
+            const float dqj_ = group_sum(l == j ? dq : 0.0f);                                         \
+            const float s0_ = fmaf(-(sg * dqj_), di, ll + lr);                                        \
+            const float sum_ = fminf(fmaxf(s0_, 0.0f), 100.0f);                                       \
+            const float dl_ = sum_ - ll;                                                              \
+            LD(L_LIM + 2 * js + 1) = sum_;                                                            \
+            dq += col * (sg * dl_);                                                                   \
+        }
     SPROF(3);
     SBLK_MARK(sb_t1)
     static_assert(KLIM == 2 && KOS == 4, "the sweeps below are written out for KLIM = 2, KOS = 4");
@@ -2183,12 +2296,43 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     // completed (workgroup scope: the CU's vector L1 is write-through and shared by the workgroup -- no cache maintenance;
     // an agent-scope fence would write back the XCD's L2)
     if (ng_max > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    // byte offsets into D.grows (32 bits: rr_create checks N; a uniform base + a 32-bit lane offset is one address operand
-    // of the load instead of a 64-bit add per row)
-    const int grow_base = (int)((unsigned)env * (unsigned)(GROWS * 256));      // row 0 of this env
-    const int zrow = (int)((unsigned)P.N * (unsigned)(GROWS * 256));           // an all-zero row behind the last env's rows
-    const unsigned lane_off = (unsigned)l << 4;
-#define GROW_AT(IDX) (*(const float4 *)((const char *)D.grows + ((unsigned)(IDX) + lane_off)))
+    // ---- generic rows: BLOCK Gauss-Seidel.  Rows are swept in blocks -- the normal rows of four consecutive contacts, the two
+    // lateral rows of a contact, its (up to) three torsional rows -- whose J . v are formed SIDE BY SIDE from the velocities in
+    // front of the block; row k's value then takes the impulse changes of the block's rows i < k through the cross terms
+    // J_k . M^-1 J_i^T (stored with the block, times -1/diag_k).  Algebraically the very Gauss-Seidel sequence (same order, same
+    // clamps); at one wave per SIMD a kernel lasts as long as its instruction count, and a block of four costs 29 VALU
+    // instructions instead of 4 x 14 (two rows: 18 instead of 28):
+    //   * lane (h, g) = (bit 3, bit 2) of the group ends up with the sum of row 2 g + h (two-row block: row h).  The J pairs are
+    //     STORED in the order each lane needs ({own row, partner's row} x {slot A, slot B}, builder / repack above), so that the
+    //     products are two packed multiply-adds per pair and the 16-lane sums of all four rows take five DPP adds: across the
+    //     halves (row_ror 8: my second value is my partner's first), across the quads (row_half_mirror), inside the quad;
+    //   * the clamp of row k is evaluated by the lanes of row k (their scalars rhs, 1/diag, bound, lambda come from LDS), its impulse
+    //     change goes to all lanes with one DPP row_newbcast and updates the running sums s (one FMA) and the velocities
+    //     (dq, vb) (one packed FMA with the row's (M^-1 J^T)_A, (M^-1 J^T)_B pair);
+    //   * a lane's s stops changing once its own row is done (its later cross terms are zero): `sum` after the last step is the
+    //     row's new lambda in every lane of the row.
+    // The blocks are streamed from global memory (L2 / L1 resident: the wave wrote them) through ONE register set: every part of
+    // the next block is requested as soon as the registers it lands in are free (BLK4_STEP), its scalars from LDS behind the
+    // step.  Measured (profiles/r05_*): two sets (a block further ahead) were slower everywhere -- the 24 registers they take
+    // push the object lanes' rows into AGPR traffic (+17 % on a sweep without generic rows) -- and three sets spilled.  A normal
+    // block takes ~210 shader cycles (52 per row; the row-by-row step of round 4: 82), a lateral pair ~140.  Dummy blocks (contact
+    // MAXC: all-zero records and scalars; all-zero normal blocks behind an env's own) are what a group sweeps while another env of
+    // its wave has blocks left.  Byte offsets are 32 bits (rr_create checks N).
+    const unsigned gp_l = (unsigned)env * (unsigned)GP_ENV_BYTES + ((unsigned)l << 4);
+    // (LDS is addressed through 32-bit address-space-3 pointers made from byte addresses: the generic-pointer form costs an add per access)
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const v4f_ lds_cf4;
+    typedef __attribute__((address_space(3))) float lds_f;
+    typedef __attribute__((address_space(3))) const unsigned char lds_cu8;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)g_slds;
+#define LDS_F4(BYTE) (*(lds_cf4 *)(size_t)(unsigned)(BYTE))
+#define LDS_F(BYTE) (*(lds_f *)(size_t)(unsigned)(BYTE))
+    const bool hh = (l & 8) != 0, gg = (l & 4) != 0;
+    const int rho = (gg ? 2 : 0) + (hh ? 1 : 0);
+    const unsigned gsc_b = lds0 + 4u * (unsigned)L_GSC;             // byte address of the generic row scalars in LDS
+    const int nb_g = (ng + 3) >> 2;                                 // normal blocks of this group's env
+    const int nb_max = (ng_max + 3) >> 2;
+    const unsigned list_b = lds0 + 4u * (unsigned)(fix + LF_LISTA); // byte address of listA (listT: + 64)
     // object lane (11 + O) -> slots, and back; comps 0..5 = dv.xyz, dw.xyz
 #define TO_SLOT(O, C, REG, SLOTREG, LANE) { const float t_ = row_bcast<NB + (O)>(REG); SLOTREG = (l == (LANE)) ? t_ : SLOTREG; }
 #define FROM_SLOT(O, C, REG, SLOTREG, LANE) { const float t_ = row_bcast<LANE>(SLOTREG); REG = (l == NB + (O)) ? t_ : REG; }
@@ -2207,7 +2351,107 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         V23 = pk_fma(P2(os_n1[i].z, os_n1[i].w), P2(sm_, l0_), V23);
         V45 = pk_fma(P2(os_n2[i].x, os_n2[i].y), P2(l0_, l0_), V45);
     }
-    int nF = 0, nT = 0;                                   // entries of this env's lateral / torsional row lists
+    int nA = 0, nT = 0;                                   // entries of this env's lists of active contacts (lateral / torsional pass)
+    if (ng_max > 0) {                                     // (both lists start as all dummies)
+#pragma unroll
+        for (int k = 0; k < 64; k += 16) { listA[k + l] = (unsigned char)MAXC; listT[k + l] = (unsigned char)MAXC; }
+    }
+    // the register set of the block in flight: records {j0, j1, m0, m1, x}, scalars {rhs, 1/diag, lambda, upper bound}, the LDS
+    // byte address of the scalars (lambda goes back there)
+#define BLK_DECL(R) float4 R##j0 = make_float4(0, 0, 0, 0), R##j1 = R##j0, R##m0 = R##j0, R##m1 = R##j0; float R##x0 = 0.0f, R##x1 = 0.0f, R##x2 = 0.0f, R##rhs = 0.0f, R##di = 0.0f, R##lam = 0.0f, R##hi = 0.0f; int R##a = 0;
+    BLK_DECL(A)
+    // where block I of the pass lives: N pass: block I itself (a group whose env has fewer blocks than its wave sweeps the all-zero
+    // blocks the repack left behind its own); F / T pass: the contact in entry I of the pass' list (dummy MAXC: all-zero records)
+#define BLK_ENTRY(I) ((int)*(lds_cu8 *)(size_t)(lst_b + (unsigned)(I)))
+#define GP_PTR(OFF) ((const char *)D.grows + (unsigned)(OFF))
+#define BLK4_FETCH(R, OFF) { const char *bp__ = GP_PTR(OFF); R##j0 = *(const float4 *)bp__; R##j1 = *(const float4 *)(bp__ + 256); R##m0 = *(const float4 *)(bp__ + 512);   \
+                             R##m1 = *(const float4 *)(bp__ + 768); R##x0 = *(const float *)(bp__ + 1024); R##x1 = *(const float *)(bp__ + 1028); R##x2 = *(const float *)(bp__ + 1032); }
+#define BLK2_FETCH(R, OFF) { const char *bp__ = GP_PTR(OFF); R##j0 = *(const float4 *)bp__; R##m0 = *(const float4 *)(bp__ + 256); R##x0 = *(const float *)(bp__ + 512); }
+#define SC_SET(R, HIEXPR) { const v4f_ sc__ = LDS_F4(R##a); R##rhs = sc__.x; R##di = sc__.y; R##lam = sc__.w; R##hi = (HIEXPR); }
+    // N pass: the lane's row is the normal row of contact 4 b + rho
+    const unsigned gpn_l = gp_l + GP_N * 256, nsc_l = gsc_b + (unsigned)rho * 96u;
+#define N_OFF(I) (gpn_l + (unsigned)(I) * 1280u)
+    typedef __attribute__((address_space(3))) const v2f lds_cf2;
+    // (the bound coefficient of a normal row is not read: a 16-byte read whose third word is dead makes the next writer of that register wait for the LDS)
+#define N_SC(R, I) { R##a = (int)(nsc_l + (unsigned)(I) * 384u); const v2f rd__ = *(lds_cf2 *)(size_t)(unsigned)R##a; R##rhs = rd__.x; R##di = rd__.y; R##lam = LDS_F(R##a + 12); R##hi = 1e10f; }
+    // F pass: the lateral rows 6 j + 1 + h of contact j; T pass: the torsional rows 6 j + 3 + rho (rho 3: absent -> dummy contact)
+    const unsigned gpf_l = gp_l + GP_F * 256, fsc_l = gsc_b + (hh ? 32u : 16u), gpt_l = gp_l + GP_T * 256, tsc_l = gsc_b + (rho == 3 ? MAXC * 96u : 48u + 16u * (unsigned)rho);
+#define F_OFF(J) (gpf_l + (unsigned)(J) * 768u)
+#define F_SC(R, J) { const unsigned t__ = (unsigned)(J) * 96u; R##a = (int)(fsc_l + t__); const float ln__ = LDS_F(gsc_b + t__ + 12u); SC_SET(R, sc__.z * ln__) }
+#define T_OFF(J) (gpt_l + (unsigned)(J) * 1280u)
+#define T_SC(R, J) { const unsigned t__ = (unsigned)(J) * 96u; R##a = (int)(tsc_l + (rho == 3 ? 0u : t__)); const float ln__ = LDS_F(gsc_b + t__ + 12u); SC_SET(R, sc__.z * ln__) }
+#define DPPF(CTRL, V) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(V), (CTRL), 0xf, 0xf, false))
+#define BLK_ROW(R, LANE, X, M0, M1)                                                                                    \
+                {                                                                                                      \
+                    sum_ = __builtin_amdgcn_fmed3f(s_, lo_, hi_);                                                      \
+                    const float b_ = row_bcast<LANE>(sum_ - lam_);                                                     \
+                    s_ = fmaf((X), b_, s_);                                                                            \
+                    V_ = pk_fma(P2((M0), (M1)), P2(b_, b_), V_);                                                       \
+                }
+#define BLK_LAST(R, LANE, M0, M1)                                                                                      \
+                {                                                                                                      \
+                    sum_ = __builtin_amdgcn_fmed3f(s_, lo_, hi_);                                                      \
+                    const float b_ = row_bcast<LANE>(sum_ - lam_);                                                     \
+                    V_ = pk_fma(P2((M0), (M1)), P2(b_, b_), V_);                                                       \
+                }
+    // one block of four rows (HI: upper bound of the lane's row; lower bound LO).  NEXT: byte offset of the block the register
+    // set sweeps next: each part of it is requested as soon as the registers it lands in are free -- the J pairs right behind
+    // the products, the first M^-1 J^T pair behind row 1, the rest behind the last row
+#define SCHED_FENCE __builtin_amdgcn_sched_barrier(0);
+#define BLK4_STEP(R, LO, HI, NEXT)                                                                                     \
+                {                                                                                                      \
+                    const char *bp__ = GP_PTR(NEXT);                                                                   \
+                    v2f p01_ = P2(R##j0.x, R##j0.y) * P2(dq, dq);                                                      \
+                    v2f p23_ = P2(R##j1.x, R##j1.y) * P2(dq, dq);                                                      \
+                    p01_ = pk_fma(P2(R##j0.z, R##j0.w), P2(vb, vb), p01_);                                             \
+                    p23_ = pk_fma(P2(R##j1.z, R##j1.w), P2(vb, vb), p23_);                                             \
+                    SCHED_FENCE                                                                                        \
+                    R##j0 = *(const float4 *)bp__; R##j1 = *(const float4 *)(bp__ + 256);                             \
+                    SCHED_FENCE                                                                                        \
+                    const float s0_ = p01_.x + dpp_ror<8>(p01_.y);                                                     \
+                    const float s1_ = p23_.x + dpp_ror<8>(p23_.y);                                                     \
+                    float u_ = s0_ + DPPF(0x141, s1_);                                                                 \
+                    u_ += DPPF(0xB1, u_);                                                                              \
+                    u_ += DPPF(0x4E, u_);                                                                              \
+                    const float lam_ = R##lam, lo_ = (LO), hi_ = (HI);                                                 \
+                    float s_ = fmaf(-u_, R##di, lam_ + R##rhs), sum_;                                                  \
+                    v2f V_ = P2(dq, vb);                                                                               \
+                    BLK_ROW(R, 0, R##x0, R##m0.x, R##m0.y)                                                             \
+                    BLK_ROW(R, 8, R##x1, R##m0.z, R##m0.w)                                                             \
+                    SCHED_FENCE                                                                                        \
+                    R##m0 = *(const float4 *)(bp__ + 512);                                                             \
+                    SCHED_FENCE                                                                                        \
+                    BLK_ROW(R, 4, R##x2, R##m1.x, R##m1.y)                                                             \
+                    BLK_LAST(R, 12, R##m1.z, R##m1.w)                                                                  \
+                    dq = V_.x; vb = V_.y;                                                                              \
+                    LDS_F(R##a + 12) = sum_;                                                                           \
+                    R##m1 = *(const float4 *)(bp__ + 768); R##x0 = *(const float *)(bp__ + 1024); R##x1 = *(const float *)(bp__ + 1028); R##x2 = *(const float *)(bp__ + 1032); \
+                }
+    // one block of two rows (lanes 0..7: the first row, 8..15: the second)
+#define BLK2_STEP(R, LO, HI, NEXT)                                                                                     \
+                {                                                                                                      \
+                    const char *bp__ = GP_PTR(NEXT);                                                                   \
+                    v2f p_ = P2(R##j0.x, R##j0.y) * P2(dq, dq);                                                        \
+                    p_ = pk_fma(P2(R##j0.z, R##j0.w), P2(vb, vb), p_);                                                 \
+                    SCHED_FENCE                                                                                        \
+                    R##j0 = *(const float4 *)bp__;                                                                     \
+                    SCHED_FENCE                                                                                        \
+                    float u_ = p_.x + dpp_ror<8>(p_.y);                                                                \
+                    u_ += DPPF(0x141, u_);                                                                             \
+                    u_ += DPPF(0xB1, u_);                                                                              \
+                    u_ += DPPF(0x4E, u_);                                                                              \
+                    const float lam_ = R##lam, lo_ = (LO), hi_ = (HI);                                                 \
+                    float s_ = fmaf(-u_, R##di, lam_ + R##rhs), sum_;                                                  \
+                    v2f V_ = P2(dq, vb);                                                                               \
+                    BLK_ROW(R, 0, R##x0, R##m0.x, R##m0.y)                                                             \
+                    BLK_LAST(R, 8, R##m0.z, R##m0.w)                                                                   \
+                    dq = V_.x; vb = V_.y;                                                                              \
+                    LDS_F(R##a + 12) = sum_;                                                                           \
+                    R##m0 = *(const float4 *)(bp__ + 256); R##x0 = *(const float *)(bp__ + 512);                       \
+                }
+    if (GEN) *(volatile int *)&LD(fix + LF_ENVW) = env;
+    // (coop: groups 1..3 of the wave have no rows of their own -- their lanes are switched off for the sweeps)
+    if (!(coop && cg != 0))
     for (int it = 0; it < P.iters; it++) {
         // compiler barrier: the row data in LDS / global memory is loop invariant, but hoisting hundreds of such loads out
         // of the sweep loop exhausts the register file (everything that should live in registers is held explicitly)
@@ -2225,39 +2469,25 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
         SPROF(4);
         SWEEP_MOTORS
         LIMIT_STEP(0) LIMIT_STEP(1)
-#pragma unroll 1
-        for (unsigned rem = limmask; rem; rem &= rem - 1) {   // further joint limits (existing rows only)
-            const int js = __ffs(rem) - 1;
-            float lr = LD(L_LIM + 2 * js);
-            int j = js >> 1;
-            float dqj = group_sum(l == j ? dq : 0.0f);
-            float ll = LD(L_LIM + 2 * js + 1);
-            float sg = (js & 1) == 0 ? 1.0f : -1.0f;
-            float dl = lr - sg * dqj * LD(L_MOT + 3 * j + 1);
-            float sum = ll + dl;
-            if (sum < 0) { dl = -ll; sum = 0; }
-            else if (sum > 100.0f) { dl = 100.0f - ll; sum = 100.0f; }
-            if (l == 0) LD(L_LIM + 2 * js + 1) = sum;
-            if (l < NB) dq += LD(L_MINV + l * NB + j) * (sg * dl);
-        }
+        LIMIT_LOOP
         SPROF(7);
         if (OW) continue;                         // (the object chains are the object wave's)
 #pragma unroll 1
         for (int pass = 0; pass < 3; pass++) {    // all normals, then all lateral frictions, then all torsional frictions
-            // ---- the generic sweep of this pass: its first rows are requested before the object lanes' own work
-            const int cnt = pass == 0 ? ng : (pass == 1 ? nF : nT);
-            const int cmax = pass == 0 ? ng_max : max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
-                                                      max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
-            const unsigned short *lst = pass == 1 ? listF : listT;
-#define ENTRY(I) ((I) < cnt ? (pass == 0 ? 6 * (I) : (int)lst[(I) < cnt ? (I) : 0]) : 0xffff)        /* row id | k << 9 */
-#define ENTRY_IDX(E) ((E) == 0xffff ? zrow : grow_base + ((E) & 511) * 256)
-            int e_cur = ENTRY(l), e_nxt = ENTRY(16 + l);
-            int idx_cur = ENTRY_IDX(e_cur), idx_nxt = ENTRY_IDX(e_nxt);
-            float4 Q0, Q1, Q2, Q3, Q4, Q5, Q6, Q7;
+            // ---- the generic sweep of this pass: its first blocks are requested before the object lanes' own work
+            const int cnt = pass == 0 ? nb_g : (pass == 1 ? nA : nT);
+#define WAVE_MAX4(V) (coop ? __builtin_amdgcn_readlane((V), 0) : max(max(__builtin_amdgcn_readlane((V), 0), __builtin_amdgcn_readlane((V), 16)), max(__builtin_amdgcn_readlane((V), 32), __builtin_amdgcn_readlane((V), 48))))
+            const int cmax = pass == 0 ? nb_max : WAVE_MAX4(cnt);
+            const unsigned lst_b = list_b + (pass == 2 ? 64u : 0u);
+            int jn_ = MAXC;                                   // (F / T pass: the contact of the block after the next one)
             if (cmax > 0) {
-                Q0 = GROW_AT(row_bcast_i<0>(idx_cur)); Q1 = GROW_AT(row_bcast_i<1>(idx_cur)); Q2 = GROW_AT(row_bcast_i<2>(idx_cur));
-                Q3 = GROW_AT(row_bcast_i<3>(idx_cur)); Q4 = GROW_AT(row_bcast_i<4>(idx_cur)); Q5 = GROW_AT(row_bcast_i<5>(idx_cur));
-                Q6 = GROW_AT(row_bcast_i<6>(idx_cur)); Q7 = GROW_AT(row_bcast_i<7>(idx_cur));
+                if (pass == 0) {
+                    BLK4_FETCH(A, N_OFF(0))
+                } else if (pass == 1) {
+                    BLK2_FETCH(A, F_OFF(BLK_ENTRY(0)))
+                } else {
+                    BLK4_FETCH(A, T_OFF(BLK_ENTRY(0)))
+                }
             }
             // ---- object-vs-static rows of this pass (object lanes, side by side; all register resident)
             if (pass == 0) { OSN_STEP(0) OSN_STEP(1) OSN_STEP(2) OSN_STEP(3) }
@@ -2265,89 +2495,84 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
             else { OST_STEP(0) OST_STEP(1) OST_STEP(2) OST_STEP(3) }
             SPROF(8);
             if (cmax == 0) continue;
-            // ---- generic rows of this pass, blocks of 16 rows: lane k of the group holds the scalars of the block's row k
             OBJ_SLOTS(TO_SLOT)
             SPROF(9);
-            for (int i0 = 0; i0 < cmax; i0 += 16) {
-                const int e = e_cur;
-                const bool valid = e != 0xffff;
-                const int r = valid ? (e & 511) : 0, kk = valid ? (e >> 9) : 0;
-                const float4 sc = sel4(valid, *(const float4 *)&LD(L_GSC + 4 * r));          // rhs, 1/diag, bound coefficient, lambda
-                const float lnorm = LD(L_GSC + 4 * (r - kk) + 3);                            // normal impulse of the row's contact
-                const float rhs = sc.x, dinv = sc.y;
-                float lam = sc.w;
-                const float hi = pass == 0 ? (valid ? 1e10f : 0.0f) : sc.z * lnorm, lo = pass == 0 ? 0.0f : -hi;
-                const int idx_a = idx_cur, idx_b = idx_nxt;        // this block's rows 8..15 and the next block's rows 0..7 are requested below
-                e_cur = e_nxt; idx_cur = idx_nxt;
-                e_nxt = ENTRY(i0 + 32 + l); idx_nxt = ENTRY_IDX(e_nxt);
-#define GROW_STEP(S, Q, NEXTIDX)                                                                                       \
+            // (one block per trip: the records of block i + 1 are requested inside the step of block i, its scalars behind it)
+            // (the scalars of the pass' first block: requested only now -- the object lanes' rows need the registers)
+            if (pass == 0) { N_SC(A, 0) }
+            else if (pass == 1) { const int ja_ = BLK_ENTRY(0); jn_ = BLK_ENTRY(1); F_SC(A, ja_) }
+            else { const int ja_ = BLK_ENTRY(0); jn_ = BLK_ENTRY(1); T_SC(A, ja_) }
+            if (pass == 0) {
+#define N_ITER(R, R2, I)                                                                                               \
                 {                                                                                                      \
-                    const float4 rw_ = Q;                                                                              \
-                    Q = GROW_AT(NEXTIDX);                                                                                    \
-                    const float p_ = fmaf(rw_.z, vb, rw_.x * dq);                                                      \
-                    const float jv_ = group_sum(p_);                                                                   \
-                    const float s0_ = fmaf(-jv_, dinv, lam + rhs);                                                     \
-                    const float sum_ = __builtin_amdgcn_fmed3f(s0_, lo, hi);                                           \
-                    const float dl_ = sum_ - lam;                                                                      \
-                    lam = (l == (S)) ? sum_ : lam;                                                                     \
-                    const float dlb_ = row_bcast<S>(dl_);                                                              \
-                    dq = fmaf(rw_.y, dlb_, dq); vb = fmaf(rw_.w, dlb_, vb);                                            \
+                    BLK4_STEP(R, 0.0f, R##hi, N_OFF((I) + 1))                                                          \
+                    N_SC(R2, (I) + 1)                                                                                  \
                 }
-                // (the last block of a sweep stops after the quadruple that holds the wave's last row)
-                GROW_STEP(0, Q0, row_bcast_i<8>(idx_a))   GROW_STEP(1, Q1, row_bcast_i<9>(idx_a))
-                GROW_STEP(2, Q2, row_bcast_i<10>(idx_a))  GROW_STEP(3, Q3, row_bcast_i<11>(idx_a))
-                if (i0 + 4 < cmax) {
-                GROW_STEP(4, Q4, row_bcast_i<12>(idx_a))  GROW_STEP(5, Q5, row_bcast_i<13>(idx_a))
-                GROW_STEP(6, Q6, row_bcast_i<14>(idx_a))  GROW_STEP(7, Q7, row_bcast_i<15>(idx_a))
-                if (i0 + 8 < cmax) {
-                GROW_STEP(8, Q0, row_bcast_i<0>(idx_b))   GROW_STEP(9, Q1, row_bcast_i<1>(idx_b))
-                GROW_STEP(10, Q2, row_bcast_i<2>(idx_b))  GROW_STEP(11, Q3, row_bcast_i<3>(idx_b))
-                if (i0 + 12 < cmax) {
-                GROW_STEP(12, Q4, row_bcast_i<4>(idx_b))  GROW_STEP(13, Q5, row_bcast_i<5>(idx_b))
-                GROW_STEP(14, Q6, row_bcast_i<6>(idx_b))  GROW_STEP(15, Q7, row_bcast_i<7>(idx_b))
-                } } }
-#undef GROW_STEP
-                if (valid) LD(L_GSC + 4 * r + 3) = lam;
+                for (int i0 = 0; i0 < cmax; i0++) N_ITER(A, A, i0)
+#undef N_ITER
+            } else if (pass == 1) {
+#define F_ITER(R, R2, I)                                                                                               \
+                {                                                                                                      \
+                    const int j1_ = jn_;                                                                               \
+                    jn_ = BLK_ENTRY((I) + 2);                                                                          \
+                    BLK2_STEP(R, -R##hi, R##hi, F_OFF(j1_))                                                            \
+                    F_SC(R2, j1_)                                                                                      \
+                }
+                for (int i0 = 0; i0 < cmax; i0++) F_ITER(A, A, i0)
+#undef F_ITER
+            } else {
+#define T_ITER(R, R2, I)                                                                                               \
+                {                                                                                                      \
+                    const int j1_ = jn_;                                                                               \
+                    jn_ = BLK_ENTRY((I) + 2);                                                                          \
+                    BLK4_STEP(R, -R##hi, R##hi, T_OFF(j1_))                                                            \
+                    T_SC(R2, j1_)                                                                                      \
+                }
+                for (int i0 = 0; i0 < cmax; i0++) T_ITER(A, A, i0)
+#undef T_ITER
             }
-#undef ENTRY
-#undef ENTRY_IDX
-            SPROF(10);
+            if (pass == 0) SPROF(10); else if (pass == 1) SPROF(5); else SPROF(6);      // (generic blocks: normal / lateral / torsional pass)
             OBJ_SLOTS(FROM_SLOT)
             if (pass == 0) {
-                // ---- the lateral and torsional rows that can move something: contacts with a normal impulse, or with a
-                //      lateral / torsional impulse left from the previous sweep
-                nF = 0; nT = 0;
+                // ---- the contacts whose lateral and torsional rows can move something: those with a normal impulse, or with a
+                //      lateral / torsional impulse left from the previous sweep.  The lists keep their dummy padding.
+                const int nA_old = nA, nT_old = nT;
+                nA = 0; nT = 0;
                 for (int j0 = 0; j0 < ng_max; j0 += 16) {
                     const int j = j0 + l;
-                    bool act = false, hs = false, hr = false;
+                    bool act = false, ht = false;
                     if (j < ng) {
                         // (all eight LDS reads issued together: with `||` they would form a chain of dependent round trips)
                         const int r = L_GSC + 24 * j;
                         const float l0 = LD(r + 3), l1 = LD(r + 7), l2 = LD(r + 11), l3 = LD(r + 15), l4 = LD(r + 19), l5 = LD(r + 23);
                         const float cs_ = LD(r + 14), cr_ = LD(r + 18);      // coefficients of the spinning / rolling rows
                         act = (l0 > 0.0f) | (l1 != 0.0f) | (l2 != 0.0f) | (l3 != 0.0f) | (l4 != 0.0f) | (l5 != 0.0f);
-                        hs = act & (cs_ > 0.0f);
-                        hr = act & (cr_ > 0.0f);
+                        ht = act & ((cs_ > 0.0f) | (cr_ > 0.0f));
                     }
                     const unsigned lt = (1u << l) - 1u;
-                    const unsigned ma = (unsigned)(__ballot(act) >> (16 * (grp & 3))) & 0xffffu, ms = (unsigned)(__ballot(hs) >> (16 * (grp & 3))) & 0xffffu,
-                                   mr = (unsigned)(__ballot(hr) >> (16 * (grp & 3))) & 0xffffu;
-                    if (act) {
-                        const int pf = nF + 2 * __popc(ma & lt);
-                        listF[pf] = (unsigned short)((6 * j + 1) | (1 << 9)); listF[pf + 1] = (unsigned short)((6 * j + 2) | (2 << 9));
-                        int pt = nT + __popc(ms & lt) + 2 * __popc(mr & lt);
-                        if (hs) listT[pt++] = (unsigned short)((6 * j + 3) | (3 << 9));
-                        if (hr) { listT[pt] = (unsigned short)((6 * j + 4) | (4 << 9)); listT[pt + 1] = (unsigned short)((6 * j + 5) | (5 << 9)); }
-                    }
-                    nF += 2 * __popc(ma); nT += __popc(ms) + 2 * __popc(mr);
+                    const unsigned ma = (unsigned)(__ballot(act) >> (16 * (grp & 3))) & 0xffffu, mt = (unsigned)(__ballot(ht) >> (16 * (grp & 3))) & 0xffffu;
+                    if (act) listA[nA + __popc(ma & lt)] = (unsigned char)j;
+                    if (ht) listT[nT + __popc(mt & lt)] = (unsigned char)j;
+                    nA += __popc(ma); nT += __popc(mt);
+                }
+                // (entries a shrinking list leaves behind become dummies again: sixteen behind the new end at once, more only
+                // when a list lost more than that in one sweep)
+                listA[nA + l] = (unsigned char)MAXC; listT[nT + l] = (unsigned char)MAXC;
+                if (__ballot((nA_old - nA > 16) | (nT_old - nT > 16)) != 0ull) {
+                    for (int k = 16 + l; nA + k < nA_old; k += 16) listA[nA + k] = (unsigned char)MAXC;
+                    for (int k = 16 + l; nT + k < nT_old; k += 16) listT[nT + k] = (unsigned char)MAXC;
                 }
             }
             SPROF(11);
+            SPROF(3);           // (calibration: two stamps back to back -- the cost of a stamp, once per pass)
         }
     }
     SPROF(4);
+    // (GEN: the env index is parked in LDS over the sweeps -- the kernel with the generic rows has no register to spare there)
+    if (GEN) env = *(volatile int *)&LD(fix + LF_ENVW);
     SBLK_MARK(sb_t2)
-    SBLK_END(nc, ng, n_os, nF);
+    SBLK_END(nc, ng, n_os, nA);
+    SPROF_FLUSH;
     // normal impulses of the register-resident contact rows go back to their LDS slots (contact forces below)
 #pragma unroll
     for (int i = 0; i < (OW ? 0 : KOS); i++) {
@@ -2375,8 +2600,10 @@ __device__ __forceinline__ void solve_body(const BodyParams &B, const SimParams 
     // ---- integrate: lanes 0..10 joints, lanes 11..13 objects
     bool finite = true;
     if (lt < NB) {
-        float v = qds_l + dq;
-        float qn = fmaf(dt, v, q_l);            // (the integration is written out in fused operations: both forms of the kernel must round alike)
+        // (GEN: the kernel with the generic rows reads the two values again instead of holding them over the sweeps, like the objects' below)
+        const float qds_t = GEN ? SCR(S_QDS + (lt < NB ? lt : 0)) : qds_l, q_t = GEN ? STT(ST_Q + (lt < NB ? lt : 0)) : q_l;
+        float v = qds_t + dq;
+        float qn = fmaf(dt, v, q_t);            // (the integration is written out in fused operations: both forms of the kernel must round alike)
         finite = isfinite(qn);
         q_fin = qn;
         STT(ST_QD + lt) = v;
@@ -3933,7 +4160,7 @@ __device__ __forceinline__ void raster_tile(const SimParams &P, const RenderMode
         }
     }
     __syncthreads();
-    if (tid == 0 && nclipq > CLIPQ) atomicOr(&D.errflags[env], 4u);      // (clip queue overflow: triangles were dropped -- never expected)
+    if (tid == 0 && nclipq > CLIPQ) atomicOr(&D.errflags[env], 8u);      // (clip queue overflow: triangles were dropped; a RENDER status -- the solve's dead mask ignores bit 8)
     WGM(6);
     if (PRE && pass == 0 && tid == 0 && D.item_cost) D.item_cost[(size_t)env * RM.ntiles + tile] = (unsigned)__builtin_amdgcn_s_memrealtime() - s_tc0 + 1u;      // (100 MHz ticks)
     if (tid == 0) { D.frag_count[(size_t)env * RM.ntiles + tile] = nlist; RSTAT(12, nlist); RSTAT(13, 1); RSTAT(14, nclipq); RSTAT(15, nclipq > 0 ? 1 : 0); }
@@ -4544,7 +4771,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     if (!cfg || !model_blob || !out) return fail(RR_EINVAL, "rr_create: null argument");
     if (cfg->abi_version != RR_ABI_VERSION) return fail(RR_EINVAL, "rr_create: abi_version mismatch");
     if (cfg->num_envs < 1) return fail(RR_EINVAL, "rr_create: num_envs < 1");
-    if ((unsigned long long)cfg->num_envs * GROWS * 256ull + 256ull >= (1ull << 32)) return fail(RR_EINVAL, "rr_create: more than 58253 envs per rr_env (32-bit byte offsets of the solver's row store)");
+    if ((unsigned long long)cfg->num_envs * GP_ENV_BYTES + 4096ull >= (1ull << 32)) return fail(RR_EINVAL, "rr_create: more than 33222 envs per rr_env (32-bit byte offsets of the solver's row store)");
     if (cfg->n_objects < 1 || cfg->n_objects > NOBJ) return fail(RR_EINVAL, "rr_create: n_objects must be 1..3");
     if (cfg->width < 4 || cfg->height < 1 || cfg->width % 4 != 0 || cfg->width > TILE_PIX)
         return fail(RR_EINVAL, "rr_create: width must be a multiple of 4 in [4,4096]");
@@ -4748,7 +4975,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     ALLOC(D.timestep, (size_t)N);
     ALLOC(D.errflags, (size_t)N);
     ALLOC(D.obj_home, (size_t)NOBJ * 7 * N);
-    ALLOC(D.grows, ((size_t)N * GROWS + 1) * 16);
+    ALLOC(D.grows, (size_t)N * GP_RECS * 16);        // (zeroed: the dummy block / contact records stay all zero)
     ALLOC(D.cmd, (size_t)N * 9);
     ALLOC(D.joints, (size_t)N * 9);
     ALLOC(D.touch, (size_t)N * 4);

@@ -2,12 +2,12 @@
 of its four envs, for the headline workload (full-range commands) or the macro workload (argv[1] == 'macro')."""
 import os, sys, ctypes
 sys.path.insert(0, '/root/repo')
-os.environ['RR_LIB'] = os.path.join(os.path.dirname(__file__), '..', 'real_robots_amd', 'csrc', 'librealrobot_hip_stats.so')
+os.environ.setdefault('RR_LIB', os.path.join(os.path.dirname(__file__), '..', 'real_robots_amd', 'csrc', 'librealrobot_hip_stats.so'))
 import numpy as np, torch
 from real_robots_amd import _native as nat
 from real_robots_amd.batched import BatchedREALRobotEnv
 from real_robots_amd.distributed import synthetic_actions
-N = 4096
+N = int(os.environ.get('N', '4096'))
 macro = len(sys.argv) > 1 and sys.argv[1] == 'macro'
 scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 env = BatchedREALRobotEnv(N, objects=3, width=128, height=128, want_mask=False)
@@ -20,10 +20,11 @@ else:
     T = int(sys.argv[3]) if len(sys.argv) > 3 else 200
     for t in range(T): env.step(synthetic_actions(ids, (t // 20) * 20, hold_prob=0.05) * scale, render=False)
 torch.cuda.synchronize()
-nb = N // 4
+nb = N // 4 if N > 1024 else N          # (up to 1024 envs: one env per wave -- coop form)
 buf = (ctypes.c_uint * (8 * nb))()
 lib.rr_debug_solver_blocks(buf, nb)
 a = np.array(list(buf), dtype=np.int64).reshape(nb, 8)
+if N <= 1024: a = a[:min(nb, 4096)]
 cyc, build, pgs = a[:, 0], a[:, 1], a[:, 2]
 print("workgroups %d: total cycles mean %.0f median %.0f p99 %.0f max %.0f | build mean %.0f max %.0f | pgs mean %.0f max %.0f" % (
     nb, cyc.mean(), np.median(cyc), np.percentile(cyc, 99), cyc.max(), build.mean(), build.max(), pgs.mean(), pgs.max()))

@@ -237,6 +237,39 @@ def hull_edges(pts, min_len, cos_tol=0.9995):
     return out
 
 
+# Sample points on long sharp edges, appended to a shape's collision vertices (any boundary point is a valid "vertex" of the
+# vertex-in-polytope test).  Why: a long straight edge lying across a SMOOTH convex surface -- the table's rim under an arm link,
+# a cube edge under a link -- has no vertex near the touching point, and the smooth side has no sharp edge for the edge-edge
+# pass: tests/test_narrowphase_exact.py measured such pairs overlapping by up to 22 mm unseen.  With samples every EDGE_SAMPLE
+# metres the miss is bounded by spacing^2 / (8 R) (R: radius of the smooth surface; 1 mm at R = 5 cm).  Statics: the rims the arm
+# can reach (table: top rim without the side under the shelf; shelf: its top rim); objects: all long edges; robot links: none
+# (their vertex sets are at the cap).  At most EDGE_VCAP vertices per shape (two rounds of 64 lanes in k_collide).
+EDGE_SAMPLE = 0.02
+EDGE_VCAP = 128
+
+
+def add_edge_samples(name, owner_type, verts, edges):
+    if owner_type == 1 or len(verts) >= EDGE_VCAP:
+        return verts
+    if name == 'table_base':
+        use = [e for e in edges if min(e[0][2], e[1][2]) > 0.27 and not (e[0][0] > 0.25 and e[1][0] > 0.25)]
+    elif name == 'table_upper':
+        use = [e for e in edges if min(e[0][2], e[1][2]) > 0.30]
+    elif owner_type == 2:
+        use = list(edges)
+    else:
+        return verts
+    spacing = EDGE_SAMPLE if owner_type == 0 else 0.015
+    pts = []
+    for (p0, p1, _, _) in use:                   # (longest edges first; an edge whose samples do not fit the cap any more gets none)
+        nseg = int(np.ceil(np.linalg.norm(p1 - p0) / spacing - 1e-9))
+        if len(verts) + len(pts) + nseg - 1 > EDGE_VCAP:
+            continue
+        pts += [p0 + (p1 - p0) * (k / nseg) for k in range(1, nseg)]
+    print('shape %-12s + %d edge samples on %d edges (spacing %.1f mm)' % (name, len(pts), len(use), spacing * 1e3))
+    return np.vstack([verts, np.array(pts)]) if pts else verts
+
+
 def simplify_hull(pts):
     """pts [V,3] (already in the owner's frame). Returns verts[<=VMAX,3], planes[<=FMAX,4] (n, c: n.x<=c inside),
     (vertex deviation, plane deviation) in metres."""
@@ -613,10 +646,13 @@ def main(out_path):
     # ---- collision shapes
     # owner_type: 0 static(world frame), 1 robot body, 2 object
     shapes = []
+    full_hulls = []     # per shape: ALL vertices of the convex hull of the OBJ (owner frame) -- what Bullet collides (A.1.3)
 
     def add_shape(name, owner_type, owner_idx, lid, pts_owner_frame, L, body_uid):
+        full_hulls.append(pts_owner_frame[ConvexHull(pts_owner_frame).vertices].astype(np.float32))
         verts, planes, dev = simplify_hull(pts_owner_frame)
         edges = sorted(hull_edges(pts_owner_frame, EDGE_MIN), key=lambda e: -np.linalg.norm(e[1] - e[0]))[:EMAX]
+        verts = add_edge_samples(name, owner_type, verts, edges)
         c = 0.5 * (pts_owner_frame.min(0) + pts_owner_frame.max(0))
         r = float(np.max(np.linalg.norm(pts_owner_frame - c, axis=1)))
         shapes.append(dict(name=name, otype=owner_type, oidx=owner_idx, link=lid, verts=verts, planes=planes,
@@ -905,6 +941,12 @@ def main(out_path):
         f.write(names + '\n')
     print('wrote %s (%.2f MB), %d tris, %d shapes, %d instances, %d textures' %
           (out_path, size / 1e6, len(tri_pos), NS, NI, len(textures)))
+    # RR_FULL_HULLS_OUT=tests/golden/full_hulls.npz: the full hull vertex sets as a test fixture (tests/test_narrowphase_exact.py
+    # compares the oracle's contacts with the exact signed distance of the FULL hulls; the reference's OBJ files do not travel)
+    fh = os.environ.get('RR_FULL_HULLS_OUT')
+    if fh:
+        np.savez_compressed(fh, names=np.array([S['name'] for S in shapes]), **{'hull_%d' % i: h for i, h in enumerate(full_hulls)})
+        print('wrote %s: %s hull vertices' % (fh, [len(h) for h in full_hulls]))
 
 
 if __name__ == '__main__':
