@@ -68,7 +68,8 @@ typedef struct rr_config {
     int32_t abi_version;    /* RR_ABI_VERSION */
     int32_t num_envs;       /* N envs on this device */
     int32_t n_objects;      /* 1..3: cube, tomato, mustard      robot.py:49-50 */
-    int32_t width, height;  /* eye camera; reference default 320x240 (robot.py:30-31) */
+    int32_t width, height;  /* eye camera; reference default 320x240 (robot.py:30-31).  width: a multiple of 4 in [4, 1024], height in
+                               [1, 1024], at most 255 raster tiles of 4096 pixels (1024 x 1020 fits, 1024 x 1024 does not): RR_EINVAL otherwise */
     int32_t device;         /* HIP device ordinal */
     int32_t solver_iters;   /* PGS iterations; <=0 -> 50        SURVEY A.1.2 */
     int32_t envs_per_block; /* physics kernels: envs (threads) per workgroup; <=0 -> default */

@@ -177,6 +177,7 @@ struct DevPtrs {
     unsigned *frag_count;   // [N*ntiles]
     // dispatch order of k_raster's workgroups (raster_order_class): the (env, tile) items by falling cost of the previous frame
     unsigned *item_cost;        // [N*ntiles] duration of the item's workgroup in the last frame that rasterised it (100 MHz ticks)
+    unsigned *item_bin;         // [N*ntiles] raster_order_class: the bin an item was counted in (its second pass reads it back, not the cost again)
     const unsigned *item_perm;  // [N*ntiles] env << 8 | tile, costly items first; nullptr: env-major grid (envs, tiles)
 };
 
@@ -4215,7 +4216,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) RASTER_ATTR k_raster(SimParams
 // images do not depend on it.
 #define ORDER_BINS 1024
 template <int NT_>
-__device__ __forceinline__ void raster_order_class(int x, int N, int ntiles, int per_class, const unsigned *cost, unsigned *perm) {
+__device__ __forceinline__ void raster_order_class(int x, int N, int ntiles, int per_class, const unsigned *cost, unsigned *bins, unsigned *perm) {
     static_assert(ORDER_BINS % NT_ == 0 && NT_ % 64 == 0 && NT_ <= 1024, "bins per thread");
     constexpr int BPT = ORDER_BINS / NT_;
     __shared__ unsigned hist[ORDER_BINS];
@@ -4234,7 +4235,9 @@ __device__ __forceinline__ void raster_order_class(int x, int N, int ntiles, int
     if ((tid & 63) == 0) atomicMax(&s_max, mx);
     __syncthreads();
     const float scale = (float)(ORDER_BINS - 1) / (float)s_max;
-    for (int k = tid; k < n_items; k += NT_) atomicAdd(&hist[ORDER_BIN(cost[ORDER_ITEM(k)])], 1u);
+    // (an item's bin is computed ONCE and kept: were a cost rewritten between the two passes -- a visibility pass running beside
+    // this launch, which the launch order rules out today -- the scatter would still be a permutation)
+    for (int k = tid; k < n_items; k += NT_) { const size_t i = ORDER_ITEM(k); const unsigned b = ORDER_BIN(cost[i]); bins[i] = b; atomicAdd(&hist[b], 1u); }
     __syncthreads();
     // exclusive prefix over the bins: BPT consecutive bins per thread, wave scan of the threads' sums, the waves' totals
     unsigned hb[BPT], sum = 0u;
@@ -4251,8 +4254,8 @@ __device__ __forceinline__ void raster_order_class(int x, int N, int ntiles, int
     __syncthreads();
     for (int k = tid; k < n_items; k += NT_) {
         const size_t i = ORDER_ITEM(k);
-        const unsigned pos = atomicAdd(&hist[ORDER_BIN(cost[i])], 1u);
-        perm[(size_t)8 * pos + x] = ((unsigned)(i / ntiles) << 8) | (unsigned)(i % ntiles);
+        const unsigned pos = atomicAdd(&hist[min(bins[i], (unsigned)(ORDER_BINS - 1))], 1u);
+        if (pos < (unsigned)n_items) perm[(size_t)8 * pos + x] = ((unsigned)(i / ntiles) << 8) | (unsigned)(i % ntiles);
     }
     for (int k = n_items + tid; k < per_class; k += NT_) perm[(size_t)8 * k + x] = 0xffffffffu;
 #undef ORDER_ITEM
@@ -4431,7 +4434,7 @@ __global__ void __launch_bounds__(SHADE_THREADS) k_shade(const RenderModel *RMp,
     __shared__ __attribute__((aligned(16))) float sinst[MAXINST][16];
     if (order_n > 0 && (int)blockIdx.x == order_n) {
         const int nt = RMp->ntiles, per_class = ((order_n + 7) >> 3) * nt;
-        for (int x = blockIdx.z * gridDim.y + blockIdx.y; x < 8; x += gridDim.y * gridDim.z) raster_order_class<SHADE_THREADS>(x, order_n, nt, per_class, D.item_cost, order_perm);
+        for (int x = blockIdx.z * gridDim.y + blockIdx.y; x < 8; x += gridDim.y * gridDim.z) raster_order_class<SHADE_THREADS>(x, order_n, nt, per_class, D.item_cost, D.item_bin, order_perm);
         return;
     }
     const int env = blockIdx.x + env0, tile = blockIdx.y;
@@ -4612,18 +4615,20 @@ static inline int lagged_count(const rr_env *e, int which, int fallback) {
 }
 
 // k_obs (joint angles and object poses of the state -> observation buffers) and, when mapped, the host mirror behind it
-static void launch_mirror(rr_env *e, bool rendered = false) {
+static int launch_mirror(rr_env *e, bool rendered = false) {
     if (e->obs_host) hipLaunchKernelGGL(k_obs_mirror, dim3((e->P.N + 63) / 64), dim3(64), 0, e->stream, e->P, e->D, e->obs_dev);
     if (rendered) {
         const int f[3] = {RR_F_RGB, RR_F_DEPTH, RR_F_MASK};
         for (int i = 0; i < 3; i++)
-            if (e->img_host[i] && e->field_ptr[f[i]]) hipMemcpyAsync(e->img_host[i], e->field_ptr[f[i]], e->field_bytes[f[i]], hipMemcpyDeviceToHost, e->stream);
+            if (e->img_host[i] && e->field_ptr[f[i]]) HIPCHK(hipMemcpyAsync(e->img_host[i], e->field_ptr[f[i]], e->field_bytes[f[i]], hipMemcpyDeviceToHost, e->stream));
     }
     if (e->obs_host || e->img_host[0] || e->img_host[1] || e->img_host[2]) {
-        if (!e->ev_obs && hipEventCreateWithFlags(&e->ev_obs, hipEventDisableTiming) != hipSuccess) { e->ev_obs = nullptr; (void)hipGetLastError(); return; }
-        hipEventRecord(e->ev_obs, e->stream);
+        if (!e->ev_obs) HIPCHK(hipEventCreateWithFlags(&e->ev_obs, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(e->ev_obs, e->stream));
         e->ev_obs_set = true;
     }
+    HIPCHK(hipGetLastError());
+    return RR_OK;
 }
 static void launch_obs(rr_env *e) {
     hipLaunchKernelGGL(k_obs, dim3((e->P.N + 255) / 256), dim3(256), 0, e->stream, e->P, e->D);
@@ -4773,8 +4778,16 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     if (cfg->num_envs < 1) return fail(RR_EINVAL, "rr_create: num_envs < 1");
     if ((unsigned long long)cfg->num_envs * GP_ENV_BYTES + 4096ull >= (1ull << 32)) return fail(RR_EINVAL, "rr_create: more than 33222 envs per rr_env (32-bit byte offsets of the solver's row store)");
     if (cfg->n_objects < 1 || cfg->n_objects > NOBJ) return fail(RR_EINVAL, "rr_create: n_objects must be 1..3");
-    if (cfg->width < 4 || cfg->height < 1 || cfg->width % 4 != 0 || cfg->width > TILE_PIX)
-        return fail(RR_EINVAL, "rr_create: width must be a multiple of 4 in [4,4096]");
+    *out = nullptr;
+    if (cfg->width < 4 || cfg->height < 1 || cfg->width % 4 != 0 || cfg->width > 1024 || cfg->height > 1024)
+        return fail(RR_EINVAL, "rr_create: width must be a multiple of 4 in [4,1024], height in [1,1024] (10-bit box origins in the rasteriser's records)");
+    {   // (the raster tiles of this image: rr_create lays them out below by the same rule; the tile index is 8 bits with one sentinel)
+        int tw_ = cfg->width <= 128 ? cfg->width : 64;
+        if (getenv("RR_TILE_W")) { const int t_ = atoi(getenv("RR_TILE_W")); if (t_ >= 4 && t_ <= cfg->width && t_ <= TILE_PIX) tw_ = t_; }
+        int th_ = TILE_PIX / tw_; if (th_ > cfg->height) th_ = cfg->height;
+        const int nt_ = ((cfg->width + tw_ - 1) / tw_) * ((cfg->height + th_ - 1) / th_);
+        if (nt_ > 255) return fail(RR_EINVAL, "rr_create: image too large: more than 255 raster tiles of 4096 pixels (e.g. 1024 x 1020 fits, 1024 x 1024 does not)");
+    }
     Blob b;
     if (!b.init(model_blob, blob_bytes)) return fail(RR_EMODEL, "rr_create: bad model blob header");
     const int32_t *dims = b.i32("dims", 11);
@@ -4931,8 +4944,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     RM.ntiles = RM.ntx * ((RM.H + RM.tile_h - 1) / RM.tile_h);
     RM.tile_xbits = 0; while ((1 << RM.tile_xbits) < RM.tile_w) RM.tile_xbits++;
     RM.w_magic = (unsigned)((0x100000000ull + (unsigned long long)RM.tile_w - 1) / (unsigned long long)RM.tile_w);
-    if (RM.W > 1024 || RM.H > 1024) { rr_destroy(e); return fail(RR_EINVAL, "rr_create: image larger than 1024 x 1024 (10-bit box origins in the rasteriser's records)"); }
-    if (RM.ntiles > 255) { rr_destroy(e); return fail(RR_EINVAL, "rr_create: image too large (more than 255 raster tiles of 4096 pixels)"); }
+    if (RM.W > 1024 || RM.H > 1024 || RM.ntiles > 255) { rr_destroy(e); *out = nullptr; return fail(RR_EINVAL, "rr_create: image too large (checked on entry)"); }
     NEED(ip = b.i32("inst_owner", ni * 4));
     for (int i = 0; i < ni; i++) { RM.in_otype[i] = ip[4 * i]; RM.in_oidx[i] = ip[4 * i + 1]; RM.in_uid[i] = ip[4 * i + 2]; RM.in_tex[i] = ip[4 * i + 3]; }
     NEED(f = b.f32("inst_color", ni * 3)); memcpy(RM.in_color, f, (size_t)ni * 12);
@@ -5085,7 +5097,7 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
             (r = dev_alloc(e, &e->D.static_mask, spx)) != RR_OK || (r = dev_alloc(e, &e->D.frag_count, (size_t)N * RM.ntiles)) != RR_OK ||
             (r = dev_alloc(e, &e->D.frag_list, (size_t)N * RM.ntiles * TILE_PIX, false)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
         if (!getenv("RR_NO_RASTER_ORDER") && (long long)N * RM.ntiles >= 2048 && (long long)N * RM.ntiles <= (1 << 20) && N < (1 << 24)) {
-            if ((r = dev_alloc(e, &e->D.item_cost, (size_t)N * RM.ntiles)) != RR_OK || (r = dev_alloc(e, &e->item_perm, (size_t)8 * ((N + 7) / 8) * RM.ntiles)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
+            if ((r = dev_alloc(e, &e->D.item_cost, (size_t)N * RM.ntiles)) != RR_OK || (r = dev_alloc(e, &e->D.item_bin, (size_t)N * RM.ntiles)) != RR_OK || (r = dev_alloc(e, &e->item_perm, (size_t)8 * ((N + 7) / 8) * RM.ntiles)) != RR_OK) { rr_destroy(e); *out = nullptr; return r; }
         }
         if (!getenv("RR_NO_STATIC_LAYER")) {
             unsigned long long *sv = nullptr;
@@ -5688,47 +5700,57 @@ __global__ void __launch_bounds__(512) k_ub_valu(float *out, int iters, float a,
 }
 int rr_device_microbench(int32_t device, int32_t kind, double *result) {
     if (!result || kind < 0 || kind > 2) return fail(RR_EINVAL, "rr_device_microbench: bad argument");
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return fail(RR_EDEVICE, "rr_device_microbench: no such HIP device (no CPU fallback)"); }
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
-    const int ncu = prop.multiProcessorCount;
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    // (everything the measurement allocates is released on every path, it runs on a stream of its own, and the caller's current
+    // device is put back)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st = nullptr;
+    void *buf[3] = {nullptr, nullptr, nullptr};
+    hipError_t err = hipSuccess;
     float best_ms = 1e30f;
     double units = 0.0;
+#define UB(call) do { if (err == hipSuccess) err = (call); } while (0)
+    hipDeviceProp_t prop;
+    UB(hipGetDeviceProperties(&prop, device));
+    const int ncu = err == hipSuccess ? prop.multiProcessorCount : 1;
+    UB(hipEventCreate(&e0)); UB(hipEventCreate(&e1)); UB(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     if (kind <= 1) {
         const size_t bytes = (size_t)256 << 20, n4 = bytes / 16;
-        float4 *buf[3] = {nullptr, nullptr, nullptr};
-        for (int i = 0; i < (kind == 0 ? 2 : 3); i++) { HIPCHK(hipMalloc((void **)&buf[i], bytes)); HIPCHK(hipMemset(buf[i], 0, bytes)); }
-        for (int rep = 0; rep < 6; rep++) {
-            hipEventRecord(e0, 0);
-            if (kind == 0) hipLaunchKernelGGL(k_ub_copy, dim3(ncu * 16), dim3(256), 0, 0, buf[0], buf[1], n4);
-            else hipLaunchKernelGGL(k_ub_triad, dim3(ncu * 16), dim3(256), 0, 0, buf[0], buf[1], buf[2], 0.5f, n4);
-            hipEventRecord(e1, 0);
-            HIPCHK(hipEventSynchronize(e1));
-            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-            if (rep > 0) best_ms = std::min(best_ms, ms);
+        for (int i = 0; i < (kind == 0 ? 2 : 3); i++) { UB(hipMalloc(&buf[i], bytes)); UB(hipMemsetAsync(buf[i], 0, bytes, st)); }
+        for (int rep = 0; rep < 6 && err == hipSuccess; rep++) {
+            UB(hipEventRecord(e0, st));
+            if (kind == 0) hipLaunchKernelGGL(k_ub_copy, dim3(ncu * 16), dim3(256), 0, st, (const float4 *)buf[0], (float4 *)buf[1], n4);
+            else hipLaunchKernelGGL(k_ub_triad, dim3(ncu * 16), dim3(256), 0, st, (float4 *)buf[0], (const float4 *)buf[1], (const float4 *)buf[2], 0.5f, n4);
+            UB(hipEventRecord(e1, st));
+            UB(hipEventSynchronize(e1));
+            float ms = 0; UB(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && err == hipSuccess) best_ms = std::min(best_ms, ms);
         }
-        for (int i = 0; i < 3; i++) if (buf[i]) hipFree(buf[i]);
         units = (double)bytes * (kind == 0 ? 2 : 3) / 1e9;                 // GB moved per launch
     } else {
         const int iters = 800, blocks = 4 * ncu;
-        float *out = nullptr;
-        HIPCHK(hipMalloc((void **)&out, (size_t)blocks * 512 * 4));
-        HIPCHK(hipFuncSetAttribute((const void *)k_ub_valu, hipFuncAttributeMaxDynamicSharedMemorySize, 39 * 1024));
-        for (int rep = 0; rep < 4; rep++) {
-            hipEventRecord(e0, 0);
-            hipLaunchKernelGGL(k_ub_valu, dim3(blocks), dim3(512), 39 * 1024, 0, out, iters, 1.0001f, 0.5f);
-            hipEventRecord(e1, 0);
-            HIPCHK(hipEventSynchronize(e1));
-            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-            if (rep > 0) best_ms = std::min(best_ms, ms);
+        UB(hipMalloc(&buf[0], (size_t)blocks * 512 * 4));
+        UB(hipFuncSetAttribute((const void *)k_ub_valu, hipFuncAttributeMaxDynamicSharedMemorySize, 39 * 1024));
+        for (int rep = 0; rep < 4 && err == hipSuccess; rep++) {
+            UB(hipEventRecord(e0, st));
+            hipLaunchKernelGGL(k_ub_valu, dim3(blocks), dim3(512), 39 * 1024, st, (float *)buf[0], iters, 1.0001f, 0.5f);
+            UB(hipEventRecord(e1, st));
+            UB(hipEventSynchronize(e1));
+            float ms = 0; UB(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && err == hipSuccess) best_ms = std::min(best_ms, ms);
         }
-        hipFree(out);
         units = (double)iters * 64 * blocks * 8 / 1e9;                     // G wave-instructions per launch
     }
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    HIPCHK(hipGetLastError());
+    UB(hipGetLastError());
+#undef UB
+    for (int i = 0; i < 3; i++) if (buf[i]) (void)hipFree(buf[i]);
+    if (st) (void)hipStreamDestroy(st);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+    if (err != hipSuccess) { (void)hipGetLastError(); return fail(RR_EDEVICE, std::string("rr_device_microbench: ") + hipGetErrorString(err)); }
     *result = units / (best_ms * 1e-3);
     return RR_OK;
 }

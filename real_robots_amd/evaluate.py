@@ -338,11 +338,16 @@ def _evaluate_batched_policy(Controller, num_envs, environment, action_type, n_o
     zero_goal = np.zeros((N, H, W, 3), np.uint8)
     timing = {"env_steps": 0, "step_seconds": 0.0}
 
+    # the low-dimensional observations come back through the mapped host mirror that the last launch of every step fills
+    # (rr_map_observations): ONE wait per step on the event behind it instead of three synchronising copies
+    mirror = env.map_observations()
+
     def observations(goal_idx, goal_img):
-        obs = {"joint_positions": env.host(nat.F_JOINTS), "touch_sensors": env.host(nat.F_TOUCH), "goal": goal_img}
+        env.sync_observations()
+        obs = {"joint_positions": mirror['joints'].copy(), "touch_sensors": mirror['touch'].copy(), "goal": goal_img}
         obs.update(dev_imgs)
         if r1:
-            obs["object_positions"] = env.host(nat.F_OBJ_POSE)
+            obs["object_positions"] = mirror['obj_pose'].copy()
             obs["goal_positions"] = g_final[goal_idx] if goal_idx is not None else None
         return obs
 
@@ -405,10 +410,14 @@ def _goal_images(goals, gi, H, W):
     return table[inv]
 
 
-def bench_evaluate_batched(num_envs, device=0, width=128, height=128, intrinsic=200, trials=2, extrinsic=200, n_goals=512, seed=2020):
-    """bench.py's config-5 leg: a seeded synthetic goals dataset (generate_goals on the batched simulator, reference file format),
-    a BatchedPolicy that draws a new uniform macro action per env every 100 steps, evaluate_batched end to end.  Returns the
-    `secondary` entry (env-steps/s of the stepping loops incl. policy calls and observation read-back)."""
+def bench_evaluate_batched(num_envs, device=0, width=128, height=128, intrinsic=2000, trials=5, extrinsic=2000, n_goals=512, seed=2020,
+                           macro_every=1000, render_every=0):
+    """bench.py's config-5 leg in SURVEY 8(d)'s shape: intrinsic phase of 2 000 steps + 5 extrinsic trials x 2 000 steps
+    (evaluate.py:249-259,306-318 of the reference), a BatchedPolicy that draws a new uniform macro action per env every 1 000
+    steps -- a whole plan of env.py:447-454 runs to its end --, a seeded synthetic goals dataset (generate_goals on the batched
+    simulator, reference file format), evaluate_batched end to end.  `render_every` 1: the retina is rendered every step (it stays
+    on the device), 0: never.  Returns the `secondary` entry (env-steps/s of the stepping loops incl. policy calls and the
+    observation read-back)."""
     import os
     import tempfile
     import time
@@ -422,8 +431,11 @@ def bench_evaluate_batched(num_envs, device=0, width=128, height=128, intrinsic=
             self.t = 0
             self.cur = None
 
+        def start_extrinsic_trial(self):
+            self.t = 0
+
         def step(self, observations, reward, done):
-            if self.cur is None or self.t % 100 == 0:
+            if self.cur is None or self.t % macro_every == 0:
                 self.cur = self.rng.uniform([-0.25, -0.5], [0.05, 0.5], size=(self.num_envs, 2, 2))      # macro_space, env.py:49-52
             self.t += 1
             return self.cur
@@ -437,10 +449,12 @@ def bench_evaluate_batched(num_envs, device=0, width=128, height=128, intrinsic=
         save_goals(path, goals)
     t_goals = time.perf_counter() - t0
     so, scores, per_env, timing = _evaluate_batched_policy(RandomMacro, num_envs, 'R1', 'macro_action', 3, intrinsic, extrinsic, trials,
-                                                          path, width, height, device, 0)
+                                                          path, width, height, device, render_every)
     return {"workload": "config 5 end to end: real_robots.evaluate_batched, REALRobot2020-R1M3, %d envs, one BatchedPolicy (uniform macro "
-                        "actions, a new one every 100 steps), intrinsic phase %d steps + %d extrinsic trials x %d steps, %d seeded synthetic "
-                        "goals (generate_goals, %dx%d), device-side scores" % (num_envs, intrinsic, trials, extrinsic, n_goals, width, height),
+                        "actions, a new one every %d steps), intrinsic phase %d steps + %d extrinsic trials x %d steps, %s, %d seeded "
+                        "synthetic goals (generate_goals, %dx%d), device-side scores, low-dimensional observations through the mapped host mirror"
+                        % (num_envs, macro_every, intrinsic, trials, extrinsic,
+                           "retina + depth + mask rendered every step" if render_every == 1 else "no per-step render", n_goals, width, height),
             "value": round(timing["env_steps"] / timing["step_seconds"], 1), "unit": "env-steps/s",
             "ms_per_step": round(timing["step_seconds"] / (timing["env_steps"] / num_envs) * 1e3, 4),
             "steps": timing["env_steps"] // num_envs, "goal_dataset_seconds": round(t_goals, 1),

@@ -147,14 +147,18 @@ def test_bench_workload_at_size_against_the_oracle(monkeypatch):
     env = BatchedREALRobotEnv(N, objects=3, width=128, height=128, want_mask=False)
     plain = _make(monkeypatch, {'RR_NO_SPLIT': '1', 'RR_NO_LOOKAHEAD': '1'}, N, objects=3, width=128, height=128, want_mask=False)
     o = Oracle(3, 128, 128, f32=True)
-    checks, n_heavy_checked, worst = 0, 0, dict(dj=0.0, do=0.0, dv=0.0)
+    checks, n_heavy_checked, n_light_checked, worst = 0, 0, 0, dict(dj=0.0, do=0.0, dv=0.0)
     for t in range(T):
         chk = t % 50 == 49
         if chk:
             torch.cuda.synchronize()
             st0 = env.state
             nc = env.host(nat.F_CONTACT_COUNT)
-            sel = np.argsort(-nc, kind='stable')[:8]
+            # the 8 envs with the most contacts + 8 seeded-random ones (the light-env kernel, 98 % of the batch, meets the oracle
+            # at the benchmark's size too -- not only through its bitwise equality with the generic kernel)
+            heavy8 = np.argsort(-nc, kind='stable')[:8]
+            rnd8 = np.random.default_rng(1000 + t).choice(np.setdiff1d(np.arange(N), heavy8), 8, replace=False)
+            sel = np.concatenate([heavy8, rnd8])
             cache = {int(i): env.contacts(int(i)) for i in sel}
         env.step(device_ptr=cmds[t].data_ptr(), render=True)
         plain.step(device_ptr=cmds[t].data_ptr(), render=True)
@@ -183,10 +187,11 @@ def test_bench_workload_at_size_against_the_oracle(monkeypatch):
             assert ((d < 1.0) == (dep[i] < 1.0)).all()
             checks += 1
             n_heavy_checked += int(cls[i] > 0)
+            n_light_checked += int(cls[i] == 0)
         # the unsplit, in-line run is the same run
         assert np.array_equal(st1, plain.state, equal_nan=True), t
         assert np.array_equal(rgb, plain.host(nat.F_RGB)) and np.array_equal(dep, plain.host(nat.F_DEPTH)), t
-    assert checks == 8 * (T // 50) and n_heavy_checked >= checks // 2, (checks, n_heavy_checked)
+    assert checks == 16 * (T // 50) and n_heavy_checked >= checks // 4 and n_light_checked >= checks // 4, (checks, n_heavy_checked, n_light_checked)
     assert (env.host(nat.F_ERRFLAGS) == 0).all()
     cls = env.host(nat.F_ENV_CLASS)
     assert (cls == 1).sum() > 20 and (cls == 2).sum() >= 1, ((cls == 1).sum(), (cls == 2).sum())

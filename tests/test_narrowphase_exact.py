@@ -275,22 +275,49 @@ def run_all(n, workers):
     return res
 
 
-# Stated bounds (asserted on the seeded subset below; the 2000-pose run is in tests/golden/narrowphase_exact_summary.json).
-# Penetrating and touching pairs: the deepest contact's distance is the exact signed distance to 1 mm + the 1 mm hull tolerance,
-# its normal the exact separating direction to 2 degrees -- wherever the closest feature pair is vertex-face or one of the stored
-# edge pairs.  What the candidate scheme cannot represent -- and the test counts instead of hiding -- is listed per class in the
-# summary: vertex-edge / vertex-vertex closest features of SEPARATED shapes (the plane distance under-estimates the Euclidean
-# distance: a speculative contact that is a little early, never a missed touch), and edge pairs beyond the 48 longest sharp edges.
-BOUNDS = dict(pen_err_mm=2.0, pen_angle_deg=2.0)
+# Stated bounds (round 5, with the edge samples of tools/compile_model.py in the model; 2 000 poses per class in
+# tests/golden/narrowphase_exact_summary.json, 78 000 poses in all):
+#   * NO pair whose full hulls overlap or come within 2 mm goes without a contact, in any class;
+#   * overlapping / touching pairs: the deepest contact's distance is within 2.7 mm (objects, gripper) / 4.7 mm (arm links) of the
+#     exact signed distance in 99 % of the poses, the median error is below 0.45 mm; the worst cases (3-6 mm objects / gripper,
+#     4-17 mm arm links) are overlaps along an EDGE-EDGE axis between an edge that is not stored (shorter than 1.5 cm, dihedral
+#     angle below 15 degrees, beyond the 48 longest) and a smooth surface -- `unseen_overlap` counts the poses where the hulls
+#     overlap by more than 0.5 mm and the deepest contact still reports a gap (0-29 of 667 per class);
+#   * the contact NORMAL is the exact separating direction (median 0.0 degrees) where a face is involved -- objects on table and
+#     shelf, arm links on the table --, and the face normal of the nearer shape (median 4-33 degrees off the exact direction) where
+#     the closest features are two edges or an edge and a vertex of random-oriented gripper / object pairs: the vertex-in-polytope
+#     scheme reports a FACE normal by construction, Bullet's GJK / EPA the edge-edge direction;
+#   * separated pairs (speculative contacts, 2-18 mm): the plane distance under-estimates the Euclidean distance of vertex-edge
+#     and vertex-vertex features by up to 6.7 mm -- a speculative contact that acts a little early, never a missed touch.
+BOUNDS = dict(p99_mm=dict(obj=2.8, arm=4.8), median_mm=0.45, subset_p90_mm=dict(obj=3.0, arm=6.0))
 
 
-@pytest.mark.parametrize('name,cls', classes()[:9] + classes()[9::3][:8] + classes()[-7::2])
+def _kind(name):
+    return 'arm' if name.startswith('arm:') else 'obj'
+
+
+def test_committed_summary_holds_the_stated_bounds():
+    """The 2 000-pose-per-class run (python tests/test_narrowphase_exact.py) as committed: the numbers DESIGN.md 3 quotes."""
+    d = json.load(open(os.path.join(HERE, 'golden', 'narrowphase_exact_summary.json')))
+    assert d['poses_per_class'] >= 2000 and len(d['classes']) == len(classes())
+    for name, s in d['classes'].items():
+        for regime in ('penetrating', 'touching_0_2mm'):
+            r = s[regime]
+            assert r['n'] >= 600 and r['missed'] == 0, (name, regime, r)
+            assert r['err_mm_p99'] <= BOUNDS['p99_mm'][_kind(name)] and r['err_mm_median'] <= BOUNDS['median_mm'], (name, regime, r)
+        assert s['speculative_2_18mm']['missed'] <= 4, (name, s['speculative_2_18mm'])
+
+
+@pytest.mark.parametrize('name,cls', classes())
 def test_deepest_contact_matches_exact_geometry(name, cls):
-    recs = [run_case(cls, 7000 + i) for i in range(40)]
-    s = summarise(recs)
-    assert s['n'] >= 30
-    # nothing that exact geometry has inside the margin may go unseen when the shapes overlap or touch
-    assert s['penetrating']['missed'] == 0 and s['touching_0_2mm']['missed'] == 0, s
+    """A seeded subset of fresh poses per class against the same bounds (the percentile of a small sample: p90 instead of p99)."""
+    n = 9 if cls[0] == 'arm' else 24
+    recs = [r for r in (run_case(cls, 7000 + i) for i in range(n)) if r is not None]
+    assert len(recs) >= n - 1
+    near = [r for r in recs if r['d'] < 0.002]
+    assert all(r['n_contacts'] > 0 for r in near), name          # nothing overlapping or touching goes unseen
+    e = np.array([abs(r['dist'] - r['d']) for r in near]) * 1e3
+    assert np.percentile(e, 90) <= BOUNDS['subset_p90_mm'][_kind(name)], (name, np.sort(e)[-4:])
 
 
 if __name__ == '__main__':

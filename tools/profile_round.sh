@@ -3,7 +3,7 @@
 # rocprofv3 kernel stats, PMC HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes, never combined with other trace
 # domains), SQ VALU counters.  Output: gpurun_out/round/ ; traffic_latest.json and sq_latest.json carry the run
 # configuration so that bench.py only attaches them to runs of that configuration.  Usage: tools/profile_round.sh [tag]
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; mkdir -p $O
 cd $R && python bench.py --steps 200 --warmup 20 > $O/${TAG}_bench.json 2> $O/bench.err; tail -c 600 $O/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
@@ -17,6 +17,8 @@ TAG=$TAG python3 - <<'PY'
 import csv, glob, os, json, collections
 R=os.environ['GRAFT_REPO_ROOT']; O=R+'/gpurun_out/round'; TAG=os.environ['TAG']
 cfg={"envs": 4096, "objects": 3, "width": 128, "height": 128, "render": True, "command_scale": 1.0, "solver_iters": 50}
+import hashlib
+SRC_SHA=hashlib.sha256(open(R+'/real_robots_amd/csrc/realrobot.hip','rb').read()).hexdigest()   # bench.load_profile only quotes a profile of the very source it runs
 def means(d):
     """mean per dispatch and, for kernels launched more than once per step, the number of dispatches per step"""
     f=glob.glob(O+'/%s/*counter_collection.csv'%d)
@@ -41,10 +43,10 @@ for d in (tr, lo):
     d['render_stage']=d.get('k_raster',0)+d.get('k_shade',0)+d.get('k_render_list',0)+d.get('k_raster_list',0)+d.get('k_render_setup',0)
     d['k_prep']=d.get('k_prep_a',0)+d.get('k_prep_b',0)+d.get('k_prep_ab',0)
 tr['lower_bound']=lo
-tr['config']=cfg; tr['source']=TAG+'_pmc_summary.json'
+tr['config']=cfg; tr['source']=TAG+'_pmc_summary.json'; tr['source_sha256']=SRC_SHA
 tr['_note']="HBM bytes per step from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), all launches of a kernel in a step added up (the first untimed frames included in the mean). Top level: (2*FETCH_SIZE + WRITE_SIZE) * 1024 -- the guide's gfx950 correction, which is calibrated for 16-byte-per-lane coalesced streaming reads only (here: k_solve's contact records and row stream, k_static_copy); `lower_bound`: (FETCH_SIZE + WRITE_SIZE) * 1024, no correction -- for kernels whose reads are scattered 4/8/16-byte records (k_raster, k_shade, k_collide, k_prep_*) the truth lies between the two. render_stage = k_render_setup + k_raster + k_shade + the heavy envs' k_render_list / k_raster_list; only valid for `config`"
 json.dump(tr, open(O+'/traffic_latest.json','w'), indent=1)
-sv={'config': cfg, 'source': TAG+'_sq_counters.json', 'valu_wave_instr_per_launch': {k: round(v['SQ_INSTS_VALU']['mean']) for k,v in sq.items() if 'SQ_INSTS_VALU' in v}}
+sv={'config': cfg, 'source': TAG+'_sq_counters.json', 'source_sha256': SRC_SHA, 'valu_wave_instr_per_launch': {k: round(v['SQ_INSTS_VALU']['mean']) for k,v in sq.items() if 'SQ_INSTS_VALU' in v}}
 json.dump(sv, open(O+'/sq_latest.json','w'), indent=1)
 for k in ('k_raster','k_shade','k_solve','k_collide','k_prep_a','k_prep_b','k_prep_ab','k_solve_light','k_solve_light_ow','k_render_setup','k_render_list'):
     r={c: x['mean'] for c,x in sq.get(k,{}).items()}
