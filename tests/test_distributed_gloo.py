@@ -72,7 +72,8 @@ def test_bench_plumbing_two_ranks_stub_env(scaling):
     assert out["config"]["gathered_bytes_per_step_per_rank"] == total * (9 + 4 + 21) * 4
     assert out["timed_steps"] == [5, 10] and out["value"] > 0 and "STUB" in out["data"] and out["roofline"] is None
     assert abs(out["value"] - total * 5 / (out["ms_per_step"] * 5e-3)) < 1e-2 * out["value"]
-    ranks = sorted(ln for ln in r.stderr.splitlines() if ln.startswith('RANK '))
+    import re
+    ranks = sorted(re.findall(r'RANK \d+ ids \d+ \d+ steps \d+', r.stderr))      # (the ranks' lines may interleave on the shared pipe)
     half = total // 2
     assert ranks == ["RANK 0 ids 0 %d steps 10" % half, "RANK 1 ids %d %d steps 10" % (half, total)], ranks
 
@@ -98,7 +99,8 @@ def test_bench_plumbing_four_ranks_gather_images_and_plan_check():
     assert out["n_gpus"] == 4 and cfg["world"] == 4 and cfg["ranks_seen"] == 4 and cfg["envs_total"] == 24
     assert [row[2:4] for row in cfg["plan"]] == [[0, 6], [6, 12], [12, 18], [18, 24]] and [row[4] for row in cfg["plan"]] == [0, 1, 2, 3]
     assert cfg["gathered_bytes_per_step_per_rank"] == 24 * (9 + 4 + 21) * 4 + 24 * 16 * 8 * (3 + 4)
-    ranks = sorted(ln for ln in r.stderr.splitlines() if ln.startswith('RANK '))
+    import re
+    ranks = sorted(re.findall(r'RANK \d+ ids \d+ \d+ steps \d+', r.stderr))      # (the ranks' lines may interleave on the shared pipe)
     assert ranks == ["RANK %d ids %d %d steps 7" % (k, 6 * k, 6 * k + 6) for k in range(4)], ranks
 
 

@@ -262,16 +262,27 @@ def test_bench_bookkeeping_and_committed_profiles():
     assert a['_state'] == (22 + 39 + 11) * 8 + 36 + (9 + 4 + 21) * 4 == 748
     assert a['_image'] == 128 * 128 * 7 + 22 * 12 * 4 == 115744
     cfg = {"envs": 4096, "objects": 3, "width": 128, "height": 128, "render": True, "command_scale": 1.0, "solver_iters": 50}
+    # a profile is quoted only for the configuration AND the kernel source it was collected on (recorded hash of realrobot.hip)
+    recorded = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_latest.json'))).get('source_sha256')
+    real_hash = bench.kernel_source_hash
+    bench.kernel_source_hash = lambda: recorded
     prof, why = bench.load_profile('traffic_latest.json', cfg)
     assert prof is not None and why is None and prof['config'] == cfg
     other, why = bench.load_profile('traffic_latest.json', dict(cfg, envs=1024))
     assert other is None and 'collected on' in why
+    bench.kernel_source_hash = lambda: 'another build'
+    stale, why = bench.load_profile('traffic_latest.json', cfg)
+    assert stale is None and 'stale profile' in why
+    bench.kernel_source_hash = real_hash
+    assert len(real_hash()) == 64
     assert bench.load_profile('no_such_file.json', cfg)[0] is None
+    bench.kernel_source_hash = lambda: recorded
     # the committed figures: every kernel of the step is there, the render stage stays below a full image write
     for k in ('k_prep_a', 'k_prep_b', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster', 'k_shade', 'render_stage'):
         assert prof[k] > 0, k
     assert prof['render_stage'] < a['_image'] * 4096 and prof['k_solve'] < 100e6
     sq, _ = bench.load_profile('sq_latest.json', cfg)
+    bench.kernel_source_hash = real_hash
     assert sq['valu_wave_instr_per_launch']['k_raster'] > 1e8
     assert os.path.exists(os.path.join(ROOT, 'profiles', prof['source'])) and os.path.exists(os.path.join(ROOT, 'profiles', sq['source']))
     assert bench.SIDE_STREAM_KERNELS == ('k_solve_heavy', 'render_heavy') and set(bench.SIDE_STREAM_KERNELS) <= set(nat_names())

@@ -554,9 +554,13 @@ def test_edge_edge_contact_known_answer():
         o.step(None)
         res[edges] = (o.contacts(), o.state[22 + 7:22 + 10] @ n_exp)
     c0, c1 = res[0][0], res[1][0]
-    assert (c0[:, 9] > 0.01).all() and res[0][1] < -0.95          # vertex tests alone: nothing within a centimetre, not slowed down
-    assert len(c1) == len(c0) + 1 and (c1[:len(c0)] == c0).all()  # the vertex candidates are unchanged, the edge contact comes after them
-    e = c1[-1]
+    # vertex tests alone (since round 5 the shelf's rim carries sample points every 2 cm, tools/compile_model.py): the nearest candidate
+    # is a rim sample 3.5 mm from a cube FACE -- with that face's normal, 30 degrees off the edges' common normal -- not the crossing
+    assert (c0[:, 9] > 0.003).all() and res[0][1] < -0.7
+    assert np.degrees(np.arccos(np.clip(c0[np.argmin(c0[:, 9]), 6:9] @ n_exp, -1, 1))) > 20.0
+    # with the edge pass the crossing itself is the pair's deepest contact; the other points of the manifold are unchanged
+    assert len(c1) == len(c0) and (c1[1:] == c0[1:]).all()
+    e = c1[int(np.argmin(c1[:, 9]))]
     assert e[0] == 16 and e[1] == -1
     # (the shelf's vertices are float32 in the model blob and the expected numbers use the rounded 0.079 / 0.381)
     assert np.abs(e[6:9] - n_exp).max() < 1e-3 and abs(e[9] - 0.002) < 2e-4 and np.abs(e[3:6] - x_exp).max() < 5e-4

@@ -241,9 +241,9 @@ def hull_edges(pts, min_len, cos_tol=0.9995):
 # vertex-in-polytope test).  Why: a long straight edge lying across a SMOOTH convex surface -- the table's rim under an arm link,
 # a cube edge under a link -- has no vertex near the touching point, and the smooth side has no sharp edge for the edge-edge
 # pass: tests/test_narrowphase_exact.py measured such pairs overlapping by up to 22 mm unseen.  With samples every EDGE_SAMPLE
-# metres the miss is bounded by spacing^2 / (8 R) (R: radius of the smooth surface; 1 mm at R = 5 cm).  Statics: the rims the arm
-# can reach (table: top rim without the side under the shelf; shelf: its top rim); objects: all long edges; robot links: none
-# (their vertex sets are at the cap).  At most EDGE_VCAP vertices per shape (two rounds of 64 lanes in k_collide).
+# metres the miss is bounded by spacing^2 / (8 R) (R: radius of the smooth surface; 1 mm at R = 5 cm).  Statics only: the rims the
+# arm can reach (table: top rim without the side under the shelf; shelf: its top rim); robot links: none (their vertex sets are
+# at the cap); objects: none (below).  At most EDGE_VCAP vertices per shape (two rounds of 64 lanes in k_collide).
 EDGE_SAMPLE = 0.02
 EDGE_VCAP = 128
 
@@ -255,9 +255,9 @@ def add_edge_samples(name, owner_type, verts, edges):
         use = [e for e in edges if min(e[0][2], e[1][2]) > 0.27 and not (e[0][0] > 0.25 and e[1][0] > 0.25)]
     elif name == 'table_upper':
         use = [e for e in edges if min(e[0][2], e[1][2]) > 0.30]
-    elif owner_type == 2:
-        use = list(edges)
     else:
+        # (objects: measured and dropped -- a cube edge sample inside a finger's hull takes the normal of the finger's nearest SIDE facet
+        # and wedges a grasped cube out of the gripper, tests/test_oracle_pins.py::test_touch_sensor_fires_when_gripper_closes_on_cube)
         return verts
     spacing = EDGE_SAMPLE if owner_type == 0 else 0.015
     pts = []
