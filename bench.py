@@ -401,8 +401,9 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary workloads (profiling runs)')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
                     help='weak: --envs-per-gpu envs on every rank; strong: --envs-per-gpu envs in total, split over the ranks')
-    ap.add_argument('--gather', nargs='?', const='lowdim', default='none', choices=('none', 'lowdim', 'images'),
-                    help='also all-gather observations every step (RCCL): joints/touch/object poses, or those + RGB + depth')
+    ap.add_argument('--gather', nargs='?', const='lowdim', default='none', choices=('none', 'lowdim', 'images', 'images-delta'),
+                    help='also all-gather observations every step (RCCL): joints/touch/object poses, or those + RGB + depth as full slabs '
+                         '(images) or as per-step records of the changed pixels applied to persistent copies (images-delta)')
     ap.add_argument('--stub-env', action='store_true',
                     help='plumbing test on CPU (gloo): a stub replaces the simulator; the printed line is marked as such')
     args = ap.parse_args()
@@ -427,7 +428,7 @@ def main():
     import torch.distributed as dist
     from real_robots_amd import _native as nat
     from real_robots_amd.batched import BatchedREALRobotEnv
-    from real_robots_amd.distributed import gather_images, gather_observations, shard_range
+    from real_robots_amd.distributed import DeltaImageGather, gather_images, gather_observations, shard_range
 
     stub = args.stub_env
     if stub:
@@ -489,10 +490,12 @@ def main():
         views = {'joints': torch.as_tensor(env.device_buffer(nat.F_JOINTS), device=dev),
                  'touch': torch.as_tensor(env.device_buffer(nat.F_TOUCH), device=dev),
                  'objpose': torch.as_tensor(env.device_buffer(nat.F_OBJ_POSE), device=dev)}
-        if args.gather == 'images':
+        if args.gather in ('images', 'images-delta'):
             views['rgb'] = torch.as_tensor(env.device_buffer(nat.F_RGB), device=dev)
             views['depth'] = torch.as_tensor(env.device_buffer(nat.F_DEPTH), device=dev)
     gathered_bytes = 0
+
+    delta_gather = DeltaImageGather()
 
     def one_step(t):
         nonlocal gathered_bytes
@@ -507,6 +510,9 @@ def main():
             if args.gather == 'images':
                 rgb, depth = gather_images(views['rgb'], views['depth'])
                 gathered_bytes += rgb.numel() + depth.numel() * 4
+            elif args.gather == 'images-delta':
+                delta_gather.step(views['rgb'], views['depth'])
+                gathered_bytes += world * delta_gather.bytes_last
 
     import contextlib
     on_stream = (lambda: torch.cuda.stream(stream)) if stream is not None else contextlib.nullcontext

@@ -1315,23 +1315,6 @@ __global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide(SimParams P, Dev
     }
 #endif
 }
-// The collision pass with RESIDENT workgroups (RR_COLLIDE_RESIDENT=1; experiment of round 5): `gridDim.x` workgroups take the items of
-// k_collide's launch order from an atomic counter -- no 3 us gap between two 14 us workgroups of a slot, and a shader engine that falls
-// behind hands work over.  The last workgroup out resets the counters.  No result depends on who takes which env.
-__global__ void __launch_bounds__(COLLIDE_THREADS, 4) k_collide_resident(SimParams P, DevPtrs D, int ns, int h_first, int *ctr) {
-    __shared__ int s_item;
-    const int total = P.N + h_first;
-    for (;;) {
-        __syncthreads();                                   // (the previous item's LDS is no longer read)
-        if (threadIdx.x == 0) s_item = atomicAdd(&ctr[0], 1);
-        __syncthreads();
-        const int item = __builtin_amdgcn_readfirstlane(s_item);
-        if (item >= total) break;
-        const int env = h_first > 0 ? collide_launch_env(D, item, P.N, h_first) : item;
-        if (env >= 0) collide_env(P, D, ns, env);
-    }
-    if (threadIdx.x == 0 && atomicAdd(&ctr[1], 1) == (int)gridDim.x - 1) { ctr[0] = 0; ctr[1] = 0; }
-}
 #undef CAND_ARGMAX
 #pragma clang fp contract(fast)
 
@@ -4605,8 +4588,6 @@ struct rr_env {
     bool ord_valid, ord_pending;   // item_perm holds an order; a k_raster has left costs that the next k_shade launch turns into one
     bool no_fused_setup;           // RR_NO_FUSED_SETUP: separate k_render_setup launch for the light envs
     bool collide_ordered;          // RR_COLLIDE_ORDER=0: k_collide in env order (default: last step's heavy envs first)
-    int collide_resident;          // RR_COLLIDE_RESIDENT=<workgroups>: the collision pass by resident workgroups with a work counter (0: one workgroup per env)
-    int *collide_ctr;              // its two counters
     void *obs_host;                // rr_map_observations: mapped pinned block {joints [N][9], touch [N][4], poses [N][nobj][7], timestep [N], errflags [N]} or nullptr
     ObsMirror obs_dev;             // its device-visible addresses
     hipEvent_t ev_obs;             // recorded behind the mirror's launches: rr_sync_observations waits for it alone
@@ -4837,8 +4818,6 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     e->item_perm = nullptr; e->ord_valid = e->ord_pending = false;
     e->no_fused_setup = getenv("RR_NO_FUSED_SETUP") != nullptr;
     e->collide_ordered = !(getenv("RR_COLLIDE_ORDER") && atoi(getenv("RR_COLLIDE_ORDER")) == 0);
-    e->collide_resident = getenv("RR_COLLIDE_RESIDENT") ? atoi(getenv("RR_COLLIDE_RESIDENT")) : 0;
-    e->collide_ctr = nullptr;
     e->force_hcount[0] = e->force_hcount[1] = -1;
     e->coop_all = !(getenv("RR_COOP_ALL") && atoi(getenv("RR_COOP_ALL")) == 0) && getenv("RR_NO_COOP") == nullptr;
     e->obs_host = nullptr; memset(&e->obs_dev, 0, sizeof e->obs_dev);
@@ -5007,7 +4986,6 @@ int rr_create(const rr_config *cfg, const void *model_blob, size_t blob_bytes, v
     if (e->h_hcount && hipHostGetDevicePointer((void **)&e->D.hcount_host, e->h_hcount, 0) != hipSuccess) e->D.hcount_host = nullptr;
     ALLOC(D.timestep, (size_t)N);
     ALLOC(D.errflags, (size_t)N);
-    ALLOC(e->collide_ctr, (size_t)4);
     ALLOC(D.obj_home, (size_t)NOBJ * 7 * N);
     ALLOC(D.grows, (size_t)N * GP_RECS * 16);        // (zeroed: the dummy block / contact records stay all zero)
     ALLOC(D.cmd, (size_t)N * 9);
@@ -5331,10 +5309,6 @@ static void launch_collide(rr_env *e, int sel, hipStream_t st) {
     if (sel == 0 && e->collide_ordered && e->h_hcount) {
         const int lag = lagged_count(e, 0, 0) + lagged_count(e, 1, 0);
         if (lag > 0) h_first = std::min(e->P.N, lag + 64);
-    }
-    if (sel == 0 && e->collide_resident > 0 && e->collide_ctr && e->P.N > e->collide_resident) {
-        hipLaunchKernelGGL(k_collide_resident, dim3(e->collide_resident), dim3(COLLIDE_THREADS), 0, st, e->P, e->D, e->n_shapes, h_first, e->collide_ctr);
-        return;
     }
     hipLaunchKernelGGL(k_collide, dim3(e->P.N + h_first), dim3(COLLIDE_THREADS), 0, st, e->P, e->D, e->n_shapes, sel, h_first);
 }

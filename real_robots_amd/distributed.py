@@ -68,3 +68,64 @@ def gather_images(rgb, depth, group=None):
             dist.all_gather(parts, t, group=group)
         outs.append(out)
     return outs[0], outs[1]
+
+
+class DeltaImageGather:
+    """The policy-side image gather without the full slabs: every rank keeps PERSISTENT copies of all ranks' images and a step
+    ships only the pixels that changed since the step before.
+
+    Why (SURVEY.md 8e with the measured rate instead of the 1e6 target): at 6.4 M env-steps/s per GPU a full-slab all-gather
+    (`gather_images`, 114 688 B per env-step) makes every rank SEND 0.74 TB/s and receive seven times that -- more than its seven
+    xGMI links (7 x ~153 GB/s) carry.  An env's frame differs from its previous one in ~1 250 pixels (what the renderer's
+    fragment lists hold: pixels won by moving geometry + pixels vacated): {pixel index 4 B, RGB 3 B, depth 4 B} = 11 B each,
+    ~14 KB per env-step instead of 115 KB -- 88 GB/s per rank at that rate, a tenth of a link each way.
+
+    One step: (1) the changed pixels of the local slab against the rank's own slab in the persistent copy (bit compare; a
+    renderer-side list of changed pixels can replace this pass), (2) one small all-reduce (MAX) of the per-env counts fixes the
+    padded length K of this step's records, (3) three all-gathers of [n, K] index / RGB / depth records, (4) a scatter into the
+    persistent images.  Pad records rewrite pixel 0 with its own new value.  The result is bit for bit the full-slab gather
+    (tests/test_distributed_gloo.py, 2 and 4 ranks).  The first call seeds the copies with one full-slab gather."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rgb = self.depth = None
+        self.bytes_last = 0
+
+    def step(self, rgb, depth):
+        import torch
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        n, H, W = depth.shape
+        if self.rgb is None:
+            self.rgb, self.depth = gather_images(rgb, depth, self.group)
+            self.bytes_last = rgb.numel() + depth.numel() * 4
+            return self.rgb, self.depth
+        mine_rgb = self.rgb[rank * n:(rank + 1) * n].view(n, H * W, 3)
+        mine_dep = self.depth[rank * n:(rank + 1) * n].view(n, H * W)
+        new_rgb, new_dep = rgb.contiguous().view(n, H * W, 3), depth.contiguous().view(n, H * W)
+        changed = (new_rgb != mine_rgb).any(-1) | (new_dep.view(torch.int32) != mine_dep.view(torch.int32))
+        counts = changed.sum(1)
+        kmax = counts.max().reshape(1).to(torch.int64)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX, group=self.group)
+        K = max(int(kmax.item()), 1)
+        # [n, K] records: the changed pixels of an env in pixel order, padded with pixel 0
+        order = torch.cumsum(changed, 1) - 1
+        idx = torch.zeros((n, K), dtype=torch.int64, device=depth.device)
+        rows, pix = torch.nonzero(changed, as_tuple=True)
+        idx[rows, order[rows, pix]] = pix
+        rec_rgb = torch.gather(new_rgb, 1, idx.unsqueeze(-1).expand(n, K, 3)).contiguous()
+        rec_dep = torch.gather(new_dep, 1, idx).contiguous()
+        idx32 = idx.to(torch.int32)
+        outs = []
+        for t in (idx32, rec_rgb, rec_dep):
+            out = torch.empty((world * n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            try:
+                dist.all_gather_into_tensor(out, t, group=self.group)
+            except (RuntimeError, NotImplementedError, AttributeError):
+                dist.all_gather(list(out.chunk(world, dim=0)), t, group=self.group)
+            outs.append(out)
+        all_idx = outs[0].to(torch.int64)
+        self.rgb.view(world * n, H * W, 3).scatter_(1, all_idx.unsqueeze(-1).expand(world * n, K, 3), outs[1])
+        self.depth.view(world * n, H * W).scatter_(1, all_idx, outs[2])
+        self.bytes_last = n * K * 11 + 8
+        return self.rgb, self.depth

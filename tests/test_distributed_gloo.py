@@ -38,6 +38,52 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
+def _delta_worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from real_robots_amd.distributed import DeltaImageGather, gather_images
+    n, H, W = 3, 6, 8
+    g = torch.Generator().manual_seed(100 + rank)
+    rgb = torch.randint(0, 256, (n, H, W, 3), dtype=torch.uint8, generator=g)
+    depth = torch.rand((n, H, W), generator=g)
+    dg = DeltaImageGather()
+    ok, sent = True, []
+    for t in range(8):
+        if t > 0:
+            # a frame differs from the one before in a few pixels (none at t = 3, most of them at t = 5, pixel 0 itself at t = 6)
+            k = (0 if t == 3 else (H * W - 5 if t == 5 else 4 + rank))
+            for e in range(n):
+                pix = torch.randperm(H * W, generator=g)[:k]
+                if t == 6:
+                    pix = torch.cat([pix, torch.zeros(1, dtype=torch.int64)])
+                rgb.view(n, H * W, 3)[e, pix] = torch.randint(0, 256, (len(pix), 3), dtype=torch.uint8, generator=g)
+                depth.view(n, H * W)[e, pix[::2]] = torch.rand(len(pix[::2]), generator=g)
+        a_rgb, a_dep = dg.step(rgb, depth)
+        f_rgb, f_dep = gather_images(rgb, depth)
+        ok = ok and bool(torch.equal(a_rgb, f_rgb)) and bool(torch.equal(a_dep.view(torch.int32), f_dep.view(torch.int32)))
+        sent.append(dg.bytes_last)
+    full = n * H * W * 7
+    ok = ok and sent[0] == full and sent[3] <= n * 11 + 8 and max(sent[1:3]) < full // 2      # the deltas are small; the seed frame is a full gather
+    with open(os.path.join(tmp, 'okd%d' % rank), 'w') as f:
+        f.write('1' if ok else '0 %r' % (sent,))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_delta_image_gather_is_bitwise_the_full_slab_gather(tmp_path, world):
+    """bench.py --gather images-delta: persistent gathered images + per-step records of the changed pixels give,
+    on every rank and after every step, bit for bit what the full-slab all-gather gives -- with frames that do not change at all,
+    frames that change almost everywhere, and a change of the pad pixel itself."""
+    import torch.multiprocessing as mp
+    port = 25500 + (os.getpid() * 3 + world) % 2000
+    mp.spawn(_delta_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), 'okd%d' % r)).read() == '1'
+
+
 def test_two_rank_shard_and_gather(tmp_path):
     import torch.multiprocessing as mp
     port = 29500 + os.getpid() % 2000
@@ -102,6 +148,13 @@ def test_bench_plumbing_four_ranks_gather_images_and_plan_check():
     import re
     ranks = sorted(re.findall(r'RANK \d+ ids \d+ \d+ steps \d+', r.stderr))      # (the ranks' lines may interleave on the shared pipe)
     assert ranks == ["RANK %d ids %d %d steps 7" % (k, 6 * k, 6 * k + 6) for k in range(4)], ranks
+    # the same launch with the delta gather: the stub's images never change, so a step ships one pad record per env
+    cmd2 = [a if a != 'images' else 'images-delta' for a in cmd]
+    r2 = subprocess.run(cmd2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    out2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.strip().startswith('{')][0])
+    assert out2["config"]["gather"] == 'images-delta'
+    assert out2["config"]["gathered_bytes_per_step_per_rank"] == 24 * (9 + 4 + 21) * 4 + 4 * (6 * 1 * 11 + 8)
 
 
 def test_plan_check_names_every_violation():
