@@ -190,16 +190,22 @@ def load_profile(name, cfg):
         return None, "profiles/%s was collected on %s, this run is %s" % (name, json.dumps(pc), json.dumps(cfg))
     # a profile is only quoted for the kernels it was collected on: the hash of the kernel source recorded by tools/profile_round.sh
     if prof.get('source_sha256') != kernel_source_hash():
-        return None, "stale profile: profiles/%s was collected on another build of real_robots_amd/csrc/realrobot.hip" % name
+        return None, "stale profile: profiles/%s was collected on another build of the kernel sources (real_robots_amd/csrc)" % name
     return prof, None
 
 
 def kernel_source_hash():
+    """sha256 over the kernel sources of the library (realrobot.hip and its rr_*.inc parts, in name order)."""
+    import glob
     import hashlib
-    try:
-        return hashlib.sha256(open(os.path.join(ROOT, 'real_robots_amd', 'csrc', 'realrobot.hip'), 'rb').read()).hexdigest()
-    except OSError:
+    d = os.path.join(ROOT, 'real_robots_amd', 'csrc')
+    files = sorted(glob.glob(os.path.join(d, '*.hip')) + glob.glob(os.path.join(d, 'rr_*.inc')))
+    if not files:
         return None
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b'\0' + open(f, 'rb').read())
+    return h.hexdigest()
 
 
 def secondary_workloads(torch, np, nat, BatchedREALRobotEnv, device, steps):

@@ -51,37 +51,29 @@ def _first_difference(a, b):
 # k_collide's h_first) and placements then differ from what the device-side lists actually hold -- which is exactly the
 # situation of a lagged counter, and must not matter.
 PLACEMENTS = [
-    ('default', {}),
-    ('look-ahead never on the very heavy stream: kinematics + collide on the heavy stream, dynamics on the very heavy one',
-     {'RR_LA_VH_MAX': '-1'}),
-    ('look-ahead at the tail of the main stream', {'RR_LA_VH_MAX': '-1', 'RR_MACRO_LA': '0'}),
-    ('look-ahead on the very heavy stream only while there is no very heavy env: the placement changes mid-run',
-     {'RR_LA_VH_MAX': '0'}),
-    ('very heavy render always at the tail of the main stream', {'RR_VH_ON_MAIN': '1'}),
-    ('very heavy render never on the main stream, long heavy list assumed', {'RR_VH_ON_MAIN': '0', 'RR_FORCE_HCOUNT': '2000,10'}),
-    ('long lists assumed: packed solves, three-kernel render of the heavy list, very heavy render on main, look-ahead on the side',
+    ('1: default (look-ahead behind the very heavy envs\' solve, their render behind the heavy envs\')', {}),
+    ('1, empty lists assumed: coop solves, list-walking renders, k_collide in env order', {'RR_FORCE_HCOUNT': '0,0'}),
+    ('1 with a long heavy list assumed: packed heavy solve, three-kernel render of the list, very heavy render at the main stream\'s tail',
+     {'RR_FORCE_HCOUNT': '2000,10'}),
+    ('2: many very heavy envs assumed: packed solves, kinematics + collide on the heavy stream, dynamics on the very heavy one',
      {'RR_FORCE_HCOUNT': '2000,300'}),
-    ('long lists assumed, look-ahead on the main stream', {'RR_FORCE_HCOUNT': '2000,300', 'RR_MACRO_LA': '0'}),
-    ('empty lists assumed: coop solves, list-walking renders, k_collide in env order', {'RR_FORCE_HCOUNT': '0,0'}),
-    ('split off (mostly heavy): one k_solve for all, look-ahead beside the render', {'RR_SPLIT_MAX_PCT': '0', 'RR_FORCE_HCOUNT': '1,0'}),
-    ('split off, look-ahead behind the render on the main stream', {'RR_SPLIT_MAX_PCT': '0', 'RR_FORCE_HCOUNT': '1,0', 'RR_UNSPLIT_LA_INLINE': '1'}),
-    ('split switches off mid-run (more than 2 % heavy envs)', {'RR_SPLIT_MAX_PCT': '2'}),
-    ('separate k_render_setup for the light envs, k_collide in env order', {'RR_NO_FUSED_SETUP': '1', 'RR_COLLIDE_ORDER': '0'}),
-    ('look-ahead without the split', {'RR_NO_SPLIT': '1'}),
-    ('split without the look-ahead', {'RR_NO_LOOKAHEAD': '1'}),
+    ('3: split off (mostly heavy): one k_solve for all, look-ahead beside the render', {'RR_SPLIT_MAX_PCT': '0', 'RR_FORCE_HCOUNT': '1,0'}),
+    ('1 <-> 3: the split switches off mid-run (more than 2 % heavy envs)', {'RR_SPLIT_MAX_PCT': '2'}),
+    ('1 with a separate k_render_setup for the light envs and k_collide in env order', {'RR_NO_FUSED_SETUP': '1', 'RR_COLLIDE_ORDER': '0'}),
+    ('5: look-ahead without the split', {'RR_NO_SPLIT': '1'}),
+    ('5: split without the look-ahead', {'RR_NO_LOOKAHEAD': '1'}),
 ]
 
 
-@pytest.mark.parametrize('group', [0, 1, 2])
-def test_every_schedule_placement_is_bitwise_the_inline_step(monkeypatch, group):
+def test_every_schedule_placement_is_bitwise_the_inline_step(monkeypatch):
     """448 envs, 250 full-range steps (heavy and very heavy envs appear: arms pressed on the table), per-env render flags,
     resets, teleports, home-pose edits and state restores in between; states, touch, contact counts and lists with forces,
     images, classes and error flags of every forced placement are bitwise those of the unsplit in-line step."""
     N, T = 448, 250
-    names = [p for k, p in enumerate(PLACEMENTS) if k % 3 == group]
+    names = list(PLACEMENTS)
     envs = [_make(monkeypatch, PLAIN, N, objects=3, width=128, height=128)]
     envs += [_make(monkeypatch, v, N, objects=3, width=128, height=128) for _, v in names]
-    rng = np.random.default_rng(41 + group)
+    rng = np.random.default_rng(41)
     for t in range(T):
         cmd = synthetic_actions(range(N), t, seed=3).astype(np.float32)
         ev = rng.random()

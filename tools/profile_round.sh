@@ -17,8 +17,9 @@ TAG=$TAG python3 - <<'PY'
 import csv, glob, os, json, collections
 R=os.environ['GRAFT_REPO_ROOT']; O=R+'/gpurun_out/round'; TAG=os.environ['TAG']
 cfg={"envs": 4096, "objects": 3, "width": 128, "height": 128, "render": True, "command_scale": 1.0, "solver_iters": 50}
-import hashlib
-SRC_SHA=hashlib.sha256(open(R+'/real_robots_amd/csrc/realrobot.hip','rb').read()).hexdigest()   # bench.load_profile only quotes a profile of the very source it runs
+import importlib.util
+_sp=importlib.util.spec_from_file_location('bench_mod', R+'/bench.py'); _bm=importlib.util.module_from_spec(_sp); _sp.loader.exec_module(_bm)
+SRC_SHA=_bm.kernel_source_hash()   # bench.load_profile only quotes a profile of the very kernel sources it runs
 def means(d):
     """mean per dispatch and, for kernels launched more than once per step, the number of dispatches per step"""
     f=glob.glob(O+'/%s/*counter_collection.csv'%d)
