@@ -431,3 +431,27 @@ def test_raster_dispatch_order_does_not_change_an_image(monkeypatch):
                     assert np.array_equal(x, y), (n, w, t)
         assert (env.host(nat.F_ERRFLAGS) == 0).all()
         ref.close(); env.close()
+
+
+def test_a_camera_inside_the_arm_mesh_does_not_stop_the_physics():
+    """a render-only condition must never touch simulation-visible state.  With the eye INSIDE an arm link hundreds
+    of triangles cross the near plane in every tile (the clip queue of a raster tile holds 2 048; its overflow is error flag 8, a
+    render status).  Whatever the renderer reports, the physics keeps stepping: no flag the solver's dead mask knows (1, 4) appears,
+    the clocks advance, and the states are bitwise those of a run that never renders."""
+    from real_robots_amd.mathutil import look_at, perspective
+    N, T = 32, 60
+    env = BatchedREALRobotEnv(N, objects=3, width=128, height=128)
+    ref = BatchedREALRobotEnv(N, objects=3, width=128, height=128)
+    # inside link 1 / link 2 of the arm (robot base at [-0.55, 0, -0.04]), looking along the arm
+    env.set_camera(look_at(np.array([-0.55, 0.0, 0.30]), np.array([-0.55, 0.05, 1.2]), np.array([1.0, 0.0, 0.0])), perspective(120.0, 1.0, 0.1, 100.0))
+    for t in range(T):
+        cmd = synthetic_actions(range(N), t, seed=5).astype(np.float32)
+        env.step(cmd, render=True)
+        ref.step(cmd, render=False)
+    ef = env.host(nat.F_ERRFLAGS)
+    assert (ef & ~np.uint32(8) == 0).all(), np.unique(ef)            # nothing but (possibly) the render status
+    assert (env.host(nat.F_TIMESTEP) == T).all()
+    assert np.array_equal(env.state, ref.state, equal_nan=True)
+    assert (env.host(nat.F_MASK) == 0).any()                         # the arm is in front of the lens
+    env.close()
+    ref.close()
