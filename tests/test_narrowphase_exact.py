@@ -275,21 +275,21 @@ def run_all(n, workers):
     return res
 
 
-# Stated bounds (round 5, with the edge samples of tools/compile_model.py in the model; 2 000 poses per class in
+# Stated bounds (round 5, with the rim samples of tools/compile_model.py in the model; 2 000 poses per class in
 # tests/golden/narrowphase_exact_summary.json, 78 000 poses in all):
 #   * NO pair whose full hulls overlap or come within 2 mm goes without a contact, in any class;
-#   * overlapping / touching pairs: the deepest contact's distance is within 2.7 mm (objects, gripper) / 4.7 mm (arm links) of the
-#     exact signed distance in 99 % of the poses, the median error is below 0.45 mm; the worst cases (3-6 mm objects / gripper,
-#     4-17 mm arm links) are overlaps along an EDGE-EDGE axis between an edge that is not stored (shorter than 1.5 cm, dihedral
+#   * overlapping / touching pairs: the deepest contact's distance is within 3.2 mm (objects, gripper) / 4.7 mm (arm links) of the
+#     exact signed distance in 99 % of the poses, the median error is below 0.45 mm; the worst cases (2-13 mm objects / gripper,
+#     3-17 mm arm links) are overlaps along an EDGE-EDGE axis between an edge that is not stored (shorter than 1.5 cm, dihedral
 #     angle below 15 degrees, beyond the 48 longest) and a smooth surface -- `unseen_overlap` counts the poses where the hulls
-#     overlap by more than 0.5 mm and the deepest contact still reports a gap (0-29 of 667 per class);
+#     overlap by more than 0.5 mm and the deepest contact still reports a gap (0-21 of 667 per object / gripper class, 9-29 per arm link);
 #   * the contact NORMAL is the exact separating direction (median 0.0 degrees) where a face is involved -- objects on table and
 #     shelf, arm links on the table --, and the face normal of the nearer shape (median 4-33 degrees off the exact direction) where
 #     the closest features are two edges or an edge and a vertex of random-oriented gripper / object pairs: the vertex-in-polytope
 #     scheme reports a FACE normal by construction, Bullet's GJK / EPA the edge-edge direction;
 #   * separated pairs (speculative contacts, 2-18 mm): the plane distance under-estimates the Euclidean distance of vertex-edge
 #     and vertex-vertex features by up to 6.7 mm -- a speculative contact that acts a little early, never a missed touch.
-BOUNDS = dict(p99_mm=dict(obj=2.8, arm=4.8), median_mm=0.45, subset_p90_mm=dict(obj=3.0, arm=6.0))
+BOUNDS = dict(p99_mm=dict(obj=3.3, arm=4.8), median_mm=0.45, subset_p90_mm=dict(obj=3.3, arm=6.0))
 
 
 def _kind(name):
