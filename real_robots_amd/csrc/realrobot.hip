@@ -147,7 +147,9 @@ struct DevPtrs {
     int *hlist;        // [N] the heavy envs of this step (in arrival order: placement only, never a result)
     int *hcount;       // [0] their number, [1] work counter of k_raster_list / k_render_list
     float4 *clist_next; int *ccount_next; float *cwarm_next; int *hgflag_next, *hlist2_next, *hcount2_next, *hlist_next, *hcount_next;
-    int *hpos, *hpos_next;     // [N] place of a heavy / very heavy env in its list (k_collide's launch order, collide_launch_env)
+    // dispatch order of k_collide's workgroups (dispatch_order_class with one item per env): the envs by falling duration of their last collision pass
+    unsigned *collide_cost, *collide_bin;   // [N] that duration (100 MHz ticks) / the bin it was counted in
+    unsigned *collide_perm;                 // [8 * ceil(N / 8)] env << 8, costly envs first, ~0 behind the last one of a class
     float *cforce;     // [N][MAXC] normal force of every contact of the last solved step (rr_get_contacts, touch sensors, warm start)
     int *hcount_host;  // device address of the pinned host word that receives the current number of heavy envs (or nullptr)
     int *timestep;     // [N]
@@ -175,9 +177,9 @@ struct DevPtrs {
     unsigned char *static_rgb; float *static_depth; int *static_mask;   // [H*W] shaded static layer (shared by all envs)
     uint2 *frag_list;       // [N*ntiles][TILE_PIX] pixels won by moving triangles: {depth bits, pixel-in-tile << 18 | triangle}
     unsigned *frag_count;   // [N*ntiles]
-    // dispatch order of k_raster's workgroups (raster_order_class): the (env, tile) items by falling cost of the previous frame
+    // dispatch order of k_raster's workgroups (dispatch_order_class): the (env, tile) items by falling cost of the previous frame
     unsigned *item_cost;        // [N*ntiles] duration of the item's workgroup in the last frame that rasterised it (100 MHz ticks)
-    unsigned *item_bin;         // [N*ntiles] raster_order_class: the bin an item was counted in (its second pass reads it back, not the cost again)
+    unsigned *item_bin;         // [N*ntiles] dispatch_order_class: the bin an item was counted in (its second pass reads it back, not the cost again)
     const unsigned *item_perm;  // [N*ntiles] env << 8 | tile, costly items first; nullptr: env-major grid (envs, tiles)
 };
 
@@ -370,6 +372,66 @@ __device__ void fk_all(const BodyParams &bp_, const float *q, m3 *bR, v3 *bp, v3
         bax[b] = nc::mulv(Rj, ax);
     }
 }
+
+// Dispatch order of the next frame's k_raster: the (env, tile) items by falling cost (counting sort over 1024 linear bins of the
+// durations k_raster has just measured), by a few extra workgroups of the k_shade launch that follows it (a stream of its own was
+// measured: a fifth stream shares a hardware queue with one of the step's four and serialises it, 0.67 -> 0.83 ms).  One class per
+// XCD -- workgroup index mod 8 is the XCD --: the envs = x (mod 8), so every XCD keeps an eighth of the envs with all their tiles
+// and its queue holds items of falling cost.  (Which XCD rasterises a tile does not matter to k_shade: with the tiles of an env
+// dealt to different XCDs it takes 0.089 instead of 0.088 ms.)  perm[8 * j + x] = the j-th costliest item of class x,
+// env << 8 | tile, or ~0 behind the last one.
+// Costs change little from frame to frame (5 ms of motion); an order that is off only loads the shader engines less evenly, the
+// images do not depend on it.
+// The collision pass uses the same sort with one item per env (ntiles = 1, extra workgroups of the k_prep_a / k_prep_ab launch in
+// front of it, NT_ = 64): its workgroups last 14 us +- 20 % with a tail up to 70 us, and in env order a quarter of the slots stay empty.
+#define ORDER_BINS 1024
+template <int NT_>
+__device__ __forceinline__ void dispatch_order_class(int x, int N, int ntiles, int per_class, const unsigned *cost, unsigned *bins, unsigned *perm) {
+    static_assert(ORDER_BINS % NT_ == 0 && NT_ % 64 == 0 && NT_ <= 1024, "bins per thread");
+    constexpr int BPT = ORDER_BINS / NT_;
+    __shared__ unsigned hist[ORDER_BINS];
+    __shared__ unsigned s_max, wtot[NT_ / 64];
+    const int tid = threadIdx.x;
+    const int n_items = x < N ? ntiles * ((N - x + 7) >> 3) : 0;          // items of this class: envs x, x + 8, ...
+    __syncthreads();                                                       // (a workgroup may take several classes in turn)
+    if (tid == 0) s_max = 1u;
+    for (int b = tid; b < ORDER_BINS; b += NT_) hist[b] = 0u;
+    __syncthreads();
+#define ORDER_ITEM(k) ((size_t)(x + 8 * ((k) / ntiles)) * ntiles + (size_t)((k) % ntiles))
+#define ORDER_BIN(c) (ORDER_BINS - 1 - min((unsigned)((float)(c) * scale), (unsigned)(ORDER_BINS - 1)))      /* bin 0 = the costliest items */
+    unsigned mx = 0u;
+    for (int k = tid; k < n_items; k += NT_) mx = max(mx, cost[ORDER_ITEM(k)]);
+    for (int o = 32; o; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    if ((tid & 63) == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    const float scale = (float)(ORDER_BINS - 1) / (float)s_max;
+    // (an item's bin is computed ONCE and kept: were a cost rewritten between the two passes -- a visibility pass running beside
+    // this launch, which the launch order rules out today -- the scatter would still be a permutation)
+    for (int k = tid; k < n_items; k += NT_) { const size_t i = ORDER_ITEM(k); const unsigned b = ORDER_BIN(cost[i]); bins[i] = b; atomicAdd(&hist[b], 1u); }
+    __syncthreads();
+    // exclusive prefix over the bins: BPT consecutive bins per thread, wave scan of the threads' sums, the waves' totals
+    unsigned hb[BPT], sum = 0u;
+#pragma unroll
+    for (int j = 0; j < BPT; j++) { hb[j] = hist[tid * BPT + j]; sum += hb[j]; }
+    unsigned inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned v = (unsigned)__shfl_up((int)inc, o); if ((tid & 63) >= o) inc += v; }
+    if ((tid & 63) == 63) wtot[tid >> 6] = inc;
+    __syncthreads();
+    unsigned base = inc - sum;
+    for (int w = 0; w < (tid >> 6); w++) base += wtot[w];
+#pragma unroll
+    for (int j = 0; j < BPT; j++) { hist[tid * BPT + j] = base; base += hb[j]; }
+    __syncthreads();
+    for (int k = tid; k < n_items; k += NT_) {
+        const size_t i = ORDER_ITEM(k);
+        const unsigned pos = atomicAdd(&hist[min(bins[i], (unsigned)(ORDER_BINS - 1))], 1u);
+        if (pos < (unsigned)n_items) perm[(size_t)8 * pos + x] = ((unsigned)(i / ntiles) << 8) | (unsigned)(i % ntiles);
+    }
+    for (int k = n_items + tid; k < per_class; k += NT_) perm[(size_t)8 * k + x] = 0xffffffffu;
+#undef ORDER_ITEM
+#undef ORDER_BIN
+}
+
 
 // The translation unit is kept in parts (one library, one compilation: the kernels share structs, device math and macros):
 #include "rr_prep.inc"    // k_prep: the state part of a step (forward kinematics, object terms, joint-space dynamics)

@@ -32,4 +32,9 @@ for rep in range(3):
     print('   shader engines: last end mean %.1f min %.1f max %.1f us; work max / mean %.3f' % (ends.mean() / 100.0, ends.min() / 100.0, ends.max() / 100.0, work.max() / work.mean()))
     o = np.argsort(st); q = N // 4
     print('   mean duration of the workgroups by start quarter: ' + ' '.join('%.1f' % (dur[o[i * q:(i + 1) * q]].mean() / 100.0) for i in range(4)), '; starts of the quarters (us): ' + ' '.join('%.1f' % (st[o[i * q]] / 100.0) for i in range(4)))
+    print('   start of the k-th workgroup (us): ' + ' '.join('%d:%.1f' % (k, st[o[k]] / 100.0) for k in (64, 128, 256, 512, 768, 1023, 1500, 2047, 3071, 4000, 4095)))
+    last = np.argsort(-en)[:16]
+    print('   last to end (start, duration us): ' + ' '.join('(%.0f, %.0f)' % (st[i] / 100.0, dur[i] / 100.0) for i in last))
+    busy = np.zeros(int(span) + 1); np.add.at(busy, st, 1); np.add.at(busy, en, -1); busy = np.cumsum(busy)
+    print('   workgroups resident at 5 us steps: ' + ' '.join('%d' % busy[min(int(t * 100), len(busy) - 1)] for t in np.arange(2.5, span / 100.0, 5.0)))
 env.close()
