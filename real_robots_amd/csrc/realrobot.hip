@@ -82,6 +82,8 @@ struct ShapeData {    // global memory, read uniformly
     float verts[MAXSHAPES][VMAXC][3];
     float planes[MAXSHAPES][FMAXC][4];
     float sphere[MAXSHAPES][4];
+    float roff[MAXSHAPES];           // circumradius about the sphere centre of the shape grown by the contact margin plane by plane (tools/compile_model.py
+                                     // offset_radius; +inf when the blob has none or was compiled for a smaller margin): k_collide's pair cull
     float fric[MAXSHAPES], rest[MAXSHAPES], roll[MAXSHAPES], spin[MAXSHAPES];
     int ne[MAXSHAPES];
     float edges[MAXSHAPES][EMAXC][12];    // long sharp hull edges: p0, p1 - p0, the two facet normals (owner frame)

@@ -15,8 +15,12 @@ for t in range(170):
     env.step(synthetic_actions(ids, (t // 20) * 20, hold_prob=0.05) * SCALE, render=False)
 torch.cuda.synchronize()
 WAVES = 4
-out = np.zeros((N, WAVES, 8), np.uint32)
+out = np.zeros((N, WAVES, 12), np.uint32)
 assert lib.rr_debug_collide_prof(out.ctypes.data_as(ctypes.c_void_p), N) == 0
+cnt = out[:, :, 7:12].sum(1).astype(np.float64)
+print('per env: close pairs %.2f, apart in direction 0 %.2f, apart only in direction 1 %.2f, not apart but no candidate %.2f, with contacts %.2f' % tuple(cnt.mean(0)))
+busy = out[:, :, 2:6].astype(np.float64).sum(2)
+print('pair-loop cycles per wave: mean of waves %.0f, slowest wave %.0f (mean over envs)' % (busy.mean(), busy.max(1).mean()))
 names = ['stage', 'sphere tests', 'loads + cull', 'prefilter', 'all-plane pass', 'reduction', 'record write']
 wtot = out[:, :, :7].astype(np.float64).sum(2)          # per wave
 slow = wtot.argmax(1)

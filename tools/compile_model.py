@@ -270,6 +270,23 @@ def add_edge_samples(name, owner_type, verts, edges):
     return np.vstack([verts, np.array(pts)]) if pts else verts
 
 
+ROFF_MARGIN = 0.02   # the contact margin the offset radii below are computed for (rr_create's default; a larger one disables their use)
+
+
+def offset_radius(planes, center, interior):
+    """Circumradius about `center` of the polytope {x: n.x <= c + ROFF_MARGIN for all planes}: the shape grown by the contact
+    margin PLANE BY PLANE -- the set a vertex must lie in to become a contact candidate (oracle verts_in_planes: largest signed
+    distance to the planes below the margin).  At a sharp corner it reaches beyond margin from the shape (by margin / sin of the
+    half angle), which is why radius + margin does not bound it.  k_collide: a shape whose bounding sphere of THIS radius lies
+    beyond one plane of the other shape cannot take part in any candidate of the pair, in either direction."""
+    from scipy.spatial import HalfspaceIntersection
+    pl = np.asarray(planes, np.float32).astype(np.float64)          # the planes as the kernels read them
+    hs = np.concatenate([pl[:, :3], -(pl[:, 3:4] + ROFF_MARGIN)], axis=1)
+    v = HalfspaceIntersection(hs, np.asarray(interior, np.float64)).intersections
+    r = float(np.linalg.norm(v - np.asarray(center, np.float64)[None], axis=1).max())
+    return r * 1.0005 + 2e-5
+
+
 def simplify_hull(pts):
     """pts [V,3] (already in the owner's frame). Returns verts[<=VMAX,3], planes[<=FMAX,4] (n, c: n.x<=c inside),
     (vertex deviation, plane deviation) in metres."""
@@ -690,6 +707,7 @@ def main(out_path):
     sh_roll = np.zeros((NS, 2))                 # rolling, spinning friction coefficients (URDF <contact>)
     sh_dev = np.zeros((NS, 2))                  # deviation of the reduced vertex / plane set from the full hull (m)
     sh_ne = np.zeros(NS, np.int32)
+    sh_roff = np.zeros(NS)                      # offset_radius(): circumradius of the shape grown by ROFF_MARGIN plane by plane
     sh_edges = np.zeros((NS, EMAX, 12))         # long hull edges: p0 (3), p1 - p0 (3), the two facet normals (3 + 3), owner frame
     for s, S in enumerate(shapes):
         sh_owner[s] = [S['otype'], S['oidx'], S['link'], S['uid']]
@@ -700,6 +718,8 @@ def main(out_path):
         sh_planes[s, :nf] = S['planes']
         sh_sphere[s, :3] = S['center']
         sh_sphere[s, 3] = S['radius']
+        sh_roff[s] = offset_radius(S['planes'], S['center'], np.mean(S['verts'], axis=0))
+        assert sh_roff[s] >= S['radius'] + ROFF_MARGIN, (S['name'], sh_roff[s], S['radius'])
         sh_mat[s] = [S['friction'], S['restitution']]
         sh_roll[s] = [S['rolling'], S['spinning']]
         sh_dev[s] = S['dev']
@@ -915,6 +935,7 @@ def main(out_path):
     B.add('shape_dev', sh_dev, F)
     B.add('shape_ne', sh_ne, I32)
     B.add('shape_edges', sh_edges, F)
+    B.add('shape_roff', np.concatenate([sh_roff, [ROFF_MARGIN]]), F)      # [NS] radii + the margin they hold for
     B.add('touch_links', touch_links, I32)
     B.add('link_body', link_body, I32)
     B.add('link_pos', link_pos, F)
