@@ -72,6 +72,14 @@ for rep in range(3):
             d = np.diff(full[:, :7], axis=1) / 100.0
             if len(d) == 0: continue
             print('   tile %d marks of the %d workgroups that rasterise (us, mean / median): ' % (tt, len(d)) + '; '.join('%s %.2f / %.2f' % (names[i], d[:, i].mean(), np.median(d[:, i])) for i in range(6)))
+    if SHADE and lib.rr_debug_raster_wgmarks(mk.ctypes.data_as(ctypes.c_void_p)) == 0:
+        m6 = mk[:N * 8][ok].astype(np.int64)
+        full = (m6[:, 1:7] > 0).all(axis=1)
+        seq = np.concatenate([b[ok, 0].astype(np.int64)[full, None], m6[full, 1:7], b[ok, 1].astype(np.int64)[full, None]], axis=1)
+        d = np.diff(seq, axis=1) / 100.0
+        names = ['count known', 'constants staged', 'list entry', 'key + record', 'shaded (texel)', 'stores issued', 'rest of the loop + exit']
+        print('   marks of thread 0, first trip, %d workgroups with fragments (us, mean / median / p90): ' % full.sum() + '; '.join('%s %.2f / %.2f / %.2f' % (names[i], d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90)) for i in range(7)))
+        print('   whole workgroup: mean %.2f us' % ((seq[:, -1] - seq[:, 0]).mean() / 100.0))
     per_cu = np.array([(cu == k).sum() for k in keys]); print('   workgroups per CU: min %d max %d' % (per_cu.min(), per_cu.max()))
 os.makedirs(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out'), exist_ok=True)
 np.save(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'rwgtime_last.npy'), buf[:N * 8])

@@ -106,6 +106,37 @@ def test_every_schedule_placement_is_bitwise_the_inline_step(monkeypatch):
         e.close()
 
 
+def test_collision_pass_order_and_pair_cull_change_no_result(monkeypatch):
+    """k_collide dispatches its workgroups by falling duration of the env's last pass (batches of more than 1 024 envs) and drops
+    shape pairs in its broad phase by the grown-radius rule (rr_collide.inc; tests/test_pair_cull.py states the rule against the
+    oracle): 1 531 envs -- not a multiple of eight: the order's padding entries --, 160 full-range steps with resets and teleports;
+    states, touch, contact counts, lists with forces, classes and error flags are bitwise those of the env-order pass without the cull."""
+    N, T = 1531, 160
+    a = _make(monkeypatch, {}, N, objects=3, width=32, height=32)
+    b = _make(monkeypatch, {'RR_COLLIDE_ORDER': '0', 'RR_NO_PAIR_CULL': '1'}, N, objects=3, width=32, height=32)
+    rng = np.random.default_rng(5)
+    for t in range(T):
+        cmd = synthetic_actions(range(N), t, seed=9).astype(np.float32)
+        ev = rng.random()
+        mask = (rng.random(N) < 0.1).astype(np.uint8)
+        pose = np.array([rng.uniform(-0.2, 0.0), rng.uniform(-0.3, 0.3), rng.uniform(0.3, 0.6), 0, 0, 0, 1], np.float32)
+        i, o = int(rng.integers(0, N)), int(rng.integers(0, 3))
+        for e in (a, b):
+            if ev < 0.03:
+                e.reset(mask)
+            elif ev < 0.06:
+                e.set_object_pose(i, o, pose)
+            e.step(cmd, render=False)
+        if t % 20 == 19 or t < 2:
+            for f in (nat.F_TOUCH, nat.F_CONTACT_COUNT, nat.F_JOINTS, nat.F_OBJ_POSE, nat.F_ERRFLAGS, nat.F_ENV_CLASS):
+                assert np.array_equal(a.host(f), b.host(f)), (t, f)
+            assert np.array_equal(a.state, b.state), t
+            for k in range(0, N, 61):
+                assert np.array_equal(a.contacts(k), b.contacts(k)), (t, k)
+    assert a.host(nat.F_CONTACT_COUNT).max() >= 20        # arms pressed on the table: the pass had real work
+    a.close(); b.close()
+
+
 def _bench_module():
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
