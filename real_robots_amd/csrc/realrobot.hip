@@ -167,7 +167,7 @@ struct DevPtrs {
     unsigned char *render_flags; // [N]
     unsigned char *rgb; float *depth; int *mask;
     const float *tri_pos;   // SoA [9][NT]
-    const float4 *tri_rec;  // AoS [NT][8]: one 128-byte shading record per triangle {pos[9], nrm[9], uv[6], inst, pad}
+    const float4 *tri_rec;  // AoS [NT][8]: one 128-byte shading record per triangle {pos[9], nrm[9], inst, -, uv[6], pad}
     const int *tri_inst;    // [NT]
     const float4 *cluster_sphere; // [NT/64] bounding sphere (instance frame) of each 64-triangle raster cluster
     const float *cluster_verts;   // [NT/64][3][64] the cluster's distinct vertex positions (x row, y row, z row)
