@@ -3,7 +3,7 @@
 The reference draws one placement at a time, lets a single pybullet env settle (<= 1000 steps), snapshots the retina,
 mask and poses, and rejects placements that break the separation / orientation / start-goal predicates
 (generate_goals.py:21-68 runEnv, 79-108 generatePosition, 133-226 drawPosition, 249-272 isOnShelf/isOnTable,
-275-365 generateGoalREAL2020, 435-436 file format). Here B candidate goals are drawn per round and the B envs settle in
+229-246 checkRepeatability, 275-365 generateGoalREAL2020, 435-436 file format). Here B candidate goals are drawn per round and the B envs settle in
 lock-step on the GPU; the predicates and thresholds are the reference's. Output: `np.savez_compressed(path, goals)` with
 `Goal` objects (fields initial_state, final_state, retina, retina_before, mask, challenge, subtype), loadable by
 `REALRobotEnv.load_goals`.
@@ -67,6 +67,14 @@ def _min_separation(p):          # p [n_obj, >=3]
     return d[d > 0].min()
 
 
+def two_near_objects(p, max_dist):
+    """generate_goals.py:296-313 / 325-338: some pair of objects no farther apart than max_dist (p [n_obj, >=3])."""
+    if len(p) < 2:
+        return False
+    d = np.linalg.norm(p[:, None, :3] - p[None, :, :3], axis=2)
+    return bool((d[~np.eye(len(p), dtype=bool)] <= max_dist).any())
+
+
 def is_on_shelf(obj, z):          # generate_goals.py:249-259
     return z > ({'mustard': 0.545}.get(obj, 0.55) - 0.15)
 
@@ -115,8 +123,11 @@ class _Drawer:
 
 
 def generate_goals(n_2d_goals=25, n_25d_goals=15, n_3d_goals=10, n_obj=3, seed=None, batch=64, width=320, height=240,
-                   device=0, max_rounds=50):
-    """Returns the list of Goal objects (2D, then 2.5D, then 3D) like generate_goals.main (generate_goals.py:406-436)."""
+                   device=0, max_rounds=50, max_objects_dist=2.0, repeatability=False):
+    """Returns the list of Goal objects (2D, then 2.5D, then 3D) like generate_goals.main (generate_goals.py:406-436).
+    max_objects_dist: generateGoalREAL2020's predicate of the same name (its default, 2 m, never binds on a 0.5 x 0.9 m table).
+    repeatability=True also runs check_repeatability on the result, as the reference's main does (generate_goals.py:438), and
+    returns (goals, (maxDiffPos, maxDiffOr))."""
     rng = np.random.default_rng(seed)
     env = BatchedREALRobotEnv(batch, objects=n_obj, width=width, height=height, device=device)
     drawer = _Drawer(env, rng, n_obj)
@@ -138,7 +149,10 @@ def generate_goals(n_2d_goals=25, n_25d_goals=15, n_3d_goals=10, n_obj=3, seed=N
                 shelf = goal_type == '2D' or any(is_on_shelf(names[o], ini[e, o, 2]) or is_on_shelf(names[o], fin[e, o, 2])
                                                 for o in range(n_obj))
                 moved = all(np.linalg.norm(fin[e, o, :2] - ini[e, o, :2]) >= min_start_goal for o in range(n_obj))
-                if not (shelf and moved):
+                # generate_goals.py:296-313, 325-338: (3D goals with several objects) two objects within max_objects_dist of each
+                # other in the initial state, or else in the final one
+                near = n_obj == 1 or goal_type != '3D' or two_near_objects(ini[e], max_objects_dist) or two_near_objects(fin[e], max_objects_dist)
+                if not (shelf and moved and near):
                     continue
                 g = Goal(initial_state={names[o]: ini[e, o].copy() for o in range(n_obj)},
                          final_state={names[o]: fin[e, o].copy() for o in range(n_obj)},
@@ -148,8 +162,45 @@ def generate_goals(n_2d_goals=25, n_25d_goals=15, n_3d_goals=10, n_obj=3, seed=N
         if len(got) < count:
             raise RuntimeError("could not generate %d %s goals in %d rounds" % (count, goal_type, max_rounds))
         goals += got
+    rep = check_repeatability(env, goals, drawer) if repeatability else None
     env.close()
-    return goals
+    return (goals, rep) if repeatability else goals
+
+
+def check_repeatability(env, goals, drawer=None):
+    """Batched checkRepeatability (generate_goals.py:229-246): every goal's objects are put back at its initial state
+    (generateRealPosition, :111-121: reset, settle, re-pose, settle) -- env.N goals at a time -- and the settled poses are compared
+    with the state they started from.  Returns (maxDiffPos, maxDiffOr) over the goals, the reference's two figures -- including
+    its quirk: its maxDiffOr is max(maxDiffPos, diffOr of the last goal) (:242), kept so that the two programs print the same --
+    or 1000000 when a placement does not settle within 1000 steps (:244-246)."""
+    N = env.N
+    names = list(goals[0].initial_state) if goals else []
+    n = len(names)
+    order = [OBJECT_NAMES.index(k) for k in names]
+    max_pos, max_or = 0.0, 0.0
+    for g0 in range(0, len(goals), N):
+        chunk = goals[g0:g0 + N]
+        start = np.zeros((N, env.n_objects, 7))
+        env.reset()
+        settle(env)
+        start[:] = env.host(nat.F_OBJ_POSE).astype(np.float64)          # envs beyond the chunk keep their settled default
+        for e, g in enumerate(chunk):
+            for k, o in zip(names, order):
+                start[e, o] = g.initial_state[k]
+        env.set_object_poses(start.astype(np.float32))
+        actual, failed = settle(env)
+        for e, g in enumerate(chunk):
+            p0 = np.vstack([g.initial_state[k] for k in names])
+            p1 = np.vstack([actual[e, o] for o in order])
+            diff_pos = float(np.linalg.norm(p1[:, :3] - p0[:, :3]))
+            diff_or = float(min(np.linalg.norm(p1[:, 3:] - p0[:, 3:]), np.linalg.norm(p1[:, 3:] + p0[:, 3:])))
+            max_pos = max(max_pos, diff_pos)
+            max_or = max(max_pos, diff_or)
+            print("Replicated diffPos:{} diffOr:{}".format(diff_pos, diff_or))
+            if failed[e]:
+                print("*****************FAILED************!!!!")
+                return 1000000
+    return max_pos, max_or
 
 
 def save_goals(path, goals):
@@ -171,7 +222,7 @@ def main(argv=None):
     ap.add_argument('--n_3d_goals', type=int, default=10)
     ap.add_argument('--n_obj', type=int, default=3)
     a = ap.parse_args(argv)
-    goals = generate_goals(a.n_2d_goals, a.n_25d_goals, a.n_3d_goals, a.n_obj, a.seed)
+    goals, _ = generate_goals(a.n_2d_goals, a.n_25d_goals, a.n_3d_goals, a.n_obj, a.seed, repeatability=True)      # generate_goals.py:438
     save_goals('goals-REAL2020-s{}-{}-{}-{}-{}.npy'.format(a.seed, a.n_2d_goals, a.n_25d_goals, a.n_3d_goals, a.n_obj), goals)
 
 

@@ -181,3 +181,20 @@ def test_evaluate_batched_at_4096_envs_matches_the_single_env_harness(tmp_path):
         else:
             single = [sc[goals[i].challenge][0], sc[goals[(i + 1) % N].challenge][0]]
         assert abs(single[0] - per_env[0][i]) < 1e-3 and abs(single[1] - per_env[1][i]) < 1e-3, (i, single, per_env[0][i], per_env[1][i])
+
+
+def test_goal_generator_repeatability_and_object_distance_predicate():
+    """generate_goals.py:229-246 checkRepeatability (batched: a goal's objects put back at its initial state settle where they
+    were) and :296-338 max_objects_dist (3D goals with several objects: two of them within the distance in the initial or the
+    final state) -- the two pieces of the reference's generator that were not restated before round 5."""
+    from real_robots_amd.generate_goals import generate_goals, two_near_objects
+    goals, rep = generate_goals(n_2d_goals=2, n_25d_goals=1, n_3d_goals=3, n_obj=3, seed=11, batch=48, width=64, height=64,
+                                max_objects_dist=0.3, repeatability=True)
+    assert [g.challenge for g in goals] == ['2D', '2D', '2.5D', '3D', '3D', '3D']
+    assert rep != 1000000                                   # every placement settled again
+    max_pos, max_or = rep
+    assert max_pos < 2e-3 and max_or < 2e-2, rep            # settled states are fixed points of "re-pose and settle" (m / quaternion norm)
+    for g in goals[3:]:
+        ini = np.vstack([g.initial_state[k] for k in g.initial_state])
+        fin = np.vstack([g.final_state[k] for k in g.final_state])
+        assert two_near_objects(ini, 0.3) or two_near_objects(fin, 0.3)

@@ -317,3 +317,10 @@ def test_product_package_never_imports_the_oracle():
             "real_robots_amd.cli, real_robots_amd.envs.env, real_robots; "
             "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'")
     subprocess.check_call([sys.executable, '-c', code], cwd=ROOT)
+
+
+def test_goal_generator_distance_predicate():
+    """generate_goals.py:296-313: some pair of objects no farther apart than max_objects_dist."""
+    from real_robots_amd.generate_goals import two_near_objects
+    p = np.array([[0.0, 0.0, 0.3], [0.25, 0.0, 0.3], [0.0, 0.5, 0.3]])
+    assert two_near_objects(p, 0.25) and not two_near_objects(p, 0.2) and not two_near_objects(p[:1], 10.0)
