@@ -263,11 +263,12 @@ def test_object_wave_form_of_the_light_solve_is_bitwise_equivalent(monkeypatch):
 
 
 def test_collide_launch_order_does_not_change_results(monkeypatch):
-    """k_collide launches last step's very heavy / heavy envs first (collide_launch_env); RR_COLLIDE_ORDER=0 keeps env order.  The
-    order only decides which workgroup handles which env and in which order the envs are appended to the heavy lists: states,
-    contacts, classes and images are bitwise the same over 240 full-range steps with resets in between (envs that are on a list
-    and light again, lists longer and shorter than the lagged count the launch is sized with)."""
-    N = 384
+    """k_collide takes the envs by falling duration of their last collision pass (batches of more than 1 024 envs: the order is sorted
+    by extra workgroups of the preparation launch, rr_collide.inc); RR_COLLIDE_ORDER=0 keeps env order.  The order only decides
+    which workgroup handles which env and in which order the envs are appended to the heavy lists: states, contacts, classes and
+    images are bitwise the same over 240 full-range steps with resets in between (with rendering; tests/test_gpu_round4.py has the
+    same at 1 531 envs together with the pair cull, without images)."""
+    N = 1160
     a = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
     b = _make(monkeypatch, {'RR_COLLIDE_ORDER': '0'}, N, objects=3, width=64, height=64)
     rng = np.random.default_rng(21)

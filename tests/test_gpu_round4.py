@@ -48,11 +48,11 @@ def _first_difference(a, b):
 
 # Every placement of realrobot.hip's rr_step, by the knob that forces it.  RR_FORCE_HCOUNT pins what the host-side decisions
 # read instead of the lagged counters ("heavy,very heavy"): launch shapes (coop form <= 256, list-walking render <= 768 items,
-# k_collide's h_first) and placements then differ from what the device-side lists actually hold -- which is exactly the
+# the look-ahead's placement) and placements then differ from what the device-side lists actually hold -- which is exactly the
 # situation of a lagged counter, and must not matter.
 PLACEMENTS = [
     ('1: default (look-ahead behind the very heavy envs\' solve, their render behind the heavy envs\')', {}),
-    ('1, empty lists assumed: coop solves, list-walking renders, k_collide in env order', {'RR_FORCE_HCOUNT': '0,0'}),
+    ('1, empty lists assumed: coop solves, list-walking renders', {'RR_FORCE_HCOUNT': '0,0'}),
     ('1 with a long heavy list assumed: packed heavy solve, three-kernel render of the list, very heavy render at the main stream\'s tail',
      {'RR_FORCE_HCOUNT': '2000,10'}),
     ('2: many very heavy envs assumed: packed solves, kinematics + collide on the heavy stream, dynamics on the very heavy one',
