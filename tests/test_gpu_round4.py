@@ -59,7 +59,7 @@ PLACEMENTS = [
      {'RR_FORCE_HCOUNT': '2000,300'}),
     ('3: split off (mostly heavy): one k_solve for all, look-ahead beside the render', {'RR_SPLIT_MAX_PCT': '0', 'RR_FORCE_HCOUNT': '1,0'}),
     ('1 <-> 3: the split switches off mid-run (more than 2 % heavy envs)', {'RR_SPLIT_MAX_PCT': '2'}),
-    ('1 with a separate k_render_setup for the light envs and k_collide in env order', {'RR_NO_FUSED_SETUP': '1', 'RR_COLLIDE_ORDER': '0'}),
+    ('1 with separate k_render_setup launches (no set-up in the solve kernels) and k_collide in env order', {'RR_NO_FUSED_SETUP': '1', 'RR_COLLIDE_ORDER': '0'}),
     ('5: look-ahead without the split', {'RR_NO_SPLIT': '1'}),
     ('5: split without the look-ahead', {'RR_NO_LOOKAHEAD': '1'}),
 ]
