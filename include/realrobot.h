@@ -23,8 +23,9 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 4   /* 3: RR_F_CONTACT_COUNT, RR_F_ENV_CLASS, rr_checkpoint_*, rr_evaluate_goals; 4: rr_map_observations, rr_map_images,
-                              rr_sync_observations, rr_device_microbench; checkpoint blobs carry the step parameters (version 2 header) */
+#define RR_ABI_VERSION 5   /* 3: RR_F_CONTACT_COUNT, RR_F_ENV_CLASS, rr_checkpoint_*, rr_evaluate_goals; 4: rr_map_observations, rr_map_images,
+                              rr_sync_observations, rr_device_microbench; checkpoint blobs carry the step parameters (version 2 header);
+                              5: rr_select_image_mirror */
 
 enum {
     RR_OK = 0,
@@ -162,6 +163,11 @@ int rr_map_observations(rr_env *env, void **host_ptr, size_t *bytes);
  * RR_F_RGB / RR_F_DEPTH / RR_F_MASK (pass NULL for what is not wanted), refreshed by asynchronous copies behind every rr_step that
  * renders and every rr_render; valid to read after rr_sync.  At most 256 MiB per step in total. */
 int rr_map_images(rr_env *env, void **rgb_host, void **depth_host, void **mask_host);
+/* Which of the mapped image blocks a rendered step refreshes: a mask of 1 (RGB), 2 (depth), 4 (mask); default 7.  A caller that
+ * asked for the mask once (get_observation_extended, env.py:291-312) and then goes back to plain observations (env.py:266-289)
+ * deselects it instead of paying its copy after every step; a field selected again is brought up to date at once (valid after
+ * rr_sync_observations).  The blocks stay mapped either way. */
+int rr_select_image_mirror(rr_env *env, int32_t fields);
 /* Waits until the mapped blocks (rr_map_observations / rr_map_images) hold the observations of the last step -- not for the rest of
  * the stream: with a handful of envs the state part of the NEXT step is queued behind the mirror and runs while the
  * caller computes its next action.  Without a mapping it is rr_sync. */

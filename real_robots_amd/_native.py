@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('RR_LIB', os.path.join(_HERE, 'csrc', 'librealrobot_hi
 BLOB_GZ = os.path.join(_HERE, 'data', 'realrobot_model.bin.gz')
 LINK_NAMES = open(os.path.join(_HERE, 'data', 'realrobot_model_links.txt')).read().split()
 
-RR_ABI_VERSION = 4
+RR_ABI_VERSION = 5
 (F_JOINTS, F_TOUCH, F_OBJ_POSE, F_RGB, F_DEPTH, F_MASK, F_TIMESTEP, F_ERRFLAGS, F_STATE, F_FRAG_COUNT, F_CONTACT_COUNT,
  F_ENV_CLASS) = range(12)
 NUM_KERNELS = 9
@@ -29,7 +29,7 @@ SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_objec
            'rr_get_buffer', 'rr_copy_to_host', 'rr_set_state', 'rr_sync', 'rr_link_poses', 'rr_get_contacts',
            'rr_set_timing', 'rr_get_timing', 'rr_last_error', 'rr_abi_version', 'rr_ik', 'rr_plan_macro', 'rr_get_plan',
            'rr_step_plan', 'rr_set_camera', 'rr_set_object_poses', 'rr_step_plan_masked', 'rr_checkpoint_bytes',
-           'rr_checkpoint_save', 'rr_checkpoint_restore', 'rr_evaluate_goals', 'rr_device_microbench', 'rr_map_observations', 'rr_map_images', 'rr_sync_observations')
+           'rr_checkpoint_save', 'rr_checkpoint_restore', 'rr_evaluate_goals', 'rr_device_microbench', 'rr_map_observations', 'rr_map_images', 'rr_sync_observations', 'rr_select_image_mirror')
 
 
 class Config(C.Structure):
@@ -102,6 +102,7 @@ def load_library():
     L.rr_map_observations.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.rr_sync_observations.argtypes = [vp]
     L.rr_map_images.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.rr_select_image_mirror.argtypes = [vp, C.c_int32]
     L.rr_checkpoint_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.rr_checkpoint_save.argtypes = [vp, vp, C.c_size_t]
     L.rr_checkpoint_restore.argtypes = [vp, vp, C.c_size_t]

@@ -56,6 +56,11 @@ class BatchedREALRobotEnv:
             setattr(self, key, (rgb, dep, msk))
         return getattr(self, key)
 
+    def select_image_mirror(self, rgb=True, depth=True, mask=True):
+        """Which mapped image blocks a rendered step refreshes (rr_select_image_mirror); a block selected again is brought up to
+        date at once (valid after `sync_observations()`)."""
+        nat.check(self.L.rr_select_image_mirror(self.h, (1 if rgb else 0) | (2 if depth else 0) | (4 if mask else 0)))
+
     def close(self):
         self._mirror = self._img_mirror = self._img_mirror_m = None      # (views into memory the library frees)
         if getattr(self, 'h', None):

@@ -28,6 +28,7 @@
 // (env.py:340, 536-567); the algorithm and its constants are specified in DESIGN.md and checked against
 // oracle/rr_oracle.c by tests/ (never linked here).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>

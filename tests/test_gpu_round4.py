@@ -60,6 +60,7 @@ PLACEMENTS = [
     ('3: split off (mostly heavy): one k_solve for all, look-ahead beside the render', {'RR_SPLIT_MAX_PCT': '0', 'RR_FORCE_HCOUNT': '1,0'}),
     ('1 <-> 3: the split switches off mid-run (more than 2 % heavy envs)', {'RR_SPLIT_MAX_PCT': '2'}),
     ('1 with separate k_render_setup launches (no set-up in the solve kernels) and k_collide in env order', {'RR_NO_FUSED_SETUP': '1', 'RR_COLLIDE_ORDER': '0'}),
+    ("1' with the streams' events recorded by markers instead of completing with their launches", {'RR_FORCE_HCOUNT': '40,3', 'RR_NO_EXT_EVENTS': '1'}),
     ('5: look-ahead without the split', {'RR_NO_SPLIT': '1'}),
     ('5: split without the look-ahead', {'RR_NO_LOOKAHEAD': '1'}),
 ]
@@ -323,6 +324,47 @@ def test_host_mirrors_follow_every_step():
                 assert np.array_equal(img[0], env.host(nat.F_RGB)) and np.array_equal(img[1], env.host(nat.F_DEPTH)), (N, t)
                 assert np.array_equal(img[2], env.host(nat.F_MASK)), (N, t)
         env.close()
+
+
+def test_deselected_image_mirror_is_not_refreshed_and_comes_back_up_to_date():
+    """rr_select_image_mirror (once the mask was mapped every rendered step paid its copy): a deselected block keeps
+    its last contents over rendered steps while the selected ones follow; selected again it holds the device buffer at once; and the
+    gym facade deselects the mask on a plain observation and gets a correct one on the next extended observation."""
+    env = BatchedREALRobotEnv(2, objects=3, width=96, height=64)
+    rgb, dep, msk = env.map_images(mask=True)
+    act = lambda t: synthetic_actions(range(2), t, seed=5).astype(np.float32)
+    for t in range(30):
+        env.step(act(t), render=True)
+    env.sync_observations()
+    assert np.array_equal(msk, env.host(nat.F_MASK))
+    old_mask = msk.copy()
+    env.select_image_mirror(mask=False)
+    for t in range(30, 110):
+        env.step(act(t), render=True)
+    env.sync_observations()
+    assert np.array_equal(rgb, env.host(nat.F_RGB)) and np.array_equal(dep, env.host(nat.F_DEPTH))
+    assert np.array_equal(msk, old_mask) and not np.array_equal(old_mask, env.host(nat.F_MASK))      # the arm has moved; the block has not
+    env.select_image_mirror()
+    env.sync_observations()
+    assert np.array_equal(msk, env.host(nat.F_MASK))
+    with pytest.raises(Exception):
+        nat.check(env.L.rr_select_image_mirror(env.h, 8))
+    env.close()
+    import real_robots_amd as rr
+    e = rr.make('REALRobot2020-R2J3-v0', eye_width=64, eye_height=64)
+    e.reset()
+    a = {'joint_command': np.array([0.3, 0.5, 0, -1.0, 0, 0.5, 0, 0.5, 0.5]), 'render': True}
+    for _ in range(20):
+        obs, _, _, _ = e.step(a)
+    ext = e.get_observation_extended(_rendered=True)
+    for _ in range(20):
+        obs, _, _, _ = e.step(a)                       # plain observations: the mask block is deselected
+    assert getattr(e._backend(), '_mask_mirrored', True) is False
+    ext2 = e.get_observation_extended(_rendered=True)
+    be = e._backend()
+    assert np.array_equal(ext2['mask'], be.host(nat.F_MASK)[0]) and np.array_equal(ext2['retina'], be.host(nat.F_RGB)[0])
+    assert not np.array_equal(ext2['mask'], ext['mask'])
+    e.close()
 
 
 def test_single_env_chain_is_bitwise_the_batched_step():
