@@ -23,9 +23,11 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 5   /* 3: RR_F_CONTACT_COUNT, RR_F_ENV_CLASS, rr_checkpoint_*, rr_evaluate_goals; 4: rr_map_observations, rr_map_images,
+#define RR_ABI_VERSION 6   /* 3: RR_F_CONTACT_COUNT, RR_F_ENV_CLASS, rr_checkpoint_*, rr_evaluate_goals; 4: rr_map_observations, rr_map_images,
                               rr_sync_observations, rr_device_microbench; checkpoint blobs carry the step parameters (version 2 header);
-                              5: rr_select_image_mirror */
+                              5: rr_select_image_mirror; 6: rr_config carries the motor / solver constants the reference leaves to
+                              pybullet's defaults (motor_kp .. solver_flags, in the place of reserved[7]: same struct size); checkpoint
+                              header version 3 carries them too */
 
 enum {
     RR_OK = 0,
@@ -79,8 +81,21 @@ typedef struct rr_config {
     float margin;           /* <=0 -> 0.02 */
     int32_t use_urdf_inertia; /* 0: Bullet AABB inertia for robot links (default); 1: URDF <inertia> */
     int32_t flags;          /* RR_FLAG_* */
-    int32_t reserved[7];
+    /* The constants below are NOT in the reference tree: robot.py:196-201 calls Joint.set_position -> setJointMotorControl2(
+     * POSITION_CONTROL, targetPosition) and leaves positionGain / velocityGain / force to pybullet's defaults, env.py:202-204 leaves
+     * the solver to Bullet's (unverifiable here).  They are parameters of the handle, reach every
+     * kernel as scalar arguments and are part of a checkpoint's header; 0 selects the documented default, a NEGATIVE value a
+     * literal zero (gain off / cold start / no damping).  The reference's own tracking script (tests/test_actions.py:62-71,
+     * 147-152) is met at every check point by motor_kp >= 0.5 and not by 0.1 (tests/golden/macro_sensitivity.json). */
+    float motor_kp;         /* 0 -> 0.1      positionGain: v_target = kp (target - q) / dt + (1 - kd) qd */
+    float motor_kd;         /* 0 -> 1.0      velocityGain */
+    float motor_max_force;  /* 0 -> 100000   |motor impulse| <= force dt */
+    float warmstart;        /* 0 -> 0.85     Bullet's m_warmstartingFactor on the matched normal impulses; < 0: cold start every step */
+    float lin_damping;      /* 0 -> 0.04     btMultiBody base damping of the free objects; < 0: none */
+    float ang_damping;      /* 0 -> 0.04 */
+    int32_t solver_flags;   /* RR_SOLVER_* */
 } rr_config;
+#define RR_SOLVER_NO_RATE_LIMIT 1   /* limitActionByJoint (env.py:314-321) is skipped: the clipped command itself is the motor target */
 
 typedef struct rr_env rr_env;
 

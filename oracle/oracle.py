@@ -74,6 +74,20 @@ def _lib(f32=False):
     return _libs[f32]
 
 
+def params_from_solver(solver):
+    """Oracle keyword arguments for a `solver=` dict of the product (real_robots_amd._native.SOLVER_DEFAULTS keys): the same
+    constants under the oracle's names (rr_oracle.h rro_params)."""
+    out = {}
+    for k, v in (solver or {}).items():
+        if k == 'rate_limit':
+            out['no_rate_limit'] = 0 if v else 1
+        elif k in ('lin_damping', 'ang_damping', 'erp', 'warmstart', 'motor_kp', 'motor_kd', 'motor_max_force'):
+            out[k] = float(v)
+        else:
+            raise KeyError(k)
+    return out
+
+
 LINK_NAMES = open(os.path.join(_HERE, '..', 'real_robots_amd', 'data', 'realrobot_model_links.txt')).read().split()
 
 

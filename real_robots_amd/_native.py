@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('RR_LIB', os.path.join(_HERE, 'csrc', 'librealrobot_hi
 BLOB_GZ = os.path.join(_HERE, 'data', 'realrobot_model.bin.gz')
 LINK_NAMES = open(os.path.join(_HERE, 'data', 'realrobot_model_links.txt')).read().split()
 
-RR_ABI_VERSION = 5
+RR_ABI_VERSION = 6
 (F_JOINTS, F_TOUCH, F_OBJ_POSE, F_RGB, F_DEPTH, F_MASK, F_TIMESTEP, F_ERRFLAGS, F_STATE, F_FRAG_COUNT, F_CONTACT_COUNT,
  F_ENV_CLASS) = range(12)
 NUM_KERNELS = 9
@@ -36,10 +36,34 @@ class Config(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('num_envs', C.c_int32), ('n_objects', C.c_int32),
                 ('width', C.c_int32), ('height', C.c_int32), ('device', C.c_int32), ('solver_iters', C.c_int32),
                 ('envs_per_block', C.c_int32), ('dt', C.c_float), ('erp', C.c_float), ('margin', C.c_float),
-                ('use_urdf_inertia', C.c_int32), ('flags', C.c_int32), ('reserved', C.c_int32 * 7)]
+                ('use_urdf_inertia', C.c_int32), ('flags', C.c_int32),
+                # the constants the reference leaves to pybullet's defaults (include/realrobot.h: 0 -> default, < 0 -> literal zero)
+                ('motor_kp', C.c_float), ('motor_kd', C.c_float), ('motor_max_force', C.c_float), ('warmstart', C.c_float),
+                ('lin_damping', C.c_float), ('ang_damping', C.c_float), ('solver_flags', C.c_int32)]
 
 
 FLAG_NO_MASK = 1
+SOLVER_NO_RATE_LIMIT = 1
+# `solver=` of BatchedREALRobotEnv / make(): name -> documented default (UPSTREAM, unverifiable here)
+SOLVER_DEFAULTS = {'motor_kp': 0.1, 'motor_kd': 1.0, 'motor_max_force': 100000.0, 'warmstart': 0.85, 'lin_damping': 0.04,
+                   'ang_damping': 0.04, 'erp': 0.2, 'rate_limit': True}
+
+
+def apply_solver(cfg, solver):
+    """Writes a `solver` dict (keys of SOLVER_DEFAULTS; None / missing: the default) into an rr_config.  A value of exactly 0 is
+    passed as the header's "literal zero" (a negative number); unknown keys and non-finite values raise ValueError."""
+    for k, v in (solver or {}).items():
+        if k not in SOLVER_DEFAULTS:
+            raise ValueError("unknown solver parameter %r (known: %s)" % (k, ', '.join(sorted(SOLVER_DEFAULTS))))
+        if k == 'rate_limit':
+            cfg.solver_flags = (cfg.solver_flags & ~SOLVER_NO_RATE_LIMIT) | (0 if v else SOLVER_NO_RATE_LIMIT)
+            continue
+        v = float(v)
+        if not np.isfinite(v) or v < 0:
+            raise ValueError("solver parameter %s must be finite and >= 0" % k)
+        if k == 'erp' and v == 0:
+            raise ValueError("solver parameter erp must be > 0")
+        setattr(cfg, k, v if v > 0 else -1.0)
 
 
 _lib = None

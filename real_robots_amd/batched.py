@@ -15,7 +15,10 @@ OBJECT_NAMES = ['cube', 'tomato', 'mustard']       # robot.py:49-50 (after "tabl
 
 class BatchedREALRobotEnv:
     def __init__(self, num_envs, objects=3, width=320, height=240, device=0, solver_iters=50, envs_per_block=0,
-                 stream=None, use_urdf_inertia=False, dt=0.0, erp=0.0, margin=0.0, want_mask=True):
+                 stream=None, use_urdf_inertia=False, dt=0.0, erp=0.0, margin=0.0, want_mask=True, solver=None):
+        """solver: dict overriding the constants the reference leaves to pybullet's defaults (keys of `_native.SOLVER_DEFAULTS`:
+        motor_kp 0.1, motor_kd 1.0, motor_max_force 100000, warmstart 0.85, lin_damping / ang_damping 0.04, erp 0.2, rate_limit
+        True -- robot.py:196-201, env.py:202-204, 314-321)."""
         self.L = nat.load_library()
         cfg = nat.Config()
         cfg.abi_version = nat.RR_ABI_VERSION
@@ -23,6 +26,8 @@ class BatchedREALRobotEnv:
         cfg.device, cfg.solver_iters, cfg.envs_per_block = int(device), int(solver_iters), int(envs_per_block)
         cfg.dt, cfg.erp, cfg.margin, cfg.use_urdf_inertia = dt, erp, margin, int(bool(use_urdf_inertia))
         cfg.flags = 0 if want_mask else nat.FLAG_NO_MASK
+        nat.apply_solver(cfg, solver)
+        self.solver = dict(nat.SOLVER_DEFAULTS, **({'erp': erp} if erp > 0 else {}), **(solver or {}))
         blob = nat.model_blob()
         h = C.c_void_p()
         self.h = None

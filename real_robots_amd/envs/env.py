@@ -136,8 +136,11 @@ class REALRobotEnv:
     extrinsic_trials = int(50)
 
     def __init__(self, render=False, objects=3, action_type='joints', additional_obs=True, eye_width=320,
-                 eye_height=240, device=0, solver_iters=50):
+                 eye_height=240, device=0, solver_iters=50, solver=None):
+        # solver: the constants the reference leaves to pybullet's defaults (robot.py:196-201 positionGain / velocityGain / force,
+        # env.py:202-204; keys of real_robots_amd._native.SOLVER_DEFAULTS), e.g. make(id, solver={'motor_kp': 0.5})
         self.robot = Kuka(additional_obs, objects, eye_width, eye_height, env=self)
+        self._solver = dict(solver) if solver else None
         self.isRender = render
         self._n_objects, self._device, self._solver_iters = objects, device, solver_iters
         self._additional_obs = additional_obs
@@ -237,7 +240,7 @@ class REALRobotEnv:
         if self._be is None:
             self._be = BatchedREALRobotEnv(1, objects=self._n_objects, width=self.robot.eye_width,
                                            height=self.robot.eye_height, device=self._device,
-                                           solver_iters=self._solver_iters)
+                                           solver_iters=self._solver_iters, solver=self._solver)
         return self._be
 
     def _sync_object_homes(self):

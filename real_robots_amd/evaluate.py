@@ -1,9 +1,9 @@
 """Local evaluation harness: intrinsic phase then N extrinsic trials with goal scoring
 (mirror of real_robots/evaluate.py:16-446; same argument checks, callbacks, score object).
 
-The AIcrowd event sink and the video maker of the reference are out of scope: the
-evaluation-state dictionary keeps the reference schema (evaluate.py:100-121) and is handed to an optional
-`state_sink` callable instead of aicrowd_api.
+The AIcrowd event sink of the reference is out of scope: the evaluation-state dictionary keeps
+the reference schema (evaluate.py:100-121) and is handed to an optional `state_sink` callable instead of aicrowd_api.
+`video=(intrinsic, extrinsic, debug)` makes videos like the reference's (evaluate.py:69-71 -> real_robots_amd/videomaker.py).
 """
 import numpy as np
 
@@ -22,8 +22,11 @@ class EvaluationService:
         self.visualize = visualize          # accepted for compatibility; there is no GUI (headless)
         self.goals_dataset_path = goals_dataset_path
         self.state_sink = state_sink
-        self.video = None
+        self.video = video
         self.setup_gym_env(environment, action_type, n_objects, env_kwargs or {})
+        if self.video:                      # evaluate.py:69-71
+            from .videomaker import VideoMaker
+            self.videomaker = VideoMaker(self.env, *self.video)
         self.setup_controller()
         self.setup_evaluation_state()
         self.scores = {}
@@ -83,12 +86,18 @@ class EvaluationService:
             self.sync_evaluation_state()
             steps = 0
             self.controller.start_intrinsic_phase()
+            if self.video:
+                self.videomaker.start_intrinsic()
             while not done:
                 action = self.controller.step(observation, reward, done)
                 observation, reward, done, _ = self.env.step(action)
                 steps += 1
                 self.evaluation_state["current_intrinsic_timestep"] = steps
                 self.sync_evaluation_state()
+                if self.video:
+                    self.videomaker.update_intrinsic(steps)
+            if self.video:
+                self.videomaker.end_intrinsic()
             self.evaluation_state["intrinsic_phase_state"] = "INTRINSIC_PHASE_COMPLETE"
             self.evaluation_state["state"] = "INTRINSIC_PHASE_COMPLETE"
             self.sync_evaluation_state()
@@ -104,12 +113,18 @@ class EvaluationService:
         observation = self.env.set_goal()
         self.controller.start_extrinsic_trial()
         steps = 0
+        if self.video:
+            self.videomaker.start_trial(observation, trial_number)
         while not done:
             action = self.controller.step(observation, reward, done)
             observation, reward, done, _ = self.env.step(action)
             steps += 1
             self.evaluation_state["progress_in_current_extrinsic_trial"] = float(steps) / self.extrinsic_timesteps
             self.sync_evaluation_state()
+            if self.video:
+                self.videomaker.extrinsic_trial(observation, action, steps, self.evaluation_state["evaluation_score"])
+        if self.video:
+            self.videomaker.end_trial()
         self.add_scores(*self.env.evaluateGoal())
         self.evaluation_state["num_extrinsic_trials_complete"] = trial_number + 1
         self.sync_evaluation_state()

@@ -39,7 +39,7 @@ def _batch_dict_space(space, n):
 
 class REALRobotVectorEnv(_Base):
     def __init__(self, num_envs, objects=3, additional_obs=False, eye_width=320, eye_height=240, device=0,
-                 max_episode_steps=int(15e6), render_every_step=True, device_obs=False):
+                 max_episode_steps=int(15e6), render_every_step=True, device_obs=False, solver=None):
         self.num_envs = int(num_envs)
         self._robot = Kuka(additional_obs, objects, eye_width, eye_height, env=None)
         self.single_action_space = spaces.Dict({"joint_command": self._robot.action_space, "render": spaces.MultiBinary(1)})
@@ -54,7 +54,7 @@ class REALRobotVectorEnv(_Base):
         self.max_episode_steps = int(max_episode_steps)
         self.render_every_step, self.device_obs, self.additional_obs = bool(render_every_step), bool(device_obs), bool(additional_obs)
         self._be = BatchedREALRobotEnv(self.num_envs, objects=objects, width=eye_width, height=eye_height, device=device,
-                                       want_mask=additional_obs)
+                                       want_mask=additional_obs, solver=solver)
         # host-side episode clocks (no device read-back per step): the batched env behind this adapter is private to it, every
         # path that resets an env goes through reset() / step() below and resets its clock with it
         self._steps = np.zeros(self.num_envs, np.int64)

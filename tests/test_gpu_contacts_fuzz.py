@@ -90,7 +90,9 @@ def _lists_identical(c_dev, c_orc):
     return bool((c_dev[:, keep] == c_orc[:, keep].astype(np.float32)).all())
 
 
-def _fuzz_case(case, seed0, stats, bad):
+def _fuzz_case(case, seed0, stats, bad, solver=None):
+    """solver: the product's `solver=` dict (None: documented defaults); the oracle gets the same constants."""
+    from oracle.oracle import params_from_solver
     rng = np.random.default_rng(seed0 * 1000 + case)
     N = int(rng.choice([1, 3, 5, 17, 34, 63, 130]))
     nobj = int(rng.integers(1, 4))
@@ -99,10 +101,10 @@ def _fuzz_case(case, seed0, stats, bad):
     if pool:
         os.environ['RR_SOLVER_POOL'] = str(pool)
     try:
-        env = BatchedREALRobotEnv(N, objects=nobj, width=W, height=H)
+        env = BatchedREALRobotEnv(N, objects=nobj, width=W, height=H, solver=solver)
     finally:
         os.environ.pop('RR_SOLVER_POOL', None)
-    o = Oracle(nobj, W, H, f32=True)
+    o = Oracle(nobj, W, H, f32=True, **params_from_solver(solver))
     macro = rng.random() < 0.6
     plans = None
     if macro:

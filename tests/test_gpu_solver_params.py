@@ -1,0 +1,241 @@
+"""GPU tests (-m gpu) of the UPSTREAM constants as run-time parameters of the device (ABI 6: rr_config.motor_kp .. solver_flags).
+
+The reference leaves the position motors' gains and force, the solver's warm start and ERP and the free bodies' damping to
+pybullet's defaults (robot.py:196-201 -> Joint.set_position -> setJointMotorControl2; env.py:202-204), which
+cannot be read here: pybullet is absent.  The only dynamic known answers the reference holds -- its macro tracking script,
+tests/test_actions.py:62-71,101-117,147-152 -- are met at every check point by kp >= 0.5 and not by the documented 0.1
+(tests/golden/macro_sensitivity.json, made on the float64 oracle).  These tests run the device at both, and the differential
+suites at a second parameter set, so that a first PyBullet recording selects constants instead of forcing a kernel rebuild."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle.kinematics import generate_plan
+from oracle.oracle import Oracle, params_from_solver
+from real_robots_amd import _native as nat
+from real_robots_amd.batched import BatchedREALRobotEnv
+from real_robots_amd.distributed import synthetic_actions
+
+pytestmark = pytest.mark.gpu
+
+# every constant moved away from its default at once (motor force 300 N m = the URDF's <limit effort>, kuka_gripper.urdf)
+SECOND = {'motor_kp': 0.5, 'motor_kd': 0.8, 'motor_max_force': 300.0, 'warmstart': 0.5, 'lin_damping': 0.0,
+          'ang_damping': 0.1, 'erp': 0.4, 'rate_limit': False}
+CHECK_T = (199, 249, 749, 849, 999)
+HOME = np.array([-0.55, 0.0, 1.27])
+HOME2 = np.array([-0.419, 0.0, 1.14])
+
+
+def _script_on_device(pairs, plans, solver):
+    """The reference's script for all pairs at once, one env per pair (objects parked on the shelf, test_actions.py:95-98),
+    following the float64 checker's plans row by row: distances of the gripper base from the five check points [36, 5]."""
+    N = len(pairs)
+    env = BatchedREALRobotEnv(N, objects=3, width=64, height=64, solver=solver)
+    for i in range(N):
+        for o, y in enumerate((0.0, -0.3, 0.3)):
+            env.set_object_pose(i, o, [0.2, y, 0.75, 0, 0, 0, 1])
+    base = nat.LINK_NAMES.index('base')
+    out = np.zeros((N, len(CHECK_T)))
+    for t in range(1000):
+        env.step(np.stack([plans[i][t] for i in range(N)]).astype(np.float32))
+        if t in CHECK_T:
+            lp = env.link_poses()[:, base, :3].astype(np.float64)
+            for i, (p1, p2) in enumerate(pairs):
+                tg = {199: [p1[0], p1[1], 0.6], 249: [p1[0], p1[1], 0.46], 749: [p2[0], p2[1], 0.46], 849: HOME2, 999: HOME}[t]
+                out[i, CHECK_T.index(t)] = np.linalg.norm(lp[i] - np.asarray(tg))
+    assert (env.host(nat.F_ERRFLAGS) == 0).all() and (env.host(nat.F_TIMESTEP) == 1000).all()
+    env.close()
+    return out
+
+
+def test_reference_macro_script_on_the_device_at_kp_01_and_05():
+    """The 36-pair script (tests/test_actions.py:62-71,101-117,147-152) on the HIP path under four motor models: kp 0.1 (the
+    documented pybullet default) and kp 0.5, each with limitActionByJoint (env.py:314-321) before the motor and without.  The
+    device (float32) reproduces the float64 oracle's distance tables of tests/golden/macro_sensitivity.json to 1e-4 m at all
+    five check points, and with them the fixture's verdict: under kp 0.1 NO pair is within the script's 1 cm at t = 849, under
+    kp 0.5 all 36 are."""
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'macro_sensitivity.json')))
+    pairs = [tuple(map(tuple, p)) for p in fx['pairs']]
+    assert len(pairs) == 36 and fx['check_steps'] == list(CHECK_T)
+    plans = [generate_plan(np.zeros(11), p) for p in pairs]
+    TOL = 1e-4
+    for kp in (0.1, 0.5):
+        for rl in (True, False):
+            key = "kp=%g,rate_limit=%s" % (kp, "on" if rl else "off")
+            want = np.array(fx['distance_m'][key])
+            got = _script_on_device(pairs, plans, {'motor_kp': kp, 'rate_limit': rl})
+            worst = np.abs(got - want).max()
+            print("%s: device vs fixture, worst %.2e m; pairs within 1 cm per check point %s (fixture %s)"
+                  % (key, worst, (got < 0.01).sum(0).tolist(), fx['pairs_within_tolerance'][key]))
+            assert worst < TOL, (key, worst, np.unravel_index(np.abs(got - want).argmax(), got.shape))
+            # the verdict of the fixture, wherever it is not within TOL of the threshold itself
+            clear = np.abs(want - 0.01) > 2 * TOL
+            assert ((got < 0.01) == (want < 0.01))[clear].all(), key
+    # what the tables say (fixture = device): t = 849 is met by NO pair under kp 0.1 + rate limit and by all 36 under kp 0.5; the
+    # 12 pairs short at t = 199 under every motor model start at the corners (0.05, +-0.5), where the plan's way point at z = 0.6
+    # has no exact IK solution (tests/test_oracle_pins.py), the one short at t = 749 is the script's longest sweep
+    w01 = np.array(fx['pairs_within_tolerance']['kp=0.1,rate_limit=on'])
+    w05 = np.array(fx['pairs_within_tolerance']['kp=0.5,rate_limit=on'])
+    assert w01.tolist() == [18, 36, 35, 0, 36] and w05.tolist() == [24, 36, 35, 36, 36]
+
+
+def test_explicit_defaults_are_the_defaults_bit_for_bit():
+    """solver=None, solver={every key at its documented default} and the zero-filled rr_config fields are one and the same run."""
+    N = 64
+    a = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    b = BatchedREALRobotEnv(N, objects=3, width=64, height=64, solver=dict(nat.SOLVER_DEFAULTS))
+    assert a.solver == b.solver == nat.SOLVER_DEFAULTS
+    for t in range(150):
+        cmd = synthetic_actions(range(N), t, seed=3).astype(np.float32)
+        a.step(cmd, render=(t % 50 == 49))
+        b.step(cmd, render=(t % 50 == 49))
+    assert np.array_equal(a.state, b.state) and np.array_equal(a.host(nat.F_RGB), b.host(nat.F_RGB))
+    assert (a.host(nat.F_CONTACT_COUNT) > 0).any()
+    a.close()
+    b.close()
+
+
+def test_every_constant_reaches_the_kernels():
+    """Each key of the solver dict changes the run on its own (none is accepted and then ignored), and each single-key run
+    follows the float64 oracle with the same key to the free-running tolerance of a contact-free stretch (1e-4 over 60 steps:
+    the objects are falling / have just landed, the arm moves)."""
+    N = 4
+    cmd = [synthetic_actions(range(N), t, seed=11).astype(np.float32) for t in range(60)]
+
+    def run(solver):
+        env = BatchedREALRobotEnv(N, objects=3, width=64, height=64, solver=solver)
+        o = Oracle(3, 64, 64, **params_from_solver(solver))
+        st = env.state
+        st[:, 22 + 7:22 + 10] = [0.3, 0.1, 0.0]              # the cube drifts and spins: the damping terms act on something
+        st[:, 22 + 10:22 + 13] = [0.0, 0.0, 2.0]
+        env.state = st
+        o.state = st[0].astype(np.float64)
+        for t in range(60):
+            env.step(cmd[t])
+            o.step(cmd[t][0].astype(np.float64))
+        out = env.state
+        env.close()
+        return out, o.state
+
+    base, base_o = run(None)
+    assert np.abs(base[0] - base_o).max() < 1e-4
+    for key, val in (('motor_kp', 0.3), ('motor_kd', 0.5), ('motor_max_force', 20.0), ('lin_damping', 0.5), ('ang_damping', 0.5),
+                     ('rate_limit', False)):
+        got, want = run({key: val})
+        assert np.abs(got[0] - want).max() < 1e-4, (key, np.abs(got[0] - want).max())
+        assert np.abs(got - base).max() > 1e-3, key
+    # ERP and the warm-start factor act through contacts: objects resting on the table, 150 steps
+    def rest(solver):
+        env = BatchedREALRobotEnv(N, objects=3, width=64, height=64, solver=solver)
+        for t in range(150):
+            env.step(None)
+        out = env.state, np.concatenate([env.contacts(i)[:, 10] for i in range(N)])
+        env.close()
+        return out
+    s0, f0 = rest(None)
+    for key, val in (('erp', 0.8), ('warmstart', 0.0)):
+        s1, f1 = rest({key: val})
+        assert not np.array_equal(s0, s1), key
+        assert np.abs(s1[:, 22 + 2] - s0[:, 22 + 2]).max() < 2e-3, key          # the cube rests at the same height either way
+
+
+def test_solver_dict_validation_and_checkpoint_header():
+    """Unknown keys / negative / non-finite values raise before anything reaches the library; a checkpoint taken under one
+    parameter set is refused by a handle that steps under another (it would silently diverge), accepted by an equal one."""
+    for bad in ({'kp': 0.5}, {'motor_kp': -1.0}, {'motor_kd': float('nan')}, {'erp': 0.0}):
+        with pytest.raises(ValueError):
+            BatchedREALRobotEnv(2, objects=1, width=64, height=64, solver=bad)
+    N = 8
+    a = BatchedREALRobotEnv(N, objects=3, width=64, height=64, solver=SECOND)
+    for t in range(40):
+        a.step(synthetic_actions(range(N), t, seed=1).astype(np.float32))
+    ck = a.checkpoint()
+    for other in (None, dict(SECOND, motor_kp=0.4), dict(SECOND, rate_limit=True), dict(SECOND, ang_damping=0.2)):
+        b = BatchedREALRobotEnv(N, objects=3, width=64, height=64, solver=other)
+        with pytest.raises(nat.NativeError):
+            b.restore(ck)
+        b.close()
+    b = BatchedREALRobotEnv(N, objects=3, width=64, height=64, solver=dict(SECOND))
+    b.restore(ck)
+    for t in range(40, 80):
+        cmd = synthetic_actions(range(N), t, seed=1).astype(np.float32)
+        a.step(cmd)
+        b.step(cmd)
+    assert np.array_equal(a.state, b.state)
+    a.close()
+    b.close()
+
+
+def test_fuzz_differential_at_a_second_parameter_set():
+    """tests/test_gpu_contacts_fuzz.py's seeded differential run (contact lists bit for bit, states within the force-scaled
+    one-step bounds, solver-independent properties, image masks / depths exact) with EVERY constant away from its default."""
+    from tests.test_gpu_contacts_fuzz import CRUSH_FORCE, SENS_FACTOR, _fuzz_case
+    stats = dict(checks=0, contacts=0, crush=0, dj=0.0, do=0.0, dv=0.0, c_dj=0.0, c_do=0.0, c_dv=0.0, ill=0, ill_share=0.0)
+    bad = []
+    n_cases = int(os.environ.get('RR_FUZZ_CASES2', '80'))
+    for case in range(n_cases):
+        _fuzz_case(case, 7, stats, bad, solver=SECOND)
+    print("fuzz at the second parameter set: %d cases, %d one-step checks, %d contacts, %d above %.0f N; worst share of the bound -- joints %.2f "
+          "object pose %.2f object velocity %.2f; %d steps held to %.0f x the oracle's one-ulp spread (worst share %.2f); %d violations"
+          % (n_cases, stats['checks'], stats['contacts'], stats['crush'], CRUSH_FORCE, stats['dj'], stats['do'], stats['dv'], stats['ill'],
+             SENS_FACTOR, stats['ill_share'], len(bad)))
+    for b in bad[:20]:
+        print("   violation:", b)
+    assert not bad, bad[:20]
+    assert stats['checks'] >= 3 * n_cases and stats['contacts'] > 10 * n_cases
+    assert stats['ill'] <= 0.005 * stats['checks'] + 1
+
+
+def test_bench_workload_at_size_at_a_second_parameter_set(monkeypatch):
+    """BASELINE config 3 at size (4096 envs, 3 objects, 128x128 RGB + depth every step, bench.make_commands, split + look-ahead
+    active) for 220 steps under SECOND: every 50 steps the 8 envs with the most contacts and 8 random ones against the float
+    oracle with the same constants -- contact lists bit for bit, states within the one-step bounds, depths exact."""
+    import importlib.util
+    import torch
+    from tests.test_gpu_contacts_fuzz import _lists_identical, state_bounds
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    N, T = bench.ENVS_PER_GPU, 220
+    cmds = bench.make_commands(torch, np, np.arange(N), T, 1.0, 'cuda:0')
+    env = BatchedREALRobotEnv(N, objects=3, width=128, height=128, want_mask=False, solver=SECOND)
+    o = Oracle(3, 128, 128, f32=True, **params_from_solver(SECOND))
+    checks = with_contacts = 0
+    for t in range(T):
+        chk = t % 50 == 49
+        if chk:
+            torch.cuda.synchronize()
+            st0 = env.state
+            nc = env.host(nat.F_CONTACT_COUNT)
+            heavy8 = np.argsort(-nc, kind='stable')[:8]
+            rnd8 = np.random.default_rng(2000 + t).choice(np.setdiff1d(np.arange(N), heavy8), 8, replace=False)
+            sel = np.concatenate([heavy8, rnd8])
+            cache = {int(i): env.contacts(int(i)) for i in sel}
+        env.step(device_ptr=cmds[t].data_ptr(), render=True)
+        if not chk:
+            continue
+        st1 = env.state
+        dep = env.host(nat.F_DEPTH)
+        cmd_h = cmds[t].cpu().numpy()
+        for i in map(int, sel):
+            o.state = st0[i].astype(np.float64)
+            o.set_contact_cache(cache[i])
+            o.step(cmd_h[i].astype(np.float64))
+            cd, co = env.contacts(i), o.contacts()
+            assert _lists_identical(cd, co), (t, i, len(cd), len(co))
+            fmax = float(cd[:, 10].max()) if len(cd) else 0.0
+            dj = float(np.abs(st1[i][:22] - o.state[:22]).max())
+            dobj = np.abs((st1[i][22:] - o.state[22:]).reshape(3, 13))
+            bj, bo, bv = state_bounds(fmax)
+            assert dj <= bj and dobj[:, :7].max() <= bo and dobj[:, 7:].max() <= bv, (t, i, fmax, dj, dobj[:, :7].max(), dobj[:, 7:].max())
+            o.state = st1[i].astype(np.float64)
+            _, d, _ = o.render()
+            assert np.abs(d - dep[i]).max() <= 1e-5, (t, i)
+            checks += 1
+            with_contacts += int(len(cd) > 0)
+    assert checks == 16 * (T // 50) and with_contacts >= checks // 2
+    assert (env.host(nat.F_ERRFLAGS) == 0).all()
+    env.close()

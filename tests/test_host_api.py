@@ -63,6 +63,12 @@ def test_create_rejects_bad_arguments_and_fails_loudly_without_gpu():
     bad = nat.Config.from_buffer_copy(cfg)
     bad.abi_version = 99
     assert L.rr_create(C.byref(bad), blob, len(blob), None, C.byref(h)) == -1
+    bad = nat.Config.from_buffer_copy(cfg)
+    bad.solver_flags = 2
+    assert L.rr_create(C.byref(bad), blob, len(blob), None, C.byref(h)) == -1 and b'solver_flags' in L.rr_last_error()
+    bad = nat.Config.from_buffer_copy(cfg)
+    bad.motor_kp = float('nan')
+    assert L.rr_create(C.byref(bad), blob, len(blob), None, C.byref(h)) == -1 and b'non-finite' in L.rr_last_error()
     assert L.rr_create(C.byref(cfg), b'garbage' * 10, 70, None, C.byref(h)) == -3     # RR_EMODEL
     import torch
     if not torch.cuda.is_available():
@@ -71,6 +77,24 @@ def test_create_rejects_bad_arguments_and_fails_loudly_without_gpu():
         env = rr.make('REALRobot2020-R2J3-v0')
         with pytest.raises(RuntimeError):
             env.reset()
+
+
+def test_solver_dict_reaches_the_config_struct():
+    """ABI 6: the constants the reference leaves to pybullet's defaults travel in rr_config (same 80 bytes as ABI 5's reserved
+    words); 0 = default, an explicit zero is passed as the header's "literal zero" (negative)."""
+    assert C.sizeof(nat.Config) == 80
+    cfg = nat.Config()
+    nat.apply_solver(cfg, None)
+    assert cfg.motor_kp == 0 and cfg.solver_flags == 0
+    nat.apply_solver(cfg, {'motor_kp': 0.5, 'warmstart': 0.0, 'rate_limit': False, 'erp': 0.3})
+    assert abs(cfg.motor_kp - 0.5) < 1e-7 and cfg.warmstart < 0 and cfg.solver_flags == nat.SOLVER_NO_RATE_LIMIT and abs(cfg.erp - 0.3) < 1e-7
+    nat.apply_solver(cfg, {'rate_limit': True})
+    assert cfg.solver_flags == 0
+    for bad in ({'kp': 1}, {'motor_kd': -0.1}, {'lin_damping': float('inf')}, {'erp': 0}):
+        with pytest.raises(ValueError):
+            nat.apply_solver(nat.Config(), bad)
+    env = rr.make('REALRobot2020-R2J1-v0', solver={'motor_kp': 0.5})
+    assert env._solver == {'motor_kp': 0.5}
 
 
 def test_null_env_calls_return_einval():
