@@ -59,12 +59,22 @@ class BatchedREALRobotEnv:
             dep = np.frombuffer((C.c_float * npx).from_address(pd.value), dtype=np.float32).reshape(self.N, self.H, self.W)
             msk = np.frombuffer((C.c_int32 * npx).from_address(pm.value), dtype=np.int32).reshape(self.N, self.H, self.W) if mask else None
             setattr(self, key, (rgb, dep, msk))
+        # (whoever asks for the views with the mask gets a mask block that is being refreshed: a block deselected by
+        # select_image_mirror is selected again here -- and brought up to date at once by the library -- so that no holder of these
+        # views reads a stale mask without an error)
+        sel = getattr(self, '_img_sel', 7)
+        if mask and not sel & 4:
+            self.select_image_mirror(rgb=bool(sel & 1), depth=bool(sel & 2), mask=True)
         return getattr(self, key)
 
     def select_image_mirror(self, rgb=True, depth=True, mask=True):
         """Which mapped image blocks a rendered step refreshes (rr_select_image_mirror); a block selected again is brought up to
-        date at once (valid after `sync_observations()`)."""
-        nat.check(self.L.rr_select_image_mirror(self.h, (1 if rgb else 0) | (2 if depth else 0) | (4 if mask else 0)))
+        date at once (valid after `sync_observations()`).  The selection is tracked here: `map_images(mask=True)` selects a
+        deselected mask block again."""
+        sel = (1 if rgb else 0) | (2 if depth else 0) | (4 if mask else 0)
+        if sel != getattr(self, '_img_sel', 7):
+            nat.check(self.L.rr_select_image_mirror(self.h, sel))
+            self._img_sel = sel
 
     def close(self):
         self._mirror = self._img_mirror = self._img_mirror_m = None      # (views into memory the library frees)

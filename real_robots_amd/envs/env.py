@@ -342,9 +342,9 @@ class REALRobotEnv:
         rgb, dep, msk = be.map_images(mask=need_mask)
         # (the mask block, once mapped by an extended observation, is refreshed after a step only while extended observations keep
         # being asked for: a plain get_observation deselects it, the next extended one selects it again -- brought up to date at once)
-        if getattr(be, '_img_mirror_m', None) is not None and need_mask != getattr(be, '_mask_mirrored', True):
-            be.select_image_mirror(mask=need_mask)
-            be._mask_mirrored = need_mask
+        # (the backend tracks the selection: map_images(mask=True) above has selected the block again if it was deselected)
+        if not need_mask and getattr(be, '_img_mirror_m', None) is not None:
+            be.select_image_mirror(mask=False)
         be.sync_observations()
         return rgb[0].copy(), (msk[0].copy() if need_mask else None), dep[0].astype(np.float64)
 

@@ -20,9 +20,15 @@ from real_robots_amd.distributed import synthetic_actions
 
 pytestmark = pytest.mark.gpu
 
-# every constant moved away from its default at once (motor force 300 N m = the URDF's <limit effort>, kuka_gripper.urdf)
+# Every numeric constant moved away from its default at once (motor force 300 N m = the URDF's <limit effort>, kuka_gripper.urdf).
+# The rate limit stays ON in this set: kp 0.5 WITHOUT limitActionByJoint under full-range random commands asks the motors for
+# 100 x the command error in rad/s (hundreds of rad/s, 2.5 rad per step) and the explicit integration of the velocity-product
+# terms diverges within ~130 steps -- in the float64 oracle just as on the device (Bullet clamps joint velocities at
+# m_maxCoordinateVelocity = 100, an UPSTREAM detail this restatement does not carry).  The switch itself is covered at the
+# default gain (THIRD), on the reference's own smooth plans at kp 0.5 (the macro script below) and key by key.
 SECOND = {'motor_kp': 0.5, 'motor_kd': 0.8, 'motor_max_force': 300.0, 'warmstart': 0.5, 'lin_damping': 0.0,
-          'ang_damping': 0.1, 'erp': 0.4, 'rate_limit': False}
+          'ang_damping': 0.1, 'erp': 0.4, 'rate_limit': True}
+THIRD = {'rate_limit': False}
 CHECK_T = (199, 249, 749, 849, 999)
 HOME = np.array([-0.55, 0.0, 1.27])
 HOME2 = np.array([-0.419, 0.0, 1.14])
@@ -152,7 +158,7 @@ def test_solver_dict_validation_and_checkpoint_header():
     for t in range(40):
         a.step(synthetic_actions(range(N), t, seed=1).astype(np.float32))
     ck = a.checkpoint()
-    for other in (None, dict(SECOND, motor_kp=0.4), dict(SECOND, rate_limit=True), dict(SECOND, ang_damping=0.2)):
+    for other in (None, dict(SECOND, motor_kp=0.4), dict(SECOND, rate_limit=False), dict(SECOND, ang_damping=0.2)):
         b = BatchedREALRobotEnv(N, objects=3, width=64, height=64, solver=other)
         with pytest.raises(nat.NativeError):
             b.restore(ck)
@@ -163,20 +169,20 @@ def test_solver_dict_validation_and_checkpoint_header():
         cmd = synthetic_actions(range(N), t, seed=1).astype(np.float32)
         a.step(cmd)
         b.step(cmd)
-    assert np.array_equal(a.state, b.state)
+    assert np.array_equal(a.state, b.state) and np.isfinite(a.state).all() and (a.host(nat.F_ERRFLAGS) == 0).all()
     a.close()
     b.close()
 
 
 def test_fuzz_differential_at_a_second_parameter_set():
     """tests/test_gpu_contacts_fuzz.py's seeded differential run (contact lists bit for bit, states within the force-scaled
-    one-step bounds, solver-independent properties, image masks / depths exact) with EVERY constant away from its default."""
+    one-step bounds, solver-independent properties, image masks / depths exact) with EVERY numeric constant away from its default (SECOND), every fourth case without the rate limit instead (THIRD)."""
     from tests.test_gpu_contacts_fuzz import CRUSH_FORCE, SENS_FACTOR, _fuzz_case
     stats = dict(checks=0, contacts=0, crush=0, dj=0.0, do=0.0, dv=0.0, c_dj=0.0, c_do=0.0, c_dv=0.0, ill=0, ill_share=0.0)
     bad = []
     n_cases = int(os.environ.get('RR_FUZZ_CASES2', '80'))
     for case in range(n_cases):
-        _fuzz_case(case, 7, stats, bad, solver=SECOND)
+        _fuzz_case(case, 7, stats, bad, solver=SECOND if case % 4 else THIRD)     # (every fourth case: no rate limit, default gains)
     print("fuzz at the second parameter set: %d cases, %d one-step checks, %d contacts, %d above %.0f N; worst share of the bound -- joints %.2f "
           "object pose %.2f object velocity %.2f; %d steps held to %.0f x the oracle's one-ulp spread (worst share %.2f); %d violations"
           % (n_cases, stats['checks'], stats['contacts'], stats['crush'], CRUSH_FORCE, stats['dj'], stats['do'], stats['dv'], stats['ill'],
