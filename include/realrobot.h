@@ -61,7 +61,11 @@ enum {
     RR_F_ENV_CLASS = 11,     /* i32 [N]      diagnostic: 0 light, 1 heavy, 2 very heavy -- which launch solved / rendered the env in the last
                                              step.  Both fields live in fixed buffers written by the solve kernels: a pointer
                                              from rr_get_buffer stays valid over steps like every other field's */
-    RR_F_COUNT = 12
+    RR_F_PREP = 12,          /* f32 [N, 378]  diagnostic: the preparation's record of every env, as the last preparation launch left it -- frames of the
+                                             eleven bodies (R 99, position 33, joint axis 33), M^-1 (121), unconstrained joint velocities (11), the objects'
+                                             rotation / world inverse inertia / unconstrained velocities / collision position (27 + 27 + 9 + 9 + 9); after a
+                                             step with the look-ahead it describes the state the step LEFT (tests compare the kernel's forms through it) */
+    RR_F_COUNT = 13
 };
 
 /* rr_config.flags */

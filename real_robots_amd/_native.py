@@ -16,7 +16,8 @@ LINK_NAMES = open(os.path.join(_HERE, 'data', 'realrobot_model_links.txt')).read
 
 RR_ABI_VERSION = 6
 (F_JOINTS, F_TOUCH, F_OBJ_POSE, F_RGB, F_DEPTH, F_MASK, F_TIMESTEP, F_ERRFLAGS, F_STATE, F_FRAG_COUNT, F_CONTACT_COUNT,
- F_ENV_CLASS) = range(12)
+ F_ENV_CLASS, F_PREP) = range(13)
+PREP_FLOATS = 378          # RR_F_PREP: frames 165, M^-1 121, qd* 11, object terms 81 -- in this order (realrobot.hip S_*)
 NUM_KERNELS = 9
 # id 5 = image set-up outside the two render kernels: the full static copy of the first frame (and the earlier schemes
 # RR_FULL_COPY / RR_SEPARATE_RESTORE); it does not run in steady state

@@ -42,7 +42,7 @@ class BatchedREALRobotEnv:
             nat.F_MASK: ((self.N, self.H, self.W), np.int32), nat.F_TIMESTEP: ((self.N,), np.int32),
             nat.F_ERRFLAGS: ((self.N,), np.uint32), nat.F_STATE: ((self.N, 61), np.float32),
             nat.F_FRAG_COUNT: ((self.N, 1), np.uint32), nat.F_CONTACT_COUNT: ((self.N,), np.int32),
-            nat.F_ENV_CLASS: ((self.N,), np.int32)}
+            nat.F_ENV_CLASS: ((self.N,), np.int32), nat.F_PREP: ((self.N, nat.PREP_FLOATS), np.float32)}
         p_, n_ = C.c_void_p(), C.c_size_t()                  # the tile count is the library's choice: ask for it
         nat.check(self.L.rr_get_buffer(self.h, nat.F_FRAG_COUNT, C.byref(p_), C.byref(n_)))
         self._shapes[nat.F_FRAG_COUNT] = ((self.N, max(1, n_.value // (4 * self.N))), np.uint32)

@@ -157,6 +157,7 @@ struct DevPtrs {
     int *hcount_host;  // device address of the pinned host word that receives the current number of heavy envs (or nullptr)
     int *timestep;     // [N]
     unsigned *errflags;// [N]
+    const float *body_tab; // [NB][16] per-body constants of k_prep16's body lanes (BT_*: com, inertia, mass, joint damping, axis)
     float *obj_home;   // [NOBJ*7][N] per-env pose an object is put back to by reset / the out-of-bounds rule (robot.py:19-24, mutable there)
     float4 *grows;     // [N * GP_RECS][16] generic solver rows in the slot layout, as canonical normal rows and as the blocks the sweeps stream (GP_*)
     float *cmd;        // [N][9]

@@ -359,9 +359,19 @@ def test_deselected_image_mirror_is_not_refreshed_and_comes_back_up_to_date():
     ext = e.get_observation_extended(_rendered=True)
     for _ in range(20):
         obs, _, _, _ = e.step(a)                       # plain observations: the mask block is deselected
-    assert getattr(e._backend(), '_mask_mirrored', True) is False
-    ext2 = e.get_observation_extended(_rendered=True)
     be = e._backend()
+    assert be._img_sel == 3                            # (the selection is tracked by the backend: RGB + depth)
+    # any OTHER holder of the views asks map_images(mask=True) and gets a block that is refreshed again -- no stale
+    # mask without an error -- and brought up to date at once
+    views = be.map_images(mask=True)
+    assert be._img_sel == 7
+    be.sync_observations()
+    assert np.array_equal(views[2], be.host(nat.F_MASK))
+    for _ in range(5):
+        obs, _, _, _ = e.step(a)
+    assert be._img_sel == 3
+    ext2 = e.get_observation_extended(_rendered=True)
+    assert be._img_sel == 7
     assert np.array_equal(ext2['mask'], be.host(nat.F_MASK)[0]) and np.array_equal(ext2['retina'], be.host(nat.F_RGB)[0])
     assert not np.array_equal(ext2['mask'], ext['mask'])
     e.close()

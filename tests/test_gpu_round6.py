@@ -1,0 +1,137 @@
+"""GPU tests (-m gpu) of round 6: the preparation on sixteen lanes per env (k_prep16) against the thread-per-env kernels, the
+video maker through evaluate(), and the delta image records of the renderer."""
+import os
+
+import numpy as np
+import pytest
+
+from real_robots_amd import _native as nat
+from real_robots_amd.batched import BatchedREALRobotEnv
+from real_robots_amd.distributed import synthetic_actions
+
+pytestmark = pytest.mark.gpu
+
+S_BR, S_BP, S_BAX, S_MINV, S_QDS, S_OR, S_OIINV, S_OVS, S_OWS, S_OP, S_TOTAL = 0, 99, 132, 165, 286, 297, 324, 351, 360, 369, 378
+
+
+def _make(monkeypatch, envvars, *a, **k):
+    for key, v in envvars.items():
+        monkeypatch.setenv(key, v)
+    try:
+        return BatchedREALRobotEnv(*a, **k)
+    finally:
+        for key in envvars:
+            monkeypatch.delenv(key)
+
+
+def _rich_states(N, seed):
+    """States off a run: arms anywhere in their range and moving, objects pushed around / toppled / in flight."""
+    env = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    for t in range(260):
+        env.step(synthetic_actions(range(N), t, seed=seed).astype(np.float32))
+    st = env.state
+    env.close()
+    rng = np.random.default_rng(seed)
+    st[:, 11:22] += rng.normal(0, 2.0, size=(N, 11)).astype(np.float32)          # joint velocities up to several rad/s
+    return st
+
+
+@pytest.mark.parametrize("N", [4096, 5])
+def test_prep16_matches_the_thread_per_env_preparation(monkeypatch, N):
+    """k_prep_b16 (sixteen lanes per env) against k_prep_b (a thread per env) on the same states, through the diagnostic field
+    RR_F_PREP, with the look-ahead off (the step then prepares itself in line: k_prep_a + k_prep_b / k_prep_b16 on the state that
+    was set): M^-1 and the unconstrained joint velocities agree to rounding (a different association of the compiler's fused
+    multiply-adds: 2e-5 of the row's diagonal / 1e-4 rad/s at velocities of several rad/s); frames and object terms -- k_prep_a in
+    both -- are bit for bit the same.  Then the look-ahead form: k_prep_ab16 alone produces, bit for bit, what k_prep_a + k_prep_b16
+    produce (frames through its own contraction-free chain on the row lanes, object terms on the object lanes)."""
+    st = _rich_states(N, 3)
+    recs = {}
+    for name, envv in (('scalar', {'RR_PREP_SCALAR': '1', 'RR_NO_LOOKAHEAD': '1'}), ('p16', {'RR_NO_LOOKAHEAD': '1'})):
+        env = _make(monkeypatch, envv, N, objects=3, width=64, height=64)
+        env.state = st
+        env.step(None)
+        recs[name] = env.host(nat.F_PREP)
+        env.close()
+    a, b = recs['scalar'], recs['p16']
+    assert a.shape == (N, nat.PREP_FLOATS)
+    assert np.array_equal(a[:, :S_MINV], b[:, :S_MINV]) and np.array_equal(a[:, S_OR:], b[:, S_OR:])       # k_prep_a's part
+    Ma, Mb = a[:, S_MINV:S_QDS].reshape(N, 11, 11).astype(np.float64), b[:, S_MINV:S_QDS].reshape(N, 11, 11).astype(np.float64)
+    diag = np.sqrt(np.einsum('nii,njj->nij', Ma, Ma))
+    rel = np.abs(Ma - Mb) / diag
+    dq = np.abs(a[:, S_QDS:S_OR] - b[:, S_QDS:S_OR])
+    print("N=%d: M^-1 worst |diff| / sqrt(M^-1_ii M^-1_jj) %.2e; qd* worst |diff| %.2e rad/s (|qd*| up to %.1f)" % (N, rel.max(), dq.max(), np.abs(a[:, S_QDS:S_OR]).max()))
+    assert rel.max() < 2e-5 and dq.max() < 1e-4
+    assert np.abs(Ma - np.swapaxes(Ma, 1, 2)).max() / np.abs(Ma).max() < 1e-5                           # (and it is an inverse mass matrix: symmetric)
+    # the look-ahead form: the record a step leaves is the one an in-line preparation of the SAME state computes
+    la = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    la.state = st
+    la.step(None)                         # k_prep_a + k_prep_b16 in line (the state was set from outside), solve, then k_prep_ab16 ahead
+    rec_la, st1 = la.host(nat.F_PREP), la.state
+    la.close()
+    il = _make(monkeypatch, {'RR_NO_LOOKAHEAD': '1'}, N, objects=3, width=64, height=64)
+    il.state = st1
+    il.step(None)
+    rec_il = il.host(nat.F_PREP)
+    il.close()
+    assert np.array_equal(rec_la, rec_il)
+
+
+def test_runs_under_both_preparations_stay_together(monkeypatch):
+    """Free-running: 64 envs x 400 full-range steps under the two preparations.  Until an env's first contact involving the robot the
+    two runs differ by rounding only (1e-4 rad); afterwards they are two samples of the same chaotic system (like device vs float64
+    oracle, tests/test_gpu_trajectory.py) -- what must hold is that neither flags an error and most envs stay within 1e-2 rad."""
+    N, T = 64, 400
+    a = _make(monkeypatch, {'RR_PREP_SCALAR': '1'}, N, objects=3, width=64, height=64)
+    b = BatchedREALRobotEnv(N, objects=3, width=64, height=64)
+    free = np.ones(N, bool)
+    worst_free = 0.0
+    for t in range(T):
+        cmd = synthetic_actions(range(N), t, seed=21).astype(np.float32)
+        a.step(cmd)
+        b.step(cmd)
+        if t % 20 == 19:
+            sa, sb = a.state, b.state
+            for i in np.where(free)[0]:
+                c = a.contacts(int(i))
+                if len(c) and ((c[:, 0] >= 0) & (c[:, 0] < 16)).any():
+                    free[i] = False
+            d = np.abs(sa[:, :11] - sb[:, :11]).max(1)
+            worst_free = max(worst_free, float(d[free].max()) if free.any() else 0.0)
+    print("two preparations, %d steps: worst joint difference before an env's first robot contact %.2e rad; %d envs never touched; "
+          "%d of %d envs within 1e-2 rad at the end" % (T, worst_free, int(free.sum()), int((d < 1e-2).sum()), N))
+    assert worst_free < 1e-4
+    assert (d < 1e-2).sum() >= N // 2
+    assert (a.host(nat.F_ERRFLAGS) == 0).all() and (b.host(nat.F_ERRFLAGS) == 0).all()
+    a.close()
+    b.close()
+
+
+def test_evaluate_writes_videos_with_goal_and_start_insets(tmp_path, monkeypatch):
+    """f3 (videomaker.py:94-129) end to end: evaluate(video=(intrinsic, extrinsic, debug)) films the debug camera of the reference's
+    VideoMaker through the HIP rasteriser; a trial's frames carry the goal image top right and the start image top left."""
+    import real_robots_amd as rr
+    from real_robots_amd import videomaker as vm
+    from real_robots_amd.generate_goals import generate_goals, save_goals
+    monkeypatch.chdir(tmp_path)
+    goals = generate_goals(2, 0, 0, n_obj=1, seed=5, batch=8, width=64, height=64)
+    save_goals(str(tmp_path / 'goals.npy'), goals)
+
+    class Still(rr.BasePolicy):
+        def step(self, observation, reward, done):
+            return {'joint_command': np.zeros(9), 'render': True}
+    svc_video = (range(0, 17), {0}, False)
+    from real_robots_amd.evaluate import EvaluationService
+    svc = EvaluationService(Still, 'R1', 'joints', 1, 16, 16, 1, False, str(tmp_path / 'goals.npy.npz'), svc_video,
+                            env_kwargs={'eye_width': 64, 'eye_height': 64})
+    svc.run_intrinsic_phase()
+    svc.run_extrinsic_phase()
+    files = svc.videomaker.files
+    assert len(files) == 2 and all(os.path.exists(f) for f in files)
+    raw = open(files[1], 'rb').read()
+    fb = 320 * 240 * 3
+    n = (len(raw) - raw.index(b'movi') - 4) // (fb + 8)
+    assert n == 2                                                   # steps 8 and 16
+    frame = np.frombuffer(raw[-fb:], np.uint8).reshape(240, 320, 3)[::-1, :, ::-1]
+    goal_inset = vm.make_inset(goals[0].retina, "GOAL")
+    assert np.array_equal(frame[:80, 320 - 106:], goal_inset)
+    assert frame[120:, :].std() > 5                                 # the debug camera sees the scene (not a blank frame)
