@@ -59,6 +59,8 @@ def _lib(f32=False):
         L.rro_set_state.argtypes = [C.c_void_p, C.c_void_p]
         L.rro_get_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rro_timestep.argtypes = [C.c_void_p]
+        L.rro_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.rro_run.restype = C.c_int
         L.rro_link_pose.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rro_contacts.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.rro_set_object_pose.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -149,6 +151,19 @@ class Oracle:
         j, t, p = np.empty(9), np.empty(4), np.empty(3 * self.n_objects)
         self.L.rro_get_obs(self.h, j.ctypes.data, t.ctypes.data, p.ctypes.data)
         return j, t, p.reshape(self.n_objects, 3)
+
+    def run(self, actions, state_every=0):
+        """T steps in ONE library call (the GIL is released for all of it: oracles on a thread pool run in parallel): actions [T, 9]
+        -> dict(ncontacts [T], nrobot [T] (contacts whose body A is a robot body), touch [T, 4], states [T // state_every, 61])."""
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        T = len(a)
+        assert a.shape == (T, 9)
+        nc, nr, touch = np.zeros(T, np.int32), np.zeros(T, np.int32), np.zeros((T, 4))
+        states = np.zeros((T // state_every if state_every else 0, 61))
+        n = self.L.rro_run(self.h, a.ctypes.data, T, nc.ctypes.data, nr.ctypes.data, touch.ctypes.data, int(state_every),
+                           states.ctypes.data if state_every else None)
+        assert n == len(states), n
+        return dict(ncontacts=nc, nrobot=nr, touch=touch, states=states)
 
     @property
     def timestep(self):

@@ -767,7 +767,7 @@ static void collide(rr_oracle *o) {
 int rro_pair_contacts(rr_oracle *o, int sa, int sb, double *out, int maxc, double *xf24) {
     const model_t *m = &o->m;
     if (sa < 0 || sb < 0 || sa >= m->ns || sb >= m->ns) return -1;
-    static contact_t keep[MAXC];
+    static __thread contact_t keep[MAXC];
     const int nkeep = o->ncontacts;
     memcpy(keep, o->contacts, sizeof(contact_t) * (size_t)nkeep);
     forward_kinematics(o);
@@ -903,9 +903,11 @@ static real build_row_torsional(const rr_oracle *o, row_t *r, const contact_t *c
 
 /* the contact problem of the last rro_step (any oracle instance): rows, where the normal rows start, the unconstrained
  * velocities -- kept for rro_solution_residual() */
-static row_t g_rows[NROWS];
-static int g_nr, g_first_normal, g_ncontacts;
-static real g_qds[NB], g_ovs[NOBJ][3], g_ows[NOBJ][3];
+/* (thread-local: oracles stepped on a thread pool -- rro_run, tests/test_gpu_trajectory.py -- must not share work areas; the
+ * residual check runs on the thread that stepped) */
+static __thread row_t g_rows[NROWS];
+static __thread int g_nr, g_first_normal, g_ncontacts;
+static __thread real g_qds[NB], g_ovs[NOBJ][3], g_ows[NOBJ][3];
 
 static void solve_and_integrate(rr_oracle *o) {
     const model_t *m = &o->m;
@@ -1141,7 +1143,7 @@ int rro_step(rr_oracle *o, const double *action9) {
     /* scene.global_step() env.py:340 */
     forward_kinematics(o);
     {
-        static contact_t prev[MAXC];
+        static __thread contact_t prev[MAXC];
         const int nprev = o->ncontacts;
         memcpy(prev, o->contacts, sizeof(contact_t) * (size_t)nprev);
         collide(o);
@@ -1215,6 +1217,23 @@ void rro_get_obs(const rr_oracle *o, double *joints9, double *touch4, double *ob
         for (int k = 0; k < 3; k++) objpos[3 * i + k] = o->opos[i][k];
 }
 int rro_timestep(const rr_oracle *o) { return o->timestep; }
+
+/* T steps in one call (free-running statistics, tests/test_gpu_trajectory.py: one ctypes call per env, so that a thread pool scales):
+ * actions [T][9]; per step the contact count, the robot-involving contact count and the four touch sensors; every `state_every`-th
+ * step (t + 1 divisible by it) the state.  Returns the number of states written, or -1 - t when action t is not finite. */
+int rro_run(rr_oracle *o, const double *actions, int T, int *ncontacts, int *nrobot, double *touch, int state_every, double *states) {
+    int ns = 0;
+    for (int t = 0; t < T; t++) {
+        if (rro_step(o, actions + 9 * t) != 0) return -1 - t;
+        int nr = 0;
+        for (int c = 0; c < o->ncontacts; c++) nr += o->contacts[c].bodyA >= 0 && o->contacts[c].bodyA < 16;
+        if (ncontacts) ncontacts[t] = o->ncontacts;
+        if (nrobot) nrobot[t] = nr;
+        if (touch) for (int i = 0; i < 4; i++) touch[4 * t + i] = o->touch[i];
+        if (states && state_every > 0 && (t + 1) % state_every == 0) rro_get_state(o, states + (size_t)RRO_STATE * ns++);
+    }
+    return ns;
+}
 
 void rro_link_pose(const rr_oracle *oc, int link, double *pose7) {
     rr_oracle *o = (rr_oracle *)oc;
@@ -1458,7 +1477,7 @@ void rro_render(rr_oracle *o, uint8_t *rgb, float *depth, int32_t *mask) {
     camera_matrices(o, VP);
     uint64_t *vis = (uint64_t *)malloc(sizeof(uint64_t) * W * H);
     for (int i = 0; i < W * H; i++) vis[i] = ~0ull;
-    static float MVPs[MAXINST][16], Rs[MAXINST][9];
+    static __thread float MVPs[MAXINST][16], Rs[MAXINST][9];
     for (int i = 0; i < m->ni; i++) {
         float p[3];
         instance_xform(o, i, Rs[i], p);

@@ -72,6 +72,9 @@ void rro_set_state(rr_oracle *o, const double *state61);      /* also forgets th
 void rro_set_contact_cache(rr_oracle *o, const double *rec12, int n);
 void rro_get_obs(const rr_oracle *o, double *joints9, double *touch4, double *objpos /*[nobj*3]*/);
 int rro_timestep(const rr_oracle *o);
+/* T steps in one call: per step the contact count, the number of contacts whose body A is a robot body, the four touch sensors;
+ * the state every `state_every` steps.  Returns the number of states written (-1 - t: action t not finite). */
+int rro_run(rr_oracle *o, const double *actions, int T, int *ncontacts, int *nrobot, double *touch, int state_every, double *states);
 /* world pose (xyz + xyzw quaternion) of the COM frame of robot link `link` (0..16, URDF depth-first) */
 void rro_link_pose(const rr_oracle *o, int link, double *pose7);
 /* contacts of the last step: per contact 12 doubles {bodyA, bodyB, linkA, x,y,z, nx,ny,nz, dist, normal_force, mu};

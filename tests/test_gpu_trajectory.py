@@ -82,3 +82,129 @@ def test_free_running_trajectories_against_the_float64_oracle():
             h, np.median(ej[:, h]), np.percentile(ej[:, h], 90), ej[:, h].max(), np.median(eo[:, h]), np.percentile(eo[:, h], 90), eo[:, h].max()))
     assert wj <= JOINT_TOL and wo <= POSE_TOL, (wj, wo)
     assert (div == T).sum() * 2 >= N and np.percentile(div, 10) >= P10_DIV_MIN, pct(div)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# A tolerance that holds AFTER first contact (review of round 5): distributions, not trajectories.
+SN, ST = 512, 2000          # envs x steps of the statistical run
+KS_MAX = 0.05               # two-sample Kolmogorov-Smirnov distance, device vs oracle (1 536 object samples / 512 env samples; the 0.1 %
+                            # critical value for INDEPENDENT samples of these sizes is 0.070 / 0.122 -- the two runs share their commands)
+
+
+def ks_distance(a, b):
+    """sup |F_a - F_b| of two samples."""
+    a, b = np.sort(np.asarray(a, np.float64).ravel()), np.sort(np.asarray(b, np.float64).ravel())
+    grid = np.concatenate([a, b])
+    return float(np.abs(np.searchsorted(a, grid, side='right') / len(a) - np.searchsorted(b, grid, side='right') / len(b)).max())
+
+
+def goal_scores(obj_pos, goals):
+    """REALRobotEnv.evaluateGoal (env.py:181-200): sum over the objects of exp(-(ln 4 / 0.10) |goal - position|)."""
+    return np.exp(-(np.log(4) / 0.10) * np.linalg.norm(goals - obj_pos, axis=-1)).sum(-1)
+
+
+def trajectory_statistics(states, ncontacts, touch, rest, goals, sample_steps):
+    """states [K, N, 61] at sample_steps, ncontacts [T, N], touch [T, N, 4], rest [N, 3, 3] resting positions, goals [N, 3, 3]."""
+    out = {}
+    for k, t in enumerate(sample_steps):
+        pos = states[k][:, 22:61].reshape(-1, 3, 13)[:, :, :3]
+        # per-object displacement from rest [N * 3]; below 5 mm an object counts as "not moved" (the two precisions settle a few
+        # micrometres apart and the resting tomato can creeps 1.2 um per step in both: without the floor the KS distance would measure those on the unmoved majority)
+        out['disp%d' % t] = np.maximum(np.linalg.norm(pos - rest, axis=-1).ravel(), 5e-3)
+    pos = states[-1][:, 22:61].reshape(-1, 3, 13)[:, :, :3]
+    out['score'] = goal_scores(pos, goals)                                             # [N]
+    out['nc_hist'] = np.bincount(ncontacts.ravel(), minlength=49)[:49] / ncontacts.size
+    out['nc_mean'] = float(ncontacts.mean())
+    tmax = touch.max(-1)
+    out['touch_duty'] = float((tmax > 0).mean())                                        # robot.py:152-163: any of the four skins loaded
+    out['touch_force'] = tmax[tmax > 0]
+    return out
+
+
+def compare_statistics(dev, orc, sample_steps, label):
+    print("\n%s -- distributions over %d env-steps:" % (label, SN * ST))
+    worst = 0.0
+    for t in sample_steps:
+        a, b = dev['disp%d' % t], orc['disp%d' % t]
+        ks = ks_distance(a, b)
+        worst = max(worst, ks)
+        print("  object displacement from rest at step %4d: KS %.4f; moved > 1 cm: %.3f vs %.3f of the objects; median of the moved %.3f vs %.3f m; "
+              "off the table (> 0.5 m): %.3f vs %.3f" % (t, ks, (a > 0.01).mean(), (b > 0.01).mean(), np.median(a[a > 0.01]) if (a > 0.01).any() else 0,
+                                                      np.median(b[b > 0.01]) if (b > 0.01).any() else 0, (a > 0.5).mean(), (b > 0.5).mean()))
+        assert ks <= KS_MAX, (t, ks)
+        assert abs((a > 0.01).mean() - (b > 0.01).mean()) <= 0.03, t
+    ks = ks_distance(dev['score'], orc['score'])
+    print("  evaluateGoal score at the last step: KS %.4f; mean %.4f vs %.4f" % (ks, dev['score'].mean(), orc['score'].mean()))
+    assert ks <= 2 * KS_MAX and abs(dev['score'].mean() - orc['score'].mean()) <= 0.02 * orc['score'].mean() + 0.01
+    tv = 0.5 * np.abs(dev['nc_hist'] - orc['nc_hist']).sum()
+    print("  contacts per env-step: mean %.3f vs %.3f; total-variation distance of the histograms %.4f" % (dev['nc_mean'], orc['nc_mean'], tv))
+    assert tv <= 0.03 and abs(dev['nc_mean'] - orc['nc_mean']) <= 0.03 * orc['nc_mean']
+    print("  touch-sensor duty cycle (any skin loaded): %.4f vs %.4f of the env-steps; loaded-sensor force median %.1f vs %.1f N, KS %.4f"
+          % (dev['touch_duty'], orc['touch_duty'], np.median(dev['touch_force']) if len(dev['touch_force']) else 0,
+             np.median(orc['touch_force']) if len(orc['touch_force']) else 0,
+             ks_distance(dev['touch_force'], orc['touch_force']) if len(dev['touch_force']) and len(orc['touch_force']) else 0))
+    assert abs(dev['touch_duty'] - orc['touch_duty']) <= 0.15 * orc['touch_duty'] + 0.002
+    return worst
+
+
+def statistical_setup(n, T):
+    """Commands of the headline workload for n envs, a seeded goal per env and object (the objects' resting places +- 15 cm)."""
+    cmds = np.zeros((T, n, 9), np.float32)
+    cur = None
+    for t in range(T):
+        if t % 20 == 0:
+            cur = synthetic_actions(np.arange(n), t, hold_prob=0.05).astype(np.float32)
+        cmds[t] = cur
+    rng = np.random.default_rng(77)
+    return cmds, rng.uniform(-0.15, 0.15, size=(n, 3, 3)) * np.array([1.0, 1.0, 0.0])
+
+
+def oracle_statistics(cmds, every, f32=False):
+    """The oracle's side: every env on a thread of a pool, all its steps in one library call (Oracle.run)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    T, n = cmds.shape[:2]
+
+    def one(i):
+        o = Oracle(3, 32, 32, f32=f32)
+        settle = o.run(np.zeros((300, 9)), 300)                   # objects dropped from the reset poses come to rest
+        return settle['states'][-1], o.run(cmds[:, i].astype(np.float64), every)
+    with ThreadPoolExecutor(max(1, min(64, os.cpu_count() or 1))) as ex:
+        res = list(ex.map(one, range(n)))
+    rest = np.stack([r[0][22:61].reshape(3, 13)[:, :3] for r in res])
+    states = np.stack([r[1]['states'] for r in res], 1)                                  # [K, n, 61]
+    return rest, states, np.stack([r[1]['ncontacts'] for r in res], 1), np.stack([r[1]['touch'] for r in res], 1)
+
+
+def test_statistical_agreement_after_contact_device_vs_float64_oracle():
+    """512 envs x 2 000 steps of the headline workload, free-running on the device (f32) and on the float64 oracle with the same
+    commands.  Trajectories part at the first stick-slip decision (test above); what is asserted here is that the two are samples of
+    the SAME system: the distribution of every object's displacement from its resting place at steps 500 / 1000 / 2000 (KS distance
+    <= KS_MAX, share of moved objects within 0.03), the distribution of REALRobotEnv.evaluateGoal scores (env.py:181-200) for a fixed
+    goal set at the last step -- on the device through rr_evaluate_goals --, the histogram of contacts per env-step (total variation
+    <= 0.03, mean within 3 %) and the touch sensors' duty cycle (robot.py:152-163; within 15 %)."""
+    from real_robots_amd import _native as nat
+    every = 500
+    sample_steps = (500, 1000, 1500, 2000)
+    cmds, goal_off = statistical_setup(SN, ST)
+    rest_o, st_o, nc_o, tc_o = oracle_statistics(cmds, every)
+    env = BatchedREALRobotEnv(SN, objects=3, width=32, height=32)
+    for _ in range(300):
+        env.step(None)
+    rest_d = env.state[:, 22:61].reshape(SN, 3, 13)[:, :, :3].astype(np.float64)
+    assert np.abs(rest_d - rest_o).max() < 1e-4                    # both sides start from the same resting scene
+    goals = rest_o + goal_off
+    st_d, nc_d, tc_d = [], np.zeros((ST, SN), np.int32), np.zeros((ST, SN, 4))
+    for t in range(ST):
+        env.step(cmds[t])
+        nc_d[t] = env.host(nat.F_CONTACT_COUNT)
+        tc_d[t] = env.host(nat.F_TOUCH)
+        if (t + 1) % every == 0:
+            st_d.append(env.state.astype(np.float64))
+    score_dev = env.evaluate_goals(goals.astype(np.float32)).astype(np.float64)
+    assert (env.host(nat.F_ERRFLAGS) == 0).all()
+    env.close()
+    dev = trajectory_statistics(np.stack(st_d), nc_d, tc_d, rest_o, goals, sample_steps)
+    assert np.abs(dev['score'] - score_dev).max() < 1e-4           # rr_evaluate_goals is the formula
+    orc = trajectory_statistics(st_o, nc_o, tc_o, rest_o, goals, sample_steps)
+    compare_statistics(dev, orc, sample_steps, "device f32 vs oracle f64, %d envs x %d steps" % (SN, ST))
