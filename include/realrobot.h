@@ -27,7 +27,7 @@ extern "C" {
                               rr_sync_observations, rr_device_microbench; checkpoint blobs carry the step parameters (version 2 header);
                               5: rr_select_image_mirror; 6: rr_config carries the motor / solver constants the reference leaves to
                               pybullet's defaults (motor_kp .. solver_flags, in the place of reserved[7]: same struct size); checkpoint
-                              header version 3 carries them too */
+                              header version 3 carries them too; RR_F_PREP; rr_pack_image_delta, rr_apply_image_delta */
 
 enum {
     RR_OK = 0,
@@ -191,6 +191,20 @@ int rr_select_image_mirror(rr_env *env, int32_t fields);
  * the stream: with a handful of envs the state part of the NEXT step is queued behind the mirror and runs while the
  * caller computes its next action.  Without a mapping it is rr_sync. */
 int rr_sync_observations(rr_env *env);
+
+/* Delta records for the observation gather of a sharded batch (the reference has one env per process and no gather):
+ * the pixels in which the last rendered frame of every env may differ from the one before are the entries of the renderer's
+ * fragment lists (RR_F_FRAG_COUNT of them per (env, tile) item).  rr_pack_image_delta writes one 12-byte record per entry --
+ * { env * H * W + row * W + col, r | g << 8 | b << 16, depth bits }, the pixel's NEW value -- at offsets_dev[item] + i, where
+ * offsets_dev (u32 [N * tiles], device) is the exclusive prefix sum of RR_F_FRAG_COUNT made by the caller; records beyond
+ * `capacity` are dropped.  On the library's stream.  After a frame that rewrote whole images (the first render of a handle,
+ * rr_set_camera) the lists do not describe the change: ship the slabs then.
+ * rr_apply_image_delta is the receiving side, with no env handle: `world` blocks of `capacity` records of which the first
+ * totals_dev[r] are valid, applied to persistent images of world * pixels_per_rank pixels (rank r's records address its block);
+ * enqueued on `stream` (a hipStream_t or NULL) of the current device. */
+int rr_pack_image_delta(rr_env *env, const uint32_t *offsets_dev, uint32_t *records_dev, uint32_t capacity);
+int rr_apply_image_delta(const uint32_t *records_dev, const uint32_t *totals_dev, int32_t world, uint32_t capacity, size_t pixels_per_rank,
+                         uint8_t *rgb_dev, float *depth_dev, void *stream);
 
 /* Replaces robot.parts[name].get_position()/get_pose() (env.py:230-232): world pose of the COM frame of
  * every robot link, f32 [N, 17, 7] (URDF depth-first link order, see data/realrobot_model_links.txt). */

@@ -30,7 +30,8 @@ SYMBOLS = ('rr_create', 'rr_destroy', 'rr_set_stream', 'rr_reset', 'rr_set_objec
            'rr_get_buffer', 'rr_copy_to_host', 'rr_set_state', 'rr_sync', 'rr_link_poses', 'rr_get_contacts',
            'rr_set_timing', 'rr_get_timing', 'rr_last_error', 'rr_abi_version', 'rr_ik', 'rr_plan_macro', 'rr_get_plan',
            'rr_step_plan', 'rr_set_camera', 'rr_set_object_poses', 'rr_step_plan_masked', 'rr_checkpoint_bytes',
-           'rr_checkpoint_save', 'rr_checkpoint_restore', 'rr_evaluate_goals', 'rr_device_microbench', 'rr_map_observations', 'rr_map_images', 'rr_sync_observations', 'rr_select_image_mirror')
+           'rr_checkpoint_save', 'rr_checkpoint_restore', 'rr_evaluate_goals', 'rr_device_microbench', 'rr_map_observations', 'rr_map_images', 'rr_sync_observations', 'rr_select_image_mirror',
+           'rr_pack_image_delta', 'rr_apply_image_delta')
 
 
 class Config(C.Structure):
@@ -128,6 +129,8 @@ def load_library():
     L.rr_sync_observations.argtypes = [vp]
     L.rr_map_images.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.rr_select_image_mirror.argtypes = [vp, C.c_int32]
+    L.rr_pack_image_delta.argtypes = [vp, vp, vp, C.c_uint32]
+    L.rr_apply_image_delta.argtypes = [vp, vp, i32, C.c_uint32, C.c_size_t, vp, vp, vp]
     L.rr_checkpoint_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.rr_checkpoint_save.argtypes = [vp, vp, C.c_size_t]
     L.rr_checkpoint_restore.argtypes = [vp, vp, C.c_size_t]

@@ -444,4 +444,5 @@ __device__ __forceinline__ void dispatch_order_class(int x, int N, int ntiles, i
 #include "rr_state.inc"    // reset / state io / observation kernels, render set-up
 #include "rr_ik.inc"    // inverse kinematics and macro plans (K8)
 #include "rr_render.inc"    // rasteriser: k_raster, k_shade, the list-walking render kernels
+#include "rr_gather.inc"    // delta image records for the observation gather (k_pack_delta, k_apply_delta)
 #include "rr_host.inc"    // host side: model blob, rr_env, the C ABI

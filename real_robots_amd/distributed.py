@@ -72,60 +72,151 @@ def gather_images(rgb, depth, group=None):
 
 class DeltaImageGather:
     """The policy-side image gather without the full slabs: every rank keeps PERSISTENT copies of all ranks' images and a step
-    ships only the pixels that changed since the step before.
+    ships only the pixels that may differ from the step before.
 
-    Why (SURVEY.md 8e with the measured rate instead of the 1e6 target): at 6.4 M env-steps/s per GPU a full-slab all-gather
-    (`gather_images`, 114 688 B per env-step) makes every rank SEND 0.74 TB/s and receive seven times that -- more than its seven
-    xGMI links (7 x ~153 GB/s) carry.  An env's frame differs from its previous one in ~1 250 pixels (what the renderer's
-    fragment lists hold: pixels won by moving geometry + pixels vacated): {pixel index 4 B, RGB 3 B, depth 4 B} = 11 B each,
-    ~14 KB per env-step instead of 115 KB -- 88 GB/s per rank at that rate, a tenth of a link each way.
+    Why (SURVEY.md 8e with the measured rate instead of the 1e6 target): at 6.9 M env-steps/s per GPU a full-slab all-gather
+    (`gather_images`, 114 688 B per env-step) makes every rank SEND 0.79 TB/s and receive seven times that -- more than its seven
+    xGMI links (7 x ~153 GB/s) carry.  An env's frame differs from its previous one in ~1 250 pixels -- exactly what the renderer's
+    fragment lists hold (pixels won by moving geometry + pixels vacated) -- 12 B per record {pixel address, RGB, depth}: ~15 KB per
+    env-step instead of 115 KB, ~100 GB/s per rank at that rate.
 
-    One step: (1) the changed pixels of the local slab against the rank's own slab in the persistent copy (bit compare; a
-    renderer-side list of changed pixels can replace this pass), (2) one small all-reduce (MAX) of the per-env counts fixes the
-    padded length K of this step's records, (3) three all-gathers of [n, K] index / RGB / depth records, (4) a scatter into the
-    persistent images.  Pad records rewrite pixel 0 with its own new value.  The result is bit for bit the full-slab gather
-    (tests/test_distributed_gloo.py, 2 and 4 ranks).  The first call seeds the copies with one full-slab gather."""
+    One step: (1) the local records, PREFIX-PACKED (an env with a full-frame change costs its own records, not everybody's):
+    with `env` (a BatchedREALRobotEnv whose last step rendered) straight from the renderer's lists by a HIP kernel
+    (rr_pack_image_delta; one cumsum over RR_F_FRAG_COUNT for the offsets, no compare pass over the slabs); without it -- CPU tensors,
+    the gloo tests -- from a bit compare against the rank's own block of the persistent copy; (2) one small all-gather of the ranks'
+    record totals; (3) one all-gather of `cap` records per rank; (4) the records of every rank applied to the persistent images
+    (rr_apply_image_delta on a GPU).  `cap`, the per-rank length of the payload collective, is
+      * the largest total of THIS step, read on the host (one small blocking read per step) -- the default, always exact; or
+      * with `sync_free=True`, `slack` x the largest total of the PREVIOUS step + `margin`, known without waiting for the device: no
+        host synchronisation in steady state.  A step whose total outgrows that (resets, goal set-up, a camera move -- host-initiated
+        events: call `invalidate()` with them and the next step ships the slabs) drops the surplus records; it is reported one step
+        late in `stale_last` and repaired by a slab gather in the step after.
+    When the records would outweigh the slabs (cap x 12 >= n x H x W x 7) the step ships the slabs and reseeds the copies.
+    The result of an exact step is bit for bit the full-slab gather (tests/test_distributed_gloo.py, 2 and 4 ranks; on a GPU
+    tests/test_gpu_round6.py).  The first call seeds the copies with one full-slab gather.
 
-    def __init__(self, group=None):
-        self.group = group
+    The returned tensors ARE the persistent copies: the next call updates them in place -- clone what must outlive a step."""
+
+    def __init__(self, group=None, env=None, sync_free=False, slack=1.5, margin=4096):
+        self.group, self.env, self.sync_free, self.slack, self.margin = group, env, bool(sync_free), float(slack), int(margin)
         self.rgb = self.depth = None
         self.bytes_last = 0
+        self.stale_last = False          # sync_free: the step BEFORE the last one dropped records (it has been repaired since)
+        self.slab_steps = 0              # steps that shipped the slabs (seed, fallback, repair)
+        self._lag = None                 # (pinned host copy of the last step's totals and overflow flag, event)
+        self._rec = None
+
+    def invalidate(self):
+        """The next step ships the full slabs (call with whatever rewrites whole frames: resets of many envs, set_goal, rr_set_camera)."""
+        self.rgb = self.depth = None
+        self._lag = None
+
+    def _seed(self, rgb, depth):
+        self.rgb, self.depth = gather_images(rgb, depth, self.group)
+        self.bytes_last = rgb.numel() + depth.numel() * 4
+        self.slab_steps += 1
+        self._lag = None
+        return self.rgb, self.depth
+
+    def _all_gather(self, t, world):
+        import torch
+        import torch.distributed as dist
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        try:
+            dist.all_gather_into_tensor(out, t, group=self.group)
+        except (RuntimeError, NotImplementedError, AttributeError):
+            dist.all_gather(list(out.chunk(world, dim=0)), t, group=self.group)
+        return out
 
     def step(self, rgb, depth):
         import torch
         import torch.distributed as dist
+        from . import _native as nat
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         n, H, W = depth.shape
+        npix = n * H * W
         if self.rgb is None:
-            self.rgb, self.depth = gather_images(rgb, depth, self.group)
-            self.bytes_last = rgb.numel() + depth.numel() * 4
-            return self.rgb, self.depth
-        mine_rgb = self.rgb[rank * n:(rank + 1) * n].view(n, H * W, 3)
-        mine_dep = self.depth[rank * n:(rank + 1) * n].view(n, H * W)
-        new_rgb, new_dep = rgb.contiguous().view(n, H * W, 3), depth.contiguous().view(n, H * W)
-        changed = (new_rgb != mine_rgb).any(-1) | (new_dep.view(torch.int32) != mine_dep.view(torch.int32))
-        counts = changed.sum(1)
-        kmax = counts.max().reshape(1).to(torch.int64)
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX, group=self.group)
-        K = max(int(kmax.item()), 1)
-        # [n, K] records: the changed pixels of an env in pixel order, padded with pixel 0
-        order = torch.cumsum(changed, 1) - 1
-        idx = torch.zeros((n, K), dtype=torch.int64, device=depth.device)
-        rows, pix = torch.nonzero(changed, as_tuple=True)
-        idx[rows, order[rows, pix]] = pix
-        rec_rgb = torch.gather(new_rgb, 1, idx.unsqueeze(-1).expand(n, K, 3)).contiguous()
-        rec_dep = torch.gather(new_dep, 1, idx).contiguous()
-        idx32 = idx.to(torch.int32)
-        outs = []
-        for t in (idx32, rec_rgb, rec_dep):
-            out = torch.empty((world * n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            try:
-                dist.all_gather_into_tensor(out, t, group=self.group)
-            except (RuntimeError, NotImplementedError, AttributeError):
-                dist.all_gather(list(out.chunk(world, dim=0)), t, group=self.group)
-            outs.append(out)
-        all_idx = outs[0].to(torch.int64)
-        self.rgb.view(world * n, H * W, 3).scatter_(1, all_idx.unsqueeze(-1).expand(world * n, K, 3), outs[1])
-        self.depth.view(world * n, H * W).scatter_(1, all_idx, outs[2])
-        self.bytes_last = n * K * 11 + 8
+            return self._seed(rgb, depth)
+        dev = depth.device
+        on_gpu = self.env is not None and dev.type == 'cuda'
+        # ---- (1) the local records and their number
+        if on_gpu:
+            fc = torch.as_tensor(self.env.device_buffer(nat.F_FRAG_COUNT), device=dev).view(torch.int32).reshape(-1)
+            csum = torch.cumsum(fc, 0)
+            total = csum[-1:].to(torch.int64)
+            offsets = (csum - fc).to(torch.int32)
+            local = None
+        else:
+            mine_rgb = self.rgb[rank * n:(rank + 1) * n].reshape(npix, 3)
+            mine_dep = self.depth[rank * n:(rank + 1) * n].reshape(npix)
+            new_rgb, new_dep = rgb.contiguous().reshape(npix, 3), depth.contiguous().reshape(npix)
+            changed = (new_rgb != mine_rgb).any(-1) | (new_dep.view(torch.int32) != mine_dep.view(torch.int32))
+            pix = torch.nonzero(changed).reshape(-1)
+            c = new_rgb[pix].to(torch.int32)
+            local = torch.stack([pix.to(torch.int32), c[:, 0] | (c[:, 1] << 8) | (c[:, 2] << 16), new_dep[pix].view(torch.int32)], 1)
+            total = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+        # ---- (2) every rank's total
+        totals = self._all_gather(total, world)
+        # ---- the length of the payload collective
+        self.stale_last = False
+        if self.sync_free:
+            lag = self._lag
+            self._lag = None
+            if lag is None:
+                cap = None                                  # (no history yet: this step ships the slabs)
+            else:
+                if lag[2] is not None:
+                    lag[2].synchronize()                    # (recorded a step ago: long complete)
+                lag_tot, lag_cap = lag[0], lag[1]
+                if int(lag_tot.max()) > lag_cap:            # the previous step dropped records: repair with the slabs
+                    self.stale_last = True
+                    cap = None
+                else:
+                    cap = int(self.slack * int(lag_tot.max())) + self.margin
+        else:
+            cap = max(1, int(totals.max().item()))
+        if cap is None or cap * 12 >= npix * 7:
+            out = self._seed(rgb, depth)
+            if self.sync_free:
+                self._note_totals(totals, 1 << 62, dev)
+            return out
+        # ---- (3) the payload: cap records per rank
+        if on_gpu:
+            if self._rec is None or self._rec.shape[0] < cap:
+                self._rec = torch.empty((max(cap, 1), 3), dtype=torch.int32, device=dev)
+            rec = self._rec[:cap]
+            nat.check(self.env.L.rr_pack_image_delta(self.env.h, offsets.data_ptr(), rec.data_ptr(), cap))
+        else:
+            rec = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+            k = min(cap, local.shape[0])
+            rec[:k] = local[:k]
+        allrec = self._all_gather(rec.contiguous(), world)
+        # ---- (4) into the persistent images
+        if on_gpu:
+            nat.check(nat.load_library().rr_apply_image_delta(allrec.data_ptr(), totals.to(torch.int32).data_ptr(), world, cap, npix,
+                                                              self.rgb.data_ptr(), self.depth.data_ptr(), None))
+        else:
+            allrec = allrec.view(world, cap, 3)
+            valid = torch.arange(cap, device=dev).unsqueeze(0) < totals.clamp(max=cap).unsqueeze(1)
+            r_idx, j_idx = torch.nonzero(valid, as_tuple=True)
+            v = allrec[r_idx, j_idx]
+            addr = r_idx * npix + v[:, 0].to(torch.int64)
+            flat_rgb, flat_dep = self.rgb.view(world * npix, 3), self.depth.view(world * npix)
+            flat_rgb[addr] = torch.stack([v[:, 1] & 255, (v[:, 1] >> 8) & 255, (v[:, 1] >> 16) & 255], 1).to(torch.uint8)
+            flat_dep[addr] = v[:, 2].contiguous().view(torch.float32)
+        if self.sync_free:
+            self._note_totals(totals, cap, dev)
+        self.bytes_last = cap * 12 + 8
         return self.rgb, self.depth
+
+    def _note_totals(self, totals, cap, dev):
+        """sync_free: this step's totals travel to the host behind the step (pinned copy + event); the NEXT step reads them."""
+        import torch
+        if dev.type == 'cuda':
+            host = torch.empty(totals.shape, dtype=totals.dtype, pin_memory=True)
+            host.copy_(totals, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._lag = (host, cap, ev)
+        else:
+            self._lag = (totals.clone(), cap, None)
