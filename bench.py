@@ -501,7 +501,8 @@ def main():
             views['depth'] = torch.as_tensor(env.device_buffer(nat.F_DEPTH), device=dev)
     gathered_bytes = 0
 
-    delta_gather = DeltaImageGather()
+    # (records straight from the renderer's fragment lists on a GPU: rr_pack_image_delta; the stub / CPU path compares the slabs)
+    delta_gather = DeltaImageGather(env=None if stub else env)
 
     def one_step(t):
         nonlocal gathered_bytes

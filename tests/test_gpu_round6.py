@@ -138,3 +138,52 @@ def test_evaluate_writes_videos_with_goal_and_start_insets(tmp_path, monkeypatch
     goal_inset = vm.make_inset(goals[0].retina, "GOAL")
     assert np.array_equal(frame[:80, 320 - 106:], goal_inset)
     assert frame[120:, :].std() > 5                                 # the debug camera sees the scene (not a blank frame)
+
+
+def test_delta_image_records_from_the_renderers_lists_single_rank_self_gather():
+    """The delta gather fed by the renderer (rr_pack_image_delta: records of the pixels in the fragment lists, prefix-packed by one
+    cumsum over RR_F_FRAG_COUNT) and applied by rr_apply_image_delta, as a world-1 RCCL self-gather on one GPU: after every step the
+    persistent copy equals the device images bit for bit -- full-range commands, objects pushed around, a masked reset and a
+    teleport on the way; exact mode (payload sized from this step's totals) and sync-free mode (from the previous step's: no
+    host read; a frame that outgrows its cap is flagged one step late and repaired)."""
+    import torch
+    import torch.distributed as dist
+    from real_robots_amd.distributed import DeltaImageGather
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29000 + os.getpid() % 2000))
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        N, H, W = 96, 128, 128
+        for sync_free in (False, True):
+            env = BatchedREALRobotEnv(N, objects=3, width=W, height=H, want_mask=False)
+            rgb = torch.as_tensor(env.device_buffer(nat.F_RGB), device='cuda:0')
+            dep = torch.as_tensor(env.device_buffer(nat.F_DEPTH), device='cuda:0')
+            dg = DeltaImageGather(env=env, sync_free=sync_free)
+            rng = np.random.default_rng(5)
+            n_delta, worst_share, inexact = 0, 0.0, []
+            for t in range(120):
+                if t == 60:
+                    env.reset((rng.random(N) < 0.3).astype(np.uint8))
+                if t == 80:
+                    env.set_object_pose(3, 1, np.array([-0.1, 0.1, 0.5, 0, 0, 0, 1], np.float32))
+                env.step(synthetic_actions(range(N), t, seed=8).astype(np.float32), render=True)
+                slabs_before = dg.slab_steps
+                g_rgb, g_dep = dg.step(rgb, dep)
+                torch.cuda.synchronize()
+                same = bool(torch.equal(g_rgb, rgb)) and bool(torch.equal(g_dep.view(torch.int32), dep.view(torch.int32)))
+                if not same:
+                    inexact.append(t)
+                if dg.slab_steps == slabs_before:
+                    n_delta += 1
+                    worst_share = max(worst_share, dg.bytes_last / (N * H * W * 7))
+            if not sync_free:
+                assert not inexact, inexact
+                assert n_delta >= 115 and worst_share < 0.25, (n_delta, worst_share)        # the records are a fraction of the slabs
+            else:
+                # (every inexact frame was flagged in the following step and repaired there)
+                assert len(inexact) <= 3 and n_delta >= 100, (inexact, n_delta)
+            print("delta gather, sync_free=%s: %d of 120 steps shipped records (worst %.3f of the slab bytes), %d slab steps, inexact frames %s"
+                  % (sync_free, n_delta, worst_share, dg.slab_steps, inexact))
+            env.close()
+    finally:
+        dist.destroy_process_group()
