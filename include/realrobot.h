@@ -100,6 +100,11 @@ typedef struct rr_config {
     int32_t solver_flags;   /* RR_SOLVER_* */
 } rr_config;
 #define RR_SOLVER_NO_RATE_LIMIT 1   /* limitActionByJoint (env.py:314-321) is skipped: the clipped command itself is the motor target */
+#define RR_SOLVER_IK_SINGLE_SEED 2  /* rr_ik / rr_plan_macro: ONE damped-least-squares solve per target, seeded with the env's current joints --
+                                       the literal call pattern of the reference (env.py:372-375, 421-427: one calculateInverseKinematics per
+                                       way point, no stepping in between).  Default (0): the best of several seeds -- current joints, an
+                                       elbow-up posture, the previous way point -- by convergence, then elbow height / continuity: which branch
+                                       pybullet's own solver lands on from one seed is not specified by the reference */
 
 typedef struct rr_env rr_env;
 

@@ -103,7 +103,7 @@ def _dls(q, target_pos, Rt, max_iters, residual, damping, prev=None):
     return q, err
 
 
-def inverse_kinematics(q11, target_pos, target_quat, max_iters=1000, residual=1e-3, damping=0.1, prefer=None):
+def inverse_kinematics(q11, target_pos, target_quat, max_iters=1000, residual=1e-3, damping=0.1, prefer=None, single_seed=False):
     """Damped least squares IK for link 7 (gripper base) position + orientation; returns all 11 dofs like pybullet
     does (the fingers keep their current values).  pybullet seeds DLS with the current joints and the branch it lands
     on is an implementation detail of its solver; here two seeds are tried (current joints, a canonical elbow-up
@@ -113,6 +113,8 @@ def inverse_kinematics(q11, target_pos, target_quat, max_iters=1000, residual=1e
     Rt = quat_to_mat(np.asarray(target_quat, dtype=np.float64) / np.linalg.norm(target_quat))
     best, best_key = None, None
     seeds = [q0[:7], ELBOW_UP_SEED] + ([np.asarray(prefer, dtype=np.float64)[:7]] if prefer is not None else [])
+    if single_seed:                # the reference's literal semantics: ONE solve from the simulator's current joints (env.py:372-375, 421-427)
+        seeds = seeds[:1]
     for seed in seeds:
         q = q0.copy()
         q[:7] = seed
@@ -146,11 +148,12 @@ def ik_candidates(q11, target_pos, target_quat, prefer=None, max_iters=1000, res
     return out
 
 
-def generate_plan(q_seed11, macro_action):
+def generate_plan(q_seed11, macro_action, single_seed=False):
     """The reference's 1000-step macro plan of 9-vectors (real_robots/envs/env.py:388-454): 100x home2, 100x above
     p1 (z 0.6), 50x at p1 (z 0.46), 500x p1->p2 at z 0.46 in <= 5 cm IK segments, 50x above p2, 100x home2, 100x home.
     IK orientation getQuaternionFromEuler([0, 3.14, -1.57]) (env.py:422); each IK result is cut to its first 9 dofs
-    (env.py:427)."""
+    (env.py:427).  single_seed: every way point from ONE solve seeded with q_seed11 (the reference calls calculateInverseKinematics once per
+    way point without stepping in between: every call starts from the same current joints) instead of the best of several seeds."""
     point_1, point_2 = np.asarray(macro_action[0], dtype=np.float64), np.asarray(macro_action[1], dtype=np.float64)
     home = np.zeros(9)
     home2 = np.zeros(9)
@@ -162,7 +165,7 @@ def generate_plan(q_seed11, macro_action):
     last = [None]
 
     def goToPosXY(coords):
-        q = inverse_kinematics(q_seed, coords, orient, prefer=last[0])
+        q = inverse_kinematics(q_seed, coords, orient, prefer=last[0], single_seed=single_seed)
         last[0] = q
         return q[:9].copy()
 

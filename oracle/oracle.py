@@ -81,6 +81,8 @@ def params_from_solver(solver):
     constants under the oracle's names (rr_oracle.h rro_params)."""
     out = {}
     for k, v in (solver or {}).items():
+        if k == 'ik_single_seed':
+            continue                      # (planning only: oracle/kinematics.py generate_plan(single_seed=...))
         if k == 'rate_limit':
             out['no_rate_limit'] = 0 if v else 1
         elif k in ('lin_damping', 'ang_damping', 'erp', 'warmstart', 'motor_kp', 'motor_kd', 'motor_max_force'):

@@ -46,9 +46,10 @@ class Config(C.Structure):
 
 FLAG_NO_MASK = 1
 SOLVER_NO_RATE_LIMIT = 1
+SOLVER_IK_SINGLE_SEED = 2
 # `solver=` of BatchedREALRobotEnv / make(): name -> documented default (UPSTREAM, unverifiable here)
 SOLVER_DEFAULTS = {'motor_kp': 0.1, 'motor_kd': 1.0, 'motor_max_force': 100000.0, 'warmstart': 0.85, 'lin_damping': 0.04,
-                   'ang_damping': 0.04, 'erp': 0.2, 'rate_limit': True}
+                   'ang_damping': 0.04, 'erp': 0.2, 'rate_limit': True, 'ik_single_seed': False}
 
 
 def apply_solver(cfg, solver):
@@ -59,6 +60,9 @@ def apply_solver(cfg, solver):
             raise ValueError("unknown solver parameter %r (known: %s)" % (k, ', '.join(sorted(SOLVER_DEFAULTS))))
         if k == 'rate_limit':
             cfg.solver_flags = (cfg.solver_flags & ~SOLVER_NO_RATE_LIMIT) | (0 if v else SOLVER_NO_RATE_LIMIT)
+            continue
+        if k == 'ik_single_seed':
+            cfg.solver_flags = (cfg.solver_flags & ~SOLVER_IK_SINGLE_SEED) | (SOLVER_IK_SINGLE_SEED if v else 0)
             continue
         v = float(v)
         if not np.isfinite(v) or v < 0:

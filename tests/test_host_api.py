@@ -64,7 +64,7 @@ def test_create_rejects_bad_arguments_and_fails_loudly_without_gpu():
     bad.abi_version = 99
     assert L.rr_create(C.byref(bad), blob, len(blob), None, C.byref(h)) == -1
     bad = nat.Config.from_buffer_copy(cfg)
-    bad.solver_flags = 2
+    bad.solver_flags = 4
     assert L.rr_create(C.byref(bad), blob, len(blob), None, C.byref(h)) == -1 and b'solver_flags' in L.rr_last_error()
     bad = nat.Config.from_buffer_copy(cfg)
     bad.motor_kp = float('nan')
