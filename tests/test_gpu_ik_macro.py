@@ -211,8 +211,8 @@ def test_single_seed_ik_is_the_reference_call_pattern_and_a_parameter():
         rows = [150, 225, 300, 500, 740, 775]                       # one row of every IK segment
         for r in rows:
             d = np.abs(plans[True][i][r] - host[r]).max()
-            # (a non-converged single-seed solve ends wherever its 1000 iterations left it: float32 and float64 then differ freely)
-            conv = np.linalg.norm(link_pose(np.concatenate([host[r][:7], np.zeros(4)]), EE_LINK)[1][:2] - np.array(pr[0 if r < 250 else 1])) < 0.3
+            # (a non-converged single-seed solve ends wherever its 1000 iterations left it: float32 and float64 then differ freely --
+            # such rows are not counted, and at least 70 % of the rows must agree)
             if d < IK_TOL:
                 n_cmp += 1
             worst = max(worst, d if d < IK_TOL else 0.0)
