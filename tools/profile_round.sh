@@ -3,7 +3,7 @@
 # rocprofv3 kernel stats, PMC HBM traffic (separate FETCH_SIZE / WRITE_SIZE passes, never combined with other trace
 # domains), SQ VALU counters.  Output: gpurun_out/round/ ; traffic_latest.json and sq_latest.json carry the run
 # configuration so that bench.py only attaches them to runs of that configuration.  Usage: tools/profile_round.sh [tag]
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; mkdir -p $O
 cd $R && python bench.py --steps 200 --warmup 20 > $O/${TAG}_bench.json 2> $O/bench.err; tail -c 600 $O/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
@@ -42,7 +42,7 @@ for k in set(fe)|set(wr):
     tr[k]=round((2*f+w)*1024); lo[k]=round((f+w)*1024)
 for d in (tr, lo):
     d['render_stage']=d.get('k_raster',0)+d.get('k_shade',0)+d.get('k_render_list',0)+d.get('k_raster_list',0)+d.get('k_render_setup',0)
-    d['k_prep']=d.get('k_prep_a',0)+d.get('k_prep_b',0)+d.get('k_prep_ab',0)
+    d['k_prep']=sum(d.get(k,0) for k in ('k_prep_a','k_prep_b','k_prep_ab','k_prep_a16','k_prep_b16','k_prep_ab16'))
     d['k_solve']=d.get('k_solve',0)+d.get('k_solve_rs',0)      # (k_solve_rs: the heavy classes' solve of a step that draws -- the same kernel with the render set-up in its tail)
 tr['lower_bound']=lo
 tr['config']=cfg; tr['source']=TAG+'_pmc_summary.json'; tr['source_sha256']=SRC_SHA
@@ -50,7 +50,7 @@ tr['_note']="HBM bytes per step from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (se
 json.dump(tr, open(O+'/traffic_latest.json','w'), indent=1)
 sv={'config': cfg, 'source': TAG+'_sq_counters.json', 'source_sha256': SRC_SHA, 'valu_wave_instr_per_launch': {k: round(v['SQ_INSTS_VALU']['mean']) for k,v in sq.items() if 'SQ_INSTS_VALU' in v}}
 json.dump(sv, open(O+'/sq_latest.json','w'), indent=1)
-for k in ('k_raster','k_shade','k_solve','k_solve_rs','k_collide','k_prep_a','k_prep_b','k_prep_ab','k_solve_light','k_solve_light_ow','k_render_setup','k_render_list'):
+for k in ('k_raster','k_shade','k_solve','k_solve_rs','k_collide','k_prep_a','k_prep_b','k_prep_ab','k_prep_a16','k_prep_b16','k_prep_ab16','k_solve_light','k_solve_light_ow','k_render_setup','k_render_list'):
     r={c: x['mean'] for c,x in sq.get(k,{}).items()}
     if not r: continue
     wc=r.get('SQ_WAVE_CYCLES',0) or 1
