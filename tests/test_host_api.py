@@ -302,7 +302,7 @@ def test_bench_bookkeeping_and_committed_profiles():
     assert bench.load_profile('no_such_file.json', cfg)[0] is None
     bench.kernel_source_hash = lambda: recorded
     # the committed figures: every kernel of the step is there, the render stage stays below a full image write
-    for k in ('k_prep_a', 'k_prep_b', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster', 'k_shade', 'render_stage'):
+    for k in ('k_prep_a16', 'k_prep_b16', 'k_prep_ab16', 'k_prep', 'k_collide', 'k_solve', 'k_render_setup', 'k_raster', 'k_shade', 'render_stage'):
         assert prof[k] > 0, k
     assert prof['render_stage'] < a['_image'] * 4096 and prof['k_solve'] < 100e6
     sq, _ = bench.load_profile('sq_latest.json', cfg)
