@@ -189,53 +189,78 @@ def test_delta_image_records_from_the_renderers_lists_single_rank_self_gather():
         dist.destroy_process_group()
 
 
-def test_schedule_choices_off_the_bench_workload(monkeypatch):
+_SCHEDULE_SCRIPT = r"""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from real_robots_amd import _native as nat
+from real_robots_amd.batched import BatchedREALRobotEnv
+from oracle.kinematics import inverse_kinematics, quat_from_euler
+N = 4096
+press = inverse_kinematics(np.zeros(11), [-0.15, 0.25, 0.40], quat_from_euler(0, 3.14, -1.57))
+press = np.concatenate([press[:7], [0.0, 0.0]]).astype(np.float32)
+workloads = {'no heavy env': np.zeros((N, 9), np.float32), '30 %% heavy': np.zeros((N, 9), np.float32)}
+workloads['30 %% heavy'][np.arange(N) %% 10 < 3] = press
+
+def ms_per_step(force, cmd_dev):
+    if force is None:
+        os.environ.pop('RR_FORCE_HCOUNT', None)
+    else:
+        os.environ['RR_FORCE_HCOUNT'] = '%%d,%%d' %% force
+    env = BatchedREALRobotEnv(N, objects=3, width=128, height=128, want_mask=False)
+    for _ in range(150):
+        env.step(device_ptr=cmd_dev.data_ptr(), render=True)
+    best = 1e9
+    for _ in range(3):
+        env.sync()
+        t0 = time.perf_counter()
+        for _ in range(120):
+            env.step(device_ptr=cmd_dev.data_ptr(), render=True)
+        env.sync()
+        best = min(best, (time.perf_counter() - t0) / 120 * 1e3)
+    cls = env.host(nat.F_ENV_CLASS)
+    env.close()
+    return best, int((cls == 1).sum()), int((cls == 2).sum())
+
+out = {}
+for name, cmd in workloads.items():
+    cmd_dev = torch.from_numpy(cmd).cuda()
+    auto, nh, nvh = ms_per_step(None, cmd_dev)
+    auto = min(auto, ms_per_step(None, cmd_dev)[0])
+    forced = {}
+    for h in (0, 150, 600, 1300, 2600):
+        for vh in (0, 30, 200, 1200):
+            if vh <= max(h, 1) * 4:
+                forced['%%d,%%d' %% (h, vh)] = ms_per_step((h, vh), cmd_dev)[0]
+    out[name] = dict(auto=auto, heavy=nh, very_heavy=nvh, forced=forced)
+print('RESULT ' + json.dumps(out))
+"""
+
+
+def test_schedule_choices_off_the_bench_workload():
     """The placement of a step (rr_step: which stream solves / renders which class, where the look-ahead goes, list walker or grid
     for the heavy envs' visibility pass) is chosen from lagged host copies of the two heavy-list lengths through constants that were
-    tuned on the benchmark's workload (LA_VH_MAX, RENDER_LIST_WGS, split_max_pct).  Two workloads the benchmark never shows -- NO
-    heavy env at all (arms at home, objects at rest) and 30 % of the envs pressing the gripper on the table (heavy and very heavy
-    from the first contact on) -- are timed under the automatic choice and under every forced reading of the counts
-    (RR_FORCE_HCOUNT: placements only, results are bitwise the same, tests/test_gpu_round4.py): the automatic choice is within 3 %
-    of the best forced one."""
-    import time
-    import torch
-    from oracle.kinematics import inverse_kinematics, quat_from_euler
-    N = 4096
-    press = inverse_kinematics(np.zeros(11), [-0.15, 0.25, 0.40], quat_from_euler(0, 3.14, -1.57))
-    press = np.concatenate([press[:7], [0.0, 0.0]]).astype(np.float32)
-    workloads = {'no heavy env': np.zeros((N, 9), np.float32), '30 % heavy': np.zeros((N, 9), np.float32)}
-    workloads['30 % heavy'][np.arange(N) % 10 < 3] = press
-
-    def ms_per_step(envv, cmd_dev):
-        env = _make(monkeypatch, envv, N, objects=3, width=128, height=128, want_mask=False)
-        for _ in range(150):
-            env.step(device_ptr=cmd_dev.data_ptr(), render=True)
-        best = 1e9
-        for _ in range(2):
-            env.sync()
-            t0 = time.perf_counter()
-            for _ in range(120):
-                env.step(device_ptr=cmd_dev.data_ptr(), render=True)
-            env.sync()
-            best = min(best, (time.perf_counter() - t0) / 120 * 1e3)
-        cls = env.host(nat.F_ENV_CLASS)
-        env.close()
-        return best, int((cls == 1).sum()), int((cls == 2).sum())
-
-    for name, cmd in workloads.items():
-        cmd_dev = torch.from_numpy(cmd).cuda()
-        auto, nh, nvh = ms_per_step({}, cmd_dev)
-        auto = min(auto, ms_per_step({}, cmd_dev)[0])            # (the automatic choice is measured twice: the bound below is tight)
-        forced = {}
-        for h in (0, 150, 600, 1300, 2600):
-            for vh in (0, 30, 200, 1200):
-                if vh <= max(h, 1) * 4:
-                    forced[(h, vh)] = ms_per_step({'RR_FORCE_HCOUNT': '%d,%d' % (h, vh)}, cmd_dev)[0]
-        best = min(forced, key=forced.get)
-        print("%s (%d heavy, %d very heavy envs): automatic %.4f ms per step; forced readings: best %.4f at %s, worst %.4f at %s"
-              % (name, nh, nvh, auto, forced[best], best, max(forced.values()), max(forced, key=forced.get)))
+    tuned on the benchmark's workload (LA_VH_MAX, RENDER_LIST_WGS, split_max_pct, the walker / grid threshold).  Two workloads the
+    benchmark never shows -- NO heavy env at all (arms at home, objects at rest) and 30 % of the envs pressing the gripper on the
+    table (heavy from the first contact on) -- are timed under the automatic choice and under every forced reading of the counts
+    (RR_FORCE_HCOUNT: placements only, results are bitwise the same, tests/test_gpu_round4.py): the automatic choice is within 3 % of
+    the best forced one.  (In a process of its own: the suite's other tests leave streams, RCCL threads and a warm allocator behind
+    that add a millisecond-scale jitter to 0.4 ms steps.  The first run of this test moved the walker / grid threshold from a quarter
+    of the batch to a third: at 1 230 heavy envs the walker was 3.6 % ahead; the macro workload, 1 486 heavy envs and up, wants the grid.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', _SCHEDULE_SCRIPT % dict(root=root)], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('RESULT ')][0][7:])
+    for name, o in out.items():
+        best = min(o['forced'], key=o['forced'].get)
+        worst = max(o['forced'], key=o['forced'].get)
+        print("%s (%d heavy, %d very heavy envs): automatic %.4f ms per step; forced readings: best %.4f at (%s), worst %.4f at (%s)"
+              % (name, o['heavy'], o['very_heavy'], o['auto'], o['forced'][best], best, o['forced'][worst], worst))
         if name == 'no heavy env':
-            assert nh == 0 and nvh == 0
+            assert o['heavy'] == 0 and o['very_heavy'] == 0
         else:
-            assert nh + nvh >= 0.25 * N
-        assert auto <= 1.03 * forced[best], (name, auto, forced)
+            assert o['heavy'] + o['very_heavy'] >= 0.25 * 4096
+        assert o['auto'] <= 1.03 * o['forced'][best], (name, o)
