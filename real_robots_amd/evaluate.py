@@ -182,7 +182,7 @@ def evaluate(Controller, environment='R1', action_type='macro_action', n_objects
 
 def evaluate_batched(Controller, num_envs, environment='R1', action_type='macro_action', n_objects=1,
                      intrinsic_timesteps=1000, extrinsic_timesteps=1000, extrinsic_trials=5,
-                     goals_dataset_path="./goals.npy.npz", eye_width=320, eye_height=240, device=0, render_every=0):
+                     goals_dataset_path="./goals.npy.npz", eye_width=320, eye_height=240, device=0, render_every=0, solver=None):
     """`evaluate()` for `num_envs` independent agents stepped in lock-step on one GPU (BASELINE config 5): env i owns
     its own `Controller` instance and walks the goal list from goal i (cyclically), so every env sees
     `extrinsic_trials` different goals. Phases, callbacks and the scoring formula are those of the single-env harness
@@ -192,6 +192,7 @@ def evaluate_batched(Controller, num_envs, environment='R1', action_type='macro_
     A `Controller` derived from `real_robots_amd.policy.BatchedPolicy` takes the batched path instead: ONE controller
     object, one `step()` call per step for all envs, images stay on the device, the only per-step read-back is the
     low-dimensional observation, goal scores are computed on the device (rr_evaluate_goals) -- BASELINE config 5 at 4096 envs.
+    `solver`: the constants the reference leaves to pybullet's defaults (`BatchedREALRobotEnv(solver=...)`).
     Returns (score_object, scores) aggregated over all envs and trials."""
     from . import _native as nat
     from .batched import BatchedREALRobotEnv, OBJECT_NAMES
@@ -205,7 +206,7 @@ def evaluate_batched(Controller, num_envs, environment='R1', action_type='macro_
     if isinstance(Controller, type) and issubclass(Controller, BatchedPolicy):
         return _evaluate_batched_policy(Controller, num_envs, environment, action_type, n_objects, intrinsic_timesteps,
                                         extrinsic_timesteps, extrinsic_trials, goals_dataset_path, eye_width, eye_height,
-                                        device, render_every)[:2]
+                                        device, render_every, solver=solver)[:2]
     if not issubclass(Controller, BasePolicy):
         raise Exception("Supplied Controller is not a Sub-Class of real_robots.policy.BasePolicy")
     proto = REALRobotEnv(objects=n_objects, action_type=action_type, additional_obs=(environment == 'R1'),
@@ -216,7 +217,7 @@ def evaluate_batched(Controller, num_envs, environment='R1', action_type='macro_
     names = OBJECT_NAMES[:n_objects]
     N = int(num_envs)
     env = BatchedREALRobotEnv(N, objects=n_objects, width=eye_width, height=eye_height, device=device,
-                              want_mask=(environment == 'R1'))
+                              want_mask=(environment == 'R1'), solver=solver)
     ctrls = [Controller(proto.action_space, proto.observation_space) for _ in range(N)]
     zero_img = np.zeros((eye_height, eye_width, 3), np.uint8)
     zero_depth = np.zeros((eye_height, eye_width))
@@ -310,7 +311,7 @@ def _score_object(scores):
 
 def _evaluate_batched_policy(Controller, num_envs, environment, action_type, n_objects, intrinsic_timesteps,
                              extrinsic_timesteps, extrinsic_trials, goals_dataset_path, eye_width, eye_height, device,
-                             render_every, env=None):
+                             render_every, env=None, solver=None):
     """The batched-policy path of evaluate_batched (phases: evaluate.py:203-324 of the reference; goal set-up env.py:151-166;
     scoring env.py:181-200).  Per step: one `Controller.step` call, one rr_step / rr_step_plan, one read-back of joints +
     touch (+ object poses in R1).  Env i walks the goal list from goal i (cyclically), trial k takes goal (i + k) % len(goals).
@@ -329,7 +330,7 @@ def _evaluate_batched_policy(Controller, num_envs, environment, action_type, n_o
     own_env = env is None
     if own_env:
         env = BatchedREALRobotEnv(N, objects=n_objects, width=eye_width, height=eye_height, device=device,
-                                  want_mask=(environment == 'R1'))
+                                  want_mask=(environment == 'R1'), solver=solver)
     ctrl = Controller(N, proto.action_space, proto.observation_space)
     r1 = environment == 'R1'
     dev_imgs = {"retina": env.device_buffer(nat.F_RGB), "depth": env.device_buffer(nat.F_DEPTH)}
