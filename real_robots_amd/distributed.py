@@ -87,8 +87,8 @@ class DeltaImageGather:
     record totals; (3) one all-gather of `cap` records per rank; (4) the records of every rank applied to the persistent images
     (rr_apply_image_delta on a GPU).  `cap`, the per-rank length of the payload collective, is
       * the largest total of THIS step, read on the host (one small blocking read per step) -- the default, always exact; or
-      * with `sync_free=True`, `slack` x the largest total of the PREVIOUS step + `margin`, known without waiting for the device: no
-        host synchronisation in steady state.  A step whose total outgrows that (resets, goal set-up, a camera move -- host-initiated
+      * with `sync_free=True`, `slack` x the largest total of the PREVIOUS step + `margin`, known without waiting for THIS step: the
+        only wait is for the previous step's totals (an event recorded a whole step earlier) -- the host keeps one step of slack.  A step whose total outgrows that (resets, goal set-up, a camera move -- host-initiated
         events: call `invalidate()` with them and the next step ships the slabs) drops the surplus records; it is reported one step
         late in `stale_last` and repaired by a slab gather in the step after.
     When the records would outweigh the slabs (cap x 12 >= n x H x W x 7) the step ships the slabs and reseeds the copies.
@@ -193,8 +193,11 @@ class DeltaImageGather:
         allrec = self._all_gather(rec.contiguous(), world)
         # ---- (4) into the persistent images
         if on_gpu:
-            nat.check(nat.load_library().rr_apply_image_delta(allrec.data_ptr(), totals.to(torch.int32).data_ptr(), world, cap, npix,
-                                                              self.rgb.data_ptr(), self.depth.data_ptr(), None))
+            # (on torch's current stream -- the one the collectives above were enqueued on; the env's own stream is expected to be that
+            # stream too, as in bench.py: rr_pack_image_delta runs on the library's stream)
+            tot32 = totals.to(torch.int32)
+            nat.check(nat.load_library().rr_apply_image_delta(allrec.data_ptr(), tot32.data_ptr(), world, cap, npix, self.rgb.data_ptr(),
+                                                              self.depth.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
         else:
             allrec = allrec.view(world, cap, 3)
             valid = torch.arange(cap, device=dev).unsqueeze(0) < totals.clamp(max=cap).unsqueeze(1)
