@@ -187,7 +187,7 @@ def plane_deviation(hv, eq, chosen):
 # Long edges of a shape's full hull: the vertex-in-polytope candidates of the narrow phase cannot see two edges that cross away
 # from any vertex (a cube edge lying across a shelf edge); edges shorter than EDGE_MIN are covered by their end points.
 EMAX = 48           # long edges kept per shape (the longest first)
-EDGE_MIN = 0.015    # m
+EDGE_MIN = 0.004    # m  (1.5 cm until round 6: the cube's bevel edges and the skin pads' short edges were not stored -- tests/test_narrowphase_exact.py)
 EDGE_COS = 0.9659   # only sharp edges (dihedral angle >= 15 degrees): on a rounded surface the end points of an edge are close to it
 
 
