@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RR_LIB', os.path.join(_HERE, 'csrc', 'librealrobot_hip.so'))
-BLOB_GZ = os.path.join(_HERE, 'data', 'realrobot_model.bin.gz')
+BLOB_GZ = os.environ.get('RR_MODEL', os.path.join(_HERE, 'data', 'realrobot_model.bin.gz'))      # (RR_MODEL: another compiled model, A/B)
 LINK_NAMES = open(os.path.join(_HERE, 'data', 'realrobot_model_links.txt')).read().split()
 
 RR_ABI_VERSION = 6
