@@ -222,6 +222,12 @@ def run_case(cls, seed):
     if len(c):
         k = int(np.argmin(c[:, 9]))
         rec.update(dist=float(c[k, 9]), angle=float(np.degrees(np.arccos(np.clip(c[k, 6:9] @ n, -1.0, 1.0)))))
+        # (round 6) the kept contact that REPRESENTS the exact closest feature pair: among the <= 4 contacts of the pair the one whose
+        # distance is nearest the exact signed distance.  For separated shapes the "deepest" contact above is usually a vertex candidate
+        # whose plane distance under-estimates the gap (a speculative contact that activates, correctly, when the vertex enters the
+        # other hull through that face); the edge-edge candidate beside it carries the true distance and direction.
+        m = int(np.argmin(np.abs(c[:, 9] - d)))
+        rec.update(match_err=float(abs(c[m, 9] - d)), match_angle=float(np.degrees(np.arccos(np.clip(c[m, 6:9] @ n, -1.0, 1.0)))))
     return rec
 
 
@@ -255,7 +261,9 @@ def summarise(recs):
                          deeper_mm_max=float(max(0.0, (-e).max()) * 1e3) if len(e) else 0.0,      # oracle reports the shapes CLOSER than they are
                          farther_mm_max=float(max(0.0, e.max()) * 1e3) if len(e) else 0.0,
                          angle_deg_max=float(a.max()) if len(a) else 0.0, angle_deg_p99=float(np.percentile(a, 99)) if len(a) else 0.0,
-                         angle_deg_median=float(np.median(a)) if len(a) else 0.0)
+                         angle_deg_median=float(np.median(a)) if len(a) else 0.0,
+                         match_angle_deg_median=float(np.median([r['match_angle'] for r in have])) if have else 0.0,
+                         match_err_mm_median=float(np.median([r['match_err'] for r in have]) * 1e3) if have else 0.0)
     return out
 
 
