@@ -537,7 +537,7 @@ static int verts_in_planes(const rr_oracle *o, int sa, const xform_t *Xa, int sb
 
 /* Edge-edge candidates.  The vertex tests above cannot see two edges that cross away from any vertex (a cube edge lying
  * across a shelf edge: GJK/EPA in Bullet reports the closest points of the two edges).  For every pair of long sharp hull
- * edges (tools/compile_model.py: >= 1.5 cm, dihedral angle >= 15 degrees, the 48 longest of a shape) whose lines' closest
+ * edges (tools/compile_model.py: >= 4 mm, dihedral angle >= 15 degrees, the 48 longest of a shape) whose lines' closest
  * points lie strictly inside both segments: the common normal n = +-(d1 x d2)/|d1 x d2| is a contact normal iff it is a
  * face of the Minkowski difference, i.e. the direction u from A towards B lies in the fan between the two facet normals
  * of A's edge and -u in the fan of B's edge.  With the closest points inside both segments such a pair is the closest

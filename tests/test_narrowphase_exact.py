@@ -288,7 +288,7 @@ def run_all(n, workers):
 #   * NO pair whose full hulls overlap or come within 2 mm goes without a contact, in any class;
 #   * overlapping / touching pairs: the deepest contact's distance is within 3.2 mm (objects, gripper) / 4.7 mm (arm links) of the
 #     exact signed distance in 99 % of the poses, the median error is below 0.45 mm; the worst cases (2-13 mm objects / gripper,
-#     3-17 mm arm links) are overlaps along an EDGE-EDGE axis between an edge that is not stored (shorter than 1.5 cm, dihedral
+#     3-17 mm arm links) are overlaps along an EDGE-EDGE axis between an edge that is not stored (shorter than 4 mm, dihedral
 #     angle below 15 degrees, beyond the 48 longest) and a smooth surface -- `unseen_overlap` counts the poses where the hulls
 #     overlap by more than 0.5 mm and the deepest contact still reports a gap (0-21 of 667 per object / gripper class, 9-29 per arm link);
 #   * the contact NORMAL is the exact separating direction (median 0.0 degrees) where a face is involved -- objects on table and
