@@ -199,8 +199,11 @@ from oracle.kinematics import inverse_kinematics, quat_from_euler
 N = 4096
 press = inverse_kinematics(np.zeros(11), [-0.15, 0.25, 0.40], quat_from_euler(0, 3.14, -1.57))
 press = np.concatenate([press[:7], [0.0, 0.0]]).astype(np.float32)
-workloads = {'no heavy env': np.zeros((N, 9), np.float32), '30 %% heavy': np.zeros((N, 9), np.float32)}
+crush = inverse_kinematics(np.zeros(11), [-0.15, 0.25, 0.33], quat_from_euler(0, 3.14, -1.57))
+crush = np.concatenate([crush[:7], [0.0, 0.0]]).astype(np.float32)
+workloads = {'no heavy env': np.zeros((N, 9), np.float32), '30 %% heavy': np.zeros((N, 9), np.float32), '10 %% very heavy': np.zeros((N, 9), np.float32)}
 workloads['30 %% heavy'][np.arange(N) %% 10 < 3] = press
+workloads['10 %% very heavy'][np.arange(N) %% 10 == 0] = crush
 
 def ms_per_step(force, cmd_dev):
     if force is None:
@@ -241,12 +244,14 @@ def test_schedule_choices_off_the_bench_workload():
     """The placement of a step (rr_step: which stream solves / renders which class, where the look-ahead goes, list walker or grid
     for the heavy envs' visibility pass) is chosen from lagged host copies of the two heavy-list lengths through constants that were
     tuned on the benchmark's workload (LA_VH_MAX, RENDER_LIST_WGS, split_max_pct, the walker / grid threshold).  Two workloads the
-    benchmark never shows -- NO heavy env at all (arms at home, objects at rest) and 30 % of the envs pressing the gripper on the
-    table (heavy from the first contact on) -- are timed under the automatic choice and under every forced reading of the counts
+    benchmark never shows -- NO heavy env at all (arms at home, objects at rest), 30 % of the envs pressing the gripper on the
+    table (heavy from the first contact on) and 10 % crushing it onto the table (very heavy) -- are timed under the automatic choice and under every forced reading of the counts
     (RR_FORCE_HCOUNT: placements only, results are bitwise the same, tests/test_gpu_round4.py): the automatic choice is within 3 % of
     the best forced one.  (In a process of its own: the suite's other tests leave streams, RCCL threads and a warm allocator behind
     that add a millisecond-scale jitter to 0.4 ms steps.  The first run of this test moved the walker / grid threshold from a quarter
-    of the batch to a third: at 1 230 heavy envs the walker was 3.6 % ahead; the macro workload, 1 486 heavy envs and up, wants the grid.)"""
+    of the batch to a third: at 1 230 heavy envs the walker was 3.6 % ahead; the macro workload, 1 486 heavy envs and up, wants the grid.
+    The third workload, added later in the round, found the automatic choice 7.8 % behind: 410 very heavy envs and no other heavy one
+    want placement 1 and the one-env-per-wave solve -- both rules had been fitted to the macro workload, where BOTH lists are long.)"""
     import json
     import subprocess
     import sys
@@ -261,6 +266,8 @@ def test_schedule_choices_off_the_bench_workload():
               % (name, o['heavy'], o['very_heavy'], o['auto'], o['forced'][best], best, o['forced'][worst], worst))
         if name == 'no heavy env':
             assert o['heavy'] == 0 and o['very_heavy'] == 0
-        else:
+        elif name == '30 % heavy':
             assert o['heavy'] + o['very_heavy'] >= 0.25 * 4096
+        else:
+            assert o['very_heavy'] >= 0.08 * 4096
         assert o['auto'] <= 1.03 * o['forced'][best], (name, o)
