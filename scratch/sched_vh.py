@@ -1,4 +1,5 @@
-"""Off-bench schedule check, third workload: 10 % of the envs crush the gripper onto the table (very heavy from contact on)."""
+"""Off-bench schedule checks: scratch/sched_vh.py <fraction of envs> [target height of the gripper base: 0.33 crushes it onto the table
+(very heavy), 0.40 presses it (heavy)]; the automatic placement against a grid of forced readings of the two heavy counts."""
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
@@ -6,7 +7,8 @@ from real_robots_amd import _native as nat
 from real_robots_amd.batched import BatchedREALRobotEnv
 from oracle.kinematics import inverse_kinematics, quat_from_euler
 N = 4096
-press = inverse_kinematics(np.zeros(11), [-0.15, 0.25, 0.33], quat_from_euler(0, 3.14, -1.57))
+zt = float(sys.argv[2]) if len(sys.argv) > 2 else 0.33       # 0.33: crushed (very heavy); 0.40: pressed (heavy)
+press = inverse_kinematics(np.zeros(11), [-0.15, 0.25, zt], quat_from_euler(0, 3.14, -1.57))
 press = np.concatenate([press[:7], [0.0, 0.0]]).astype(np.float32)
 frac = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
 cmd = np.zeros((N, 9), np.float32)
