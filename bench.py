@@ -445,9 +445,18 @@ def main():
         torch.cuda.set_device(local_rank)
         dev = 'cuda:%d' % local_rank
         device_sync = torch.cuda.synchronize
-    if world > 1:
+    if world > 1 or os.environ.get('RR_BENCH_FORCE_PG'):
+        # (RR_BENCH_FORCE_PG: diagnostics -- a one-rank process group and one collective in front of the env's creation, as every rank
+        # of an N > 1 run has: does RCCL's own set-up change what the step's streams get?  scratch/README.md)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        if world == 1:
+            os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('gloo' if stub else 'nccl')          # "nccl" = RCCL on ROCm
+        if world == 1:
+            probe = torch.ones(8, device=dev)
+            dist.all_reduce(probe)
+            device_sync()
 
     if args.scaling == 'strong':
         total = args.envs_per_gpu
