@@ -43,3 +43,14 @@ def test_dpp_hazard_gate_passes_today_and_catches_each_hazard(tmp_path):
     assert far.returncode == 1 and 'v_cmpx_gt_i32' in far.stdout
     none = _run(tmp_path, NO_BLOCK)           # the gate must notice when it no longer sees what it is there for
     assert none.returncode == 1 and 'no inline-asm DPP block' in none.stdout
+
+
+def test_archived_object_heavy_class_patch_still_applies():
+    """scratch/object_heavy_class.patch is the round-6 experiment as built (NOTEBOOK.md "Round 6 -- measured and dropped"): kept as
+    a patch against the kernel sources, which only means something while it applies to them."""
+    patch = os.path.join(ROOT, 'scratch', 'object_heavy_class.patch')
+    assert os.path.exists(patch)
+    r = subprocess.run(['git', 'apply', '--check', patch], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(patch).read()
+    assert 'k_solve_oh' in text and 'oh_object_wave' in text

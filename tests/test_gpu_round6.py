@@ -36,6 +36,24 @@ def _rich_states(N, seed):
     return st
 
 
+def test_unused_streams_in_front_of_the_side_streams_change_no_result(monkeypatch):
+    """RR_SKIP_QUEUES only decides which hardware queues the side streams get (worth 50 % of the step time in the wrong
+    process): states, contacts and frames of a run with it are those of a run without, bit for bit."""
+    N, T = 96, 120
+    cmds = [synthetic_actions(range(N), t, seed=11).astype(np.float32) for t in range(T)]
+    runs = []
+    for setting in (None, '1,1', '2,0'):
+        env = _make(monkeypatch, {} if setting is None else {'RR_SKIP_QUEUES': setting}, N, objects=3, width=64, height=64)
+        for t in range(T):
+            env.step(cmds[t], render=True)
+        runs.append((env.state, env.host(nat.F_RGB), env.host(nat.F_DEPTH), env.host(nat.F_TOUCH), env.host(nat.F_ENV_CLASS)))
+        env.close()
+    assert (runs[0][4] > 0).any()                     # (heavy envs -- the side streams -- were in play)
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
 @pytest.mark.parametrize("N", [4096, 5])
 def test_prep16_matches_the_thread_per_env_preparation(monkeypatch, N):
     """k_prep_b16 (sixteen lanes per env) against k_prep_b (a thread per env) on the same states, through the diagnostic field
