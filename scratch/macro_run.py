@@ -9,9 +9,14 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 450
 N = 4096
 env = BatchedREALRobotEnv(N, objects=3, width=128, height=128, want_mask=False)
 env.plan_macro(np.random.default_rng(0).uniform([-0.25, -0.5], [0.05, 0.5], size=(N, 2, 2)))
-for t in range(300): env.step_plan(render=True)
+K = int(os.environ.get('SYNC_EVERY', '0'))          # bound the host's run-ahead: a sync every K steps (0: never)
+for t in range(300):
+    env.step_plan(render=True)
+    if K and t % K == K - 1: env.sync()
 env.sync(); t0 = time.perf_counter()
-for t in range(T - 300): env.step_plan(render=True)
+for t in range(T - 300):
+    env.step_plan(render=True)
+    if K and t % K == K - 1: env.sync()
 env.sync()
 cls = env.host(nat.F_ENV_CLASS)
 print('macro workload: %.4f ms per step over steps 300..%d; heavy %d very heavy %d' % ((time.perf_counter() - t0) / (T - 300) * 1e3, T, (cls == 1).sum(), (cls == 2).sum()))

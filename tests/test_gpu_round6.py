@@ -36,14 +36,15 @@ def _rich_states(N, seed):
     return st
 
 
-def test_unused_streams_in_front_of_the_side_streams_change_no_result(monkeypatch):
+def test_stream_order_and_run_ahead_bound_change_no_result(monkeypatch):
     """RR_SKIP_QUEUES only decides which hardware queues the side streams get (worth 50 % of the step time in the wrong
     process): states, contacts and frames of a run with it are those of a run without, bit for bit."""
     N, T = 96, 120
     cmds = [synthetic_actions(range(N), t, seed=11).astype(np.float32) for t in range(T)]
     runs = []
-    for setting in (None, '1,1', '2,0'):
-        env = _make(monkeypatch, {} if setting is None else {'RR_SKIP_QUEUES': setting}, N, objects=3, width=64, height=64)
+    # (... and the bound on the host's run-ahead, RR_RUN_AHEAD, only decides how old the list lengths are that pick a placement)
+    for setting in (None, {'RR_SKIP_QUEUES': '1,1'}, {'RR_SKIP_QUEUES': '2,0'}, {'RR_RUN_AHEAD': '0'}, {'RR_RUN_AHEAD': '2'}):
+        env = _make(monkeypatch, setting or {}, N, objects=3, width=64, height=64)
         for t in range(T):
             env.step(cmds[t], render=True)
         runs.append((env.state, env.host(nat.F_RGB), env.host(nat.F_DEPTH), env.host(nat.F_TOUCH), env.host(nat.F_ENV_CLASS)))
