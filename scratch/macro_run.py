@@ -6,16 +6,17 @@ import numpy as np
 from real_robots_amd import _native as nat
 from real_robots_amd.batched import BatchedREALRobotEnv
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 450
+RENDER = os.environ.get('RENDER', '1') != '0'
 N = 4096
 env = BatchedREALRobotEnv(N, objects=3, width=128, height=128, want_mask=False)
 env.plan_macro(np.random.default_rng(0).uniform([-0.25, -0.5], [0.05, 0.5], size=(N, 2, 2)))
 K = int(os.environ.get('SYNC_EVERY', '0'))          # bound the host's run-ahead: a sync every K steps (0: never)
 for t in range(300):
-    env.step_plan(render=True)
+    env.step_plan(render=RENDER)
     if K and t % K == K - 1: env.sync()
 env.sync(); t0 = time.perf_counter()
 for t in range(T - 300):
-    env.step_plan(render=True)
+    env.step_plan(render=RENDER)
     if K and t % K == K - 1: env.sync()
 env.sync()
 cls = env.host(nat.F_ENV_CLASS)

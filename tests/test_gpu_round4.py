@@ -138,6 +138,37 @@ def test_collision_pass_order_and_pair_cull_change_no_result(monkeypatch):
     a.close(); b.close()
 
 
+def test_steps_without_camera_side_by_side_are_bitwise_the_one_launch_step(monkeypatch):
+    """Placement 3b (rr_host.inc step_single): a batch of more than 1 024 envs stepping WITHOUT camera solves its classes side by side on
+    the three streams once the very heavy list is long (macro actions without the retina) -- forced here by the reading, on a population
+    that has both heavy classes; mixed with rendered steps (the split placements and their look-ahead in between).  Bitwise the default run."""
+    N, T = 1100, 170
+    a = _make(monkeypatch, {}, N, objects=3, width=32, height=32)
+    b = _make(monkeypatch, {'RR_FORCE_HCOUNT': '400,100'}, N, objects=3, width=32, height=32)
+    c = _make(monkeypatch, {'RR_FORCE_HCOUNT': '30,600'}, N, objects=3, width=32, height=32)      # (a very heavy list read longer than the one-env-per-wave form's cap)
+    rng = np.random.default_rng(8)
+    for t in range(T):
+        cmd = synthetic_actions(range(N), t, seed=12).astype(np.float32)
+        ev = rng.random()
+        mask = (rng.random(N) < 0.1).astype(np.uint8)
+        render = bool(t % 7 == 3)
+        for e in (a, b, c):
+            if ev < 0.03:
+                e.reset(mask)
+            e.step(cmd, render=render)
+        if t % 20 == 19 or t < 2:
+            for e in (b, c):
+                for f in (nat.F_TOUCH, nat.F_CONTACT_COUNT, nat.F_JOINTS, nat.F_OBJ_POSE, nat.F_ERRFLAGS, nat.F_ENV_CLASS, nat.F_RGB, nat.F_DEPTH):
+                    assert np.array_equal(a.host(f), e.host(f)), (t, f)
+                assert np.array_equal(a.state, e.state), t
+                for k in range(0, N, 53):
+                    assert np.array_equal(a.contacts(k), e.contacts(k)), (t, k)
+    cls = a.host(nat.F_ENV_CLASS)
+    assert (cls == 1).sum() >= 3 and (cls == 2).sum() >= 1, ((cls == 1).sum(), (cls == 2).sum())
+    for e in (a, b, c):
+        e.close()
+
+
 def _bench_module():
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
